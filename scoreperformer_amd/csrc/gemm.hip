@@ -1,0 +1,229 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(alpha * A.B)  with fp32 accumulation.
+//
+// Replaces every nn.Linear / F.linear call site on the ScorePerformer hot path (SURVEY.md Appendix A,
+// K3/K5/K7/K8/K11: attention.py:135-142,210-218; feedforward.py:13-21,51-64; embeddings.py:104,139,211,255,
+// 345-349; transformer.py:131,185; layers.py:37,46) and their autograd backward GEMMs.
+//
+// Operand storage (all bf16, leading dimensions in elements, multiples of 8, 16-byte aligned bases):
+//   A: !TA -> A[m][k] = a[m*lda + k]   (K contiguous; activations in forward, dY in dX = dY.W)
+//       TA -> A[m][k] = a[k*lda + m]   (M contiguous; dY^T in dW = dY^T.X)
+//   B: !TB -> B[k][n] = b[n*ldb + k]   (K contiguous; an nn.Linear weight [N,K])
+//       TB -> B[k][n] = b[k*ldb + n]   (N contiguous; W in dX = dY.W, X in dW = dY^T.X)
+// K-contiguous tiles are staged [rows][64] with a 16-byte XOR swizzle and read with ds_read_b128;
+// M/N-contiguous tiles are staged [64][rows] and read with ds_read_b64_tr_b16 (hardware transpose), so no
+// operand ever needs a transposed copy in HBM.
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
+// Global->register->LDS double buffering: tile t+1 is in flight in registers while tile t is multiplied.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, 16 KiB
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const float* bias;        // [N] or null
+    const float* residual;    // [M, ldr] fp32 or null: C = residual + rowscale * (alpha*acc + bias)
+    const uint8_t* rowmask;   // [M] or null (query-row mask of attention.py:216-218)
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    float alpha;
+    int accumulate;           // C += (fp32 C only)
+    int batch;                // blockIdx.z
+    long sA, sB, sC;          // batch strides in elements
+};
+
+// ---- LDS addressing -------------------------------------------------------------------------------------
+// K-contiguous tile: [128 rows][64 k] bf16, row = 128 B = 8 chunks of 16 B, chunk index XOR (row & 7).
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// R-contiguous tile: [64 k][128 r] bf16, row = 256 B = 16 chunks; swizzle spreads the 4 k-rows of one
+// transpose-read (and the neighbouring lane group's 4 rows) over distinct 32-byte windows.
+__device__ __forceinline__ int rc_swz(int krow) { return (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1); }
+__device__ __forceinline__ int rc_off(int krow, int chunk) { return krow * 256 + ((chunk ^ rc_swz(krow)) << 4); }
+
+template <bool T>
+struct Stage {
+    uint4 r[4];
+    // operand tile origin: row0 = first m (or n) of the tile, k0 = first k
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ p, int ld, int R, int K, int row0, int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (!T) {
+                const int row = (tid >> 3) + 32 * i, kc = tid & 7;
+                const int gr = row0 + row, gk = k0 + kc * 8;
+                if (gr < R && gk < K) v = *reinterpret_cast<const uint4*>(p + (long)gr * ld + gk);
+            } else {
+                const int krow = (tid >> 4) + 16 * i, rc = tid & 15;
+                const int gk = k0 + krow, gr = row0 + rc * 8;
+                if (gk < K && gr < R) v = *reinterpret_cast<const uint4*>(p + (long)gk * ld + gr);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off;
+            if (!T) {
+                const int row = (tid >> 3) + 32 * i, kc = tid & 7;
+                off = kc_off(row, kc);
+            } else {
+                const int krow = (tid >> 4) + 16 * i, rc = tid & 15;
+                off = rc_off(krow, rc);
+            }
+            *reinterpret_cast<uint4*>(lds + off) = r[i];
+        }
+    }
+};
+
+// fragment for 16 rows starting at r_base, k-step ks (32 k each): lane l holds row r_base+(l&15), k = 32ks+(l>>4)*8+0..7
+template <bool T>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int r_base, int ks, int lane) {
+    if (!T) {
+        const int row = r_base + (lane & 15);
+        const int chunk = ks * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(lds + kc_off(row, chunk));
+    } else {
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int g = lane >> 4, p = lane & 15;
+        const int col_byte = (r_base + 4 * (p & 3)) * 2;
+        const int chunk = col_byte >> 4, within = col_byte & 15;
+        const int k0 = ks * 32 + g * 8 + (p >> 2);
+        const int o0 = rc_off(k0, chunk) + within;
+        const int o1 = rc_off(k0 + 4, chunk) + within;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + o0));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + o1));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+template <bool TA, bool TB, typename OutT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // stage s: A tile at smem + s*2*TILE_BYTES, B tile right behind it
+#define LDS_A(s_) (smem + (s_) * 2 * TILE_BYTES)
+#define LDS_B(s_) (smem + (s_) * 2 * TILE_BYTES + TILE_BYTES)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const bf16_t* A = g.A + (long)blockIdx.z * g.sA;
+    const bf16_t* B = g.B + (long)blockIdx.z * g.sB;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage<TA> sa;
+    Stage<TB> sb;
+    const int nt = (g.K + BK - 1) / BK;
+    sa.load(A, g.lda, g.M, g.K, m0, 0, tid);
+    sb.load(B, g.ldb, g.N, g.K, n0, 0, tid);
+    sa.store(LDS_A(0), tid);
+    sb.store(LDS_B(0), tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            sa.load(A, g.lda, g.M, g.K, m0, (t + 1) * BK, tid);
+            sb.load(B, g.ldb, g.N, g.K, n0, (t + 1) * BK, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(LDS_A(cur), wm * 64 + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(LDS_B(cur), wn * 64 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) {
+            sa.store(LDS_A(cur ^ 1), tid);
+            sb.store(LDS_B(cur ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r -------------------
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + 16 * i + (lane >> 4) * 4 + r;
+            if (m >= g.M) continue;
+            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * j + (lane & 15);
+                if (n >= g.N) continue;
+                float v = acc[i][j][r] * g.alpha;
+                if (g.bias) v += g.bias[n];
+                v *= rs;
+                if (g.residual) v += g.residual[(long)m * g.ldr + n];
+                OutT* dst = C + (long)m * g.ldc + n;
+                if constexpr (sizeof(OutT) == 4) {
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                } else {
+                    *dst = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB, typename OutT>
+int launch(const GemmArgs& g, hipStream_t stream) {
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT>), grid, dim3(256), 4 * TILE_BYTES, stream, g);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+}  // namespace
+
+// C-ABI ---------------------------------------------------------------------------------------------------
+// flags: bit0 = A is M-contiguous (transposed storage), bit1 = B is N-contiguous, bit2 = C is fp32 (else bf16),
+//        bit3 = accumulate into C (fp32 C only).
+extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
+                             const uint8_t* rowmask, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
+                             float alpha, int flags, int batch, long strideA, long strideB, long strideC,
+                             hipStream_t stream) {
+    SPN_REQUIRE(A && B && C, "spn_gemm_bf16: null operand");
+    SPN_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "spn_gemm_bf16: empty problem");
+    SPN_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "spn_gemm_bf16: lda/ldb must be multiples of 8 elements");
+    SPN_REQUIRE((((uintptr_t)A) & 15) == 0 && (((uintptr_t)B) & 15) == 0, "spn_gemm_bf16: A/B must be 16-byte aligned");
+    const bool ta = flags & 1, tb = flags & 2, f32 = flags & 4, accum = flags & 8;
+    SPN_REQUIRE(!(accum && !f32), "spn_gemm_bf16: accumulate requires fp32 C");
+    // contiguous extents are read in 8-element chunks
+    SPN_REQUIRE(ta ? (M % 8 == 0) : (K % 8 == 0), "spn_gemm_bf16: contiguous extent of A must be a multiple of 8");
+    SPN_REQUIRE(tb ? (N % 8 == 0) : (K % 8 == 0), "spn_gemm_bf16: contiguous extent of B must be a multiple of 8");
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.residual = residual; g.rowmask = rowmask;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
+    g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    if (f32) {
+        if (!ta && !tb) return launch<false, false, float>(g, stream);
+        if (!ta && tb) return launch<false, true, float>(g, stream);
+        if (ta && !tb) return launch<true, false, float>(g, stream);
+        return launch<true, true, float>(g, stream);
+    } else {
+        if (!ta && !tb) return launch<false, false, bf16_t>(g, stream);
+        if (!ta && tb) return launch<false, true, bf16_t>(g, stream);
+        if (ta && !tb) return launch<true, false, bf16_t>(g, stream);
+        return launch<true, true, bf16_t>(g, stream);
+    }
+}

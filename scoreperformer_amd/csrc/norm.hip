@@ -1,0 +1,229 @@
+// LayerNorm / AdaptiveLayerNorm forward + backward for gfx950 (HBM-bound; one 64-lane wave per row, float4 I/O).
+//
+// Replaces nn.LayerNorm / F.layer_norm (eps 1e-5) at modules/transformer/transformer.py:106,123-125,192-193,217,
+// models/scoreperformer/transformer.py:121,171, models/scoreperformer/embeddings.py:101,139,341,346 and
+// `AdaptiveLayerNorm.forward` (modules/layers.py:41-47):  y = gamma_t * LN(x) + beta_t with per-token
+// (gamma_t, beta_t) = Linear(cond).chunk(2) supplied as a [T, 2D] fp32 tensor.
+// Statistics are fp32 two-pass (mean, then centred variance) like ATen's CPU kernel.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct IO;
+template <> struct IO<float> {
+    static __device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct IO<bf16_t> {
+    static __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+        uint2 u = *reinterpret_cast<const uint2*>(p);
+        return f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+    }
+    static __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+        uint2 u; u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+template <typename TIn, typename TOut, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ gb, long ldgb,
+                                                     TOut* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int T, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const TIn* xr = x + (long)row * ldx;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        v[i] = col < D ? IO<TIn>::load4(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mu = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        if (col < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; sq += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+    TOut* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        if (col >= D) continue;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs;
+        if (gb) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + D + col);
+            o = o * ga + be;
+        } else if (gamma) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
+            o = o * ga + be;
+        }
+        IO<TOut>::store4(yr + col, o);
+    }
+}
+
+// backward.  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// dgamma/dbeta (affine): per-block register partials -> LDS -> one atomicAdd per column per block.
+// dgb (adaptive): [T, 2D] bf16 rows (dy * xhat | dy), consumed as a GEMM operand by the AdaLN linear's backward.
+template <typename TIn, typename TDx, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ gb, long ldgb,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ dres, long lddres, TDx* __restrict__ dx, long lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     bf16_t* __restrict__ dgb, long lddgb, int T, int D, int rows_per_block) {
+    __shared__ float red[4][64 * NV * 4 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 pg[NV], pb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { pg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(T, row_begin + rows_per_block);
+    for (int row = row_begin + w; row < row_end; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], gq[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            xh[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (col >= D) continue;
+            const f32x4 xv = IO<TIn>::load4(x + (long)row * ldx + col);
+            const f32x4 d = IO<bf16_t>::load4(dy + (long)row * lddy + col);
+            f32x4 ga = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (gb) ga = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
+            else if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (xv[e] - mu) * rs;
+                gq[i][e] = d[e] * ga[e];
+                s1 += gq[i][e];
+                s2 += gq[i][e] * xh[i][e];
+            }
+            if (dgb) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = d[e] * xh[i][e];
+                IO<bf16_t>::store4(dgb + (long)row * lddgb + col, t);
+                IO<bf16_t>::store4(dgb + (long)row * lddgb + D + col, d);
+            } else if (dgamma) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pg[i][e] += d[e] * xh[i][e]; pb[i][e] += d[e]; }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            if (col >= D) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (gq[i][e] - s1 - xh[i][e] * s2);
+            if (dres) o += *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col);
+            IO<TDx>::store4(dx + (long)row * lddx + col, o);
+        }
+    }
+    if (dgamma && !dgb) {
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[w][(lane + 64 * i) * 4 + e] = pass == 0 ? pg[i][e] : pb[i][e];
+            __syncthreads();
+            for (int col = threadIdx.x; col < D; col += 256) {
+                const float s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+                atomicAdd((pass == 0 ? dgamma : dbeta) + col, s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const float* gamma, const float* beta, const float* gb,
+               long ldgb, void* y, long ldy, float* mean, float* rstd, int T, int D, float eps) {
+#define CASE(NV_)                                                                                                        \
+    case NV_:                                                                                                            \
+        hipLaunchKernelGGL((ln_fwd_kernel<TIn, TOut, NV_>), grid, dim3(256), 0, s, (const TIn*)x, ldx, gamma, beta, gb,  \
+                           ldgb, (TOut*)y, ldy, mean, rstd, T, D, eps);                                                  \
+        break;
+    switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
+#undef CASE
+    return SPN_OK;
+}
+
+template <typename TIn, typename TDx>
+int launch_bwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const void* dy, long lddy, const float* gamma,
+               const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx,
+               long lddx, float* dgamma, float* dbeta, bf16_t* dgb, long lddgb, int T, int D, int rpb) {
+#define CASE(NV_)                                                                                                        \
+    case NV_:                                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<TIn, TDx, NV_>), grid, dim3(256), 0, s, (const TIn*)x, ldx, (const bf16_t*)dy, \
+                           lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, (TDx*)dx, lddx, dgamma, dbeta, dgb, lddgb, T, D, \
+                           rpb);                                                                                         \
+        break;
+    switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
+#undef CASE
+    return SPN_OK;
+}
+
+static inline int round_nv(int nv) { return nv <= 2 ? nv : nv <= 4 ? 4 : nv <= 6 ? 6 : 8; }
+
+}  // namespace
+
+// dtype codes: 0 = fp32, 1 = bf16.  gamma/beta: [D] fp32 or null;  gb: [T, 2D] fp32 (ldgb) or null.
+extern "C" int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, const float* gb,
+                                 long ldgb, void* y, int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps,
+                                 hipStream_t stream) {
+    SPN_REQUIRE(x && y && T > 0 && D > 0, "spn_layernorm_fwd: bad arguments");
+    SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && ldy % 4 == 0 && ldgb % 4 == 0,
+                "spn_layernorm_fwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
+    const int nv = round_nv((D + 255) / 256);
+    dim3 grid(cdiv(T, 4));
+    int rc;
+    if (x_dtype == 0 && y_dtype == 1) rc = launch_fwd<float, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
+    else if (x_dtype == 0 && y_dtype == 0) rc = launch_fwd<float, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
+    else if (x_dtype == 1 && y_dtype == 1) rc = launch_fwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
+    else rc = launch_fwd<bf16_t, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
+    if (rc) { spn_set_error("spn_layernorm_fwd: unsupported width"); return rc; }
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// dx[T,D] (fp32 or bf16) = (dres or 0) + LN backward; dy is bf16.  Affine: dgamma/dbeta [D] fp32 are ACCUMULATED
+// (atomics; zero them first).  Adaptive: dgb [T,2D] bf16 rows are written.
+extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma,
+                                 const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres,
+                                 long lddres, void* dx, int dx_dtype, long lddx, float* dgamma, float* dbeta, void* dgb,
+                                 long lddgb, int T, int D, hipStream_t stream) {
+    SPN_REQUIRE(x && dy && mean && rstd && dx && T > 0 && D > 0, "spn_layernorm_bwd: bad arguments");
+    SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldgb % 4 == 0 && lddgb % 4 == 0 &&
+                lddres % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
+    const int nv = round_nv((D + 255) / 256);
+    int rpb = cdiv(T, 2048);  // <= 2048 blocks
+    rpb = ((rpb + 3) / 4) * 4;
+    dim3 grid(cdiv(T, rpb));
+    int rc;
+    if (x_dtype == 0 && dx_dtype == 0) rc = launch_bwd<float, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else if (x_dtype == 0 && dx_dtype == 1) rc = launch_bwd<float, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else if (x_dtype == 1 && dx_dtype == 0) rc = launch_bwd<bf16_t, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else rc = launch_bwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    if (rc) { spn_set_error("spn_layernorm_bwd: unsupported width"); return rc; }
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

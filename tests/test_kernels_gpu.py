@@ -1,0 +1,162 @@
+"""GPU parity tests of the individual HIP kernels (through the C-ABI) against fp32 PyTorch math on the same inputs.
+
+Tolerances: operands are bf16, accumulation fp32.  A bf16 result is compared at rtol 2^-7 on the tensor scale.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1000, 264, 520), (264, 1000, 2048)])
+def test_gemm_layouts(dev, ta, tb, M, N, K):
+    from scoreperformer_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    b = torch.randn(K, N, generator=g).to(dev).bfloat16()  # asymmetric by construction
+    ref = a.float() @ b.float()
+    a_store = a.t().contiguous() if ta else a
+    b_store = b if tb else b.t().contiguous()
+    out = ops.gemm(a_store, b_store, ta=ta, tb=tb, out_dtype=torch.float32)
+    assert rel_err(out, ref) < 2e-3
+    out16 = ops.gemm(a_store, b_store, ta=ta, tb=tb, out_dtype=torch.bfloat16)
+    assert rel_err(out16, ref) < 1e-2
+
+
+def test_gemm_epilogue(dev):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 192, 136
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    w = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) > 0.3).to(dev)
+    ref = res + mask[:, None] * (0.5 * (a.float() @ w.float().t()) + bias)
+    out = ops.gemm(a, w, out_dtype=torch.float32, bias=bias, residual=res, rowmask=mask, alpha=0.5)
+    assert rel_err(out, ref) < 2e-3
+    acc = torch.ones(M, N, device=dev)
+    ops.gemm(a, w, out=acc, accumulate=True)
+    assert rel_err(acc, 1 + a.float() @ w.float().t()) < 2e-3
+    # strided views (slices of wider buffers)
+    wide = torch.randn(M, 3 * K, generator=g).to(dev).bfloat16()
+    outw = torch.zeros(M, 2 * N, device=dev, dtype=torch.bfloat16)
+    ops.gemm(wide[:, K:2 * K], w, out=outw[:, N:])
+    assert rel_err(outw[:, N:], wide[:, K:2 * K].float() @ w.float().t()) < 1e-2
+    assert outw[:, :N].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("D", [128, 320, 512, 1280, 1536])
+@pytest.mark.parametrize("mode", ["affine", "ada", "plain"])
+def test_layernorm(dev, D, mode):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(D)
+    T = 77
+    x = (torch.randn(T, D, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev) if mode == "affine" else None
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev) if mode == "affine" else None
+    gb = torch.cat([1 + 0.1 * torch.randn(T, D, generator=g), 0.1 * torch.randn(T, D, generator=g)], -1).to(dev) \
+        if mode == "ada" else None
+    dy = torch.randn(T, D, generator=g).to(dev).bfloat16()
+
+    xr = x.clone().requires_grad_(True)
+    leaves = [xr]
+    if mode == "affine":
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xr, (D,), gr, br)
+        leaves += [gr, br]
+    elif mode == "ada":
+        gbr = gb.clone().requires_grad_(True)
+        ref = gbr[:, :D] * torch.nn.functional.layer_norm(xr, (D,)) + gbr[:, D:]
+        leaves += [gbr]
+    else:
+        ref = torch.nn.functional.layer_norm(xr, (D,))
+    ref.backward(dy.float())
+
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, gb, out_dtype=torch.float32)
+    assert rel_err(y, ref) < 1e-5
+    y16, _, _ = ops.layernorm_fwd(x, gamma, beta, gb, out_dtype=torch.bfloat16)
+    assert rel_err(y16, ref) < 1e-2
+    dgamma = torch.zeros(D, device=dev) if mode == "affine" else None
+    dbeta = torch.zeros(D, device=dev) if mode == "affine" else None
+    dres = torch.randn(T, D, generator=g).to(dev)
+    dx, dgb = ops.layernorm_bwd(x, dy, gamma, gb, mean, rstd, dres=dres, dgamma=dgamma, dbeta=dbeta, want_dgb=mode == "ada")
+    assert rel_err(dx - dres, xr.grad) < 1e-4
+    if mode == "affine":
+        assert rel_err(dgamma, leaves[1].grad) < 1e-4
+        assert rel_err(dbeta, leaves[2].grad) < 1e-4
+    if mode == "ada":
+        assert rel_err(dgb, leaves[1].grad) < 1e-2
+
+
+def attn_reference(q, k, v, kmask, slopes, causal, scale):
+    """fp32 restatement of attend.py:58-126 + attention.py:162-197 (same as oracle/ref_cpu.attention core)."""
+    b, nq, h, dh = q.shape
+    nk, kvh = k.shape[1], k.shape[2]
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).expand(b, h, nk, dh)
+    vf = v.float().permute(0, 2, 1, 3).expand(b, h, nk, dh)
+    dots = qf @ kf.transpose(-1, -2) * scale
+    ii = torch.arange(nk - nq, nk, device=q.device)
+    jj = torch.arange(nk, device=q.device)
+    dist = (jj[None, :] - ii[:, None])
+    if slopes is not None:
+        dots = dots - slopes.view(1, h, 1, 1) * dist.abs().float()
+    allowed = torch.ones(b, 1, nq, nk, dtype=torch.bool, device=q.device)
+    if kmask is not None:
+        allowed = allowed & kmask[:, None, None, :]
+    if causal:
+        allowed = allowed & (dist <= 0)
+    dots = torch.where(allowed, dots, torch.full_like(dots, -1.7014118e38))
+    p = dots.softmax(-1)
+    return (p @ vf).permute(0, 2, 1, 3), dots.logsumexp(-1)
+
+
+@pytest.mark.parametrize("mqa", [True, False])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("b,h,nq,nk", [(2, 4, 128, 128), (3, 8, 200, 200), (2, 2, 47, 48), (1, 8, 300, 333)])
+def test_attention_fwd_bwd(dev, mqa, causal, b, h, nq, nk):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(b * 1000 + h * 100 + nq + nk + int(mqa) * 7 + int(causal))
+    kvh = 1 if mqa else h
+    width = h * 64 + 2 * kvh * 64
+    qkv = torch.randn(b, nk, width, generator=g).to(dev).bfloat16()  # fused projection buffer
+    if nq != nk:
+        q = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+    else:
+        q = qkv[..., :h * 64].unflatten(-1, (h, 64))
+    k = qkv[..., h * 64:h * 64 + kvh * 64].unflatten(-1, (kvh, 64))
+    v = qkv[..., h * 64 + kvh * 64:].unflatten(-1, (kvh, 64))
+    lens = torch.randint(nk // 2, nk + 1, (b,), generator=g)
+    kmask = (torch.arange(nk)[None, :] < lens[:, None]).to(dev)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / h) for i in range(h)], device=dev) * 1.3
+    scale = 64 ** -0.5
+    d_o = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+
+    qr, kr, vr, sr = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True), \
+        slopes.clone().requires_grad_(True)
+    ref, ref_lse = attn_reference(qr, kr, vr, kmask, sr, causal, scale)
+    ref.backward(d_o.float())
+
+    o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=slopes, causal=causal, scale=scale)
+    assert rel_err(o, ref) < 2e-2
+    assert (lse - ref_lse).abs().max().item() < 2e-2
+
+    dqkv = torch.zeros(b, nk, width, device=dev, dtype=torch.bfloat16)
+    dq = torch.zeros_like(q) if nq != nk else dqkv[..., :h * 64].unflatten(-1, (h, 64))
+    dk = dqkv[..., h * 64:h * 64 + kvh * 64].unflatten(-1, (kvh, 64))
+    dv = dqkv[..., h * 64 + kvh * 64:].unflatten(-1, (kvh, 64))
+    dslope = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=slopes, causal=causal,
+                          scale=scale, want_dslope=True)
+    assert rel_err(dq, qr.grad) < 3e-2
+    assert rel_err(dk, kr.grad) < 3e-2
+    assert rel_err(dv, vr.grad) < 3e-2
+    assert rel_err(dslope, sr.grad) < 3e-2
