@@ -89,6 +89,10 @@ def run_train_variant(name, cfg_kwargs, batch_kwargs):
     named = dict(model.named_parameters())
     grads = {k: p.grad for k, p in named.items() if p.grad is not None}
     fix = {f"in/{k}": v.numpy() for k, v in batch.items()}
+    sd = model.state_dict()
+    fix["meta/state_dict_keys"] = np.array("\n".join(sd.keys()))
+    fix["meta/state_dict_shapes"] = np.array("\n".join(",".join(map(str, v.shape)) for v in sd.values()))
+    fix["meta/num_params"] = np.array(sum(p.numel() for p in model.parameters()))
     for i, z in enumerate(rec.samples):
         fix[f"z/{i}"] = z.numpy()
     fix["out/loss"] = out.loss.detach().numpy()
@@ -108,9 +112,9 @@ def run_train_variant(name, cfg_kwargs, batch_kwargs):
     # a few full gradients (small tensors, and the tied ones that collect 4 contributions)
     for k in grads:
         if any(t in k for t in ("learned_logslopes", "embs.Velocity.index_weight", "vae_head.bar_mean.linear.weight",
-                                "layers.0.0.0.linear.bias", "layers.1.1.ff.3.weight", "embs.Tempo.value_layer.1.0.weight",
+                                "layers.0.0.0.linear.bias", "perf_decoder.model.transformer.layers.1.1.ff.3.weight", "embs.Tempo.value_layer.1.0.weight",
                                 "perf_decoder.model.token_emb.norm.weight")):
-            fix[f"grad/{k}"] = g.numpy()
+            fix[f"grad/{k}"] = grads[k].clone().numpy()
 
     # one optimizer step: clip_grad_norm_(2.0) + AdamW(lr 2e-4, wd 1e-6) as experiments/optimizers.py:151-169
     params = [p for p in model.parameters() if p.grad is not None]

@@ -32,8 +32,11 @@ def fill_like(name: str, ref: torch.Tensor, seed: int = 0) -> torch.Tensor:
     r = torch.randn(ref.shape, generator=g, dtype=torch.float32)
     if name.endswith("learned_logslopes"):
         return ref.clone().float() + 0.1 * r
-    if ref.ndim == 1:  # LayerNorm weight/bias, Linear bias, AdaLN bias (keep init pattern + noise)
-        return ref.clone().float() + 0.05 * r
+    if ref.ndim == 1:
+        # LayerNorm weight/bias and the AdaLN bias have a deterministic 0/1 init pattern: keep it + noise;
+        # nn.Linear biases are randomly initialised -> replaced entirely (so the fill is independent of RNG state)
+        pattern = bool(((ref == 0) | (ref == 1)).all())
+        return (ref.clone().float() if pattern else 0.) + 0.05 * r
     if name.endswith("index_weight"):
         return 0.5 * r
     fan_in = ref.shape[-1] if ref.ndim >= 2 else 1

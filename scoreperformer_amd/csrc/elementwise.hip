@@ -1,0 +1,258 @@
+// Element-wise / small reduction kernels (HBM-bound): GLU / activation, casts with row masks, bias gradients,
+// Mish, row predicates.  bf16 tensors are processed 8 elements (16 B) per lane.
+//
+// Replaces: `GLU.forward` x * act(gate) and the non-GLU activation (modules/transformer/feedforward.py:13-21,51-56),
+// the `out * mask[..., None]` row masks (modules/transformer/attention.py:216-218,
+// models/scoreperformer/mmd_transformer.py:213-214,278), bias gradients of nn.Linear, nn.Mish of the
+// dense-continuous embedding MLP (modules/transformer/embeddings.py:202-213).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = 1.f / (1.f + __expf(-x));
+    return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+template <int ACT> __device__ __forceinline__ float act_f(float x) { return ACT == 0 ? silu_f(x) : gelu_f(x); }
+template <int ACT> __device__ __forceinline__ float act_g(float x) { return ACT == 0 ? silu_grad(x) : gelu_grad(x); }
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { f[2 * e] = bf2f(w[e] & 0xffff); f[2 * e + 1] = bf2f(w[e] >> 16); }
+}
+__device__ __forceinline__ uint4 pack8f(const float* f) {
+    uint4 u;
+    u.x = pack_bf2(f[0], f[1]); u.y = pack_bf2(f[2], f[3]); u.z = pack_bf2(f[4], f[5]); u.w = pack_bf2(f[6], f[7]);
+    return u;
+}
+
+// out[t, i] = u[t, i] * act(u[t, I + i])     (GLU) ;  GLU=false: out[t,i] = act(u[t,i])
+template <int ACT, bool GLU>
+__global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* __restrict__ out, long ldo, long T, int I) {
+    const int chunks = I / 8;
+    const long total = T * chunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long t = idx / chunks;
+        const int c = (idx % chunks) * 8;
+        float a[8], g[8], o[8];
+        if (GLU) {
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), a);
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + I + c), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = a[e] * act_f<ACT>(g[e]);
+        } else {
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = act_f<ACT>(g[e]);
+        }
+        *reinterpret_cast<uint4*>(out + t * ldo + c) = pack8f(o);
+    }
+}
+
+template <int ACT, bool GLU>
+__global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf16_t* __restrict__ dout, long lddo,
+                               bf16_t* __restrict__ du, long lddu, long T, int I) {
+    const int chunks = I / 8;
+    const long total = T * chunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long t = idx / chunks;
+        const int c = (idx % chunks) * 8;
+        float a[8], g[8], d[8], da[8], dg[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + t * lddo + c), d);
+        if (GLU) {
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), a);
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + I + c), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { da[e] = d[e] * act_f<ACT>(g[e]); dg[e] = d[e] * a[e] * act_g<ACT>(g[e]); }
+            *reinterpret_cast<uint4*>(du + t * lddu + c) = pack8f(da);
+            *reinterpret_cast<uint4*>(du + t * lddu + I + c) = pack8f(dg);
+        } else {
+            unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dg[e] = d[e] * act_g<ACT>(g[e]);
+            *reinterpret_cast<uint4*>(du + t * lddu + c) = pack8f(dg);
+        }
+    }
+}
+
+// y[b,t,:] = cast(x[b,t,:] * rowmask[b*t_len + t])  for [B, t_len, D] views with (batch, row) strides; D multiple of 4
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ x, long x_bs, long x_ts, TD* __restrict__ y, long y_bs, long y_ts,
+                            const uint8_t* __restrict__ rowmask, long B, long t_len, int D) {
+    const int chunks = D / 4;
+    const long total = B * t_len * chunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / chunks;
+        const int c = (idx % chunks) * 4;
+        const long bb = r / t_len, tt = r % t_len;
+        const TS* xp = x + bb * x_bs + tt * x_ts + c;
+        TD* yp = y + bb * y_bs + tt * y_ts + c;
+        float v[4];
+        if constexpr (sizeof(TS) == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xp);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        } else {
+            const uint2 a = *reinterpret_cast<const uint2*>(xp);
+            v[0] = bf2f(a.x & 0xffff); v[1] = bf2f(a.x >> 16); v[2] = bf2f(a.y & 0xffff); v[3] = bf2f(a.y >> 16);
+        }
+        if (rowmask && !rowmask[r]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        if constexpr (sizeof(TD) == 4) {
+            *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(yp) = o;
+        }
+    }
+}
+
+// out[n] += sum_t x[t, n]   (bias gradient). block = 256 threads: 64 columns x 4 row groups; grid.x = column tiles,
+// grid.y = row slabs; one atomicAdd per column per block.
+template <typename TS>
+__global__ void colsum_kernel(const TS* __restrict__ x, long ldx, float* __restrict__ out, long T, int N, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(T, r0 + rows_per_block);
+    float acc = 0.f;
+    if (col < N)
+        for (long t = r0 + rg; t < r1; t += 4) {
+            if constexpr (sizeof(TS) == 4) acc += x[t * ldx + col];
+            else acc += bf2f(x[t * ldx + col]);
+        }
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void mish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float sp = v > 20.f ? v : log1pf(__expf(v));
+        y[i] = v * tanhf(sp);
+    }
+}
+__global__ void mish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float sp = v > 20.f ? v : log1pf(__expf(v));
+        const float th = tanhf(sp);
+        const float sg = 1.f / (1.f + __expf(-v));
+        dx[i] = dy[i] * (th + v * (1.f - th * th) * sg);
+    }
+}
+
+// mask[r] = all(x[r, :] != 0)     (mmd_transformer.py:342); one wave per row
+__global__ void rows_all_nonzero_kernel(const float* __restrict__ x, long ldx, uint8_t* __restrict__ mask, long R, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    bool ok = true;
+    for (int c = lane; c < D; c += 64) ok = ok && (x[row * ldx + c] != 0.f);
+    const unsigned long long b = __ballot(ok);
+    if (lane == 0) mask[row] = (b == ~0ull) ? 1 : 0;
+}
+
+// y[r, :] = x[r, :] * (m[r] ? 1 : 0)  fp32 rows (latents * latents_mask etc.)
+__global__ void mask_rows_kernel(const float* __restrict__ x, long ldx, const uint8_t* __restrict__ m, float* __restrict__ y, long ldy,
+                                 long R, int D, int invert) {
+    const long total = R * D;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / D;
+        const int c = idx % D;
+        const bool keep = (m[r] != 0) != (invert != 0);
+        y[r * ldy + c] = keep ? x[r * ldx + c] : 0.f;
+    }
+}
+
+inline int grid_for(long total, int block = 256) { long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+// act: 0 = SiLU, 1 = GELU(erf).  glu != 0: u is [T, 2I] (value | gate), out [T, I];  glu == 0: u [T, I].
+extern "C" int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, hipStream_t s) {
+    SPN_REQUIRE(u && out && T > 0 && I > 0 && I % 8 == 0 && ldu % 8 == 0 && ldo % 8 == 0, "spn_act_fwd: bad arguments (I, ld multiples of 8)");
+    const int g = grid_for(T * (I / 8));
+    const bf16_t* up = (const bf16_t*)u; bf16_t* op = (bf16_t*)out;
+    if (act == 0 && glu) hipLaunchKernelGGL((act_fwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
+    else if (act == 0) hipLaunchKernelGGL((act_fwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
+    else if (glu) hipLaunchKernelGGL((act_fwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
+    else hipLaunchKernelGGL((act_fwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act,
+                           int glu, hipStream_t s) {
+    SPN_REQUIRE(u && dout && du && T > 0 && I > 0 && I % 8 == 0 && ldu % 8 == 0 && lddo % 8 == 0 && lddu % 8 == 0,
+                "spn_act_bwd: bad arguments (I, ld multiples of 8)");
+    const int g = grid_for(T * (I / 8));
+    const bf16_t* up = (const bf16_t*)u; const bf16_t* dp = (const bf16_t*)dout; bf16_t* op = (bf16_t*)du;
+    if (act == 0 && glu) hipLaunchKernelGGL((act_bwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
+    else if (act == 0) hipLaunchKernelGGL((act_bwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
+    else if (glu) hipLaunchKernelGGL((act_bwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
+    else hipLaunchKernelGGL((act_bwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// dtype: 0 = fp32, 1 = bf16.  y[b,t,:] = cast(x[b,t,:]) * (rowmask ? rowmask[b*t_len+t] != 0 : 1); element strides (batch, row).
+extern "C" int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dtype, long y_bs, long y_ts,
+                        const uint8_t* rowmask, long B, long t_len, int D, hipStream_t s) {
+    SPN_REQUIRE(x && y && B > 0 && t_len > 0 && D > 0 && D % 4 == 0 && x_bs % 4 == 0 && x_ts % 4 == 0 && y_bs % 4 == 0 && y_ts % 4 == 0,
+                "spn_cast: bad arguments (D and strides multiples of 4)");
+    const int g = grid_for(B * t_len * (D / 4));
+    if (x_dtype == 0 && y_dtype == 1) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, s, (const float*)x, x_bs, x_ts, (bf16_t*)y, y_bs, y_ts, rowmask, B, t_len, D);
+    else if (x_dtype == 1 && y_dtype == 0) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, x_bs, x_ts, (float*)y, y_bs, y_ts, rowmask, B, t_len, D);
+    else if (x_dtype == 0 && y_dtype == 0) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, s, (const float*)x, x_bs, x_ts, (float*)y, y_bs, y_ts, rowmask, B, t_len, D);
+    else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, x_bs, x_ts, (bf16_t*)y, y_bs, y_ts, rowmask, B, t_len, D);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// out[N] (fp32) += column sums of x [T, N]
+extern "C" int spn_colsum(const void* x, int x_dtype, long ldx, float* out, long T, int N, hipStream_t s) {
+    SPN_REQUIRE(x && out && T > 0 && N > 0, "spn_colsum: bad arguments");
+    int slabs = (int)((T + 1023) / 1024);
+    if (slabs > 512) slabs = 512;
+    const int rpb = (int)((T + slabs - 1) / slabs);
+    dim3 grid(cdiv(N, 64), cdiv(T, rpb));
+    if (x_dtype == 0) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, out, T, N, rpb);
+    else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, T, N, rpb);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_mish_fwd(const float* x, float* y, long n, hipStream_t s) {
+    SPN_REQUIRE(x && y && n > 0, "spn_mish_fwd: bad arguments");
+    hipLaunchKernelGGL(mish_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+extern "C" int spn_mish_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t s) {
+    SPN_REQUIRE(x && dy && dx && n > 0, "spn_mish_bwd: bad arguments");
+    hipLaunchKernelGGL(mish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_rows_all_nonzero(const float* x, long ldx, uint8_t* mask, long R, int D, hipStream_t s) {
+    SPN_REQUIRE(x && mask && R > 0 && D > 0, "spn_rows_all_nonzero: bad arguments");
+    hipLaunchKernelGGL(rows_all_nonzero_kernel, dim3(cdiv(R, 4)), dim3(256), 0, s, x, ldx, mask, R, D);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_mask_rows(const float* x, long ldx, const uint8_t* m, float* y, long ldy, long R, int D, int invert, hipStream_t s) {
+    SPN_REQUIRE(x && m && y && R > 0 && D > 0, "spn_mask_rows: bad arguments");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(R * D)), dim3(256), 0, s, x, ldx, m, y, ldy, R, D, invert);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

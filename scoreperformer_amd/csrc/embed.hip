@@ -1,0 +1,395 @@
+// Tuple-token embedding kernels for gfx950.
+//
+// K1  spn_table_build_{fwd,bwd}: all per-key tables of one TupleTokenEmbeddings in ONE launch.
+//     `DiscreteDenseContinuousEmbedding.weight` (modules/transformer/embeddings.py:118-152,202-213):
+//       rows in `discrete_ids`  <- index_weight rows
+//       every other row         <- Linear(E,E)(Mish(Linear(1,E)(token_value)))      (dense)  or  token_value * w (plain)
+//     (with `discrete=True` index_weight is added on every row).  The reference rebuilds these ~60 tiny ops per
+//     use and 5 uses per step; here one launch per step feeds the 3 encoders/decoder gathers and the tied LM head.
+// K2  spn_embed_fwd / spn_embed_bwd: gather the K per-key rows of each note tuple, concatenate to [T, sum E] and
+//     LayerNorm (models/scoreperformer/embeddings.py:121-143), output bf16 for the projection GEMM.  Backward
+//     recomputes the gather, applies the LayerNorm backward and scatter-adds into the table gradients through an
+//     LDS-privatised copy of the (tiny, heavily contended) table: ds_add_f32 per element, one global atomic per
+//     table element per block.  Rows with token == padding_idx receive no gradient (F.embedding semantics).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 16;
+
+struct TableKey {
+    const float* tv;   // [V] token values
+    const float* w0;   // [E]   Linear(1,E).weight  (dense)  or value_layer.weight (plain)
+    const float* b0;   // [E]   (dense only)
+    const float* w1;   // [E,E] (dense only)
+    const float* b1;   // [E]   (dense only)
+    const float* iw;   // [V,E] index_weight or null
+    float* out;        // [V,E]
+    float* h1;         // [V,E] workspace: Mish output (dense only)
+    int V, E, row0, dense, discrete;
+};
+struct TableDesc {
+    TableKey k[MAXK];
+    int nkeys;
+    unsigned ids_mask;  // bit i set <=> i in discrete_ids
+};
+struct TableGrad {
+    const float* dout[MAXK];  // [V,E]
+    float* dw0[MAXK]; float* db0[MAXK]; float* db1[MAXK]; float* diw[MAXK];
+    float* dval[MAXK];        // [V,E] workspace (rows in discrete_ids zeroed) for the dW1 GEMM
+};
+
+__device__ __forceinline__ float mish_f(float v) {
+    const float sp = v > 20.f ? v : log1pf(__expf(v));
+    return v * tanhf(sp);
+}
+__device__ __forceinline__ float mish_g(float v) {
+    const float sp = v > 20.f ? v : log1pf(__expf(v));
+    const float th = tanhf(sp);
+    const float sg = 1.f / (1.f + __expf(-v));
+    return th + v * (1.f - th * th) * sg;
+}
+
+__device__ __forceinline__ int find_key(const TableDesc& d, int row) {
+    int kk = 0;
+    for (int i = 1; i < d.nkeys; ++i) if (row >= d.k[i].row0) kk = i;
+    return kk;
+}
+
+__global__ __launch_bounds__(128) void table_fwd_kernel(TableDesc d) {
+    __shared__ float hs[512];
+    const int kk = find_key(d, blockIdx.x);
+    const TableKey& K = d.k[kk];
+    const int v = blockIdx.x - K.row0, E = K.E;
+    const float tv = K.tv[v];
+    const bool is_id = v < 32 && ((d.ids_mask >> v) & 1u);
+    if (K.dense) {
+        for (int e = threadIdx.x; e < E; e += blockDim.x) {
+            const float h = mish_f(tv * K.w0[e] + K.b0[e]);
+            hs[e] = h;
+            K.h1[(long)v * E + e] = h;
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float val;
+        if (K.dense) {
+            val = K.b1[e];
+            const float* wr = K.w1 + (long)e * E;
+            for (int j = 0; j < E; ++j) val = fmaf(wr[j], hs[j], val);
+        } else {
+            val = tv * K.w0[e];
+        }
+        if (is_id) val = 0.f;
+        float tw = 0.f;
+        if (K.iw && (K.discrete || is_id)) tw = K.iw[(long)v * E + e];
+        K.out[(long)v * E + e] = tw + val;
+    }
+}
+
+__global__ __launch_bounds__(128) void table_bwd_kernel(TableDesc d, TableGrad g) {
+    __shared__ float dv[512];
+    const int kk = find_key(d, blockIdx.x);
+    const TableKey& K = d.k[kk];
+    const int v = blockIdx.x - K.row0, E = K.E;
+    const float tv = K.tv[v];
+    const bool is_id = v < 32 && ((d.ids_mask >> v) & 1u);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const float go = g.dout[kk][(long)v * E + e];
+        const float val_g = is_id ? 0.f : go;
+        dv[e] = val_g;
+        if (g.diw[kk]) g.diw[kk][(long)v * E + e] = (K.discrete || is_id) ? go : 0.f;
+        if (K.dense) {
+            g.dval[kk][(long)v * E + e] = val_g;
+            if (val_g != 0.f) atomicAdd(g.db1[kk] + e, val_g);
+        } else if (val_g != 0.f) {
+            atomicAdd(g.dw0[kk] + e, val_g * tv);
+        }
+    }
+    if (!K.dense || is_id) return;
+    __syncthreads();
+    for (int j = threadIdx.x; j < E; j += blockDim.x) {
+        float dh = 0.f;
+        for (int e = 0; e < E; ++e) dh = fmaf(K.w1[(long)e * E + j], dv[e], dh);
+        const float dpre = dh * mish_g(tv * K.w0[j] + K.b0[j]);
+        atomicAdd(g.dw0[kk] + j, dpre * tv);
+        atomicAdd(g.db0[kk] + j, dpre);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct GatherDesc {
+    const float* table[MAXK];
+    float* dtable[MAXK];
+    int width[MAXK], col0[MAXK], rows[MAXK];
+    int nkeys, D;
+};
+
+template <int NV>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        bf16_t* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int T, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (col < d.D) {
+            int kk = 0;
+            for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
+            const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
+            v[i] = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
+        }
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    float mu = 0.f, rs = 1.f;
+    if (gamma) {
+        mu = wave_sum(sum) / (float)d.D;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            if (col < d.D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+            }
+        }
+        rs = rsqrtf(wave_sum(sq) / (float)d.D + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (lane + 64 * i) * 4;
+        if (col >= d.D) continue;
+        f32x4 o = v[i];
+        if (gamma) {
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * ga[e] + be[e];
+        }
+        uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(y + (long)row * ldy + col) = pk;
+    }
+}
+
+// backward pass 1: per-row LN-backward sums s1 = mean(g), s2 = mean(g*xhat) with g = dy*gamma, and dgamma/dbeta.
+template <int NV>
+__global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+                                                              const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ s1o, float* __restrict__ s2o,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int T,
+                                                              int rows_per_block) {
+    __shared__ float red[4][64 * NV * 4 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 pg[NV], pb[NV];
+    int key_of[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        pg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int col = (lane + 64 * i) * 4;
+        int kk = 0;
+        for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
+        key_of[i] = kk;
+    }
+    const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
+    for (int row = row_begin + w; row < row_end; row += 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            if (col >= d.D) continue;
+            const int kk = key_of[i];
+            const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
+            const uint2 u = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + col);
+            const float dyv[4] = {bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[e] - mu) * rs, gq = dyv[e] * ga[e];
+                s1 += gq; s2 += gq * xh;
+                pg[i][e] += dyv[e] * xh; pb[i][e] += dyv[e];
+            }
+        }
+        s1 = wave_sum(s1) / (float)d.D;
+        s2 = wave_sum(s2) / (float)d.D;
+        if (lane == 0) { s1o[row] = s1; s2o[row] = s2; }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[w][(lane + 64 * i) * 4 + e] = pass == 0 ? pg[i][e] : pb[i][e];
+        __syncthreads();
+        for (int col = threadIdx.x; col < d.D; col += 256)
+            atomicAdd((pass == 0 ? dgamma : dbeta) + col, red[0][col] + red[1][col] + red[2][col] + red[3][col]);
+        __syncthreads();
+    }
+}
+
+// backward pass 2: grid (chunks, keys).  Each block owns one key's table copy in LDS (if it fits) and a slab of rows.
+__global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+                                                                const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ gamma,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ s1, const float* __restrict__ s2, int T,
+                                                                int rows_per_block, int padding_idx, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int kk = blockIdx.y, E = d.width[kk], V = d.rows[kk], c0 = d.col0[kk];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < V * E; i += 256) acc[i] = 0.f;
+        __syncthreads();
+    }
+    const float* tab = d.table[kk];
+    float* dtab = d.dtable[kk];
+    const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
+    for (int row = row_begin + w; row < row_end; row += 4) {
+        const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
+        if (tok == padding_idx) continue;
+        float mu = 0.f, rs = 1.f, a1 = 0.f, a2 = 0.f;
+        if (gamma) { mu = mean[row]; rs = rstd[row]; a1 = s1[row]; a2 = s2[row]; }
+        for (int c = lane; c < E; c += 64) {
+            float g = bf2f(dy[(long)row * lddy + c0 + c]);
+            if (gamma) {
+                const float xh = (tab[tok * E + c] - mu) * rs;
+                g = rs * (g * gamma[c0 + c] - a1 - xh * a2);
+            }
+            if (use_lds) atomicAdd(&acc[tok * E + c], g);
+            else atomicAdd(dtab + tok * E + c, g);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < V * E; i += 256) {
+            const float v = acc[i];
+            if (v != 0.f) atomicAdd(dtab + i, v);
+        }
+    }
+}
+
+inline int round_nv(int nv) { return nv <= 2 ? nv : nv <= 4 ? 4 : nv <= 6 ? 6 : 8; }
+
+}  // namespace
+
+// Per-key pointer tables are passed as arrays of nkeys entries (host memory; copied into the kernel argument block).
+extern "C" int spn_table_build_fwd(int nkeys, const float* const* tv, const float* const* w0, const float* const* b0,
+                                   const float* const* w1, const float* const* b1, const float* const* iw, float* const* out,
+                                   float* const* h1, const int* V, const int* E, int dense, int discrete, unsigned ids_mask,
+                                   hipStream_t stream) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= MAXK, "spn_table_build_fwd: 1..16 keys");
+    TableDesc d;
+    memset(&d, 0, sizeof(d));
+    int rows = 0;
+    for (int i = 0; i < nkeys; ++i) {
+        SPN_REQUIRE(E[i] <= 512, "spn_table_build_fwd: embedding dim must be <= 512");
+        d.k[i] = TableKey{tv[i], w0[i], dense ? b0[i] : nullptr, dense ? w1[i] : nullptr, dense ? b1[i] : nullptr, iw ? iw[i] : nullptr,
+                          out[i], dense ? h1[i] : nullptr, V[i], E[i], rows, dense, discrete};
+        rows += V[i];
+    }
+    d.nkeys = nkeys; d.ids_mask = ids_mask;
+    hipLaunchKernelGGL(table_fwd_kernel, dim3(rows), dim3(128), 0, stream, d);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// dout: per-key [V,E] gradients of the tables.  dw0/db0/db1 are accumulated with atomics (zero them first);
+// diw (may be null per key) and dval (workspace for the dW1 = dval^T.h1 GEMM, dense only) are written.
+extern "C" int spn_table_build_bwd(int nkeys, const float* const* tv, const float* const* w0, const float* const* b0,
+                                   const float* const* w1, const float* const* dout, float* const* dw0, float* const* db0,
+                                   float* const* db1, float* const* diw, float* const* dval, const int* V, const int* E, int dense,
+                                   int discrete, unsigned ids_mask, hipStream_t stream) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= MAXK, "spn_table_build_bwd: 1..16 keys");
+    TableDesc d;
+    TableGrad g;
+    memset(&d, 0, sizeof(d));
+    memset(&g, 0, sizeof(g));
+    int rows = 0;
+    for (int i = 0; i < nkeys; ++i) {
+        d.k[i] = TableKey{tv[i], w0[i], dense ? b0[i] : nullptr, dense ? w1[i] : nullptr, nullptr, nullptr, nullptr, nullptr, V[i], E[i],
+                          rows, dense, discrete};
+        g.dout[i] = dout[i]; g.dw0[i] = dw0[i]; g.db0[i] = dense ? db0[i] : nullptr; g.db1[i] = dense ? db1[i] : nullptr;
+        g.diw[i] = diw ? diw[i] : nullptr; g.dval[i] = dense ? dval[i] : nullptr;
+        rows += V[i];
+    }
+    d.nkeys = nkeys; d.ids_mask = ids_mask;
+    hipLaunchKernelGGL(table_bwd_kernel, dim3(rows), dim3(128), 0, stream, d, g);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+static int fill_gather(GatherDesc& d, int nkeys, const float* const* tables, float* const* dtables, const int* V, const int* E) {
+    memset(&d, 0, sizeof(d));
+    int col = 0;
+    for (int i = 0; i < nkeys; ++i) {
+        if (E[i] % 4) return -1;
+        d.table[i] = tables[i]; d.dtable[i] = dtables ? dtables[i] : nullptr;
+        d.width[i] = E[i]; d.col0[i] = col; d.rows[i] = V[i];
+        col += E[i];
+    }
+    d.nkeys = nkeys; d.D = col;
+    return col;
+}
+
+// tokens: int64 [B, t_len, >= nkeys] view with element strides (tok_bs, tok_ts); T = B * t_len rows.  y: bf16 [T, sum E].  gamma == null: plain concatenation.
+extern "C" int spn_embed_fwd(int nkeys, const float* const* tables, const int* V, const int* E, const long* tokens, long tok_bs, long tok_ts, int t_len,
+                             const float* gamma, const float* beta, void* y, long ldy, float* mean, float* rstd, int T, float eps,
+                             hipStream_t stream) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= MAXK && tokens && y && T > 0, "spn_embed_fwd: bad arguments");
+    GatherDesc d;
+    const int D = fill_gather(d, nkeys, tables, nullptr, V, E);
+    SPN_REQUIRE(D > 0 && D <= 2048 && ldy % 4 == 0, "spn_embed_fwd: widths must be multiples of 4, total <= 2048");
+    SPN_REQUIRE(!gamma || (mean && rstd && beta), "spn_embed_fwd: mean/rstd/beta required with gamma");
+    const int nv = round_nv((D + 255) / 256);
+    dim3 grid(cdiv(T, 4));
+#define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_fwd_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, gamma, beta, (bf16_t*)y, ldy, mean, rstd, T, eps); break;
+    switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
+#undef CASE
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// dtables (fp32 [V,E] per key) and dgamma/dbeta are ACCUMULATED.  ws: 2*T floats of workspace.
+extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const* dtables, const int* V, const int* E,
+                             const long* tokens, long tok_bs, long tok_ts, int t_len, const void* dy, long lddy, const float* gamma, const float* mean,
+                             const float* rstd, float* dgamma, float* dbeta, float* ws, int T, int padding_idx, hipStream_t stream) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= MAXK && tokens && dy && dtables && T > 0, "spn_embed_bwd: bad arguments");
+    GatherDesc d;
+    const int D = fill_gather(d, nkeys, tables, dtables, V, E);
+    SPN_REQUIRE(D > 0 && D <= 2048 && lddy % 4 == 0, "spn_embed_bwd: widths must be multiples of 4, total <= 2048");
+    float* s1 = ws; float* s2 = ws ? ws + T : nullptr;
+    if (gamma) {
+        SPN_REQUIRE(mean && rstd && dgamma && dbeta && ws, "spn_embed_bwd: LayerNorm buffers required with gamma");
+        const int nv = round_nv((D + 255) / 256);
+        int rpb = cdiv(T, 1024); rpb = ((rpb + 3) / 4) * 4;
+        dim3 grid(cdiv(T, rpb));
+#define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_bwd_stats_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, dgamma, dbeta, T, rpb); break;
+        switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
+#undef CASE
+    }
+    int maxve = 0;
+    for (int i = 0; i < nkeys; ++i) maxve = V[i] * E[i] > maxve ? V[i] * E[i] : maxve;
+    const int lds_bytes = maxve * 4;
+    const int use_lds = lds_bytes <= 150 * 1024;
+    static bool attr_set = false;
+    if (use_lds && !attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    int chunks = 1024 / nkeys;
+    if (chunks > cdiv(T, 64)) chunks = cdiv(T, 64);
+    if (chunks < 1) chunks = 1;
+    int rpb = cdiv(T, chunks); rpb = ((rpb + 3) / 4) * 4;
+    dim3 grid(cdiv(T, rpb), nkeys);
+    hipLaunchKernelGGL(embed_bwd_scatter_kernel, grid, dim3(256), use_lds ? lds_bytes : 0, stream, d, tokens, tok_bs, tok_ts, t_len,
+                       (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, T, rpb, padding_idx, use_lds);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

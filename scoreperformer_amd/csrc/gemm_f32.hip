@@ -1,0 +1,78 @@
+// Exact-fp32 GEMM for the small / skinny contractions of the path (VALU, LDS-tiled 64x64x16):
+//   the VAE heads `MMDVAE.linear` with growing input width 512->544->564->572 and N <= 32
+//   (models/scoreperformer/mmd_transformer.py:53-56,144-156), the dense-continuous embedding MLP
+//   (modules/transformer/embeddings.py:202-213) and their backward contractions.
+// Arbitrary element strides:  A(m,k) = a[m*sam + k*sak],  B(k,n) = b[k*sbk + n*sbn],  C[m*ldc + n].
+// C = alpha * A.B + bias[n] (+ C if accumulate).  No alignment requirements.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, long sam, long sak, const float* __restrict__ b,
+                                                       long sbk, long sbn, float* __restrict__ c, long ldc,
+                                                       const float* __restrict__ bias, int M, int N, int K, float alpha,
+                                                       int accumulate, const uint8_t* __restrict__ rowmask) {
+    __shared__ float As[TK][TM + 4];
+    __shared__ float Bs[TK][TN + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;        // 1024 elements per tile
+            {   // A tile: element (m = e % 64, k = e / 64) when A is m-contiguous friendly, else (m = e / 16, k = e % 16)
+                const int m = (sam == 1) ? (e & 63) : (e >> 4), k = (sam == 1) ? (e >> 6) : (e & 15);
+                const int gm = m0 + m, gk = k0 + k;
+                As[k][m] = (gm < M && gk < K) ? a[gm * sam + gk * sak] : 0.f;
+            }
+            {
+                const int n = (sbn == 1) ? (e & 63) : (e >> 4), k = (sbn == 1) ? (e >> 6) : (e & 15);
+                const int gn = n0 + n, gk = k0 + k;
+                Bs[k][n] = (gn < N && gk < K) ? b[gk * sbk + gn * sbn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[k][ty * 4 + i]; bv[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+        const float rs = rowmask ? (rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float v = acc[i][j] * alpha + (bias ? bias[n] : 0.f);
+            v *= rs;
+            if (accumulate) v += c[m * ldc + n];
+            c[m * ldc + n] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, long sbn, float* c, long ldc,
+                            const float* bias, const uint8_t* rowmask, int M, int N, int K, float alpha, int accumulate,
+                            hipStream_t stream) {
+    SPN_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "spn_gemm_f32: bad arguments");
+    dim3 grid(cdiv(N, TN), cdiv(M, TM));
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha,
+                       accumulate, rowmask);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

@@ -1,0 +1,326 @@
+// Loss-side kernels: cross-entropy over per-key logits, segment (bar/beat/onset) aggregation, Gaussian-kernel MMD.
+//
+// K11/CE  `F.cross_entropy(logits.transpose(1,2), labels[..., i], ignore_index=-100)` per key
+//         (models/scoreperformer/wrappers.py:49-59): fp32 log-sum-exp per row, mean over non-ignored rows.
+// K9      segment means `(out^T @ one_hot) / counts` (models/scoreperformer/mmd_transformer.py:325-340) done as a
+//         run-length scan per (sequence, column) instead of the reference's dense (b,t,S) one-hot matmul, and the
+//         scatter-back `embeddings[(b, segments)]` (mmd_transformer.py:362).
+// K10     `MMDLoss.compute_mmd` (mmd_transformer.py:521-534): k(x,y) = exp(-||x-y||^2 / D^2); weighted by a 0/1 validity
+//         weight per latent so that the boolean-mask gather `latents[mask]` (mmd:513) needs no host sync.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// cross entropy: one wave per row
+// ---------------------------------------------------------------------------------------------------------
+template <typename TL>
+__device__ __forceinline__ float ld_logit(const TL* p) {
+    if constexpr (sizeof(TL) == 4) return *p; else return bf2f(*p);
+}
+
+// per row: lse[row]; loss_sum += (lse - logit[label]) and count += 1 for non-ignored rows; argmax[row] (optional)
+template <typename TL>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                     long lab_bs, long lab_ts, int t_len, int ignore_index, float* __restrict__ lse,
+                                                     float* __restrict__ sums /* [2]: loss sum, count */, int* __restrict__ argmax,
+                                                     long T, int V) {
+    __shared__ float blk[2][4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + w;
+    float loss = 0.f, cnt = 0.f;
+    if (row < T) {
+        const TL* lr = logits + row * ld;
+        float m = -INFINITY;
+        int am = 0;
+        for (int c = lane; c < V; c += 64) {
+            const float v = ld_logit(lr + c);
+            if (v > m) { m = v; am = c; }
+        }
+        // wave argmax (first index on ties, like torch.argmax)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64);
+            const int oa = __shfl_xor(am, o, 64);
+            if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        }
+        float s = 0.f;
+        for (int c = lane; c < V; c += 64) s += __expf(ld_logit(lr + c) - m);
+        s = wave_sum(s);
+        const float l = m + __logf(s);
+        if (lane == 0) {
+            lse[row] = l;
+            if (argmax) argmax[row] = am;
+            const long lab = labels[(row / t_len) * lab_bs + (row % t_len) * lab_ts];
+            if (lab != ignore_index) { loss = l - ld_logit(lr + lab); cnt = 1.f; }
+        }
+    }
+    if (lane == 0) { blk[0][w] = loss; blk[1][w] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float ls = blk[0][0] + blk[0][1] + blk[0][2] + blk[0][3], cs = blk[1][0] + blk[1][1] + blk[1][2] + blk[1][3];
+        if (cs > 0.f) { atomicAdd(sums, ls); atomicAdd(sums + 1, cs); }
+    }
+}
+
+// dlogits[row, c] = coef * (softmax - onehot) for non-ignored rows, 0 otherwise (also for pad columns V..Vpad-1);
+// coef = *coef_ptr (device scalar = upstream grad / (count * n_active_keys))
+template <typename TL>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                     long lab_bs, long lab_ts, int t_len, int ignore_index, const float* __restrict__ lse,
+                                                     const float* __restrict__ coef_ptr, bf16_t* __restrict__ dlogits, long ldd,
+                                                     long T, int V, int Vpad) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const long lab = labels[(row / t_len) * lab_bs + (row % t_len) * lab_ts];
+    const bool live = lab != ignore_index;
+    const float coef = live ? *coef_ptr : 0.f;
+    const float l = lse[row];
+    const TL* lr = logits + row * ld;
+    for (int c = lane; c < Vpad; c += 64) {
+        float g = 0.f;
+        if (live && c < V) g = coef * (__expf(ld_logit(lr + c) - l) - (c == lab ? 1.f : 0.f));
+        dlogits[row * ldd + c] = f2bf(g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// segments
+// ---------------------------------------------------------------------------------------------------------
+__global__ void seg_count_kernel(const long* __restrict__ seg, float* __restrict__ counts, long BT, int t, int S) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < BT; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / t;
+        atomicAdd(counts + b * S + seg[i], 1.f);
+    }
+}
+
+// out[b, s, c] += sum over maximal runs of equal ids of x[b, t, c] * scale(b, s);  one thread per (b, c), grid.y = b.
+// scale = 1 / max(counts, 1) when counts != null (mean) else 1 (sum).  Runs are flushed with one atomicAdd, so ids need
+// not be sorted (sorted ids -- the collator's contract -- give exactly one atomic per segment and column).
+template <typename TX>
+__global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, const long* __restrict__ seg,
+                               const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out,
+                               int t, int S, int d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= d) return;
+    const TX* xb = x + (long)b * x_bs;
+    const long* sb = seg + (long)b * t;
+    float acc = 0.f;
+    long cur = sb[0];
+    for (int i = 0; i < t; ++i) {
+        const long s = sb[i];
+        if (s != cur) {
+            const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f;
+            if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * sc);
+            acc = 0.f; cur = s;
+        }
+        float v;
+        if constexpr (sizeof(TX) == 4) v = xb[(long)i * x_ts + c]; else v = bf2f(xb[(long)i * x_ts + c]);
+        if (rowmask && !rowmask[(long)b * t + i]) v = 0.f;
+        acc += v;
+    }
+    const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f;
+    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * sc);
+}
+
+// y[b, t, c] = src[b, seg[b,t], c] * scale * (rowmask ? rowmask[b,t] : 1);  scale = 1/max(counts[b,seg],1) if counts
+__global__ void seg_gather_kernel(const float* __restrict__ src, const long* __restrict__ seg, const float* __restrict__ counts,
+                                  const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, long BT, int t, int S, int d,
+                                  int accumulate) {
+    const long total = BT * d;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / d;
+        const int c = idx % d;
+        const long b = r / t;
+        const long s = seg[r];
+        float v = src[(b * S + s) * d + c];
+        if (counts) v /= fmaxf(counts[b * S + s], 1.f);
+        if (rowmask && !rowmask[r]) v = 0.f;
+        if (accumulate) y[r * y_ld + c] += v; else y[r * y_ld + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MMD.  sums[0] = sum_ij k(z_i,z_j), sums[1] = sum_ij w_i w_j k(y_i,y_j), sums[2] = sum_ij w_j k(z_i,y_j), sums[3] = sum w
+// grid (ceil(Na/64), ceil(Nb/64), 3 pair types); block 256: thread (i = tid&63 row of a-tile) loops over 16 b columns
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MMD_MAXD = 64;
+
+__global__ __launch_bounds__(256) void mmd_fwd_kernel(const float* __restrict__ z, int Z, const float* __restrict__ y,
+                                                      const float* __restrict__ w, int N, int D, float* __restrict__ sums) {
+    __shared__ float at[64][MMD_MAXD + 1], bt[64][MMD_MAXD + 1], wa[64], wb[64], red[4];
+    const int type = blockIdx.z;  // 0: zz, 1: yy, 2: zy
+    const float* A = type == 1 ? y : z;  const int NA = type == 1 ? N : Z;
+    const float* B = type == 0 ? z : y;  const int NB = type == 0 ? Z : N;
+    const int a0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+    if (a0 >= NA || b0 >= NB) return;
+    for (int e = threadIdx.x; e < 64 * D; e += 256) {
+        const int r = e / D, c = e % D;
+        at[r][c] = (a0 + r < NA) ? A[(long)(a0 + r) * D + c] : 0.f;
+        bt[r][c] = (b0 + r < NB) ? B[(long)(b0 + r) * D + c] : 0.f;
+    }
+    if (threadIdx.x < 64) {
+        const int r = threadIdx.x;
+        wa[r] = (a0 + r < NA) ? (type == 1 ? w[a0 + r] : 1.f) : 0.f;
+        wb[r] = (b0 + r < NB) ? (type == 0 ? 1.f : w[b0 + r]) : 0.f;
+    }
+    __syncthreads();
+    const int i = threadIdx.x & 63, jg = threadIdx.x >> 6;
+    const float inv = 1.f / ((float)D * (float)D);
+    float acc = 0.f;
+    if (wa[i] != 0.f)
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = jg * 16 + jj;
+            if (wb[j] == 0.f) continue;
+            float d2 = 0.f;
+            for (int c = 0; c < D; ++c) { const float t = at[i][c] - bt[j][c]; d2 = fmaf(t, t, d2); }
+            acc += wa[i] * wb[j] * __expf(-d2 * inv);
+        }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[jg] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + type, red[0] + red[1] + red[2] + red[3]);
+        if (type == 1 && blockIdx.y == 0) { float s = 0.f; for (int r = 0; r < 64; ++r) s += wa[r]; atomicAdd(sums + 3, s); }
+    }
+}
+
+// dy_j = coef[0] * sum_i w_i w_j k(y_i,y_j) * (-2/D^2) (y_j - y_i) * 2      (yy term, symmetric -> factor 2)
+//      + coef[1] * sum_i w_j k(z_i,y_j) * (-2/D^2) (y_j - z_i)              (zy term)
+// coef (device): coef[0] = g / n^2, coef[1] = -2 g / (Z n).   grid (ceil(N/64)); block 256 = 64 rows j x 4 slices of i.
+// DP = D padded to a power of two (zero columns), so that the per-lane gradient lives in registers.
+template <int DP>
+__global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ z, int Z, const float* __restrict__ y,
+                                                      const float* __restrict__ w, int N, int D, const float* __restrict__ coef,
+                                                      float* __restrict__ dy) {
+    __shared__ float yt[64][DP + 1], ot[64][DP + 1], wo[64], res[64][DP + 1];
+    const int j0 = blockIdx.x * 64;
+    const int j = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < 64 * DP; e += 256) {
+        const int r = e / DP, c = e % DP;
+        yt[r][c] = (j0 + r < N && c < D) ? y[(long)(j0 + r) * D + c] : 0.f;
+        res[r][c] = 0.f;
+    }
+    const float wj = (j0 + j < N) ? w[j0 + j] : 0.f;
+    const float inv = 1.f / ((float)D * (float)D);
+    float g[DP];
+#pragma unroll
+    for (int c = 0; c < DP; ++c) g[c] = 0.f;
+    const float c_yy = coef[0] * 2.f, c_zy = coef[1];
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: others = y (weights w), pass 1: others = z (weights 1)
+        const float* O = pass == 0 ? y : z;
+        const int NO = pass == 0 ? N : Z;
+        const float cc = pass == 0 ? c_yy : c_zy;
+        for (int o0 = 0; o0 < NO; o0 += 64) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 64 * DP; e += 256) {
+                const int r = e / DP, c = e % DP;
+                ot[r][c] = (o0 + r < NO && c < D) ? O[(long)(o0 + r) * D + c] : 0.f;
+            }
+            if (threadIdx.x < 64) wo[threadIdx.x] = (o0 + threadIdx.x < NO) ? (pass == 0 ? w[o0 + threadIdx.x] : 1.f) : 0.f;
+            __syncthreads();
+            if (wj != 0.f)
+                for (int ii = 0; ii < 16; ++ii) {
+                    const int i = sl * 16 + ii;
+                    if (wo[i] == 0.f) continue;
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < DP; ++c) { const float t = yt[j][c] - ot[i][c]; d2 = fmaf(t, t, d2); }
+                    const float kk = cc * wj * wo[i] * __expf(-d2 * inv) * (-2.f * inv);
+#pragma unroll
+                    for (int c = 0; c < DP; ++c) g[c] = fmaf(kk, yt[j][c] - ot[i][c], g[c]);
+                }
+        }
+    }
+    for (int s4 = 0; s4 < 4; ++s4) {
+        __syncthreads();
+        if (sl == s4) {
+#pragma unroll
+            for (int c = 0; c < DP; ++c) res[j][c] += g[c];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * D; e += 256) {
+        const int r = e / D, c = e % D;
+        if (j0 + r < N) dy[(long)(j0 + r) * D + c] = res[r][c];
+    }
+}
+
+inline int grid_for(long total, int block = 256) { long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+// logits: [T, V] (fp32 dtype 0 / bf16 dtype 1, row stride ld); labels int64 [B, t_len] view, element strides (lab_bs, lab_ts), T = B*t_len.
+// sums[2] (loss sum, valid count) are ACCUMULATED (zero first).  argmax may be null.
+extern "C" int spn_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index, float* lse,
+                          float* sums, int* argmax, long T, int V, hipStream_t s) {
+    SPN_REQUIRE(logits && labels && lse && sums && T > 0 && V > 0, "spn_ce_fwd: bad arguments");
+    dim3 grid(cdiv(T, 4));
+    if (dtype == 0) hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
+    else hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_ce_bwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index,
+                          const float* lse, const float* coef, void* dlogits, long ldd, long T, int V, int Vpad, hipStream_t s) {
+    SPN_REQUIRE(logits && labels && lse && coef && dlogits && T > 0 && V > 0 && Vpad >= V, "spn_ce_bwd: bad arguments");
+    dim3 grid(cdiv(T, 4));
+    if (dtype == 0) hipLaunchKernelGGL((ce_bwd_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, coef, (bf16_t*)dlogits, ldd, T, V, Vpad);
+    else hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, coef, (bf16_t*)dlogits, ldd, T, V, Vpad);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// counts[b, S] fp32 (zeroed by caller) += number of rows per segment id
+extern "C" int spn_segment_count(const long* seg, float* counts, int b, int t, int S, hipStream_t s) {
+    SPN_REQUIRE(seg && counts && b > 0 && t > 0 && S > 0, "spn_segment_count: bad arguments");
+    hipLaunchKernelGGL(seg_count_kernel, dim3(grid_for((long)b * t)), dim3(256), 0, s, seg, counts, (long)b * t, t, S);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// out[b,S,d] fp32 (zeroed by caller) += segment sums (counts == null) or means (counts given) of x[b,t,d]
+extern "C" int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
+                               const uint8_t* rowmask, float* out, int b, int t, int S, int d, hipStream_t s) {
+    SPN_REQUIRE(x && seg && out && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_sum: bad arguments");
+    dim3 grid(cdiv(d, 64), b);
+    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d);
+    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// y[b*t, d] (row stride y_ld) (+)= src[b, seg, :] (/ counts) (* rowmask)
+extern "C" int spn_segment_gather(const float* src, const long* seg, const float* counts, const uint8_t* rowmask, float* y, long y_ld,
+                                  int b, int t, int S, int d, int accumulate, hipStream_t s) {
+    SPN_REQUIRE(src && seg && y && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_gather: bad arguments");
+    hipLaunchKernelGGL(seg_gather_kernel, dim3(grid_for((long)b * t * d)), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
+                       (long)b * t, t, S, d, accumulate);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// sums[4] fp32 (zeroed by caller): kzz, kyy (weighted), kzy (weighted), sum of weights
+extern "C" int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w, int N, int D, float* sums, hipStream_t s) {
+    SPN_REQUIRE(z && y && w && sums && Z > 0 && N > 0 && D > 0 && D <= MMD_MAXD, "spn_mmd_fwd: bad arguments (D <= 64)");
+    const int mx = Z > N ? Z : N;
+    hipLaunchKernelGGL(mmd_fwd_kernel, dim3(cdiv(mx, 64), cdiv(mx, 64), 3), dim3(256), 0, s, z, Z, y, w, N, D, sums);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, int D, const float* coef, float* dy,
+                           hipStream_t s) {
+    SPN_REQUIRE(z && y && w && coef && dy && Z > 0 && N > 0 && D > 0 && D <= MMD_MAXD, "spn_mmd_bwd: bad arguments (D <= 64)");
+    dim3 grid(cdiv(N, 64));
+    if (D <= 4) hipLaunchKernelGGL((mmd_bwd_kernel<4>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
+    else if (D <= 8) hipLaunchKernelGGL((mmd_bwd_kernel<8>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
+    else if (D <= 16) hipLaunchKernelGGL((mmd_bwd_kernel<16>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
+    else if (D <= 32) hipLaunchKernelGGL((mmd_bwd_kernel<32>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
+    else hipLaunchKernelGGL((mmd_bwd_kernel<64>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

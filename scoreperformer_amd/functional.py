@@ -1,0 +1,632 @@
+"""Autograd functions built on the C-ABI kernels (``ops``).  Every forward/backward is HIP; there is no fallback.
+
+dtype plan: residual stream fp32, GEMM operands bf16 (weights use the arena's bf16 compute copy),
+fp32 accumulation and statistics, small "exact" contractions (VAE heads, embedding MLP, MMD) fp32.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from .ops import BF16, F32
+
+ACT_SILU, ACT_GELU = 0, 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 compute copies of fp32 master weights
+# ---------------------------------------------------------------------------------------------------------
+
+def bf16_weight(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of a (fp32 master) weight.  Arena parameters carry a persistent copy refreshed by the fused optimizer;
+    anything else is converted on use and cached against the tensor's version counter."""
+    if w.dtype == BF16:
+        return w
+    shadow = getattr(w, "_spn_shadow", None)
+    ver = w._version
+    if shadow is not None and shadow.device == w.device:
+        if getattr(w, "_spn_shadow_version", None) != ver:
+            ops.cast(w.detach().reshape(-1, w.shape[-1]) if w.ndim > 1 else w.detach().view(1, -1), BF16,
+                     out=shadow.view(-1, w.shape[-1]) if w.ndim > 1 else shadow.view(1, -1))
+            w._spn_shadow_version = ver
+        return shadow
+    cached = getattr(w, "_spn_cast_cache", None)
+    if cached is not None and cached[0] == ver and cached[1].device == w.device:
+        return cached[1]
+    wd = w.detach()
+    out = ops.cast(wd if wd.ndim > 1 else wd.view(1, -1), BF16)
+    out = out.view(w.shape)
+    try:
+        w._spn_cast_cache = (ver, out)
+    except Exception:
+        pass
+    return out
+
+
+def to_bf16(x: torch.Tensor, rowmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if x.dtype == BF16 and rowmask is None and x.stride(-1) == 1:
+        return x
+    return ops.cast(x, BF16, rowmask=rowmask)
+
+
+def _accumulate_wgrad(w: torch.Tensor, compute, shape):
+    """Weight gradient: accumulate straight into the arena's fp32 grad view when there is one (returns None to
+    autograd), else return a fresh fp32 gradient."""
+    main = getattr(w, "_spn_main_grad", None)
+    if main is not None:
+        compute(main, True)
+        hook = getattr(w, "_spn_grad_ready", None)
+        if hook is not None:
+            hook()
+        return None
+    g = torch.empty(shape, device=w.device, dtype=F32)
+    compute(g, False)
+    return g
+
+
+def _pend(w: torch.Tensor):
+    """Count a pending gradient contribution (data-parallel bucket readiness; see parallel.py)."""
+    cb = getattr(w, "_spn_grad_pending", None)
+    if cb is not None:
+        cb()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Linear:  y = residual + rowmask * (x @ W^T + b)
+# ---------------------------------------------------------------------------------------------------------
+
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, rowmask, out_fp32: bool, kn_layout: bool):
+        # weight: [N, K] (nn.Linear) or, with kn_layout, [K, N] used as x @ W (tied LM-head projection,
+        # models/scoreperformer/embeddings.py:346)
+        lead = x.shape[:-1]
+        x2 = to_bf16(x).reshape(-1, x.shape[-1])
+        wb = bf16_weight(weight)
+        N = weight.shape[1] if kn_layout else weight.shape[0]
+        res2 = residual.reshape(-1, N) if residual is not None else None
+        y = ops.gemm(x2, wb, tb=kn_layout, out_dtype=F32 if (out_fp32 or residual is not None) else BF16,
+                     bias=bias.detach() if bias is not None else None, residual=res2, rowmask=rowmask)
+        ctx.save_for_backward(x2, rowmask)
+        ctx.weight_ref = weight
+        ctx.has_bias, ctx.has_res, ctx.kn, ctx.bias_ref = bias is not None, residual is not None, kn_layout, bias
+        ctx.x_dtype, ctx.x_shape = x.dtype, x.shape
+        if weight.requires_grad:
+            _pend(weight)
+        if bias is not None and bias.requires_grad:
+            _pend(bias)
+        return y.view(*lead, N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, rowmask = ctx.saved_tensors
+        weight = ctx.weight_ref
+        N = weight.shape[1] if ctx.kn else weight.shape[0]
+        d_res = dy if ctx.has_res else None
+        dyb = to_bf16(dy.reshape(-1, N), rowmask=rowmask)
+        wb = bf16_weight(weight)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dyb, wb, tb=not ctx.kn, out_dtype=BF16 if ctx.x_dtype == BF16 else F32).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            if ctx.kn:   # dW[K,N] = x^T dy
+                dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(x2, dyb, ta=True, tb=True, out=out, accumulate=acc),
+                                       weight.shape)
+            else:        # dW[N,K] = dy^T x
+                dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(dyb, x2, ta=True, tb=True, out=out, accumulate=acc),
+                                       weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            bias = ctx.bias_ref
+            main = getattr(bias, "_spn_main_grad", None)
+            if main is not None:
+                ops.colsum(dyb, out=main)
+                hook = getattr(bias, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            else:
+                db = ops.colsum(dyb)
+        return dx, dw, db, d_res, None, None, None
+
+
+def linear(x, weight, bias=None, *, residual=None, rowmask=None, out_fp32=False, kn_layout=False):
+    return LinearFn.apply(x, weight, bias, residual, rowmask, out_fp32, kn_layout)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LayerNorm (affine) and AdaptiveLayerNorm (gamma/beta = Linear(cond))
+# ---------------------------------------------------------------------------------------------------------
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_fp32: bool, eps: float):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma.detach() if gamma is not None else None,
+                                          beta.detach() if beta is not None else None, None,
+                                          out_dtype=F32 if out_fp32 else BF16, eps=eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        for p in (gamma, beta):
+            if p is not None and p.requires_grad:
+                _pend(p)
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma_ref, ctx.beta_ref
+        D = x.shape[-1]
+        dyb = to_bf16(dy.reshape(-1, D))
+        dgamma = dbeta = None
+        g_main = getattr(gamma, "_spn_main_grad", None) if gamma is not None else None
+        b_main = getattr(beta, "_spn_main_grad", None) if beta is not None else None
+        fused = g_main is not None and b_main is not None
+        if gamma is not None:
+            dgamma = g_main if fused else torch.zeros(D, device=x.device, dtype=F32)
+            dbeta = b_main if fused else torch.zeros(D, device=x.device, dtype=F32)
+        dx, _ = ops.layernorm_bwd(x, dyb, gamma.detach() if gamma is not None else None, None, mean, rstd,
+                                  dx_dtype=x.dtype, dgamma=dgamma, dbeta=dbeta)
+        if fused:
+            for p in (gamma, beta):
+                hook = getattr(p, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            dgamma = dbeta = None
+        return dx.view(x.shape), dgamma, dbeta, None, None
+
+
+def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, out_fp32, eps)
+
+
+class AdaLayerNormFn(Function):
+    """y = gamma_t * LN(x) + beta_t,  (gamma_t | beta_t) = cond @ W^T + b   (modules/layers.py:31-47)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, weight, bias, out_fp32: bool, eps: float):
+        D = x.shape[-1]
+        cb = to_bf16(cond)
+        c2 = cb.reshape(-1, cb.shape[-1])
+        gb = ops.gemm(c2, bf16_weight(weight), out_dtype=F32, bias=bias.detach())
+        y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
+        ctx.save_for_backward(x, c2, gb, mean, rstd)
+        ctx.weight_ref, ctx.bias_ref, ctx.cond_shape, ctx.cond_dtype = weight, bias, cond.shape, cond.dtype
+        _pend(weight); _pend(bias)
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, c2, gb, mean, rstd = ctx.saved_tensors
+        weight, bias = ctx.weight_ref, ctx.bias_ref
+        D = x.shape[-1]
+        dyb = to_bf16(dy.reshape(-1, D))
+        dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dx_dtype=x.dtype, want_dgb=True)
+        dcond = None
+        if ctx.needs_input_grad[1]:
+            dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
+            dcond = dcond.view(ctx.cond_shape)
+        dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(dgb, c2, ta=True, tb=True, out=out, accumulate=acc), weight.shape)
+        main = getattr(bias, "_spn_main_grad", None)
+        db = None
+        if main is not None:
+            ops.colsum(dgb, out=main)
+            hook = getattr(bias, "_spn_grad_ready", None)
+            if hook is not None:
+                hook()
+        else:
+            db = ops.colsum(dgb)
+        return dx.view(x.shape), dcond, dw, db, None, None
+
+
+def ada_layer_norm(x, cond, weight, bias, *, out_fp32=False, eps=1e-5):
+    return AdaLayerNormFn.apply(x, cond, weight, bias, out_fp32, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention core on fused projection buffers
+# ---------------------------------------------------------------------------------------------------------
+
+class SelfAttnFn(Function):
+    """qkv: [b, n, (h + 2*kvh)*64] bf16 fused projection (q | k | v);  returns o [b, n, h*64] bf16."""
+
+    @staticmethod
+    def forward(ctx, qkv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float):
+        b, n, _ = qkv.shape
+        q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
+        k = qkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
+        v = qkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
+        sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
+        o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale)
+        ctx.save_for_backward(qkv, o, lse, sl, kmask)
+        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None)
+        return o.view(b, n, heads * 64)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_o):
+        qkv, o, lse, sl, kmask = ctx.saved_tensors
+        heads, kv_heads, causal, scale, sshape = ctx.cfg
+        b, n, _ = qkv.shape
+        q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
+        k = qkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
+        v = qkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
+        dqkv = torch.empty_like(qkv)
+        dq = dqkv[..., :heads * 64].unflatten(-1, (heads, 64))
+        dk = dqkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
+        dv = dqkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
+        d_o = to_bf16(d_o).contiguous().view(b, n, heads, 64)
+        dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=sl, causal=causal, scale=scale,
+                           want_dslope=sl is not None and ctx.needs_input_grad[1])
+        return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None
+
+
+class CrossAttnFn(Function):
+    """q: [b, nq, h*64]; kv: [b, nk, 2*kvh*64] (k | v) fused projection of the context."""
+
+    @staticmethod
+    def forward(ctx, q, kv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float):
+        b, nq, _ = q.shape
+        q4 = q.unflatten(-1, (heads, 64))
+        k = kv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
+        v = kv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
+        sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
+        o, lse = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale)
+        ctx.save_for_backward(q, kv, o, lse, sl, kmask)
+        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None)
+        return o.view(b, nq, heads * 64)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_o):
+        q, kv, o, lse, sl, kmask = ctx.saved_tensors
+        heads, kv_heads, causal, scale, sshape = ctx.cfg
+        b, nq, _ = q.shape
+        q4 = q.unflatten(-1, (heads, 64))
+        k = kv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
+        v = kv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dk = dkv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
+        dv = dkv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
+        d_o = to_bf16(d_o).contiguous().view(b, nq, heads, 64)
+        dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, slopes=sl,
+                           causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2])
+        return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GLU / activation
+# ---------------------------------------------------------------------------------------------------------
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, u, act: int, glu: bool):
+        ctx.save_for_backward(u)
+        ctx.cfg = (act, glu)
+        out = ops.act_fwd(u, act=act, glu=glu)
+        return out.view(*u.shape[:-1], out.shape[-1])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (u,) = ctx.saved_tensors
+        act, glu = ctx.cfg
+        du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu)
+        return du.view(u.shape), None, None
+
+
+def glu_act(u, *, act=ACT_SILU, glu=True):
+    return ActFn.apply(u, act, glu)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# concat-with-cast: bf16 [.., sum D_i] from parts of either dtype (strided [b, t, D] views allowed)
+# ---------------------------------------------------------------------------------------------------------
+
+class CatCastFn(Function):
+    @staticmethod
+    def forward(ctx, *parts):
+        lead = parts[0].shape[:-1]
+        rows = 1
+        for s in lead:
+            rows *= s
+        widths = [p.shape[-1] for p in parts]
+        out = torch.empty((rows, sum(widths)), device=parts[0].device, dtype=BF16)
+        off = 0
+        for p, w in zip(parts, widths):
+            ops.cast(p, BF16, out=out[:, off:off + w])
+            off += w
+        ctx.meta = [(p.shape, p.dtype) for p in parts]
+        return out.view(*lead, sum(widths))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        d2 = dout.reshape(-1, dout.shape[-1])
+        grads, off = [], 0
+        for i, (shape, dtype) in enumerate(ctx.meta):
+            w = shape[-1]
+            if ctx.needs_input_grad[i]:
+                grads.append(ops.cast(d2[:, off:off + w], dtype).view(shape))
+            else:
+                grads.append(None)
+            off += w
+        return tuple(grads)
+
+
+def cat_cast(*parts):
+    return CatCastFn.apply(*parts)
+
+
+class CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype, rowmask):
+        ctx.src_dtype = x.dtype
+        ctx.save_for_backward(rowmask)
+        return ops.cast(x, dtype, rowmask=rowmask).view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (rowmask,) = ctx.saved_tensors
+        return ops.cast(dy, ctx.src_dtype, rowmask=rowmask).view(dy.shape), None, None
+
+
+def cast(x, dtype, rowmask=None):
+    if x.dtype == dtype and rowmask is None:
+        return x
+    return CastFn.apply(x, dtype, rowmask)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# exact fp32 linear (small heads)
+# ---------------------------------------------------------------------------------------------------------
+
+class LinearF32Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowmask):
+        x2 = x.reshape(-1, x.shape[-1])
+        y = ops.gemm_f32(x2, weight.detach(), bias=bias.detach() if bias is not None else None, rowmask=rowmask)
+        ctx.save_for_backward(x2, weight, rowmask)
+        ctx.bias_ref, ctx.x_shape = bias, x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, weight, rowmask = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if rowmask is not None:
+            dy2 = ops.mask_rows(dy2, rowmask)
+        dx = ops.gemm_f32(dy2, weight.detach(), tb=True).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm_f32(dy2, x2, ta=True, tb=True)
+        db = ops.colsum(dy2) if ctx.bias_ref is not None else None
+        return dx, dw, db, None
+
+
+def linear_f32(x, weight, bias=None, rowmask=None):
+    return LinearF32Fn.apply(x, weight, bias, rowmask)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# embedding tables and tuple gather
+# ---------------------------------------------------------------------------------------------------------
+
+class TableBuildFn(Function):
+    """All per-key tables of one embedding set (modules/transformer/embeddings.py:118-152).  Inputs are the flattened
+    per-key parameter lists: tv*n, w0*n, [b0*n, w1*n, b1*n if dense], [iw*n if has_iw]."""
+
+    @staticmethod
+    def forward(ctx, n: int, dense: bool, discrete: bool, has_iw: bool, ids_mask: int, *params):
+        tv, w0 = list(params[:n]), list(params[n:2 * n])
+        pos = 2 * n
+        b0 = w1 = b1 = iw = None
+        if dense:
+            b0, w1, b1 = list(params[pos:pos + n]), list(params[pos + n:pos + 2 * n]), list(params[pos + 2 * n:pos + 3 * n])
+            pos += 3 * n
+        if has_iw:
+            iw = list(params[pos:pos + n])
+        det = lambda lst: [t.detach() for t in lst] if lst is not None else None
+        tables, h1 = ops.table_build_fwd(det(tv), det(w0), det(b0), det(w1), det(b1), det(iw), dense=dense, discrete=discrete,
+                                         ids_mask=ids_mask)
+        ctx.cfg = (n, dense, discrete, has_iw, ids_mask)
+        ctx.lists = (tv, w0, b0, w1, h1)
+        return tuple(tables)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dtables):
+        n, dense, discrete, has_iw, ids_mask = ctx.cfg
+        tv, w0, b0, w1, h1 = ctx.lists
+        det = lambda lst: [t.detach() for t in lst] if lst is not None else None
+        dts = [d if d is not None else torch.zeros(tv[i].numel(), w0[i].numel(), device=w0[i].device) for i, d in enumerate(dtables)]
+        dw0, db0, dw1, db1, diw = ops.table_build_bwd(det(tv), det(w0), det(b0), det(w1), dts, h1, has_iw=has_iw, dense=dense,
+                                                      discrete=discrete, ids_mask=ids_mask)
+        grads: List[Optional[torch.Tensor]] = [None] * n                       # token_values (buffer)
+        grads += [g.view_as(w) for g, w in zip(dw0, w0)]
+        if dense:
+            grads += db0 + dw1 + db1
+        if has_iw:
+            grads += diw
+        return (None, None, None, None, None) + tuple(grads)
+
+
+class EmbedFn(Function):
+    """gather + concat (+ LayerNorm) -> bf16 [b, t, sum E]   (models/scoreperformer/embeddings.py:121-143)."""
+
+    @staticmethod
+    def forward(ctx, tokens, gamma, beta, eps: float, *tables):
+        tabs = [t.detach() for t in tables]
+        y, mean, rstd = ops.embed_fwd(tabs, tokens, gamma.detach() if gamma is not None else None,
+                                      beta.detach() if beta is not None else None, eps)
+        ctx.save_for_backward(tokens, mean, rstd, *tabs)
+        ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        for p in (gamma, beta):
+            if p is not None and p.requires_grad:
+                _pend(p)
+        return y.view(tokens.shape[0], tokens.shape[1], -1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        tokens, mean, rstd, *tabs = ctx.saved_tensors
+        gamma, beta = ctx.gamma_ref, ctx.beta_ref
+        D = dy.shape[-1]
+        dgamma = dbeta = None
+        fused = False
+        if gamma is not None:
+            g_main, b_main = getattr(gamma, "_spn_main_grad", None), getattr(beta, "_spn_main_grad", None)
+            fused = g_main is not None and b_main is not None
+            dgamma = g_main if fused else torch.zeros(D, device=dy.device, dtype=F32)
+            dbeta = b_main if fused else torch.zeros(D, device=dy.device, dtype=F32)
+        dts = ops.embed_bwd(tabs, tokens, to_bf16(dy), gamma.detach() if gamma is not None else None, mean, rstd,
+                            dgamma=dgamma, dbeta=dbeta, padding_idx=0)
+        if fused:
+            for p in (gamma, beta):
+                hook = getattr(p, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            dgamma = dbeta = None
+        return (None, dgamma, dbeta, None) + tuple(dts)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# tied LM head column block + cross entropy, fused so that dlogits stays bf16 and never meets autograd
+# ---------------------------------------------------------------------------------------------------------
+
+class HeadCEFn(Function):
+    """logits = e @ table^T (fp32 [T, V] view of a padded buffer);  (loss_sum, count) over non-ignored labels.
+    Returns (logits, sums[2]).  Gradient flows from `sums[0]` (loss sum) only; `logits` is a non-differentiable output."""
+
+    @staticmethod
+    def forward(ctx, e, table, bias, labels, ignore_index: int, want_argmax: bool, state=None, key=None):
+        # `state`: optional dict shared with the caller; after the caller's single host sync it holds
+        # state["active"] = set of keys with at least one valid label, letting backward skip dead keys' GEMMs.
+        ctx.state, ctx.key = state, key
+        V, K = table.shape
+        Vp = ((V + 7) // 8) * 8
+        e2 = e.reshape(-1, K)
+        tb = bf16_weight(table) if getattr(table, "_spn_shadow", None) is not None else None
+        if tb is None:  # computed table: pad rows to a multiple of 8 for the dX GEMM's 16-byte loads
+            tpad = torch.zeros((Vp, K), device=e.device, dtype=BF16)
+            ops.cast(table.detach(), BF16, out=tpad[:V])
+            tb = tpad[:V]
+        else:
+            tpad = None
+        logits = torch.empty((e2.shape[0], Vp), device=e.device, dtype=F32)[:, :V]
+        ops.gemm(e2, tb, out=logits, bias=bias.detach() if bias is not None else None)
+        lse = sums = am = None
+        if labels is not None:
+            lse, sums, am = ops.ce_fwd(logits, V, labels, ignore_index=ignore_index, want_argmax=want_argmax)
+        ctx.save_for_backward(e2, table, logits, lse, labels, sums, tpad)
+        ctx.cfg = (ignore_index, e.shape, bias)
+        ctx.mark_non_differentiable(logits)
+        if am is not None:
+            ctx.mark_non_differentiable(am)
+        return logits, sums, am
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _dlogits, dsums, _dam):
+        e2, table, logits, lse, labels, sums, tpad = ctx.saved_tensors
+        ignore_index, e_shape, bias = ctx.cfg
+        V, K = table.shape
+        Vp = ((V + 7) // 8) * 8
+        dead = ctx.state is not None and ctx.state.get("active") is not None and ctx.key not in ctx.state["active"]
+        if dsums is None or labels is None or dead:
+            return None, None, None, None, None, None, None, None
+        coef = dsums[:1].contiguous()  # d(loss)/d(loss_sum) as a device scalar
+        dl = ops.ce_bwd(logits, V, labels, lse, coef, ignore_index=ignore_index, Vpad=Vp)  # bf16 [T, Vp]
+        if tpad is None:
+            tpad = torch.zeros((Vp, K), device=e2.device, dtype=BF16)
+            ops.cast(table.detach(), BF16, out=tpad[:V])
+        de = ops.gemm(dl, tpad, tb=True, out_dtype=BF16).view(e_shape) if ctx.needs_input_grad[0] else None
+        dtab = None
+        if ctx.needs_input_grad[1]:
+            full = ops.gemm(dl, e2, ta=True, tb=True, out_dtype=F32)  # [Vp, K]
+            dtab = full[:V]
+        db = ops.colsum(dl)[:V] if bias is not None else None
+        return de, dtab, db, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# segments / masks / MMD
+# ---------------------------------------------------------------------------------------------------------
+
+class SegmentMeanFn(Function):
+    """x [b,t,d] -> [b,S,d] per-segment means (mmd_transformer.py:330-340)."""
+
+    @staticmethod
+    def forward(ctx, x, seg, S: int, counts):
+        ctx.save_for_backward(seg, counts)
+        ctx.x_dtype = x.dtype
+        return ops.segment_sum(x, seg, S, counts=counts)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        seg, counts = ctx.saved_tensors
+        dx = ops.segment_gather(dout.contiguous(), seg, counts=counts)
+        if ctx.x_dtype != F32:
+            dx = ops.cast(dx, ctx.x_dtype)
+        return dx, None, None, None
+
+
+class SegmentGatherFn(Function):
+    """src [b,S,d] -> [b,t,d] = src[b, seg] * rowmask (mmd_transformer.py:362,366)."""
+
+    @staticmethod
+    def forward(ctx, src, seg, rowmask):
+        ctx.save_for_backward(seg, rowmask)
+        ctx.S = src.shape[1]
+        return ops.segment_gather(src, seg, rowmask=rowmask)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        seg, rowmask = ctx.saved_tensors
+        return ops.segment_sum(dy.contiguous(), seg, ctx.S, rowmask=rowmask), None, None
+
+
+class MaskRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, mask, invert: bool):
+        ctx.save_for_backward(mask)
+        ctx.invert = invert
+        return ops.mask_rows(x.contiguous(), mask, invert)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return ops.mask_rows(dy.contiguous(), mask, ctx.invert), None, None
+
+
+def mask_rows(x, mask, invert=False):
+    return MaskRowsFn.apply(x, mask, invert)
+
+
+class MMDFn(Function):
+    """compute_mmd(z, y[w>0]) with 0/1 row weights w instead of a boolean gather (mmd_transformer.py:511-534)."""
+
+    @staticmethod
+    def forward(ctx, y, w, z):
+        sums = ops.mmd_fwd(z, y, w)
+        Z = float(z.shape[0])
+        n = sums[3].clamp_min(1.0)
+        mmd = sums[0] / (Z * Z) + sums[1] / (n * n) - 2.0 * sums[2] / (Z * n)
+        ctx.save_for_backward(y, w, z, n)
+        return mmd
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, w, z, n = ctx.saved_tensors
+        Z = float(z.shape[0])
+        coef = torch.stack([g / (n * n), -2.0 * g / (Z * n)]).float().contiguous()
+        return ops.mmd_bwd(z, y, w, coef), None, None

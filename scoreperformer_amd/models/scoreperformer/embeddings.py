@@ -1,0 +1,353 @@
+"""Tuple-token embeddings and LM heads with the reference's contract (`models/scoreperformer/embeddings.py:31-462`).
+
+HIP execution: all per-key tables are built in one launch and shared (per forward pass) by the three transformers and the
+tied LM head; gather + concat + LayerNorm is one kernel; projections are MFMA GEMMs; the tied LM head is one GEMM to the
+concatenated embedding space, one LayerNorm and a per-key GEMM + fused cross-entropy.
+"""
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Union, Dict, Optional, List, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import functional as F_
+from ...modules.constructor import Constructor, Registry, VariableModuleConfig
+from ...modules.transformer.embeddings import DiscreteContinuousEmbedding, DiscreteDenseContinuousEmbedding
+from ...modules.layers import LayerNorm
+from ...utils.config import MISSING
+
+# ---------------------------------------------------------------------------------------------------------
+# table building (K1), shared per forward pass
+# ---------------------------------------------------------------------------------------------------------
+
+_TABLE_CACHE = {"enabled": False, "tables": {}}
+
+
+@contextmanager
+def shared_tables():
+    """Within this context every per-key table is built once and reused (the reference rebuilds `emb.weight` at each of
+    its 5 uses per step, modules/transformer/embeddings.py:158-163)."""
+    outer = _TABLE_CACHE["enabled"]
+    if not outer:
+        _TABLE_CACHE["enabled"], _TABLE_CACHE["tables"] = True, {}
+    try:
+        yield
+    finally:
+        if not outer:
+            _TABLE_CACHE["enabled"], _TABLE_CACHE["tables"] = False, {}
+
+
+def build_tables(embs: List[nn.Module]) -> List[Tensor]:
+    """fp32 [V, E] table per embedding module; continuous tables of equal kind are built by one kernel launch."""
+    cache = _TABLE_CACHE["tables"] if _TABLE_CACHE["enabled"] else {}
+    key = lambda m: (id(m), torch.is_grad_enabled())
+    todo = [m for m in dict.fromkeys(embs) if key(m) not in cache]
+    groups: Dict[tuple, List[nn.Module]] = {}
+    for m in todo:
+        if isinstance(m, DiscreteContinuousEmbedding) and m.continuous:
+            groups.setdefault((m.dense, m.discrete, m.has_discrete, m.ids_mask), []).append(m)
+        else:
+            cache[key(m)] = m.index_weight if isinstance(m, DiscreteContinuousEmbedding) else m.weight
+    for (dense, discrete, has_iw, ids_mask), mods in groups.items():
+        for start in range(0, len(mods), 16):
+            chunk = mods[start:start + 16]
+            cols = list(zip(*[m.table_params() for m in chunk]))  # tv, w0, b0, w1, b1, iw
+            flat = list(cols[0]) + list(cols[1])
+            if dense:
+                flat += list(cols[2]) + list(cols[3]) + list(cols[4])
+            if has_iw:
+                flat += list(cols[5])
+            tables = F_.TableBuildFn.apply(len(chunk), dense, discrete, has_iw, ids_mask, *flat)
+            for m, t in zip(chunk, tables):
+                cache[key(m)] = t
+    return [cache[key(m)] for m in embs]
+
+
+TupleTokenEmbeddingsRegistry = type("_TupleTokenEmbeddingsRegistry", (Registry,), {})()
+
+
+@dataclass
+class TupleTokenEmbeddingsConfig(VariableModuleConfig):
+    _target_: str = "simple"
+    num_tokens: Dict[str, int] = MISSING
+    emb_dims: Union[Dict[str, int], int] = MISSING
+    mode: str = "cat"
+    project_emb_dim: int = 512
+    emb_norm: bool = False
+    discrete: bool = True
+    continuous: Union[bool, List[str]] = False
+    continuous_dense: bool = False
+    token_values: Optional[Dict[str, list]] = None
+    discrete_ids: Optional[List[int]] = None
+    tie_keys: Optional[Dict[str, str]] = None
+
+
+@TupleTokenEmbeddingsRegistry.register("simple")
+class TupleTokenEmbeddings(nn.Module, Constructor):
+    def __init__(self, num_tokens: Dict[str, int], emb_dims: Union[Dict[str, int], int], mode: str = "cat",
+                 project_emb_dim: int = 512, emb_norm: bool = False, discrete: bool = True,
+                 continuous: Union[bool, List[str]] = False, continuous_dense: bool = False,
+                 token_values: Optional[Dict[str, list]] = None, discrete_ids: Optional[List[int]] = None,
+                 tie_keys: Optional[Dict[str, str]] = None):
+        super().__init__()
+        self.mode = mode
+        if mode != "cat":
+            raise NotImplementedError("TupleTokenEmbeddings mode 'sum' is not used by any shipped recipe and is not "
+                                      "implemented by the gather kernel (DESIGN.md 'out of scope')")
+        continuous_keys = continuous
+        if isinstance(continuous, bool):
+            continuous_keys = [key for key in num_tokens] if continuous else []
+        else:
+            continuous_keys = list(continuous)
+            continuous = len(continuous_keys) > 0
+        total_emb_dim = 0
+        embeddings = {}
+        token_values = token_values or {}
+        for key, num in num_tokens.items():
+            emb_dim = emb_dims if isinstance(emb_dims, int) else emb_dims[key]
+            if tie_keys and key in tie_keys:
+                embeddings[key] = embeddings[tie_keys[key]]
+                emb_dim = emb_dims if isinstance(emb_dims, int) else emb_dims[tie_keys[key]]
+            elif key in continuous_keys:
+                cls = DiscreteDenseContinuousEmbedding if continuous_dense else DiscreteContinuousEmbedding
+                embeddings[key] = cls(num_embeddings=num, embedding_dim=emb_dim, discrete=discrete, continuous=True,
+                                      discrete_ids=list(discrete_ids) if discrete_ids is not None else None,
+                                      token_values=token_values.get(key, None), padding_idx=0)
+            else:
+                embeddings[key] = nn.Embedding(num, emb_dim, padding_idx=0)
+            total_emb_dim += emb_dim
+        self.embs = nn.ModuleDict(embeddings)
+        self.norm = LayerNorm(total_emb_dim) if emb_norm else nn.Identity()
+        if total_emb_dim != project_emb_dim:
+            self.project_emb = nn.Linear(total_emb_dim, project_emb_dim)
+        self.num_tokens = dict(num_tokens)
+        self.emb_dims = emb_dims
+        self.total_emb_dim = total_emb_dim
+        self.continuous = continuous
+        self.continuous_keys = continuous_keys
+        self.token_values = token_values
+        self.init_()
+
+    def init_(self):
+        if not self.continuous:
+            for key, emb in self.embs.items():
+                weight_attr = "index_weight" if key in self.continuous_keys else "weight"
+                nn.init.kaiming_normal_(getattr(emb, weight_attr))
+
+    def tables(self) -> List[Tensor]:
+        return build_tables(list(self.embs.values()))
+
+    def _forward_project(self, tokens: Tensor) -> Tensor:
+        """gather + concat + LayerNorm (one kernel) and the projection GEMM; tokens int64 [b, n, >= K] (any strides)."""
+        has_norm = isinstance(self.norm, nn.LayerNorm)
+        e = F_.EmbedFn.apply(tokens, self.norm.weight if has_norm else None, self.norm.bias if has_norm else None,
+                             self.norm.eps if has_norm else 1e-5, *self.tables())
+        # quirk kept from the reference: `cat` mode calls project_emb unconditionally (embeddings.py:139)
+        return F_.linear(e, self.project_emb.weight, self.project_emb.bias)
+
+    def forward(self, x: Tensor, values: Optional[Tensor] = None, cache: Optional[Tensor] = None,
+                return_embeddings: bool = False):
+        if values is not None or return_embeddings:
+            raise NotImplementedError("`values` / `return_embeddings` are not used on the ScorePerformer hot path")
+        if cache is not None:
+            x = x[:, cache.shape[1]:]
+        token_emb = self._forward_project(x)
+        if cache is not None:
+            token_emb = torch.cat([cache, token_emb], dim=1)
+        return token_emb
+
+
+@dataclass
+class MultiSeqTupleTokenEmbeddingsConfig(TupleTokenEmbeddingsConfig):
+    _target_: str = "multi-seq"
+    multiseq_mode: str = "pre-sum"
+    num_sequences: int = 2
+
+
+@TupleTokenEmbeddingsRegistry.register("multi-seq")
+class MultiSeqTupleTokenEmbeddings(TupleTokenEmbeddings):
+    def __init__(self, num_tokens, emb_dims, mode: str = "cat", project_emb_dim: int = 512, emb_norm: bool = False,
+                 discrete: bool = True, continuous=False, continuous_dense: bool = False, token_values=None,
+                 discrete_ids=None, tie_keys=None, multiseq_mode: str = "pre-sum", num_sequences: int = 2):
+        super().__init__(num_tokens=num_tokens, emb_dims=emb_dims, mode=mode, project_emb_dim=project_emb_dim,
+                         emb_norm=emb_norm, discrete=discrete, continuous=continuous, continuous_dense=continuous_dense,
+                         token_values=token_values, discrete_ids=discrete_ids, tie_keys=tie_keys)
+        self.multiseq_mode = multiseq_mode
+        self.num_sequences = num_sequences
+        if self.multiseq_mode == "post-cat":
+            self.project_multiemb = nn.Linear(num_sequences * project_emb_dim, project_emb_dim)
+
+    def forward(self, tokens: Union[Tensor, List[Tensor]], values=None, cache: Optional[Tensor] = None,
+                return_embeddings: bool = False):
+        if isinstance(tokens, (list, tuple)) and len(tokens) == 1:
+            tokens = tokens[0]
+        if isinstance(tokens, Tensor):
+            return super().forward(tokens, values=values, cache=cache, return_embeddings=return_embeddings)
+        if values is not None or return_embeddings:
+            raise NotImplementedError("`values` / `return_embeddings` are not used on the ScorePerformer hot path")
+        if cache is not None:
+            tokens = [t[:, cache.shape[1]:] for t in tokens]
+        if self.multiseq_mode == "post-cat":
+            assert len(tokens) == self.num_sequences
+            proj = [self._forward_project(t) for t in tokens]
+            token_emb = F_.linear(F_.cat_cast(*proj), self.project_multiemb.weight, self.project_multiemb.bias)
+        elif self.multiseq_mode.startswith("post"):
+            proj = [self._forward_project(t) for t in tokens]
+            token_emb = proj[0]
+            for p in proj[1:]:
+                token_emb = token_emb + p
+        else:
+            raise NotImplementedError("multiseq_mode 'pre-sum' is not used by any shipped recipe")
+        if cache is not None:
+            token_emb = torch.cat([cache, token_emb], dim=1)
+        return token_emb
+
+
+# ---------------------------------------------------------------------------------------------------------
+# heads
+# ---------------------------------------------------------------------------------------------------------
+
+TupleTokenHeadsRegistry = type("_TupleTokenHeadsRegistry", (Registry,), {})()
+
+
+@dataclass
+class TupleTokenHeadsConfig(VariableModuleConfig):
+    dim: int = MISSING
+
+
+@dataclass
+class TupleTokenLMHeadConfig(TupleTokenHeadsConfig):
+    _target_: str = "lm"
+    num_tokens: Optional[Dict[str, int]] = None
+    embeddings: Optional[TupleTokenEmbeddings] = None
+    filter_keys: Optional[List[str]] = None
+
+
+def _wanted(i, key, keys):
+    return keys is None or i in keys or key in keys
+
+
+class _HeadBase(nn.Module):
+    """`forward(x, keys=None)` -> {key: logits}.  With `labels` (int64 [b, n, K] view, -100 = ignore) the per-key
+    cross-entropy is fused behind the logits GEMM: returns (logits, sums) with sums[key] = (loss_sum, valid_count)."""
+
+    def _per_key(self, items, labels, ignore_index, want_argmax):
+        logits, sums, argmax = {}, {}, {}
+        self.ce_state = {"active": None}
+        for i, key, e, table, bias in items:
+            lab = labels[..., i] if labels is not None else None
+            lg, sm, am = F_.HeadCEFn.apply(e, table, bias, lab, ignore_index, want_argmax, self.ce_state, key)
+            logits[key] = lg.view(*e.shape[:-1], lg.shape[-1])
+            if sm is not None:
+                sums[key] = sm
+            if am is not None:
+                argmax[key] = am.view(e.shape[:-1])
+        return logits, sums, argmax
+
+
+@TupleTokenHeadsRegistry.register("lm")
+class TupleTokenLMHead(_HeadBase, Constructor):
+    def __init__(self, dim: int, num_tokens: Optional[Dict[str, int]] = None, embeddings: Optional[TupleTokenEmbeddings] = None,
+                 filter_keys: Optional[List[str]] = None):
+        assert num_tokens is not None or embeddings is not None
+        super().__init__()
+        num_tokens = num_tokens or embeddings.num_tokens
+        self.heads = nn.ModuleDict({key: nn.Linear(dim, num) for key, num in num_tokens.items()
+                                    if not filter_keys or key in filter_keys})
+
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+        xb = F_.to_bf16(x)
+        items = [(i, key, xb, head.weight, head.bias) for i, (key, head) in enumerate(self.heads.items())
+                 if _wanted(i, key, keys)]
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        return (logits, sums, argmax) if labels is not None or want_argmax else logits
+
+
+@dataclass
+class TupleTokenTiedLMHeadConfig(TupleTokenHeadsConfig):
+    _target_: str = "lm-tied"
+    embeddings: TupleTokenEmbeddings = MISSING
+    reuse_projection: bool = True
+
+
+@TupleTokenHeadsRegistry.register("lm-tied")
+class TupleTokenTiedLMHead(_HeadBase, Constructor):
+    def __init__(self, dim: int, embeddings: TupleTokenEmbeddings, reuse_projection: bool = True):
+        super().__init__()
+        self.embs = embeddings.embs
+        self.total_emb_dim = embeddings.total_emb_dim
+        self.split_dims = [emb.embedding_dim for emb in embeddings.embs.values()]
+        if reuse_projection:
+            assert dim == embeddings.project_emb.out_features, \
+                f"Projection layer could be reused only if last input tensor dimension " \
+                f"is equal to projection layer's `out_features = {embeddings.project_emb.out_features}`"
+            self.project_emb = embeddings.project_emb
+        else:
+            self.project_emb = nn.Linear(dim, self.total_emb_dim, bias=False)
+        self.norm = LayerNorm(self.total_emb_dim)
+        self.reuse_projection = reuse_projection
+
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+        # `x @ project_emb.weight` uses the [dim, total] weight UNtransposed (embeddings.py:346)
+        if self.reuse_projection:
+            e = F_.linear(x, self.project_emb.weight, kn_layout=True)
+        else:
+            e = F_.linear(x, self.project_emb.weight)
+        e = self.norm(e)
+        tables = build_tables(list(self.embs.values()))
+        items, off = [], 0
+        for i, key in enumerate(self.embs.keys()):
+            w = self.split_dims[i]
+            if _wanted(i, key, keys):
+                items.append((i, key, e[..., off:off + w], tables[i], None))
+            off += w
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        return (logits, sums, argmax) if labels is not None or want_argmax else logits
+
+
+@dataclass
+class TupleTokenTiedSplitLMHeadConfig(TupleTokenHeadsConfig):
+    _target_: str = "lm-tied-split"
+    embeddings: TupleTokenEmbeddings = MISSING
+    filter_keys: Optional[List[str]] = None
+
+
+@TupleTokenHeadsRegistry.register("lm-tied-split")
+class TupleTokenTiedSplitLMHead(_HeadBase, Constructor):
+    def __init__(self, dim: int, embeddings: TupleTokenEmbeddings, filter_keys: Optional[List[str]] = None):
+        super().__init__()
+        to_embs = {}
+        for key, token_emb in embeddings.embs.items():
+            if not filter_keys or key in filter_keys:
+                to_embs[key] = nn.Sequential(nn.Linear(dim, token_emb.embedding_dim), LayerNorm(token_emb.embedding_dim))
+        self.to_embs = nn.ModuleDict(to_embs)
+        self.embs = embeddings.embs
+
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+        tables = build_tables(list(self.embs.values()))
+        items = []
+        for i, key in enumerate(self.embs.keys()):
+            if _wanted(i, key, keys):
+                lin, ln = self.to_embs[key]
+                items.append((i, key, ln(F_.linear(x, lin.weight, lin.bias)), tables[i], None))
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        return (logits, sums, argmax) if labels is not None or want_argmax else logits
+
+
+@dataclass
+class TupleTokenRegressionHeadConfig(TupleTokenHeadsConfig):
+    _target_: str = "regression"
+    regression_keys: List[str] = MISSING
+
+
+@TupleTokenHeadsRegistry.register("regression")
+class TupleTokenRegressionHead(nn.Module, Constructor):
+    def __init__(self, dim: int, regression_keys: List[str]):
+        super().__init__()
+        self.layers = nn.ModuleDict({key: nn.Linear(dim, 1) for key in regression_keys})
+
+    def forward(self, x: Tensor, keys=None):
+        return {key: F_.linear_f32(F_.cast(x, torch.float32), layer.weight, layer.bias)
+                for i, (key, layer) in enumerate(self.layers.items()) if _wanted(i, key, keys)}

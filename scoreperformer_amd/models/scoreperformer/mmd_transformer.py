@@ -1,0 +1,375 @@
+"""TupleTransformer with hierarchical MMD-VAE heads: contract of `models/scoreperformer/mmd_transformer.py:18-542`.
+
+HIP execution (K9/K10): the hierarchical heads run as ONE autograd function over a wide fp32 buffer
+[b, n, d + sum(latent dims)]: masked hidden states in the first d columns, each level's scattered-back embeddings in
+the following columns, so "concat(out, embeddings_i)" (mmd_transformer.py:259-261) is a column prefix, not a copy.
+Segment means are run-length scans (no (b,t,S) one-hot), validity of a latent (`all(out != 0)`, mmd:342) and the
+boolean gathers `latents[mask]` (mmd:513) become 0/1 weights, so the forward needs no host synchronisation.
+"""
+from dataclasses import dataclass
+from typing import Optional, Union, List, Dict
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ... import functional as F_
+from ... import ops
+from ...modules.transformer import TransformerConfig
+from ...utils import ExplicitEnum
+from ...utils.config import DictConfig
+from .embeddings import TupleTokenEmbeddingsConfig, TupleTokenHeadsConfig, TupleTokenRegressionHeadConfig
+from .transformer import TupleTransformerOutput, TupleTransformerConfig, TupleTransformer
+
+
+class EmbeddingAggregateModes(ExplicitEnum):
+    SAME = "same"
+    MEAN = "mean"
+    BEAT_MEAN = "beat_mean"
+    BAR_MEAN = "bar_mean"
+    ONSET_MEAN = "onset_mean"
+    ISOLATED_BAR_MEAN = "isolated_bar_mean"
+
+
+SEGMENT_MODES = (EmbeddingAggregateModes.ISOLATED_BAR_MEAN, EmbeddingAggregateModes.BAR_MEAN,
+                 EmbeddingAggregateModes.BEAT_MEAN, EmbeddingAggregateModes.ONSET_MEAN)
+
+
+@dataclass
+class MMDTupleTransformerOutput(TupleTransformerOutput):
+    latents: Optional[Union[Tensor, List[Tensor]]] = None
+    embeddings: Optional[Tensor] = None
+    full_embeddings: Optional[Tensor] = None
+    dropout_mask: Optional[Tensor] = None
+    loss: Optional[Tensor] = None
+    losses: Optional[Dict[str, Tensor]] = None
+    latents_masks: Optional[List[Tensor]] = None   # extension: validity of each latent row
+
+
+@dataclass
+class MMDTupleTransformerConfig(TupleTransformerConfig):
+    latent_dim: Union[int, List[int]] = 64
+    aggregate_mode: Union[str, List[str]] = EmbeddingAggregateModes.MEAN
+    hierarchical: bool = False
+    hierarchical_with_context: bool = True
+    latent_dropout: Union[float, List[float]] = 0.
+    inclusive_latent_dropout: bool = True
+    deadpan_zero_latent: bool = False
+    loss_weight: float = 1.0
+
+
+class MMDVAE(nn.Module):
+    def __init__(self, input_dim, latent_dim):
+        super().__init__()
+        self.latent_dim = latent_dim
+        self.linear = nn.Linear(input_dim, latent_dim)
+
+    def forward(self, inputs: Tensor):
+        return F_.linear_f32(F_.cast(inputs, torch.float32), self.linear.weight, self.linear.bias)
+
+
+class HierLatentsFn(Function):
+    """(hidden, mask, segments per level, head weights) -> (embeddings [b,n,sum L], latents_i [b,S_i,L_i] ...).
+
+    Level i:  agg_i = segment_mean(wide[..., :d_in_i]);  lat_i = (agg_i @ W_i^T + b_i) * valid_i;
+              wide[..., cols_i] = lat_i[b, seg] * mask      (mmd_transformer.py:304-368, 242-261)
+    """
+
+    @staticmethod
+    def forward(ctx, hidden, mask, hierarchical: bool, modes, segs, *wb):
+        b, n, d = hidden.shape
+        nl = len(modes)
+        Ws, bs = wb[:nl], wb[nl:]
+        Ls = [w.shape[0] for w in Ws]
+        wide = torch.empty((b, n, d + sum(Ls)), device=hidden.device, dtype=torch.float32)
+        ops.cast(hidden, torch.float32, rowmask=mask, out=wide[..., :d])
+        notmask = (~mask).long()
+        zeros_seg = torch.zeros_like(notmask)
+        saved, latents, lmasks = [], [], []
+        off = d
+        for i, mode in enumerate(modes):
+            d_in = off if hierarchical else d
+            x_view = wide[..., :d_in]
+            if mode == EmbeddingAggregateModes.MEAN:   # masked mean over the sequence (mmd_transformer.py:325-327)
+                seg_a, S, seg_g = notmask, 2, zeros_seg
+            elif mode in SEGMENT_MODES:
+                seg_a, S, seg_g = segs[i].contiguous(), n + 4, segs[i].contiguous()
+            else:
+                raise NotImplementedError(f"aggregate_mode '{mode}' is not implemented")
+            counts = ops.segment_count(seg_a, S)
+            agg = ops.segment_sum(x_view, seg_a, S, counts=counts)
+            if mode == EmbeddingAggregateModes.MEAN:
+                agg = agg[:, :1].contiguous()
+                lmask = torch.ones((b, 1), device=hidden.device, dtype=torch.bool)
+            else:
+                lmask = ops.rows_all_nonzero(agg)                     # mmd_transformer.py:342
+            lat = ops.gemm_f32(agg, Ws[i].detach(), bias=bs[i].detach(), rowmask=lmask).view(b, agg.shape[1], Ls[i])
+            ops.segment_gather(lat, seg_g, rowmask=mask, out=wide[..., off:off + Ls[i]])
+            saved.append((seg_a, seg_g, S, counts, agg, lmask, d_in, off))
+            latents.append(lat)
+            lmasks.append(lmask)
+            off += Ls[i]
+        ctx.saved = saved
+        ctx.wb = wb
+        ctx.meta = (b, n, d, Ls, modes, hierarchical)
+        ctx.save_for_backward(mask)
+        for m in lmasks:
+            ctx.mark_non_differentiable(m)
+        return (wide[..., d:].contiguous(), *latents, *lmasks)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_emb, *rest):
+        (mask,) = ctx.saved_tensors
+        b, n, d, Ls, modes, hierarchical = ctx.meta
+        nl = len(modes)
+        d_lats = rest[:nl]
+        Ws, bs = ctx.wb[:nl], ctx.wb[nl:]
+        dev = mask.device
+        dwide = torch.zeros((b, n, d + sum(Ls)), device=dev, dtype=torch.float32)
+        if d_emb is not None:
+            ops.cast(d_emb.contiguous(), torch.float32, rowmask=mask, out=dwide[..., d:])
+        dWs, dbs = [None] * nl, [None] * nl
+        for i in reversed(range(nl)):
+            seg_a, seg_g, S, counts, agg, lmask, d_in, off = ctx.saved[i]
+            S_g = agg.shape[1]
+            dlat = ops.segment_sum(dwide[..., off:off + Ls[i]], seg_g, S_g, rowmask=mask)
+            if d_lats[i] is not None:
+                dlat = dlat + d_lats[i]
+            dlat = ops.mask_rows(dlat, lmask)
+            dl2 = dlat.view(-1, Ls[i])
+            dWs[i] = ops.gemm_f32(dl2, agg.view(-1, d_in), ta=True, tb=True)
+            dbs[i] = ops.colsum(dl2)
+            dagg = ops.gemm_f32(dl2, Ws[i].detach(), tb=True).view(b, S_g, d_in)
+            if modes[i] == EmbeddingAggregateModes.MEAN:
+                dagg = torch.cat([dagg, torch.zeros_like(dagg)], dim=1)
+            ops.segment_gather(dagg, seg_a, counts=counts, out=dwide[..., :d_in], accumulate=True)
+        d_hidden = ops.cast(dwide[..., :d], torch.float32, rowmask=mask)
+        return (d_hidden, None, None, None, None, *dWs, *dbs)
+
+
+class MMDTupleTransformer(TupleTransformer):
+    def __init__(self, num_tokens: Dict[str, int], dim: int = 512, max_seq_len: int = 1024, transformer=None,
+                 token_embeddings=None, use_abs_pos_emb: bool = True, emb_norm: bool = False, emb_dropout: float = 0.0,
+                 context_emb_dim: Optional[int] = None, context_emb_mode: str = "attention", style_emb_dim: Optional[int] = None,
+                 style_emb_mode: str = "cat", lm_head=None, regression_head=None, latent_dim: Union[int, List[int]] = 64,
+                 aggregate_mode=EmbeddingAggregateModes.MEAN, hierarchical: bool = False,
+                 hierarchical_with_context: bool = True, latent_dropout: Union[float, List[float]] = 0.,
+                 inclusive_latent_dropout: bool = True, deadpan_zero_latent: bool = False, loss_weight: float = 1.0):
+        if transformer is None:
+            transformer = TransformerConfig(_target_="default")
+        if token_embeddings is None:
+            token_embeddings = TupleTokenEmbeddingsConfig()
+        super().__init__(num_tokens=num_tokens, dim=dim, max_seq_len=max_seq_len, transformer=transformer,
+                         token_embeddings=token_embeddings, use_abs_pos_emb=use_abs_pos_emb, emb_norm=emb_norm,
+                         emb_dropout=emb_dropout, context_emb_dim=context_emb_dim, context_emb_mode=context_emb_mode,
+                         style_emb_dim=style_emb_dim, style_emb_mode=style_emb_mode, lm_head=lm_head,
+                         regression_head=regression_head)
+        if not isinstance(latent_dim, int):
+            latent_dim = list(latent_dim)
+            aggregate_mode = [aggregate_mode] * len(latent_dim) if isinstance(aggregate_mode, str) else list(aggregate_mode)
+        if isinstance(aggregate_mode, str):
+            assert EmbeddingAggregateModes.has_value(aggregate_mode), \
+                f'`{aggregate_mode}` is not a valid aggregate_mode`, available modes: {EmbeddingAggregateModes.list()}'
+        else:
+            aggregate_mode = list(aggregate_mode)
+            latent_dim = [latent_dim] * len(aggregate_mode) if isinstance(latent_dim, int) else latent_dim
+            for mode in aggregate_mode:
+                assert EmbeddingAggregateModes.has_value(mode), \
+                    f'`{mode}` is not a valid aggregate_mode`, available modes: {EmbeddingAggregateModes.list()}'
+        assert not hierarchical or isinstance(aggregate_mode, list), \
+            '`hierarchical` mode can only be used with multiple VAE heads'
+        self.hierarchical = hierarchical
+        self.hierarchical_with_context = hierarchical_with_context
+        if hierarchical and not hierarchical_with_context:
+            raise NotImplementedError("hierarchical_with_context=False is not used by any shipped recipe")
+        if not isinstance(latent_dim, int):
+            latent_dropout = [latent_dropout] * len(latent_dim) if isinstance(latent_dropout, (int, float)) else list(latent_dropout)
+        self.aggregate_mode, self.latent_dim, self.latent_dropout = aggregate_mode, latent_dim, latent_dropout
+        self.inclusive_latent_dropout = inclusive_latent_dropout
+        self.deadpan_zero_latent = deadpan_zero_latent
+        if isinstance(latent_dim, int):
+            self.vae_head = MMDVAE(input_dim=dim, latent_dim=latent_dim)
+            self.embedding_dim = latent_dim
+        else:
+            self.vae_head = nn.ModuleDict()
+            input_dim = dim
+            for mode, latent_dim_i in zip(aggregate_mode, latent_dim):
+                self.vae_head[mode] = MMDVAE(input_dim=input_dim, latent_dim=latent_dim_i)
+                if self.hierarchical:
+                    input_dim += latent_dim_i
+            self.embedding_dim = sum(latent_dim)
+        self.criterion = MMDLoss()
+        self.loss_weight = loss_weight
+        self.pad_token_id, self.mask_token_id, self.sos_token_id, self.eos_token_id = 0, 1, 2, 3
+        self._mask_bars = False
+        self._z_override: Optional[List[Tensor]] = None          # test hook: inject the N(0, I) samples per level
+        self._drop_override: Optional[List[Optional[Tensor]]] = None  # test hook: inject latent dropout masks
+
+    # -- helpers -------------------------------------------------------------------------------------------
+    def _levels(self):
+        if isinstance(self.aggregate_mode, str):
+            return [self.aggregate_mode], [self.latent_dim], [self.latent_dropout], [self.vae_head]
+        return (list(self.aggregate_mode), list(self.latent_dim), list(self.latent_dropout),
+                [self.vae_head[m] for m in self.aggregate_mode])
+
+    @staticmethod
+    def _get_segments(aggregate_mode: str, bars=None, beats=None, onsets=None):
+        if aggregate_mode in (EmbeddingAggregateModes.BAR_MEAN, EmbeddingAggregateModes.ISOLATED_BAR_MEAN):
+            assert bars is not None, f'`bars` should be provided as inputs for aggregate_mode `{aggregate_mode}`'
+            return bars
+        elif aggregate_mode == EmbeddingAggregateModes.BEAT_MEAN:
+            assert beats is not None, f'`beats` should be provided as inputs for aggregate_mode `{aggregate_mode}`'
+            return beats
+        elif aggregate_mode == EmbeddingAggregateModes.ONSET_MEAN:
+            assert onsets is not None, f'`onsets` should be provided as inputs for aggregate_mode `{aggregate_mode}`'
+            return onsets
+        return None
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, x_extra=None, latents=None, bars: Optional[Tensor] = None,
+                beats: Optional[Tensor] = None, onsets: Optional[Tensor] = None, deadpan_mask: Optional[Tensor] = None,
+                return_embeddings: bool = False, return_attn: bool = False, compute_loss: bool = True, **kwargs):
+        if latents is not None:
+            raise NotImplementedError("externally supplied latents: use `latents_to_embeddings`")
+        modes, Ls, drops, heads = self._levels()
+        main_mode = modes[0]
+        x_input = x
+        if main_mode == EmbeddingAggregateModes.ISOLATED_BAR_MEAN or self._mask_bars:
+            x_input = x.clone().detach()
+            x_input[..., 0][x_input[..., 0] > self.eos_token_id] = self.mask_token_id
+        # quirk (i) of the reference kept: the block-diagonal attn_mask of isolated_bar_mean never reaches attention
+        tout = super().forward(x=x_input, mask=mask, x_extra=x_extra, return_embeddings=return_embeddings,
+                               return_attn=return_attn, **kwargs)
+        hidden = tout.hidden_state
+        b, n = hidden.shape[:2]
+        if mask is None:
+            mask = torch.ones((b, n), dtype=torch.bool, device=hidden.device)
+        assert not self.deadpan_zero_latent or deadpan_mask is not None
+
+        segs = [self._get_segments(m, bars=bars, beats=beats, onsets=onsets) for m in modes]
+        outs = HierLatentsFn.apply(hidden, mask.contiguous(), self.hierarchical, tuple(modes), tuple(segs),
+                                   *[h.linear.weight for h in heads], *[h.linear.bias for h in heads])
+        nl = len(modes)
+        embeddings, lat_list, lmasks = outs[0], list(outs[1:1 + nl]), list(outs[1 + nl:])
+
+        loss, losses = None, {}
+        flags = {}
+        if compute_loss:
+            for i, mode in enumerate(modes):
+                z = self._z_override[i] if self._z_override is not None else None
+                losses[f'MMD/{mode}'] = self.loss_weight * self.criterion(lat_list[i], mask=lmasks[i], z=z)
+                if self.deadpan_zero_latent:  # mmd_transformer.py:232-237,268-273
+                    w = (deadpan_mask[:, None] & lmasks[i]).float()
+                    sq = (lat_list[i] * lat_list[i] * w[..., None])
+                    cnt = w.sum() * lat_list[i].shape[-1]
+                    losses[f'MMD/{mode}/deadpan'] = sq.sum() / cnt.clamp_min(1.0)
+                    flags[f'MMD/{mode}/deadpan'] = (sq != 0).any()
+
+        # latent dropout (training): whole latent vectors dropped per segment, inclusive across levels (mmd:249-253)
+        drop_mask = None
+        if self.training:
+            full_embeddings = embeddings
+            level_masks, prior = [], None
+            for i, mode in enumerate(modes):
+                dm = None
+                if self._drop_override is not None:
+                    dm = self._drop_override[i]
+                elif mode != EmbeddingAggregateModes.MEAN and drops[i] > 0.:
+                    dm = (torch.rand(lmasks[i].shape, device=hidden.device) < drops[i]) & lmasks[i]
+                if dm is None:
+                    note = torch.zeros((b, n), dtype=torch.bool, device=hidden.device)
+                elif mode == EmbeddingAggregateModes.MEAN:
+                    note = dm.view(b, 1).expand(b, n)
+                else:
+                    note = torch.gather(dm.view(b, -1), 1, segs[i])
+                if self.inclusive_latent_dropout:
+                    prior = note if prior is None else (prior | note)
+                    note = prior
+                level_masks.append(note[..., None].expand(b, n, Ls[i]))
+            drop_mask = torch.cat(level_masks, dim=-1) & mask[..., None] & (~deadpan_mask[:, None, None])
+            if self._drop_override is not None or any(d > 0. for d in drops):
+                embeddings = embeddings * (~drop_mask)
+        else:
+            full_embeddings = embeddings
+
+        if compute_loss:
+            loss = sum(losses.values())
+            losses['MMD'] = loss
+        out_latents = lat_list if not isinstance(self.aggregate_mode, str) else lat_list[0]
+        res = MMDTupleTransformerOutput(
+            hidden_state=tout.hidden_state, logits=tout.logits, attentions=tout.attentions, latents=out_latents,
+            embeddings=embeddings, full_embeddings=full_embeddings, dropout_mask=drop_mask, loss=loss, losses=losses,
+            latents_masks=lmasks)
+        res._flags = flags
+        return res
+
+    # -- latents <-> embeddings helpers used by the renderer (mmd_transformer.py:388-502) -----------------
+    def embeddings_to_latents(self, embeddings: Tensor, mask=None, bars=None, beats=None, onsets=None):
+        modes, Ls, _, _ = self._levels()
+        parts = embeddings.split(Ls, dim=-1)
+        out = []
+        for mode, e in zip(modes, parts):
+            e = e.contiguous().float()
+            b, t = e.shape[:2]
+            if mode == EmbeddingAggregateModes.MEAN:
+                m = mask if mask is not None else torch.ones((b, t), dtype=torch.bool, device=e.device)
+                seg = (~m).long()
+                counts = ops.segment_count(seg, 2)
+                out.append(ops.segment_sum(e, seg, 2, counts=counts, rowmask=m)[:, :1])
+            elif mode in SEGMENT_MODES:
+                seg = self._get_segments(mode, bars=bars, beats=beats, onsets=onsets).contiguous()
+                S = int(seg.max()) + 1   # renderer-side helper: shape is part of the reference's contract here
+                counts = ops.segment_count(seg, S)
+                out.append(ops.segment_sum(e, seg, S, counts=counts))
+            else:
+                out.append(e)
+        return out if not isinstance(self.aggregate_mode, str) else out[0]
+
+    def latents_to_embeddings(self, latents, seq_len, bars=None, beats=None, onsets=None):
+        modes, Ls, _, _ = self._levels()
+        lat_list = latents if isinstance(latents, (list, tuple)) else [latents]
+        out = []
+        for mode, lat in zip(modes, lat_list):
+            lat = lat.contiguous().float()
+            if mode == EmbeddingAggregateModes.MEAN:
+                out.append(lat.expand(-1, seq_len, -1))
+            elif mode in SEGMENT_MODES:
+                seg = self._get_segments(mode, bars=bars, beats=beats, onsets=onsets)
+                out.append(ops.segment_gather(lat, seg))
+            else:
+                out.append(lat)
+        return torch.cat(out, dim=-1)
+
+
+class MMDLoss(nn.Module):
+    """Gaussian-kernel MMD between the valid latents and `num_samples` draws from N(0, I) (mmd_transformer.py:505-534)."""
+
+    def __init__(self, num_samples: int = 256, max_num_latents: int = 4096):
+        super().__init__()
+        self.num_samples = num_samples
+        self.max_num_latents = max_num_latents
+
+    def forward(self, latents: Tensor, mask: Optional[Tensor] = None, z: Optional[Tensor] = None):
+        D = latents.shape[-1]
+        y = latents.reshape(-1, D)
+        w = mask.reshape(-1).float() if mask is not None else torch.ones(y.shape[0], device=y.device)
+        if y.shape[0] > self.max_num_latents:
+            # uniform random subset of the valid latents without a host sync: top-k of random keys, invalid rows last
+            keys = torch.rand(y.shape[0], device=y.device)
+            keys = torch.where(w > 0, keys, torch.full_like(keys, -1.0))
+            top = torch.topk(keys, self.max_num_latents)
+            y = y.index_select(0, top.indices)
+            w = (top.values >= 0).float()
+        if z is None:
+            z = torch.randn(self.num_samples, D, device=y.device, dtype=torch.float32)
+        return F_.MMDFn.apply(y.contiguous(), w.contiguous(), z.contiguous())
+
+    @staticmethod
+    def compute_mmd(x, y):
+        return F_.MMDFn.apply(y.contiguous(), torch.ones(y.shape[0], device=y.device), x.contiguous())
+
+
+def dropout_latent_mask(mask, dropout):
+    return ((torch.rand(mask.shape, device=mask.device) < dropout) & mask)[..., None]

@@ -1,0 +1,121 @@
+"""Transformer attention layer with the reference's contract (`modules/transformer/attention.py:22-222`).
+
+HIP execution plan per call: one fused QKV projection GEMM (q | k | v columns of one buffer; MQA = 512+64+64 columns),
+the flash-style attention kernel reading that buffer in place through strides, and the out-projection GEMM whose
+epilogue applies the query-row mask (attention.py:216-218) and, inside a Transformer stack, the residual add.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import functional as F_
+from ...utils import default
+from ..constructor import Constructor, ModuleConfig
+from .attend import AttentionIntermediates, Attend, warn_dropout_once
+from .embeddings import ALiBiPositionalBias, LearnedALiBiPositionalBias
+
+
+@dataclass
+class AttentionSharedIntermediates:
+    rel_pos_bias: Optional[Tensor] = None
+
+
+@dataclass
+class AttentionConfig(ModuleConfig):
+    dim: int = 512
+    dim_head: int = 64
+    heads: int = 8
+    causal: bool = False
+    dropout: float = 0.
+    one_kv_head: bool = False
+    num_mem_kv: int = 0
+    shared_kv: bool = False
+    value_dim_head: Optional[int] = None
+    max_attend_past: Optional[int] = None
+    alibi_pos_bias: bool = False
+    alibi_num_heads: Optional[int] = None
+    alibi_symmetric: bool = True
+    alibi_learned: bool = False
+
+
+class Attention(nn.Module, Constructor):
+    # parameter groups that the ParamArena lays out contiguously and exposes as one fused GEMM operand
+    _spn_fuse_groups = {"_w_qkv": ("to_q.weight", "to_k.weight", "to_v.weight"), "_w_kv": ("to_k.weight", "to_v.weight")}
+
+    def __init__(self, dim: int, dim_head: int = 64, heads: int = 8, causal: bool = False, dropout: float = 0.,
+                 one_kv_head: bool = False, num_mem_kv: int = 0, max_attend: Optional[int] = None, alibi_pos_bias: bool = False,
+                 alibi_num_heads: Optional[int] = None, alibi_symmetric: bool = True, alibi_learned: bool = False):
+        super().__init__()
+        if dim_head != 64:
+            raise NotImplementedError("the attention kernels are built for dim_head = 64 (every shipped recipe)")
+        if num_mem_kv > 0 or max_attend is not None:
+            raise NotImplementedError("num_mem_kv / max_attend are not reachable from any recipe and are not implemented")
+        self.scale = dim_head ** -0.5
+        self.heads, self.causal, self.max_attend = heads, causal, max_attend
+        self.one_kv_head = one_kv_head
+        self.kv_heads = 1 if one_kv_head else heads
+        out_dim = q_dim = dim_head * heads
+        kv_dim = dim_head if one_kv_head else dim_head * heads
+        self.to_q = nn.Linear(dim, q_dim, bias=False)
+        self.to_k = nn.Linear(dim, kv_dim, bias=False)
+        self.to_v = nn.Linear(dim, kv_dim, bias=False)
+        self.rel_pos = None
+        if alibi_pos_bias:
+            alibi_num_heads = default(alibi_num_heads, heads)
+            assert alibi_num_heads <= heads, 'number of ALiBi heads must be less than the total number of heads'
+            klass = LearnedALiBiPositionalBias if alibi_learned else ALiBiPositionalBias
+            self.rel_pos = klass(heads=alibi_num_heads, total_heads=heads, symmetric=alibi_symmetric or causal)
+        self.attend = Attend(causal=causal, dropout=dropout, scale=self.scale)
+        self.num_mem_kv = num_mem_kv
+        self.to_out = nn.Linear(out_dim, dim, bias=False)
+        self._w_qkv = None   # fused arena views (set by ParamArena)
+        self._w_kv = None
+
+    def _fused(self, name, parts):
+        w = getattr(self, name)
+        if w is not None and w.device == parts[0].device:
+            return w
+        return torch.cat(parts, dim=0)
+
+    def forward(self, x: Tensor, context: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+                context_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None, prev_attn: Optional[Tensor] = None,
+                mem: Optional[Tensor] = None, cache: Optional[AttentionIntermediates] = None,
+                shared_cache: Optional[AttentionSharedIntermediates] = None, residual: Optional[Tensor] = None):
+        b, n = x.shape[:2]
+        h, kvh = self.heads, self.kv_heads
+        has_context, has_mem, has_cache = context is not None, mem is not None, cache is not None
+        assert not (has_mem and has_cache), 'cache is not compatible with memory keys'
+        assert not (has_context and has_cache), 'cache is not compatible with context yet'
+        if has_mem or attn_mask is not None or prev_attn is not None:
+            raise NotImplementedError("mem / attn_mask / prev_attn are not reachable from the ScorePerformer models")
+        if self.training and self.attend.dropout > 0:
+            warn_dropout_once("Attention")
+        slopes = self.rel_pos.padded_slopes() if self.rel_pos is not None else None
+        key_mask = mask if context_mask is None else context_mask
+
+        if not has_context and not has_cache:
+            qkv = F_.linear(x, self._fused("_w_qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight)))
+            o = F_.SelfAttnFn.apply(qkv, slopes, key_mask, h, kvh, self.causal, self.scale)
+            k_view, v_view = qkv[..., h * 64:(h + kvh) * 64], qkv[..., (h + kvh) * 64:]
+        else:
+            q = F_.linear(x, self.to_q.weight)
+            kv = F_.linear(context if has_context else x, self._fused("_w_kv", (self.to_k.weight, self.to_v.weight)))
+            if has_cache:  # attention.py:155-156 (K/V of earlier positions; layout b n (kvh d))
+                ck = cache.keys if cache.keys.ndim == 3 else cache.keys.permute(0, 2, 1, 3).flatten(-2)
+                cv = cache.values if cache.values.ndim == 3 else cache.values.permute(0, 2, 1, 3).flatten(-2)
+                kv = torch.cat([torch.cat([ck, kv[..., :kvh * 64]], dim=1), torch.cat([cv, kv[..., kvh * 64:]], dim=1)], dim=-1)
+            o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale)
+            k_view, v_view = kv[..., :kvh * 64], kv[..., kvh * 64:]
+
+        qmask = mask
+        if mask is not None and has_cache:
+            qmask = mask[:, -1:]
+        out = F_.linear(o, self.to_out.weight, residual=residual, rowmask=qmask.contiguous() if qmask is not None else None,
+                        out_fp32=residual is not None)
+        if kvh != 1:  # reference layout b h n d
+            k_view = k_view.unflatten(-1, (kvh, 64)).permute(0, 2, 1, 3)
+            v_view = v_view.unflatten(-1, (kvh, 64)).permute(0, 2, 1, 3)
+        return out, AttentionIntermediates(keys=k_view, values=v_view), AttentionSharedIntermediates(rel_pos_bias=None)

@@ -1,0 +1,56 @@
+"""Transformer feed-forward (`modules/transformer/feedforward.py:13-64`): GEMM(+bias) -> GLU*SiLU / GELU -> GEMM(+residual)."""
+from dataclasses import dataclass
+
+import torch.nn as nn
+
+from ... import functional as F_
+from ..constructor import Constructor, ModuleConfig
+from .attend import warn_dropout_once
+
+
+class GLU(nn.Module):
+    def __init__(self, dim_in, dim_out, activation):
+        super().__init__()
+        self.act = activation
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        u = F_.linear(x, self.proj.weight, self.proj.bias)
+        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True)
+
+
+@dataclass
+class FeedForwardConfig(ModuleConfig):
+    dim: int = 512
+    mult: int = 4
+    glu: bool = False
+    swish: bool = False
+    post_act_ln: bool = False
+    dropout: float = 0.
+    no_bias: bool = True
+
+
+class FeedForward(nn.Module, Constructor):
+    def __init__(self, dim: int = 512, mult: int = 4, glu: bool = False, swish: bool = False, post_act_ln: bool = False,
+                 dropout: float = 0., no_bias: bool = True):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        activation = nn.SiLU() if swish else nn.GELU()
+        project_in = nn.Sequential(nn.Linear(dim, inner_dim, bias=not no_bias), activation) if not glu \
+            else GLU(dim, inner_dim, activation)
+        self.ff = nn.Sequential(project_in, nn.LayerNorm(inner_dim) if post_act_ln else nn.Identity(), nn.Dropout(dropout),
+                                nn.Linear(inner_dim, dim, bias=not no_bias))
+        self.glu, self.act_code, self.dropout = glu, (F_.ACT_SILU if swish else F_.ACT_GELU), dropout
+
+    def forward(self, x, residual=None):
+        if self.training and self.dropout > 0:
+            warn_dropout_once("FeedForward")
+        if self.glu:
+            g = self.ff[0](x)
+        else:
+            lin = self.ff[0][0]
+            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False)
+        if isinstance(self.ff[1], nn.LayerNorm):
+            g = F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps)
+        out = self.ff[3]
+        return F_.linear(g, out.weight, out.bias, residual=residual, out_fp32=residual is not None)

@@ -1,0 +1,169 @@
+"""Transformer layer stack with the reference's contract (`modules/transformer/transformer.py:25-256`).
+
+The residual stream is fp32; each sub-layer is  x <- x + f(norm(x))  with the add fused into the epilogue of f's last GEMM.
+"""
+import copy
+from dataclasses import dataclass
+from functools import partial
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import functional as F_
+from ...utils import equals
+from ...utils.config import DictConfig
+from ..constructor import VariableModuleConfig, Constructor, Registry
+from ..layers import Residual, AdaptiveLayerNorm, LayerNorm
+from .attend import AttentionIntermediates
+from .attention import Attention, AttentionConfig
+from .feedforward import FeedForward, FeedForwardConfig
+
+
+@dataclass
+class TransformerIntermediates:
+    hiddens: Optional[List[Tensor]] = None
+    attention: Optional[List[AttentionIntermediates]] = None
+
+
+TransformerRegistry = type("_TransformerRegistry", (Registry,), {})()
+
+
+@dataclass
+class TransformerConfig(VariableModuleConfig):
+    _target_: str = "default"
+    dim: int = 512
+    depth: int = 4
+    heads: int = 8
+    attention: Union[AttentionConfig, DictConfig] = None
+    feed_forward: Union[FeedForwardConfig, DictConfig] = None
+    causal: bool = False
+    cross_attend: bool = False
+    only_cross: bool = False
+    pre_norm: bool = True
+    use_adanorm: bool = False
+    style_emb_dim: Optional[int] = None
+
+
+@TransformerRegistry.register("default")
+class Transformer(nn.Module, Constructor):
+    def __init__(self, dim: int = 512, depth: int = 4, heads: int = 8, attention=None, feed_forward=None, causal: bool = False,
+                 cross_attend: bool = False, only_cross: bool = False, pre_norm: bool = True, use_adanorm: bool = False,
+                 style_emb_dim: Optional[int] = None):
+        super().__init__()
+        attention = attention if attention else AttentionConfig()
+        feed_forward = feed_forward if feed_forward else FeedForwardConfig()
+        self.dim, self.depth = dim, depth
+        self.layers = nn.ModuleList([])
+        self.pre_norm, self.ada_norm = pre_norm, use_adanorm
+        assert not use_adanorm or style_emb_dim is not None, 'condition_dim should be provided with adanorm'
+        norm_fn = partial(AdaptiveLayerNorm, dim, style_emb_dim) if use_adanorm else partial(LayerNorm, dim)
+        self.cross_attend = cross_attend
+        if cross_attend and not only_cross:
+            default_block = ('a', 'c', 'f')
+        elif cross_attend and only_cross:
+            default_block = ('c', 'f')
+        else:
+            default_block = ('a', 'f')
+        self.layer_types = default_block * depth
+        self.num_attn_layers = len(list(filter(equals('a'), self.layer_types)))
+        self.final_norm = norm_fn() if pre_norm else nn.Identity()
+        for layer_type in self.layer_types:
+            if layer_type == 'a':
+                layer = Attention.init(config=attention, dim=dim, heads=heads, causal=causal)
+            elif layer_type == 'c':
+                layer = Attention.init(config=attention, dim=dim, heads=heads)
+            elif layer_type == 'f':
+                layer = FeedForward.init(config=feed_forward, dim=dim)
+            else:
+                raise Exception(f'invalid layer type {layer_type}')
+            norms = nn.ModuleList([norm_fn() if pre_norm else None, None, norm_fn() if not pre_norm else None])
+            self.layers.append(nn.ModuleList([norms, layer, Residual(dim)]))
+
+    def _norm(self, norm, x, style, out_fp32=False):
+        if self.ada_norm:
+            return norm(x, condition=style, out_fp32=out_fp32)
+        return norm(x, out_fp32=out_fp32)
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
+                context_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None,
+                style_embeddings: Optional[Tensor] = None, mems: Optional[List[Tensor]] = None,
+                intermediates_cache: Optional[TransformerIntermediates] = None, return_hiddens: bool = False):
+        assert not (self.cross_attend ^ (context is not None)), 'context must be passed in if cross_attend is set to True'
+        assert not self.ada_norm or style_embeddings is not None, 'style_embeddings must be passed for AdaLayerNorm'
+        if mems is not None or attn_mask is not None:
+            raise NotImplementedError("mems / attn_mask are not reachable from the ScorePerformer models")
+        hiddens, attn_intermediates = [], []
+        has_cache = intermediates_cache is not None
+        intermediates_cache = copy.copy(intermediates_cache) if has_cache else None
+        if has_cache:
+            intermediates_cache.hiddens = list(intermediates_cache.hiddens)
+            intermediates_cache.attention = list(intermediates_cache.attention)
+        x = x[:, -1:] if has_cache else x
+        if has_cache and style_embeddings is not None:
+            style_embeddings = style_embeddings[:, -1:]
+        x = F_.cast(x, torch.float32)  # fp32 residual stream
+        ctx_b = F_.to_bf16(context) if context is not None else None
+
+        for layer_type, (norm, block, residual_fn) in zip(self.layer_types, self.layers):
+            cache = None
+            if layer_type == 'a':
+                if has_cache:
+                    cache_h = intermediates_cache.hiddens.pop(0)
+                    x = torch.cat([cache_h, x], dim=1)
+                if return_hiddens:
+                    hiddens.append(x)
+                x = x[:, -1:] if has_cache else x
+            if has_cache and layer_type in ('a', 'c'):
+                cache = intermediates_cache.attention.pop(0)
+            residual = x
+            pre_norm, post_branch_norm, post_main_norm = norm
+            h = self._norm(pre_norm, x, style_embeddings) if pre_norm is not None else F_.to_bf16(x)
+            fuse = residual_fn.is_plain
+            res_arg = residual if fuse else None
+            if layer_type == 'a':
+                out, inter, _ = block(h, mask=mask, cache=cache, residual=res_arg)
+            elif layer_type == 'c':
+                out, inter, _ = block(h, context=ctx_b, mask=mask, context_mask=context_mask, residual=res_arg)
+            else:
+                out = block(h, residual=res_arg)
+            x = out if fuse else residual_fn(out, residual)
+            if return_hiddens and layer_type in ('a', 'c'):
+                attn_intermediates.append(inter)
+            if post_main_norm is not None:
+                x = self._norm(post_main_norm, x, style_embeddings, out_fp32=True)
+
+        if not isinstance(self.final_norm, nn.Identity):
+            x = self._norm(self.final_norm, x, style_embeddings, out_fp32=True)
+        if has_cache:
+            cache_h = intermediates_cache.hiddens.pop(0)
+            x = torch.cat([cache_h, x], dim=1)
+        if return_hiddens:
+            hiddens.append(x)
+            return x, TransformerIntermediates(hiddens=hiddens, attention=attn_intermediates)
+        return x
+
+
+@dataclass
+class EncoderConfig(TransformerConfig):
+    _target_: str = "encoder"
+    causal: bool = False
+
+
+@TransformerRegistry.register("encoder")
+class Encoder(Transformer):
+    def __init__(self, **kwargs):
+        super().__init__(causal=False, **kwargs)
+
+
+@dataclass
+class DecoderConfig(TransformerConfig):
+    _target_: str = "decoder"
+    causal: bool = True
+
+
+@TransformerRegistry.register("decoder")
+class Decoder(Transformer):
+    def __init__(self, **kwargs):
+        super().__init__(causal=True, **kwargs)

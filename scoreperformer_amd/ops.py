@@ -175,3 +175,332 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
          ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
          c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, stream_ptr())
     return dslope
+
+
+# ---------------------------------------------------------------------------------------------------------
+# casts / element-wise
+# ---------------------------------------------------------------------------------------------------------
+
+def _bt_view(t: torch.Tensor):
+    """Return (tensor, B, t_len, D, batch_stride, row_stride) for a [.., D] view addressable as (batch, row)."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    if t.ndim == 2:
+        return t, 1, t.shape[0], t.shape[1], 0, t.stride(0)
+    if t.ndim == 3:
+        return t, t.shape[0], t.shape[1], t.shape[2], t.stride(0), t.stride(1)
+    t = t.reshape(-1, t.shape[-1])
+    return t, 1, t.shape[0], t.shape[1], 0, t.stride(0)
+
+
+def cast(x: torch.Tensor, dtype, *, rowmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[..., :] = dtype(x[..., :]) * rowmask[...]; x may be a strided [b, t, D] view, out a slice of a wider buffer."""
+    require_gpu(x)
+    x, B, t_len, D, xbs, xts = _bt_view(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    o, Bo, to, Do, obs, ots = _bt_view(out)
+    if (Bo * to, Do) != (B * t_len, D):
+        raise SpnError("cast: shape mismatch")
+    if Bo != B:  # address the output with the input's (batch,row) split
+        if o.ndim == 2:
+            obs, ots = t_len * o.stride(0), o.stride(0)
+        else:
+            raise SpnError("cast: incompatible batch split")
+    if rowmask is not None:
+        rowmask = _mask_u8(rowmask.reshape(-1))
+    call("spn_cast", ptr(x), c_int(_dt(x)), c_long(xbs), c_long(xts), ptr(o), c_int(_dt(o)), c_long(obs), c_long(ots),
+         ptr(rowmask), c_long(B), c_long(t_len), c_int(D), stream_ptr())
+    return out
+
+
+def act_fwd(u: torch.Tensor, *, act: int, glu: bool) -> torch.Tensor:
+    u2 = _rows2d(u)
+    T, W = u2.shape
+    I = W // 2 if glu else W
+    out = torch.empty((T, I), device=u.device, dtype=BF16)
+    call("spn_act_fwd", ptr(u2), c_long(u2.stride(0)), ptr(out), c_long(I), c_long(T), c_int(I), c_int(act), c_int(int(glu)),
+         stream_ptr())
+    return out
+
+
+def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool) -> torch.Tensor:
+    u2, d2 = _rows2d(u), _rows2d(dout)
+    T, W = u2.shape
+    I = W // 2 if glu else W
+    du = torch.empty((T, W), device=u.device, dtype=BF16)
+    call("spn_act_bwd", ptr(u2), c_long(u2.stride(0)), ptr(d2), c_long(d2.stride(0)), ptr(du), c_long(W), c_long(T), c_int(I),
+         c_int(act), c_int(int(glu)), stream_ptr())
+    return du
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[N] (fp32) += column sums of x [T, N]."""
+    x2 = _rows2d(x)
+    T, N = x2.shape
+    if out is None:
+        out = torch.zeros(N, device=x.device, dtype=F32)
+    call("spn_colsum", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(out), c_long(T), c_int(N), stream_ptr())
+    return out
+
+
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, ta=False, tb=False, bias=None, rowmask=None, out=None, alpha=1.0,
+             accumulate=False) -> torch.Tensor:
+    """Exact-fp32 C = alpha * op(A) @ op(B) + bias.  a: [M,K] (or [K,M] if ta), b: [N,K] nn.Linear-style (or [K,N] if tb)."""
+    require_gpu(a, b)
+    if a.dtype != F32 or b.dtype != F32:
+        raise SpnError("gemm_f32 operands must be fp32")
+    if a.ndim != 2:
+        a = a.reshape(-1, a.shape[-1])
+    if b.ndim != 2:
+        b = b.reshape(-1, b.shape[-1])
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+    if K != Kb:
+        raise SpnError("gemm_f32: inner dimensions differ")
+    sam, sak = (a.stride(1), a.stride(0)) if ta else (a.stride(0), a.stride(1))
+    sbk, sbn = (b.stride(0), b.stride(1)) if tb else (b.stride(1), b.stride(0))
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=F32)
+    if rowmask is not None:
+        rowmask = _mask_u8(rowmask.reshape(-1))
+    call("spn_gemm_f32", ptr(a), c_long(sam), c_long(sak), ptr(b), c_long(sbk), c_long(sbn), ptr(out), c_long(out.stride(0)),
+         ptr(bias), ptr(rowmask), c_int(M), c_int(N), c_int(K), c_float(alpha), c_int(int(accumulate)), stream_ptr())
+    return out
+
+
+def rows_all_nonzero(x: torch.Tensor) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    m = torch.empty(x2.shape[0], device=x.device, dtype=torch.uint8)
+    call("spn_rows_all_nonzero", ptr(x2), c_long(x2.stride(0)), ptr(m), c_long(x2.shape[0]), c_int(x2.shape[1]), stream_ptr())
+    return m.view(torch.bool).view(x.shape[:-1])
+
+
+def mask_rows(x: torch.Tensor, m: torch.Tensor, invert: bool = False) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    y = torch.empty_like(x2)
+    call("spn_mask_rows", ptr(x2), c_long(x2.stride(0)), ptr(_mask_u8(m.reshape(-1))), ptr(y), c_long(y.stride(0)),
+         c_long(x2.shape[0]), c_int(x2.shape[1]), c_int(int(invert)), stream_ptr())
+    return y.view(x.shape)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# embedding tables + tuple gather
+# ---------------------------------------------------------------------------------------------------------
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _int_array(vals):
+    return (c_int * len(vals))(*[int(v) for v in vals])
+
+
+def table_build_fwd(tv, w0, b0, w1, b1, iw, *, dense: bool, discrete: bool, ids_mask: int):
+    """Per-key lists of fp32 tensors -> (tables [list of [V,E]], h1 [list])."""
+    n = len(tv)
+    V = [t.numel() for t in tv]
+    E = [w.numel() for w in w0]
+    dev = tv[0].device
+    buf = torch.empty(sum(v * e for v, e in zip(V, E)), device=dev, dtype=F32)
+    hbuf = torch.empty_like(buf) if dense else None
+    outs, h1s, off = [], [], 0
+    for v, e in zip(V, E):
+        outs.append(buf[off:off + v * e].view(v, e))
+        h1s.append(hbuf[off:off + v * e].view(v, e) if dense else None)
+        off += v * e
+    none = [None] * n
+    call("spn_table_build_fwd", c_int(n), _ptr_array(tv), _ptr_array(w0), _ptr_array(b0 if dense else none),
+         _ptr_array(w1 if dense else none), _ptr_array(b1 if dense else none), _ptr_array(iw if iw is not None else none),
+         _ptr_array(outs), _ptr_array(h1s), _int_array(V), _int_array(E), c_int(int(dense)), c_int(int(discrete)),
+         ctypes.c_uint(ids_mask), stream_ptr())
+    return outs, h1s
+
+
+def table_build_bwd(tv, w0, b0, w1, dout, h1, *, has_iw: bool, dense: bool, discrete: bool, ids_mask: int):
+    """Returns per-key grads (dw0, db0, dw1, db1, diw)."""
+    n = len(tv)
+    V = [t.numel() for t in tv]
+    E = [w.numel() for w in w0]
+    dev = tv[0].device
+    dout = [d.contiguous() for d in dout]
+    dw0 = [torch.zeros(e, device=dev, dtype=F32) for e in E]
+    db0 = [torch.zeros(e, device=dev, dtype=F32) for e in E] if dense else [None] * n
+    db1 = [torch.zeros(e, device=dev, dtype=F32) for e in E] if dense else [None] * n
+    diw = [torch.empty(v, e, device=dev, dtype=F32) for v, e in zip(V, E)] if has_iw else [None] * n
+    dval = [torch.empty(v, e, device=dev, dtype=F32) for v, e in zip(V, E)] if dense else [None] * n
+    none = [None] * n
+    call("spn_table_build_bwd", c_int(n), _ptr_array(tv), _ptr_array(w0), _ptr_array(b0 if dense else none),
+         _ptr_array(w1 if dense else none), _ptr_array(dout), _ptr_array(dw0), _ptr_array(db0), _ptr_array(db1),
+         _ptr_array(diw), _ptr_array(dval), _int_array(V), _int_array(E), c_int(int(dense)), c_int(int(discrete)),
+         ctypes.c_uint(ids_mask), stream_ptr())
+    dw1 = [None] * n
+    if dense:  # dW1[e, j] = sum_v dval[v, e] * h1[v, j]
+        dw1 = [gemm_f32(dval[i], h1[i], ta=True, tb=True) for i in range(n)]
+    return dw0, db0, dw1, db1, diw
+
+
+def _tok_view(tokens: torch.Tensor):
+    if tokens.dtype != torch.int64 or tokens.stride(-1) != 1 or tokens.ndim != 3:
+        tokens = tokens.long().contiguous()
+        if tokens.ndim == 2:
+            tokens = tokens[None]
+    return tokens, tokens.shape[0], tokens.shape[1], tokens.stride(0), tokens.stride(1)
+
+
+def embed_fwd(tables, tokens, gamma, beta, eps: float = 1e-5):
+    """tokens int64 [b, t, >=K] (any batch/row strides) -> (y bf16 [b*t, sum E], mean, rstd)."""
+    tokens, B, t_len, tbs, tts = _tok_view(tokens)
+    T = B * t_len
+    V = [t.shape[0] for t in tables]
+    E = [t.shape[1] for t in tables]
+    D = sum(E)
+    dev = tables[0].device
+    y = torch.empty((T, D), device=dev, dtype=BF16)
+    mean = torch.empty(T, device=dev, dtype=F32) if gamma is not None else None
+    rstd = torch.empty(T, device=dev, dtype=F32) if gamma is not None else None
+    call("spn_embed_fwd", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(E), ptr(tokens), c_long(tbs),
+         c_long(tts), c_int(t_len), ptr(gamma), ptr(beta), ptr(y), c_long(D), ptr(mean), ptr(rstd), c_int(T), c_float(eps),
+         stream_ptr())
+    return y, mean, rstd
+
+
+def embed_bwd(tables, tokens, dy, gamma, mean, rstd, *, dgamma=None, dbeta=None, padding_idx: int = 0):
+    """Returns list of dtables (fp32, fresh); dgamma/dbeta accumulated in place."""
+    tokens, B, t_len, tbs, tts = _tok_view(tokens)
+    T = B * t_len
+    V = [t.shape[0] for t in tables]
+    E = [t.shape[1] for t in tables]
+    dev = tables[0].device
+    dy2 = _rows2d(dy)
+    buf = torch.zeros(sum(v * e for v, e in zip(V, E)), device=dev, dtype=F32)
+    dts, off = [], 0
+    for v, e in zip(V, E):
+        dts.append(buf[off:off + v * e].view(v, e))
+        off += v * e
+    ws = torch.empty(2 * T, device=dev, dtype=F32) if gamma is not None else None
+    call("spn_embed_bwd", c_int(len(tables)), _ptr_array(tables), _ptr_array(dts), _int_array(V), _int_array(E), ptr(tokens),
+         c_long(tbs), c_long(tts), c_int(t_len), ptr(dy2), c_long(dy2.stride(0)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma),
+         ptr(dbeta), ptr(ws), c_int(T), c_int(padding_idx), stream_ptr())
+    return dts
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses, segments, MMD
+# ---------------------------------------------------------------------------------------------------------
+
+def _label_view(labels: torch.Tensor):
+    """labels: int64 [b, t] view (possibly a strided slice labels[:, 1:, i])."""
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+    if labels.ndim == 1:
+        labels = labels[None]
+    return labels, labels.shape[0], labels.shape[1], labels.stride(0), labels.stride(1)
+
+
+def ce_fwd(logits: torch.Tensor, V: int, labels: torch.Tensor, *, ignore_index: int = -100, want_argmax: bool = False):
+    """logits [T, >=V] (row stride free) -> (lse [T], sums [2] = (loss sum, valid count), argmax int32 [T] | None)."""
+    lg = _rows2d(logits)
+    labels, B, t_len, lbs, lts = _label_view(labels)
+    T = B * t_len
+    if lg.shape[0] != T:
+        raise SpnError("ce_fwd: logits rows != labels")
+    lse = torch.empty(T, device=lg.device, dtype=F32)
+    sums = torch.zeros(2, device=lg.device, dtype=F32)
+    am = torch.empty(T, device=lg.device, dtype=torch.int32) if want_argmax else None
+    call("spn_ce_fwd", ptr(lg), c_int(_dt(lg)), c_long(lg.stride(0)), ptr(labels), c_long(lbs), c_long(lts), c_int(t_len),
+         c_int(ignore_index), ptr(lse), ptr(sums), ptr(am), c_long(T), c_int(V), stream_ptr())
+    return lse, sums, am
+
+
+def ce_bwd(logits: torch.Tensor, V: int, labels: torch.Tensor, lse: torch.Tensor, coef: torch.Tensor, *, ignore_index=-100,
+           Vpad: Optional[int] = None) -> torch.Tensor:
+    """dlogits bf16 [T, Vpad] = coef * (softmax - onehot) on non-ignored rows (pad columns zero)."""
+    lg = _rows2d(logits)
+    labels, B, t_len, lbs, lts = _label_view(labels)
+    T = B * t_len
+    Vpad = Vpad or ((V + 7) // 8) * 8
+    dl = torch.empty((T, Vpad), device=lg.device, dtype=BF16)
+    call("spn_ce_bwd", ptr(lg), c_int(_dt(lg)), c_long(lg.stride(0)), ptr(labels), c_long(lbs), c_long(lts), c_int(t_len),
+         c_int(ignore_index), ptr(lse), ptr(coef), ptr(dl), c_long(Vpad), c_long(T), c_int(V), c_int(Vpad), stream_ptr())
+    return dl
+
+
+def segment_count(seg: torch.Tensor, S: int) -> torch.Tensor:
+    seg = seg.contiguous()
+    b, t = seg.shape
+    counts = torch.zeros((b, S), device=seg.device, dtype=F32)
+    call("spn_segment_count", ptr(seg), ptr(counts), c_int(b), c_int(t), c_int(S), stream_ptr())
+    return counts
+
+
+def segment_sum(x: torch.Tensor, seg: torch.Tensor, S: int, *, counts: Optional[torch.Tensor] = None,
+                rowmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [b,t,d] (fp32/bf16, unit inner stride) -> out fp32 [b,S,d]: per-segment sums, or means when counts is given."""
+    seg = seg.contiguous()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    b, t, d = x.shape
+    out = torch.zeros((b, S, d), device=x.device, dtype=F32)
+    if rowmask is not None:
+        rowmask = _mask_u8(rowmask.reshape(-1))
+    call("spn_segment_sum", ptr(x), c_int(_dt(x)), c_long(x.stride(0)), c_long(x.stride(1)), ptr(seg), ptr(counts), ptr(rowmask),
+         ptr(out), c_int(b), c_int(t), c_int(S), c_int(d), stream_ptr())
+    return out
+
+
+def segment_gather(src: torch.Tensor, seg: torch.Tensor, *, counts: Optional[torch.Tensor] = None,
+                   rowmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                   accumulate: bool = False) -> torch.Tensor:
+    """src fp32 [b,S,d] -> y fp32 [b,t,d] (+)= src[b, seg] (/counts) (*rowmask).  `out` may be a column slice
+    `wide[..., c0:c0+d]` of a contiguous [b,t,W] buffer."""
+    seg = seg.contiguous()
+    src = src.contiguous()
+    b, S, d = src.shape
+    t = seg.shape[1]
+    if out is None:
+        out = torch.empty((b, t, d), device=src.device, dtype=F32)
+    if out.stride(-1) != 1 or out.stride(0) != t * out.stride(1):
+        raise SpnError("segment_gather: output must be a column slice of a contiguous [b,t,W] buffer")
+    if rowmask is not None:
+        rowmask = _mask_u8(rowmask.reshape(-1))
+    call("spn_segment_gather", ptr(src), ptr(seg), ptr(counts), ptr(rowmask), ptr(out), c_long(out.stride(1)), c_int(b), c_int(t),
+         c_int(S), c_int(d), c_int(int(accumulate)), stream_ptr())
+    return out
+
+
+def mmd_fwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """sums[4] = (sum k(z,z), sum w w k(y,y), sum w k(z,y), sum w)."""
+    z, y, w = z.contiguous(), y.contiguous(), w.contiguous()
+    sums = torch.zeros(4, device=y.device, dtype=F32)
+    call("spn_mmd_fwd", ptr(z), c_int(z.shape[0]), ptr(y), ptr(w), c_int(y.shape[0]), c_int(y.shape[1]), ptr(sums), stream_ptr())
+    return sums
+
+
+def mmd_bwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    z, y, w = z.contiguous(), y.contiguous(), w.contiguous()
+    dy = torch.empty_like(y)
+    call("spn_mmd_bwd", ptr(z), c_int(z.shape[0]), ptr(y), ptr(w), c_int(y.shape[0]), c_int(y.shape[1]), ptr(coef), ptr(dy),
+         stream_ptr())
+    return dy
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------------------
+
+def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.zeros(1, device=g.device, dtype=F32)
+    call("spn_sumsq", ptr(g), c_long(g.numel()), ptr(out), stream_ptr())
+    return out
+
+
+def adamw_step(p, g, m, v, shadow, normsq, *, max_norm: float, grad_scale: float, lr: float, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay: float = 0.0, step: int = 1):
+    call("spn_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), c_long(p.numel()), ptr(normsq), c_float(max_norm or 0.0),
+         c_float(grad_scale), c_float(lr), c_float(betas[0]), c_float(betas[1]), c_float(eps), c_float(weight_decay), c_int(step),
+         stream_ptr())

@@ -1,0 +1,111 @@
+"""CPU: pin the oracle (oracle/ref_cpu.py) against fixtures produced by the reference itself, and check that the
+product's module tree has the reference's state_dict layout (checkpoint compatibility)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from oracle.weights import filled_state_dict
+from scoreperformer_amd.models import ScorePerformer
+from scoreperformer_amd.synthetic import model_config
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SMALL_VOCAB = {"Bar": 40, "Position": 36, "Pitch": 28, "Velocity": 36, "Duration": 37, "Tempo": 29, "TimeSig": 10,
+               "PositionShift": 21, "NotesInOnset": 16, "PositionInOnset": 16, "RelOnsetDev": 45, "RelPerfDuration": 25}
+VARIANTS = {
+    "tiny_mixlm": dict(preset="tiny", num_tokens=SMALL_VOCAB),
+    "tiny_xattn_mha": dict(preset="tiny", context_emb_mode="attention", style_emb_mode="cat", one_kv_head=False,
+                           alibi_learned=False, num_tokens=SMALL_VOCAB),
+    "tiny_full_vocab": dict(preset="tiny"),
+}
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, f"{name}.npz"), allow_pickle=False))
+
+
+def build(name, seed=0):
+    cfg = model_config(**VARIANTS[name])
+    model = ScorePerformer.init(model_config(**VARIANTS[name]))
+    sd = filled_state_dict(model, seed=seed)
+    return cfg, model, sd
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_state_dict_layout_matches_reference(name):
+    fix = load(name)
+    _, model, _ = build(name)
+    sd = model.state_dict()
+    ref_keys = str(fix["meta/state_dict_keys"]).split("\n")
+    ref_shapes = str(fix["meta/state_dict_shapes"]).split("\n")
+    assert list(sd.keys()) == ref_keys
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == ref_shapes
+    assert sum(p.numel() for p in model.parameters()) == int(fix["meta/num_params"])
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_oracle_matches_reference_forward_backward(name):
+    fix = load(name)
+    cfg, _, sd = build(name)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v)
+          for k, v in sd.items()}
+    # tied tensors share one leaf so that gradients accumulate like in the reference module tree
+    from oracle.weights import canonical
+    leaves = {}
+    for k in list(sd):
+        c = canonical(k)
+        if c in leaves:
+            sd[k] = leaves[c]
+        else:
+            leaves[c] = sd[k]
+    batch = {k[3:]: torch.from_numpy(v) for k, v in fix.items() if k.startswith("in/")}
+    z = [torch.from_numpy(fix[f"z/{i}"]) for i in range(4)]
+    out = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
+    assert abs(float(out["loss"]) - float(fix["out/loss"])) < 2e-5
+    ref_losses = {k[7:]: float(v) for k, v in fix.items() if k.startswith("losses/")}
+    assert set(out["losses"]) == set(ref_losses)
+    for k, v in ref_losses.items():
+        assert abs(float(out["losses"][k]) - v) < 2e-5, k
+    for k, v in fix.items():
+        if k.startswith("logits/"):
+            np.testing.assert_allclose(out["logits"][k[7:]].detach().numpy(), v, atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["hidden_state"].detach().numpy(), fix["out/hidden_state"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["perf_embeddings"].detach().numpy(), fix["out/perf_embeddings"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["score_embeddings"].detach().numpy(), fix["out/score_embeddings"], atol=3e-5, rtol=1e-4)
+    out["loss"].backward()
+    checked = 0
+    for k, v in fix.items():
+        if k.startswith("gradnorm/"):
+            name_ = k[9:]
+            g = sd[name_].grad
+            assert g is not None, name_
+            assert abs(float(g.double().norm()) - float(v)) <= 1e-4 * max(1.0, float(v)), name_
+            checked += 1
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), v, atol=2e-5, rtol=2e-4)
+    assert checked > 100
+
+
+def test_oracle_units():
+    fix = load("units")
+    for h in (1, 2, 4, 6, 8, 12):
+        np.testing.assert_allclose(np.array(ref_cpu.alibi_slopes(h), dtype=np.float32), fix[f"alibi/slopes/{h}"], rtol=1e-6)
+    np.testing.assert_array_equal(ref_cpu.alibi_bias(5, 5).numpy().astype(np.int32), fix["alibi/bias_5_5"])
+    np.testing.assert_array_equal(ref_cpu.alibi_bias(1, 7).numpy().astype(np.int32), fix["alibi/bias_1_7"])
+    z, y = torch.from_numpy(fix["mmd/z"]), torch.from_numpy(fix["mmd/y"])
+    assert abs(float(ref_cpu.compute_mmd(z, y)) - float(fix["mmd/out"])) < 1e-6
+
+
+def test_oracle_greedy_matches_reference_cached_decode():
+    """The reference's KV/hidden-cached `unmask_tokens` (wrappers.py:325-407) equals the oracle's cache-free greedy
+    loop token for token."""
+    fix = load("tiny_greedy")
+    cfg = model_config(preset="tiny", num_tokens=SMALL_VOCAB)
+    model = ScorePerformer.init(model_config(preset="tiny", num_tokens=SMALL_VOCAB))
+    sd = filled_state_dict(model, seed=3)
+    tokens = torch.from_numpy(fix["in/tokens"])
+    out = ref_cpu.greedy_unmask(sd, cfg, tokens, torch.from_numpy(fix["in/masked_perf"]),
+                                torch.from_numpy(fix["out/score_embeddings"]), torch.from_numpy(fix["out/perf_embeddings"]))
+    np.testing.assert_array_equal(out.numpy(), fix["out/tokens"])
