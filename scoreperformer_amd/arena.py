@@ -1,0 +1,146 @@
+"""Flat parameter arena + fused optimizer (memory laid out for one-kernel updates and bucketed RCCL all-reduce).
+
+All unique parameters of a model are moved into ONE contiguous fp32 buffer (`params`), with parallel buffers for
+gradients, Adam moments and the bf16 compute copy.  Each `nn.Parameter` keeps its name/shape (state_dict layout is
+unchanged) but its storage is a view of the arena, so:
+
+* the optimizer step (global grad-norm clip + AdamW + bf16 refresh, `experiments/optimizers.py:151-169`) is two
+  launches over ~72 M contiguous floats instead of 218 tensors x several ops;
+* weight-gradient GEMMs accumulate straight into `grads` (no autograd accumulation pass);
+* data-parallel all-reduce works on contiguous buckets of `grads` (see parallel.py);
+* q/k/v projection weights are adjacent, which gives the fused QKV GEMM operand for free.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import BF16, F32
+
+ALIGN = 8  # elements: 16 B for bf16, 32 B for fp32
+
+
+class ParamArena:
+    def __init__(self, model: nn.Module, device: Optional[torch.device] = None):
+        params: List[nn.Parameter] = []
+        names: List[str] = []
+        seen = set()
+        for name, p in model.named_parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+                names.append(name)
+        device = device or params[0].device
+        self.model, self.param_list, self.names, self.device = model, params, names, device
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.offsets, self.total = offsets, total
+        self.params = torch.zeros(total, device=device, dtype=F32)
+        self.grads = torch.zeros(total, device=device, dtype=F32)
+        self.exp_avg = torch.zeros(total, device=device, dtype=F32)
+        self.exp_avg_sq = torch.zeros(total, device=device, dtype=F32)
+        self.shadow = torch.zeros(total, device=device, dtype=BF16)
+        self._normsq = torch.zeros(1, device=device, dtype=F32)
+        self.step_count = 0
+        with torch.no_grad():
+            for p, off in zip(params, offsets):
+                n = p.numel()
+                view = self.params[off:off + n].view(p.shape)
+                view.copy_(p.data.to(device=device, dtype=F32))
+                p.data = view
+                p.grad = self.grads[off:off + n].view(p.shape)
+                p._spn_main_grad = p.grad
+                p._spn_shadow = self.shadow[off:off + n].view(p.shape)
+                p._spn_offset = off
+        # buffers follow the model to the device
+        for mod in model.modules():
+            for bname, buf in list(mod._buffers.items()):
+                if buf is not None and buf.device != device:
+                    mod._buffers[bname] = buf.to(device)
+        self.refresh_shadow()
+        self._bind_fused_groups()
+
+    # -- bf16 compute copies ---------------------------------------------------------------------------------
+    def refresh_shadow(self):
+        """Recompute the whole bf16 copy (after load_state_dict or any out-of-band weight edit)."""
+        ops.cast(self.params.view(1, -1), BF16, out=self.shadow.view(1, -1))
+        for p in self.param_list:
+            p._spn_shadow_version = p._version
+
+    def _bind_fused_groups(self):
+        by_id = {id(p): off for p, off in zip(self.param_list, self.offsets)}
+        for mod in self.model.modules():
+            groups = getattr(mod, "_spn_fuse_groups", None)
+            if not groups:
+                continue
+            for attr, pnames in groups.items():
+                ps = []
+                for pn in pnames:
+                    obj = mod
+                    for part in pn.split("."):
+                        obj = getattr(obj, part)
+                    ps.append(obj)
+                offs = [by_id.get(id(p)) for p in ps]
+                ok = all(o is not None for o in offs)
+                for a, b_, pa in zip(offs[:-1], offs[1:], ps[:-1]):
+                    ok = ok and a is not None and b_ == a + pa.numel()   # adjacent, no padding in between
+                ok = ok and all(p.shape[1:] == ps[0].shape[1:] for p in ps)
+                if not ok:
+                    setattr(mod, attr, None)
+                    continue
+                rows = sum(p.shape[0] for p in ps)
+                n = rows * ps[0][0].numel()
+                shape = (rows,) + tuple(ps[0].shape[1:])
+                fused = self.params[offs[0]:offs[0] + n].view(shape).detach().requires_grad_(True)
+                fused._spn_main_grad = self.grads[offs[0]:offs[0] + n].view(shape)
+                fused._spn_shadow = self.shadow[offs[0]:offs[0] + n].view(shape)
+                fused._spn_shadow_version = fused._version
+                fused._spn_parts = ps
+                setattr(mod, attr, fused)
+
+    # -- training step -----------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def grad_norm_sq(self) -> torch.Tensor:
+        self._normsq.zero_()
+        return ops.sumsq(self.grads, out=self._normsq)
+
+    def step(self, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+             max_norm: Optional[float] = None, grad_scale: float = 1.0) -> torch.Tensor:
+        """clip_grad_norm_(max_norm) + AdamW over the whole arena; returns the (unclipped) grad norm as a device scalar."""
+        self.step_count += 1
+        normsq = self.grad_norm_sq()
+        ops.adamw_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, normsq,
+                       max_norm=max_norm or 0.0, grad_scale=grad_scale, lr=lr, betas=betas, eps=eps,
+                       weight_decay=weight_decay, step=self.step_count)
+        return normsq.sqrt() * grad_scale
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": torch.tensor(self.step_count)}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+
+
+class FusedAdamW:
+    """Optimizer facade with the reference's hyper-parameters (recipes/default.yaml:79-89): AdamW(lr 2e-4, wd 1e-6),
+    grad clip 2.0; `step()` = unscale/clip/update/zero_grad of `Optimizer.step` (experiments/optimizers.py:151-169)."""
+
+    def __init__(self, arena: ParamArena, lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 1e-6, grad_clip: Optional[float] = 2.0):
+        self.arena, self.lr, self.betas, self.eps, self.weight_decay, self.grad_clip = arena, lr, betas, eps, weight_decay, grad_clip
+
+    def step(self, grad_scale: float = 1.0, zero_grad: bool = True):
+        norm = self.arena.step(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
+                               max_norm=self.grad_clip, grad_scale=grad_scale)
+        if zero_grad:
+            self.arena.zero_grad()
+        return norm
