@@ -1,0 +1,115 @@
+/* spn.h — C ABI of libspn.so: hand-written HIP kernels (gfx950 / MI355X) for the ScorePerformer transformer hot path.
+ *
+ * The reference (ilya16/ScorePerformer) is pure Python/PyTorch and has NO FFI of its own; each entry
+ * point below names the reference call site(s) it replaces (file:line under scoreperformer/).  A maintainer binds them
+ * with ctypes exactly as scoreperformer_amd/lib.py does.
+ *
+ * Conventions
+ *  - plain pointers / sizes / strides; no torch types.  All device buffers are owned by the caller; kernels never
+ *    allocate, free, or retain pointers.  Pointer-table arguments (`const float* const*`) are HOST arrays of device
+ *    pointers, copied into the kernel argument block.
+ *  - every call is asynchronous on `stream`; no device/stream synchronisation, no host reads: safe under hipGraph capture.
+ *  - returns 0 on success, <0 on error (spn_last_error() gives a thread-local message).  No C++ exceptions cross the ABI.
+ *  - dtype codes: 0 = fp32, 1 = bf16.  "bf16" buffers are raw 16-bit bfloat16.  Strides/leading dimensions in ELEMENTS.
+ *  - ACCUMULATED outputs (documented per function) must be zeroed by the caller first.
+ */
+#ifndef SPN_H
+#define SPN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
+
+int spn_abi_version(void);
+const char* spn_last_error(void);
+void spn_set_error(const char* msg);
+
+/* ---- GEMM (nn.Linear / F.linear everywhere on the path: modules/transformer/attention.py:135-142,210-218;
+ *      feedforward.py:13-21,51-64; models/scoreperformer/embeddings.py:104,139,211,255,345-349; transformer.py:131,185;
+ *      modules/layers.py:37,46) and their backward contractions.
+ *      C[M,N] = residual + rowmask[m] * (alpha * A.B + bias[n]);  bf16 operands, fp32 accumulate.
+ *      flags: bit0 A stored [K,M] (M contiguous); bit1 B stored [K,N] (N contiguous; default is nn.Linear's [N,K]);
+ *             bit2 C fp32 (else bf16); bit3 C += (fp32 only). lda/ldb multiples of 8, 16-byte aligned bases. */
+int spn_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual, const uint8_t* rowmask,
+                  int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha, int flags, int batch, long strideA,
+                  long strideB, long strideC, spn_stream_t stream);
+/* exact fp32 GEMM with arbitrary strides: A(m,k)=a[m*sam+k*sak], B(k,n)=b[k*sbk+n*sbn]  (VAE heads
+ * models/scoreperformer/mmd_transformer.py:53-56; embedding value MLP modules/transformer/embeddings.py:202-213) */
+int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, long sbn, float* c, long ldc, const float* bias,
+                 const uint8_t* rowmask, int M, int N, int K, float alpha, int accumulate, spn_stream_t stream);
+
+/* ---- attention core (modules/transformer/attend.py:58-126 + mask/ALiBi assembly attention.py:162-197,
+ *      modules/transformer/embeddings.py:294-315).  head dim 64; q [b,nq,h,64], k/v [b,nk,kvh,64] through strides;
+ *      kvh = 1 is multi-query.  strides: {q_bs,q_ns,q_hs, k_.., v_.., o_..} (+ {dq_.., dk_.., dv_..} for bwd). */
+int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const float* slopes,
+                 int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, spn_stream_t stream);
+/* delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
+int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
+                 void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
+                 int nq, int nk, int causal, float scale, const long* strides, spn_stream_t stream);
+
+/* ---- LayerNorm / AdaptiveLayerNorm (modules/transformer/transformer.py:106,123-125,192-193,217;
+ *      modules/layers.py:31-47).  gb = [T,2D] fp32 per-token (gamma|beta).  bwd: dy bf16; dgamma/dbeta ACCUMULATED. */
+int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, const float* gb, long ldgb,
+                      void* y, int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps, spn_stream_t stream);
+int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma, const float* gb,
+                      long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,
+                      long lddx, float* dgamma, float* dbeta, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
+
+/* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
+int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, spn_stream_t s);
+int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act, int glu,
+                spn_stream_t s);
+int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dtype, long y_bs, long y_ts,
+             const uint8_t* rowmask, long B, long t_len, int D, spn_stream_t s);
+int spn_colsum(const void* x, int x_dtype, long ldx, float* out /* ACCUMULATED */, long T, int N, spn_stream_t s);
+int spn_mish_fwd(const float* x, float* y, long n, spn_stream_t s);
+int spn_mish_bwd(const float* x, const float* dy, float* dx, long n, spn_stream_t s);
+int spn_rows_all_nonzero(const float* x, long ldx, uint8_t* mask, long R, int D, spn_stream_t s);
+int spn_mask_rows(const float* x, long ldx, const uint8_t* m, float* y, long ldy, long R, int D, int invert, spn_stream_t s);
+
+/* ---- embedding tables + tuple gather (modules/transformer/embeddings.py:118-152,202-213;
+ *      models/scoreperformer/embeddings.py:121-143).  dw0/db0/db1, dtables, dgamma/dbeta ACCUMULATED. */
+int spn_table_build_fwd(int nkeys, const float* const* tv, const float* const* w0, const float* const* b0,
+                        const float* const* w1, const float* const* b1, const float* const* iw, float* const* out,
+                        float* const* h1, const int* V, const int* E, int dense, int discrete, unsigned ids_mask,
+                        spn_stream_t stream);
+int spn_table_build_bwd(int nkeys, const float* const* tv, const float* const* w0, const float* const* b0,
+                        const float* const* w1, const float* const* dout, float* const* dw0, float* const* db0,
+                        float* const* db1, float* const* diw, float* const* dval, const int* V, const int* E, int dense,
+                        int discrete, unsigned ids_mask, spn_stream_t stream);
+int spn_embed_fwd(int nkeys, const float* const* tables, const int* V, const int* E, const long* tokens, long tok_bs,
+                  long tok_ts, int t_len, const float* gamma, const float* beta, void* y, long ldy, float* mean, float* rstd,
+                  int T, float eps, spn_stream_t stream);
+int spn_embed_bwd(int nkeys, const float* const* tables, float* const* dtables, const int* V, const int* E, const long* tokens,
+                  long tok_bs, long tok_ts, int t_len, const void* dy, long lddy, const float* gamma, const float* mean,
+                  const float* rstd, float* dgamma, float* dbeta, float* ws, int T, int padding_idx, spn_stream_t stream);
+
+/* ---- losses (models/scoreperformer/wrappers.py:49-59 CE; mmd_transformer.py:325-368 segments, 505-534 MMD) */
+int spn_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len,
+               int ignore_index, float* lse, float* sums /* [2] ACCUMULATED */, int* argmax, long T, int V, spn_stream_t s);
+int spn_ce_bwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len,
+               int ignore_index, const float* lse, const float* coef, void* dlogits, long ldd, long T, int V, int Vpad,
+               spn_stream_t s);
+int spn_segment_count(const long* seg, float* counts /* ACCUMULATED */, int b, int t, int S, spn_stream_t s);
+int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
+                    const uint8_t* rowmask, float* out /* ACCUMULATED */, int b, int t, int S, int d, spn_stream_t s);
+int spn_segment_gather(const float* src, const long* seg, const float* counts, const uint8_t* rowmask, float* y, long y_ld,
+                       int b, int t, int S, int d, int accumulate, spn_stream_t s);
+int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w, int N, int D, float* sums /* [4] ACCUMULATED */,
+                spn_stream_t s);
+int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, int D, const float* coef, float* dy,
+                spn_stream_t s);
+
+/* ---- optimizer (experiments/optimizers.py:151-169: clip_grad_norm_ + torch.optim.AdamW) over the flat arena */
+int spn_sumsq(const float* g, long n, float* out /* ACCUMULATED */, spn_stream_t s);
+int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* normsq,
+                   float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int step, spn_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPN_H */

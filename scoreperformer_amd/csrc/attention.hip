@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dslope = 0.f;
+    // d slope_h = sum_ij dS_ij * (-|j - i - off|).  delta is computed from the bf16-rounded O, so each row's dS carries a
+    // common error -P_ij * eps_i; since sum_j dS_ij must be 0, the measured row sum r_i = -eps_i gives the exact
+    // correction  + r_i * sum_j P_ij |d_ij|  (otherwise the error is amplified by the mean attended distance).
+    float acc_d[2] = {0.f, 0.f}, acc_r[2] = {0.f, 0.f}, acc_p[2] = {0.f, 0.f};
 
     int nt = (a.nk + 63) / 64;
     if (a.causal) {
@@ -393,7 +396,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                     const float p = exp2f((sv - lse[qb]) * LOG2E);
                     const float ds = p * (dp[kb][qb][r] - dl[qb]);
                     const int dist = j - (i + off);
-                    if (i < a.nq && j < a.nk) dslope -= ds * (float)(dist < 0 ? -dist : dist);
+                    if (i < a.nq && j < a.nk) {
+                        const float ad = (float)(dist < 0 ? -dist : dist);
+                        acc_d[qb] += ds * ad; acc_r[qb] += ds; acc_p[qb] += p * ad;
+                    }
                     s[kb][qb][r] = ds * a.scale;
                 }
         }
@@ -426,6 +432,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
     }
     if (a.dslope) {
+        float dslope = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float d = group_sum(acc_d[qb]), r = group_sum(acc_r[qb]), pa = group_sum(acc_p[qb]);
+            if (g == 0) dslope += -d + r * pa;
+        }
         dslope = wave_sum(dslope);
         if (lane == 0) atomicAdd(a.dslope + hi, dslope);
     }

@@ -258,7 +258,7 @@ class TupleTokenLMHead(_HeadBase, Constructor):
                                     if not filter_keys or key in filter_keys})
 
     def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
-        xb = F_.to_bf16(x)
+        xb = F_.cast(x, torch.bfloat16)
         items = [(i, key, xb, head.weight, head.bias) for i, (key, head) in enumerate(self.heads.items())
                  if _wanted(i, key, keys)]
         logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)

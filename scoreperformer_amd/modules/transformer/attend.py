@@ -57,9 +57,9 @@ class Attend(nn.Module):
             if mask.shape[1] != 1 or mask.shape[2] != 1:
                 raise NotImplementedError("only key-padding masks (b,1,1,j) and causal masking are supported")
             mask = mask[:, 0, 0]
-        qb = F_.to_bf16(q).permute(0, 2, 1, 3)                       # b n h d view
-        kb = F_.to_bf16(k)
-        vb = F_.to_bf16(v)
+        qb = F_.cast(q, torch.bfloat16).permute(0, 2, 1, 3)                       # b n h d view
+        kb = F_.cast(k, torch.bfloat16)
+        vb = F_.cast(v, torch.bfloat16)
         kb = kb.unsqueeze(2) if kb.ndim == 3 else kb.permute(0, 2, 1, 3)
         vb = vb.unsqueeze(2) if vb.ndim == 3 else vb.permute(0, 2, 1, 3)
         kv = torch.cat([kb, vb], dim=-2).flatten(-2)               # b j (2*kvh*d)   (stand-alone path only)

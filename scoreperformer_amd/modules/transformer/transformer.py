@@ -104,7 +104,7 @@ class Transformer(nn.Module, Constructor):
         if has_cache and style_embeddings is not None:
             style_embeddings = style_embeddings[:, -1:]
         x = F_.cast(x, torch.float32)  # fp32 residual stream
-        ctx_b = F_.to_bf16(context) if context is not None else None
+        ctx_b = F_.cast(context, torch.bfloat16) if context is not None else None
 
         for layer_type, (norm, block, residual_fn) in zip(self.layer_types, self.layers):
             cache = None
@@ -119,7 +119,7 @@ class Transformer(nn.Module, Constructor):
                 cache = intermediates_cache.attention.pop(0)
             residual = x
             pre_norm, post_branch_norm, post_main_norm = norm
-            h = self._norm(pre_norm, x, style_embeddings) if pre_norm is not None else F_.to_bf16(x)
+            h = self._norm(pre_norm, x, style_embeddings) if pre_norm is not None else F_.cast(x, torch.bfloat16)
             fuse = residual_fn.is_plain
             res_arg = residual if fuse else None
             if layer_type == 'a':

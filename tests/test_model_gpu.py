@@ -48,11 +48,11 @@ def test_forward_backward_matches_reference_golden(dev, name):
     assert abs(float(out.loss) - float(fix["out/loss"])) <= 2e-2 * float(fix["out/loss"])
     for k, v in fix.items():
         if k.startswith("logits/"):
-            got = out.perf_decoder.logits[k[7:]].float().cpu().numpy()
+            got = out.perf_decoder.logits[k[7:]].detach().float().cpu().numpy()
             assert np.abs(got - v).max() <= 0.03 * np.abs(v).max(), k
-    hs = out.perf_decoder.hidden_state.float().cpu().numpy()
+    hs = out.perf_decoder.hidden_state.detach().float().cpu().numpy()
     assert np.abs(hs - fix["out/hidden_state"]).max() <= 0.03 * np.abs(fix["out/hidden_state"]).max()
-    pe = out.perf_encoder.embeddings.float().cpu().numpy()
+    pe = out.perf_encoder.embeddings.detach().float().cpu().numpy()
     assert np.abs(pe - fix["out/perf_embeddings"]).max() <= 0.03 * np.abs(fix["out/perf_embeddings"]).max() + 1e-3
 
     arena.zero_grad()
