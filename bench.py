@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — ScorePerformer train-step throughput on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + backward (+ RCCL gradient all-reduce) + global-norm clip + AdamW of the C3 model
+(6/6/6 layers, d=512, 8 heads MQA, GLU-SiLU FFN x4, hierarchical MMD-VAE style encoder, tied LM head) on one batch of
+synthetic note tuples that is already resident in HBM.  Weak scaling: 64 sequences x 2048 notes PER GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="c3")
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seq", type=int, default=1024)
+    return ap.parse_args()
+
+
+def flops_per_token_fwd(seq, d=512, h=8, dh=64, layers=18, inner=2048):
+    """BASELINE.md §3 / SURVEY.md §8(d): dense-matmul FLOPs per note-token, forward."""
+    per_layer = 2 * d * (h * dh) * 2 + 2 * 2 * d * dh + 4 * seq * h * dh + 6 * d * inner
+    return layers * per_layer + 8.1e6 + 1.7e6 + 1.9e6
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    from scoreperformer_amd import build as spn_build
+    if rank == 0:
+        spn_build.build()
+    if dist is not None:
+        dist.barrier()
+    from scoreperformer_amd import ops
+    from scoreperformer_amd.arena import ParamArena, FusedAdamW
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.parallel import GradSync
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+
+    torch.manual_seed(1234)  # identical initial replicas on every rank
+    cfg = model_config(args.preset, max_seq_len=max(args.seq, 256))
+    model = ScorePerformer.init(cfg)
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
+    arena = ParamArena(model, dev)
+    model.train()
+    model.sync_free = True
+    opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
+    sync = GradSync(arena, dist.group.WORLD if dist is not None else None)
+    batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
+    torch.manual_seed(4321 + rank)  # distinct MMD samples per rank
+
+    def step():
+        sync.begin_step()
+        out = model(**batch)
+        out.loss.backward()
+        sync.finish()
+        opt.step(grad_scale=1.0 / world)
+        return out
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    ms_per_step = dt / args.steps * 1e3
+    tokens = world * args.batch * args.seq * args.steps
+    value = tokens / dt
+    loss = float(out.loss)
+
+    result = {
+        "metric": "score-tokens/sec (train step: fwd+bwd+grad all-reduce+clip+AdamW), whole job", "value": value,
+        "unit": "note-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"C3 ScorePerformer train step: 6/6/6 layers d=512 h=8 MQA GLU-SiLUx4, MMD-VAE style encoder, "
+                               f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, dropout=0 (fused dropout not yet implemented)",
+                   "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
+                   "tokens_per_s_per_gpu": value / world, "final_loss": loss,
+                   "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = roofline_leg(ops, step, args)
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def roofline_leg(ops, step, args):
+    """Dominant kernel = the bf16 MFMA GEMM.  Every GEMM launch of a few instrumented steps is bracketed by HIP events on
+    the launch stream; achieved = algorithmic FLOPs (2*M*N*K) / measured duration, summed over the step's GEMM launches."""
+    ops.PROFILE.enable()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    recs = ops.PROFILE.collect()
+    ops.PROFILE.disable()
+    gemm = [r for r in recs if r[0] == "gemm_bf16"]
+    flops = sum(r[1] for r in gemm)
+    ms = sum(r[2] for r in gemm)
+    by_shape = {}
+    for name, f, t, tag in gemm:
+        a = by_shape.setdefault(tag, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += f; a[2] += t
+    top = sorted(by_shape.items(), key=lambda kv: -kv[1][2])[:6]
+    attn = [r for r in recs if r[0].startswith("attn")]
+    return {"bound": "mfma", "kernel": "gemm_kernel<bf16, 128x128x64, v_mfma_f32_16x16x32_bf16> (all launches of a step)",
+            "achieved": flops / (ms * 1e-3) / 1e12 if ms else None, "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": (flops / (ms * 1e-3) / 1e12 / 2500.0) if ms else None, "traffic": None,
+            "launches_per_step": len(gemm) // 2, "avg_launch_ms": ms / max(len(gemm), 1),
+            "gemm_ms_per_step": ms / 2,
+            "top_shapes": [{"MNK_layout": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2,
+                            "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in top],
+            "attention_ms_per_step": sum(r[2] for r in attn) / 2,
+            "attention_tflops": (sum(r[1] for r in attn) / (sum(r[2] for r in attn) * 1e-3) / 1e12) if attn else None}
+
+
+def cpu_baseline_leg(cfg, cpu_state, args):
+    """The CPU oracle (parity-pinned port of the reference, oracle/ref_cpu.py) timed on this host's cores: forward+backward
+    of ONE sequence of `cpu_seq` notes of the same model (bounded sample), fp32."""
+    from oracle import ref_cpu
+    from scoreperformer_amd.synthetic import synthetic_batch
+    n = args.cpu_seq
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v)
+          for k, v in cpu_state.items()}
+    batch = synthetic_batch(1, n, seed=99)
+    z = [torch.randn(256, d) for d in cfg["perf_encoder"]["latent_dim"]]
+    t0 = time.perf_counter()
+    out = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "note-tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 sequence x {n} notes, forward+backward (no optimizer), fp32, torch {torch.__version__} CPU, "
+                      f"{dt:.1f} s wall", "cpu_loss": float(out["loss"])}
+
+
+if __name__ == "__main__":
+    main()

@@ -504,3 +504,64 @@ def adamw_step(p, g, m, v, shadow, normsq, *, max_norm: float, grad_scale: float
     call("spn_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), c_long(p.numel()), ptr(normsq), c_float(max_norm or 0.0),
          c_float(grad_scale), c_float(lr), c_float(betas[0]), c_float(betas[1]), c_float(eps), c_float(weight_decay), c_int(step),
          stream_ptr())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# opt-in launch timing (bench.py roofline leg): HIP events on the launch stream around GEMM / attention launches
+# ---------------------------------------------------------------------------------------------------------
+
+class _Profile:
+    def __init__(self):
+        self.enabled, self.records = False, []
+
+    def enable(self):
+        self.enabled, self.records = True, []
+
+    def disable(self):
+        self.enabled = False
+
+    def wrap(self, name, flops, tag, fn):
+        if not self.enabled:
+            return fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        e.record()
+        self.records.append((name, flops, s, e, tag))
+        return out
+
+    def collect(self):
+        torch.cuda.synchronize()
+        return [(n, f, s.elapsed_time(e), tag) for n, f, s, e, tag in self.records]
+
+
+PROFILE = _Profile()
+_gemm_raw, _attn_fwd_raw, _attn_bwd_raw = gemm, attn_fwd, attn_bwd
+
+
+def gemm(a, b, *, ta=False, tb=False, **kw):  # noqa: F811
+    if not PROFILE.enabled:
+        return _gemm_raw(a, b, ta=ta, tb=tb, **kw)
+    a2, b2 = _rows2d(a), _rows2d(b)
+    M, K = (a2.shape[1], a2.shape[0]) if ta else (a2.shape[0], a2.shape[1])
+    N = b2.shape[1] if tb else b2.shape[0]
+    return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:{'T' if ta else 'N'}{'T' if tb else 'N'}",
+                        lambda: _gemm_raw(a, b, ta=ta, tb=tb, **kw))
+
+
+def attn_fwd(q, k, v, **kw):  # noqa: F811
+    if not PROFILE.enabled:
+        return _attn_fwd_raw(q, k, v, **kw)
+    b_, nq, h, dh = q.shape
+    fl = 4.0 * b_ * h * nq * k.shape[1] * dh * (0.5 if kw.get("causal") else 1.0)
+    return PROFILE.wrap("attn_fwd", fl, f"b{b_} h{h} nq{nq} nk{k.shape[1]} causal{int(bool(kw.get('causal')))}",
+                        lambda: _attn_fwd_raw(q, k, v, **kw))
+
+
+def attn_bwd(q, k, v, o, d_o, lse, **kw):  # noqa: F811
+    if not PROFILE.enabled:
+        return _attn_bwd_raw(q, k, v, o, d_o, lse, **kw)
+    b_, nq, h, dh = q.shape
+    fl = 10.0 * b_ * h * nq * k.shape[1] * dh * (0.5 if kw.get("causal") else 1.0)
+    return PROFILE.wrap("attn_bwd", fl, f"b{b_} h{h} nq{nq} nk{k.shape[1]} causal{int(bool(kw.get('causal')))}",
+                        lambda: _attn_bwd_raw(q, k, v, o, d_o, lse, **kw))

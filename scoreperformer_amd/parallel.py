@@ -1,0 +1,117 @@
+"""Data-parallel gradient synchronisation over RCCL/xGMI (one process per GPU, `torch.distributed` backend "nccl").
+
+The reference is single-device; DP semantics = its own gradient-accumulation semantics per rank.
+Gradients live in ONE contiguous fp32 arena, so all-reduce works on contiguous buckets.  A bucket is launched
+(asynchronously, on RCCL's stream) as soon as every parameter in it has received its last gradient contribution of the
+backward pass, i.e. while the rest of backward is still running; the 1/world factor is folded into the optimizer kernel.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, arena, group=None, bucket_mb: float = 32.0):
+        self.arena, self.group = arena, group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.handles: List = []
+        self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
+        self.bucket_of = {}
+        self.pending: List[int] = []
+        if self.world == 1:
+            return
+        # buckets in REVERSE arena order (decoder parameters come last in the arena and first in backward)
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        bounds = list(zip(arena.offsets, arena.offsets[1:] + [arena.total]))
+        cur_end, cur_start, members, groups = None, None, [], []
+        for idx in reversed(range(len(bounds))):
+            s, e = bounds[idx]
+            if cur_end is None:
+                cur_end = e
+            members.append(idx)
+            cur_start = s
+            if cur_end - cur_start >= cap:
+                groups.append((cur_start, cur_end, members))
+                cur_end, members = None, []
+        if members:
+            groups.append((cur_start, cur_end, members))
+        for b, (s, e, mem) in enumerate(groups):
+            self.buckets.append((s, e))
+            for idx in mem:
+                self.bucket_of[idx] = b
+        self._install_hooks()
+
+    # every gradient producer calls p._spn_grad_pending() in forward and p._spn_grad_ready() once its contribution has
+    # been enqueued in backward (functional.py); parameters whose gradient arrives through autograd's own accumulation
+    # use a post-accumulate hook.
+    def _install_hooks(self):
+        self.counts = [0] * len(self.arena.param_list)
+        self.bucket_left = [0] * len(self.buckets)
+        for idx, p in enumerate(self.arena.param_list):
+            p._spn_grad_pending = (lambda i=idx: self._pending(i))
+            p._spn_grad_ready = (lambda i=idx: self._ready(i))
+            p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._autograd_ready(i))
+        for mod in self.arena.model.modules():
+            for attr in getattr(mod, "_spn_fuse_groups", {}) or {}:
+                fused = getattr(mod, attr, None)
+                if fused is not None and hasattr(fused, "_spn_parts"):
+                    idxs = [self._index_of(p) for p in fused._spn_parts]
+                    fused._spn_grad_pending = (lambda ii=idxs: [self._pending(i) for i in ii])
+                    fused._spn_grad_ready = (lambda ii=idxs: [self._ready(i) for i in ii])
+
+    def _index_of(self, p):
+        for i, q in enumerate(self.arena.param_list):
+            if q is p:
+                return i
+        raise KeyError
+
+    def _pending(self, i):
+        self.counts[i] += 1
+
+    def _ready(self, i):
+        self.counts[i] -= 1
+        if self.counts[i] == 0:
+            self._param_done(i)
+
+    def _autograd_ready(self, i):
+        # autograd accumulated a returned gradient into p.grad; such parameters are not counted in forward
+        if self.counts[i] == 0:
+            self._param_done(i)
+
+    def _param_done(self, i):
+        if i in self.done:
+            return
+        self.done.add(i)
+        b = self.bucket_of[i]
+        self.bucket_left[b] -= 1
+        if self.bucket_left[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        self.launched.add(b)
+        self.handles.append(dist.all_reduce(self.arena.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin_step(self):
+        if self.world == 1:
+            return
+        self.handles, self.done, self.launched = [], set(), set()
+        self.counts = [0] * len(self.arena.param_list)
+        left = [0] * len(self.buckets)
+        for i in range(len(self.arena.param_list)):
+            left[self.bucket_of[i]] += 1
+        self.bucket_left = left
+
+    def finish(self):
+        """After backward: reduce whatever has not been launched yet (parameters that got no gradient), wait for all."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if b not in self.launched:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
