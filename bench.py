@@ -78,6 +78,9 @@ def main():
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
     sync = GradSync(arena, dist.group.WORLD if dist is not None else None)
     batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
+    # segment-slot counts are known to the (host-side) input pipeline: pass them as python ints, no device read-back
+    model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in
+                                         (("bar_mean", "bars"), ("beat_mean", "beats"), ("onset_mean", "onsets"))}
     torch.manual_seed(4321 + rank)  # distinct MMD samples per rank
 
     def step():

@@ -33,8 +33,10 @@ struct GemmArgs {
     int lda, ldb, ldc, ldr;
     float alpha;
     int accumulate;           // C += (fp32 C only)
-    int batch;                // blockIdx.z
+    int batch;                // blockIdx.z (batched) ...
     long sA, sB, sC;          // batch strides in elements
+    int splitk;               // ... or, when > 1, blockIdx.z = K slice: partial products are atomically added into fp32 C
+    int kt_per_split;         // K tiles (of 64) per slice
 };
 
 // ---- LDS addressing -------------------------------------------------------------------------------------
@@ -112,8 +114,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const bf16_t* A = g.A + (long)blockIdx.z * g.sA;
-    const bf16_t* B = g.B + (long)blockIdx.z * g.sB;
+    const bool split = g.splitk > 1;
+    const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
+    const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -123,9 +126,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
     Stage<TA> sa;
     Stage<TB> sb;
-    const int nt = (g.K + BK - 1) / BK;
-    sa.load(A, g.lda, g.M, g.K, m0, 0, tid);
-    sb.load(B, g.ldb, g.N, g.K, n0, 0, tid);
+    const int nt_all = (g.K + BK - 1) / BK;
+    const int t_begin = split ? blockIdx.z * g.kt_per_split : 0;
+    const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
+    if (nt <= 0) return;
+    const int kbase = t_begin * BK;
+    sa.load(A, g.lda, g.M, g.K, m0, kbase, tid);
+    sb.load(B, g.ldb, g.N, g.K, n0, kbase, tid);
     sa.store(LDS_A(0), tid);
     sb.store(LDS_B(0), tid);
     __syncthreads();
@@ -133,8 +140,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            sa.load(A, g.lda, g.M, g.K, m0, (t + 1) * BK, tid);
-            sb.load(B, g.ldb, g.N, g.K, n0, (t + 1) * BK, tid);
+            sa.load(A, g.lda, g.M, g.K, m0, kbase + (t + 1) * BK, tid);
+            sb.load(B, g.ldb, g.N, g.K, n0, kbase + (t + 1) * BK, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -157,7 +164,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r -------------------
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (split ? 0 : (long)blockIdx.z * g.sC);
+    const bool lead = !split || blockIdx.z == 0;   // bias / residual are added by the first K slice only
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -170,11 +178,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 const int n = n0 + wn * 64 + 16 * j + (lane & 15);
                 if (n >= g.N) continue;
                 float v = acc[i][j][r] * g.alpha;
-                if (g.bias) v += g.bias[n];
+                if (g.bias && lead) v += g.bias[n];
                 v *= rs;
-                if (g.residual) v += g.residual[(long)m * g.ldr + n];
+                if (g.residual && lead) v += g.residual[(long)m * g.ldr + n];
                 OutT* dst = C + (long)m * g.ldc + n;
                 if constexpr (sizeof(OutT) == 4) {
+                    if (split) { atomicAdd(dst, v); continue; }
                     if (g.accumulate) v += *dst;
                     *dst = v;
                 } else {
@@ -186,8 +195,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 }
 
 template <bool TA, bool TB, typename OutT>
-int launch(const GemmArgs& g, hipStream_t stream) {
-    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.batch);
+int launch(GemmArgs g, hipStream_t stream) {
+    // split-K for the weight-gradient shapes (tiny M x N, contraction over all tokens): fill the chip with K slices
+    const int tiles = cdiv(g.N, BN) * cdiv(g.M, BM), nt = cdiv(g.K, BK);
+    g.splitk = 1; g.kt_per_split = nt;
+    if (sizeof(OutT) == 4 && g.batch == 1 && tiles < 384 && nt >= 32) {
+        int want = cdiv(768, tiles);
+        if (want > nt / 8) want = nt / 8;
+        if (want > 1) {
+            g.kt_per_split = cdiv(nt, want);
+            g.splitk = cdiv(nt, g.kt_per_split);
+            if (!g.accumulate) {   // slices add atomically: C must start from zero (stream-ordered memset)
+                if (g.ldc == g.N) hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, stream);
+                else hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream);
+            }
+        }
+    }
+    dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splitk > 1 ? g.splitk : g.batch);
     hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT>), grid, dim3(256), 4 * TILE_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

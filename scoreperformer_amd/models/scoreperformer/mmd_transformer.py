@@ -78,7 +78,7 @@ class HierLatentsFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, hidden, mask, hierarchical: bool, modes, segs, *wb):
+    def forward(ctx, hidden, mask, hierarchical: bool, modes, segs, seg_sizes, *wb):
         b, n, d = hidden.shape
         nl = len(modes)
         Ws, bs = wb[:nl], wb[nl:]
@@ -95,7 +95,7 @@ class HierLatentsFn(Function):
             if mode == EmbeddingAggregateModes.MEAN:   # masked mean over the sequence (mmd_transformer.py:325-327)
                 seg_a, S, seg_g = notmask, 2, zeros_seg
             elif mode in SEGMENT_MODES:
-                seg_a, S, seg_g = segs[i].contiguous(), n + 4, segs[i].contiguous()
+                seg_a, S, seg_g = segs[i].contiguous(), int(seg_sizes[i]), segs[i].contiguous()
             else:
                 raise NotImplementedError(f"aggregate_mode '{mode}' is not implemented")
             counts = ops.segment_count(seg_a, S)
@@ -147,7 +147,7 @@ class HierLatentsFn(Function):
                 dagg = torch.cat([dagg, torch.zeros_like(dagg)], dim=1)
             ops.segment_gather(dagg, seg_a, counts=counts, out=dwide[..., :d_in], accumulate=True)
         d_hidden = ops.cast(dwide[..., :d], torch.float32, rowmask=mask)
-        return (d_hidden, None, None, None, None, *dWs, *dbs)
+        return (d_hidden, None, None, None, None, None, *dWs, *dbs)
 
 
 class MMDTupleTransformer(TupleTransformer):
@@ -205,6 +205,8 @@ class MMDTupleTransformer(TupleTransformer):
         self.loss_weight = loss_weight
         self.pad_token_id, self.mask_token_id, self.sos_token_id, self.eos_token_id = 0, 1, 2, 3
         self._mask_bars = False
+        self.segment_bounds: Optional[Dict[str, int]] = None     # {aggregate_mode: max segment id + 1} from the input pipeline
+        self.static_segments = False                              # use n + 4 slots per level (no host read, more memory)
         self._z_override: Optional[List[Tensor]] = None          # test hook: inject the N(0, I) samples per level
         self._drop_override: Optional[List[Optional[Tensor]]] = None  # test hook: inject latent dropout masks
 
@@ -249,7 +251,19 @@ class MMDTupleTransformer(TupleTransformer):
         assert not self.deadpan_zero_latent or deadpan_mask is not None
 
         segs = [self._get_segments(m, bars=bars, beats=beats, onsets=onsets) for m in modes]
-        outs = HierLatentsFn.apply(hidden, mask.contiguous(), self.hierarchical, tuple(modes), tuple(segs),
+        # number of segment slots per level: `segments.max() + 1` (mmd_transformer.py:330).  The reference reads it back
+        # from the device on every forward; here it can be supplied by the input pipeline (`segment_bounds`, python ints
+        # per aggregate mode), else it costs ONE host read for all levels; `static_segments` uses the bound n + 4.
+        if self.segment_bounds is not None:
+            sizes = [int(self.segment_bounds[m]) if s is not None else 1 for m, s in zip(modes, segs)]
+        elif self.static_segments:
+            sizes = [n + 4 if s is not None else 1 for s in segs]
+        else:
+            live = [s for s in segs if s is not None]
+            mx = torch.stack([s.max() for s in live]).tolist() if live else []
+            it = iter(mx)
+            sizes = [int(next(it)) + 1 if s is not None else 1 for s in segs]
+        outs = HierLatentsFn.apply(hidden, mask.contiguous(), self.hierarchical, tuple(modes), tuple(segs), tuple(sizes),
                                    *[h.linear.weight for h in heads], *[h.linear.bias for h in heads])
         nl = len(modes)
         embeddings, lat_list, lmasks = outs[0], list(outs[1:1 + nl]), list(outs[1 + nl:])
