@@ -36,15 +36,14 @@ extern "C" void spn_set_error(const char* msg);
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                         // round to nearest even
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 round-to-nearest-even through the native type: hipcc emits v_cvt_pk_bf16_f32 (one VALU op per PAIR);
+// a hand-written integer RNE costs ~8 VALU ops and a divergent NaN branch per element.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

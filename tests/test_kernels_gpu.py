@@ -160,3 +160,51 @@ def test_attention_fwd_bwd(dev, mqa, causal, b, h, nq, nk):
     assert rel_err(dk, kr.grad) < 3e-2
     assert rel_err(dv, vr.grad) < 3e-2
     assert rel_err(dslope, sr.grad) < 3e-2
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("use_slopes,use_mask", [(True, False), (False, False), (True, True)])
+def test_attention_fast_paths_and_rescale(dev, causal, use_slopes, use_mask):
+    """Long rows exercise the mask-free LEFT/RIGHT tile classes; a spiked key forces the deferred-max rescale branch
+    (running max jumps by far more than 2^8 in the middle of a row)."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(17 + int(causal) + 2 * int(use_slopes) + 4 * int(use_mask))
+    b, h, n = 2, 4, 640
+    qkv = torch.randn(b, n, (h + 2) * 64, generator=g)
+    # spike: key 300 of batch 0 is strongly aligned with query 500 (and 100): raw score ~ 40 * 64 / 8
+    qkv[0, 300, h * 64:(h + 1) * 64] = 5.0
+    qkv[0, 500, :64] = 8.0
+    qkv[0, 100, :64] = 8.0
+    qkv = qkv.to(dev).bfloat16()
+    q = qkv[..., :h * 64].unflatten(-1, (h, 64))
+    k = qkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64))
+    v = qkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    kmask = None
+    if use_mask:
+        kmask = torch.ones(b, n, dtype=torch.bool)
+        kmask[1, 450:] = False
+        kmask[0, 130] = False
+        kmask = kmask.to(dev)
+    slopes = torch.tensor([0.5, 0.25, 0.05, 0.01], device=dev) if use_slopes else None
+    scale = 64 ** -0.5
+    d_o = torch.randn(b, n, h, 64, generator=g).to(dev).bfloat16()
+    qr, kr, vr = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    sr = slopes.clone().requires_grad_(True) if use_slopes else None
+    ref, ref_lse = attn_reference(qr, kr, vr, kmask, sr, causal, scale)
+    ref.backward(d_o.float())
+    o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=slopes, causal=causal, scale=scale)
+    assert torch.isfinite(o.float()).all()
+    assert rel_err(o, ref) < 2e-2
+    assert (lse - ref_lse).abs().max().item() < 2e-2
+    dqkv = torch.zeros_like(qkv)
+    dq = dqkv[..., :h * 64].unflatten(-1, (h, 64))
+    dk = dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64))
+    dv = dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    dslope = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=slopes, causal=causal, scale=scale,
+                          want_dslope=use_slopes)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel_err(dq, qr.grad) < 3e-2
+    assert rel_err(dk, kr.grad) < 3e-2
+    assert rel_err(dv, vr.grad) < 3e-2
+    if use_slopes:
+        assert rel_err(dslope, sr.grad) < 3e-2

@@ -1,0 +1,35 @@
+"""Micro-benchmark of the attention kernels at the C3 layer shape (b=64, h=8 MQA, n=2048, dh=64)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scoreperformer_amd import ops
+
+def main():
+    b, h, n = int(os.environ.get("B", 64)), 8, int(os.environ.get("N", 2048))
+    reps = int(os.environ.get("REPS", 5))
+    dev = torch.device("cuda")
+    qkv = torch.randn(b, n, (h + 2) * 64, device=dev).bfloat16()
+    q = qkv[..., :h * 64].unflatten(-1, (h, 64)); k = qkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); v = qkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(h)], device=dev)
+    d_o = torch.randn(b, n, h, 64, device=dev).bfloat16()
+    dqkv = torch.empty_like(qkv)
+    dq = dqkv[..., :h * 64].unflatten(-1, (h, 64)); dk = dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); dv = dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    for causal in (False, True):
+        fl = 4.0 * b * h * n * n * 64 * (0.5 if causal else 1.0)
+        o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal)
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / reps
+        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=True)
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - t0) / reps
+        print(f"causal={causal}: fwd {tf*1e3:.3f} ms {fl/tf/1e12:.0f} TF/s | bwd {tb*1e3:.3f} ms {2.5*fl/tb/1e12:.0f} TF/s (5-matmul flops)")
+
+main()
