@@ -23,136 +23,12 @@
 // wave's 32 query rows has a LINEAR ALiBi term, whose per-row part is folded into the running max, leaving
 // add + fma + max + sub + exp + add per score; masks are only evaluated on tiles that contain a masked key, the causal
 // diagonal or the sequence end; the O accumulator is rescaled only when a row maximum grows by more than 2^8.
-#include "common.h"
+#include "attention_common.h"
+
+namespace spn_attn { int launch_attn_dkv(const AttnArgs& a, hipStream_t stream); }
 
 namespace {
-
-constexpr float NEG_FILL = -1.7014118e38f;  // -finfo(float32).max // 2   (attend.py:102)
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
-constexpr float RESCALE_THR = 8.f;          // log2 units
-
-struct AttnArgs {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v;
-    bf16_t* o; float* lse;
-    const bf16_t* d_o; const float* delta;   // backward only
-    bf16_t* dq; bf16_t* dk; bf16_t* dv; float* dslope;
-    const uint8_t* kmask;   // [b, nk] or null
-    const float* slopes;    // [h] or null
-    int b, h, kvh, nq, nk, causal;
-    long q_bs, q_ns, q_hs;
-    long k_bs, k_ns, k_hs;
-    long v_bs, v_ns, v_hs;
-    long o_bs, o_ns, o_hs;     // o and d_o share strides
-    long dq_bs, dq_ns, dq_hs;
-    long dk_bs, dk_ns, dk_hs;
-    long dv_bs, dv_ns, dv_hs;
-    float scale;
-};
-
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 B) ------------------------------------------
-// "a" layout: chunk ^ (row & 7)           -> conflict-light ds_read_b128 of (row = lane&15, chunk = lane>>4)
-// "t" layout: chunk ^ (((row>>1)&3) << 1) -> the 8 rows touched by two lane groups of a transpose read fall
-//                                            into 8 distinct 32-byte windows
-__device__ __forceinline__ int a_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-__device__ __forceinline__ int t_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
-
-// A-operand fragment, rows = tile rows r_base + (lane&15), k = 32*ks + (lane>>4)*8 + e  (row-major "a" tile)
-__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int r_base, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + a_off(r_base + (lane & 15), ks * 4 + (lane >> 4)));
-}
-
-// A-operand fragment of the TRANSPOSED tile: rows = tile columns c_base + (lane&15); contraction index e of lane
-// group g enumerates tile rows  32*u + 16*(e>>2) + 4*g + (e&3)   ("t" tile) -- the same enumeration that the
-// C-layout registers of two stacked 16x16 blocks give when used as a B operand.
-__device__ __forceinline__ bf16x8 frag_cols_t(const char* tile, int c_base, int u, int lane) {
-    const int g = lane >> 4, p = lane & 15;
-    const int col_byte = (c_base + 4 * (p & 3)) * 2;
-    const int chunk = col_byte >> 4, within = col_byte & 15;
-    const int r0 = 32 * u + 4 * g + (p >> 2);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t_off(r0, chunk) + within));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t_off(r0 + 16, chunk) + within));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-
-__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
-    uint4 u;
-    u.x = pack_bf2(a[0], a[1]); u.y = pack_bf2(a[2], a[3]);
-    u.z = pack_bf2(b[0], b[1]); u.w = pack_bf2(b[2], b[3]);
-    return __builtin_bit_cast(bf16x8, u);
-}
-
-// global -> registers for a [64][64] tile: 512 chunks of 16 B, 2 per thread (256 threads)
-struct TileRegs {
-    uint4 r[2];
-    __device__ __forceinline__ void load(const bf16_t* base, long row_stride, int row0, int nrows, int tid) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row0 + row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * row_stride + ch * 8);
-            r[i] = v;
-        }
-    }
-    template <bool T>
-    __device__ __forceinline__ void store(char* tile, int tid) const {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
-            *reinterpret_cast<uint4*>(tile + (T ? t_off(row, ch) : a_off(row, ch))) = r[i];
-        }
-    }
-};
-
-__device__ __forceinline__ bf16x8 load_row_frag(const bf16_t* base, long row_stride, int row, int nrows, int ks, int lane) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)row * row_stride + ks * 32 + (lane >> 4) * 8);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same lane&15)
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    return v + __shfl_xor(v, 32, 64);
-}
-
-// Causal work per query tile grows linearly with its index, and consecutive blockIdx.x land on consecutive XCDs
-// (block id % 8): map x -> tile so that XCD k owns tiles {k, k+8, ...} of the first half and their mirror images of the
-// second half, i.e. every XCD gets the same total number of key tiles (a speed-only remap; any mapping is correct).
-__device__ __forceinline__ int qtile_of(int x, int n, int causal) {
-    if (!causal || n < 16 || (n & 15)) return x;
-    const int half = n >> 1;
-    return x < half ? x : (n - 1 - (x - half));
-}
-
-// Tile classes for a wave's block of query rows [i_lo, i_hi] (in key coordinates, i + nk - nq) against keys [j0, j0+63]:
-enum { T_GEN = 0, T_LEFT = 1, T_RIGHT = 2, T_SKIP = 3 };
-__device__ __forceinline__ int classify(int j0, int i_lo, int i_hi, bool full, bool causal) {
-    if (causal && j0 > i_hi) return T_SKIP;            // every key is in the future of every row of this wave
-    if (!full) return T_GEN;
-    if (j0 + 63 <= i_lo) return T_LEFT;                // all distances j - i <= 0: causal-clean, |d| = i - j
-    if (j0 >= i_hi && !causal) return T_RIGHT;         // all distances >= 0: |d| = j - i
-    return T_GEN;
-}
-
-// log2-domain scores of one (kb, qb) 16x16 block column for this lane.  Returns the value relative to the per-row offset u:
-//   LEFT : t = s*c1 + slope2*(j - i)  = [s*c1 + slope2*j] + u,  u = -slope2*i
-//   RIGHT: t = s*c1 - slope2*(j - i)  = [s*c1 - slope2*j] + u,  u = +slope2*i
-//   GEN  : t = s*c1 - slope2*|j - i| (u = 0), masked entries -> NEG_FILL
-template <int MODE>
-__device__ __forceinline__ float score(float s, float c1, float slope2, float sj, float jf, float i_f, bool ok) {
-    if (MODE == T_LEFT) return fmaf(s, c1, sj);
-    if (MODE == T_RIGHT) return fmaf(s, c1, -sj);
-    const float t = fmaf(-slope2, fabsf(jf - i_f), s * c1);
-    return ok ? t : NEG_FILL;
-}
+using namespace spn_attn;
 
 // ==========================================================================================================
 // forward: grid (ceil(nq/128), h, b), 256 threads; wave w owns query rows q0 + 32w .. +31
@@ -541,140 +417,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
-// ==========================================================================================================
-// dK, dV: grid (ceil(nk/64), kvh, b); wave w owns keys j0 + 16w .. +15; loops over the heads sharing this K/V head
-// ==========================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
-    char* q_tile = smem;               // "a": A operand of S
-    char* qt_tile = smem + 8192;       // "t": Q^T A operand of dK^T
-    char* do_tile = smem + 16384;      // "a": A operand of dP
-    char* dot_tile = smem + 24576;     // "t": dO^T A operand of dV^T
-    float* nl2_s = reinterpret_cast<float*>(smem + 32768);   // -lse * log2e per row (+inf-safe: 1e30 for rows >= nq)
-    float* dl_s = nl2_s + 64;
-
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bi = blockIdx.z, kh = blockIdx.y, j0 = blockIdx.x * 64;
-    const int off = a.nk - a.nq;
-    const int heads_per_kv = a.h / a.kvh;
-    const bf16_t* kp = a.k + bi * a.k_bs + kh * a.k_hs;
-    const bf16_t* vp = a.v + bi * a.v_bs + kh * a.v_hs;
-    const int j = j0 + 16 * w + c;  // this lane's key column
-    const bool key_ok = (j < a.nk) && (a.kmask ? a.kmask[(long)bi * a.nk + j] != 0 : true);
-    const float jf = (float)j;
-    const float c1 = a.scale * LOG2E;
-    // wave-uniform: are all 16 keys of this wave valid?
-    const bool keys_full = __all(key_ok);
-    const int jw_lo = j0 + 16 * w, jw_hi = jw_lo + 15;
-
-    bf16x8 kf[2], vf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = load_row_frag(kp, a.k_ns, j, a.nk, ks, lane);
-        vf[ks] = load_row_frag(vp, a.v_ns, j, a.nk, ks, lane);
-    }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int db = 0; db < 4; ++db) { dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    const int nqt = (a.nq + 63) / 64;
-    int t_first = 0;
-    if (a.causal) {  // query i sees key j iff j <= i + off  ->  first useful row i = j0 - off
-        const int i_min = j0 - off;
-        t_first = i_min <= 0 ? 0 : i_min / 64;
-    }
-    const int n_iter = (nqt - t_first) > 0 ? (nqt - t_first) * heads_per_kv : 0;
-
-    TileRegs qr, dor;
-    float lreg = 0.f, dreg = 0.f;
-    auto issue = [&](int it) {
-        const int hh = kh * heads_per_kv + it / (nqt - t_first);
-        const int i0 = (t_first + it % (nqt - t_first)) * 64;
-        qr.load(a.q + bi * a.q_bs + hh * a.q_hs, a.q_ns, i0, a.nq, tid);
-        dor.load(a.d_o + bi * a.o_bs + hh * a.o_hs, a.o_ns, i0, a.nq, tid);
-        if (tid < 64) {
-            const int i = i0 + tid;
-            const long si = ((long)bi * a.h + hh) * a.nq + i;
-            const float lse_i = i < a.nq ? a.lse[si] : NEG_FILL;
-            lreg = lse_i > -1e37f ? -lse_i * LOG2E : NEG_FILL;   // rows beyond nq / fully masked rows: p = exp2(t + NEG) = 0
-            dreg = i < a.nq ? a.delta[si] : 0.f;
-        }
-    };
-    if (n_iter > 0) issue(0);
-    for (int it = 0; it < n_iter; ++it) {
-        const int hh = kh * heads_per_kv + it / (nqt - t_first);
-        const int i0 = (t_first + it % (nqt - t_first)) * 64;
-        const float slope2 = a.slopes ? a.slopes[hh] * LOG2E : 0.f;
-        __syncthreads();
-        qr.store<false>(q_tile, tid);
-        qr.store<true>(qt_tile, tid);
-        dor.store<false>(do_tile, tid);
-        dor.store<true>(dot_tile, tid);
-        if (tid < 64) { nl2_s[tid] = lreg; dl_s[tid] = dreg; }
-        __syncthreads();
-        if (it + 1 < n_iter) issue(it + 1);
-
-        // tile class of this wave's 16 keys against the 64 rows (key coordinates i + off)
-        const int r_lo = i0 + off, r_hi = r_lo + 63;
-        int cls = T_GEN;
-        if (a.causal && jw_lo > r_hi) cls = T_SKIP;
-        else if (keys_full && jw_hi <= r_lo) cls = T_LEFT;              // j - i <= 0 everywhere
-        else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
-        if (cls == T_SKIP) continue;
-
-        f32x4 p[4], ds[4];
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_tile, 16 * qb, ks, lane), kf[ks], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_tile, 16 * qb, ks, lane), vf[ks], acc2, 0, 0, 0);
-            }
-            const f32x4 n4 = *reinterpret_cast<const f32x4*>(nl2_s + 16 * qb + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 16 * qb + 4 * g);
-            const float ib = (float)(i0 + off + 16 * qb + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float i_f = ib + (float)r;
-                float e;   // log2-domain score minus lse
-                if (cls == T_LEFT) e = fmaf(acc[r], c1, fmaf(slope2, jf - i_f, n4[r]));
-                else if (cls == T_RIGHT) e = fmaf(acc[r], c1, fmaf(-slope2, jf - i_f, n4[r]));
-                else {
-                    const bool ok = key_ok && (!a.causal || jf <= i_f);
-                    const float t = fmaf(-slope2, fabsf(jf - i_f), acc[r] * c1);
-                    e = (ok ? t : NEG_FILL) + n4[r];
-                }
-                const float pv = fast_exp2(e);
-                p[qb][r] = pv;
-                ds[qb][r] = pv * (acc2[r] - d4[r]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            bf16x8 pf = pack8(p[2 * u], p[2 * u + 1]);
-            bf16x8 dsf = pack8(ds[2 * u], ds[2 * u + 1]);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_t(dot_tile, 16 * db, u, lane), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols_t(qt_tile, 16 * db, u, lane), dsf, dk[db], 0, 0, 0);
-            }
-        }
-    }
-    if (j < a.nk) {
-        bf16_t* pk_ = a.dk + bi * a.dk_bs + (long)j * a.dk_ns + kh * a.dk_hs;
-        bf16_t* pv_ = a.dv + bi * a.dv_bs + (long)j * a.dv_ns + kh * a.dv_hs;
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            uint2 x, y;
-            x.x = pack_bf2(dk[db][0] * a.scale, dk[db][1] * a.scale); x.y = pack_bf2(dk[db][2] * a.scale, dk[db][3] * a.scale);
-            y.x = pack_bf2(dv[db][0], dv[db][1]); y.y = pack_bf2(dv[db][2], dv[db][3]);
-            *reinterpret_cast<uint2*>(pk_ + 16 * db + 4 * g) = x;
-            *reinterpret_cast<uint2*>(pv_ + 16 * db + 4 * g) = y;
-        }
-    }
-}
-
 int check_common(const AttnArgs& a) {
     SPN_REQUIRE(a.q && a.k && a.v, "spn_attn: null q/k/v");
     SPN_REQUIRE(a.b > 0 && a.h > 0 && a.nq > 0 && a.nk > 0, "spn_attn: empty problem");
@@ -737,7 +479,7 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE((((uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "spn_attn_bwd: o/dO must be 16-byte aligned");
     const long total = (long)b * nq * h;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, delta);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(nk, 64), kvh, b), dim3(256), 0, stream, a);
+    launch_attn_dkv(a, stream);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

@@ -1,0 +1,134 @@
+// Shared definitions of the attention kernels (see attention.hip for the design notes).
+#pragma once
+#include "common.h"
+
+namespace spn_attn {
+
+constexpr float NEG_FILL = -1.7014118e38f;  // -finfo(float32).max // 2   (attend.py:102)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float RESCALE_THR = 8.f;          // log2 units
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v;
+    bf16_t* o; float* lse;
+    const bf16_t* d_o; const float* delta;   // backward only
+    bf16_t* dq; bf16_t* dk; bf16_t* dv; float* dslope;
+    const uint8_t* kmask;   // [b, nk] or null
+    const float* slopes;    // [h] or null
+    int b, h, kvh, nq, nk, causal;
+    long q_bs, q_ns, q_hs;
+    long k_bs, k_ns, k_hs;
+    long v_bs, v_ns, v_hs;
+    long o_bs, o_ns, o_hs;     // o and d_o share strides
+    long dq_bs, dq_ns, dq_hs;
+    long dk_bs, dk_ns, dk_hs;
+    long dv_bs, dv_ns, dv_hs;
+    float scale;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// [64 rows][64 cols] bf16 tile (128-byte rows, 8 chunks of 16 B) ------------------------------------------
+// "a" layout: chunk ^ (row & 7)           -> conflict-light ds_read_b128 of (row = lane&15, chunk = lane>>4)
+// "t" layout: chunk ^ (((row>>1)&3) << 1) -> the 8 rows touched by two lane groups of a transpose read fall
+//                                            into 8 distinct 32-byte windows
+__device__ __forceinline__ int a_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int t_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
+
+// A-operand fragment, rows = tile rows r_base + (lane&15), k = 32*ks + (lane>>4)*8 + e  (row-major "a" tile)
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int r_base, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + a_off(r_base + (lane & 15), ks * 4 + (lane >> 4)));
+}
+
+// A-operand fragment of the TRANSPOSED tile: rows = tile columns c_base + (lane&15); contraction index e of lane
+// group g enumerates tile rows  32*u + 16*(e>>2) + 4*g + (e&3)   ("t" tile) -- the same enumeration that the
+// C-layout registers of two stacked 16x16 blocks give when used as a B operand.
+__device__ __forceinline__ bf16x8 frag_cols_t(const char* tile, int c_base, int u, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int col_byte = (c_base + 4 * (p & 3)) * 2;
+    const int chunk = col_byte >> 4, within = col_byte & 15;
+    const int r0 = 32 * u + 4 * g + (p >> 2);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t_off(r0, chunk) + within));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + t_off(r0 + 16, chunk) + within));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    uint4 u;
+    u.x = pack_bf2(a[0], a[1]); u.y = pack_bf2(a[2], a[3]);
+    u.z = pack_bf2(b[0], b[1]); u.w = pack_bf2(b[2], b[3]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// global -> registers for a [64][64] tile: 512 chunks of 16 B, 2 per thread (256 threads)
+struct TileRegs {
+    uint4 r[2];
+    __device__ __forceinline__ void load(const bf16_t* base, long row_stride, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row0 + row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * row_stride + ch * 8);
+            r[i] = v;
+        }
+    }
+    template <bool T>
+    __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            *reinterpret_cast<uint4*>(tile + (T ? t_off(row, ch) : a_off(row, ch))) = r[i];
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 load_row_frag(const bf16_t* base, long row_stride, int row, int nrows, int ks, int lane) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nrows) v = *reinterpret_cast<const uint4*>(base + (long)row * row_stride + ks * 32 + (lane >> 4) * 8);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same lane&15)
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// Causal work per query tile grows linearly with its index, and consecutive blockIdx.x land on consecutive XCDs
+// (block id % 8): map x -> tile so that XCD k owns tiles {k, k+8, ...} of the first half and their mirror images of the
+// second half, i.e. every XCD gets the same total number of key tiles (a speed-only remap; any mapping is correct).
+__device__ __forceinline__ int qtile_of(int x, int n, int causal) {
+    if (!causal || n < 16 || (n & 15)) return x;
+    const int half = n >> 1;
+    return x < half ? x : (n - 1 - (x - half));
+}
+
+// Tile classes for a wave's block of query rows [i_lo, i_hi] (in key coordinates, i + nk - nq) against keys [j0, j0+63]:
+enum { T_GEN = 0, T_LEFT = 1, T_RIGHT = 2, T_SKIP = 3 };
+__device__ __forceinline__ int classify(int j0, int i_lo, int i_hi, bool full, bool causal) {
+    if (causal && j0 > i_hi) return T_SKIP;            // every key is in the future of every row of this wave
+    if (!full) return T_GEN;
+    if (j0 + 63 <= i_lo) return T_LEFT;                // all distances j - i <= 0: causal-clean, |d| = i - j
+    if (j0 >= i_hi && !causal) return T_RIGHT;         // all distances >= 0: |d| = j - i
+    return T_GEN;
+}
+
+// log2-domain scores of one (kb, qb) 16x16 block column for this lane.  Returns the value relative to the per-row offset u:
+//   LEFT : t = s*c1 + slope2*(j - i)  = [s*c1 + slope2*j] + u,  u = -slope2*i
+//   RIGHT: t = s*c1 - slope2*(j - i)  = [s*c1 - slope2*j] + u,  u = +slope2*i
+//   GEN  : t = s*c1 - slope2*|j - i| (u = 0), masked entries -> NEG_FILL
+template <int MODE>
+__device__ __forceinline__ float score(float s, float c1, float slope2, float sj, float jf, float i_f, bool ok) {
+    if (MODE == T_LEFT) return fmaf(s, c1, sj);
+    if (MODE == T_RIGHT) return fmaf(s, c1, -sj);
+    const float t = fmaf(-slope2, fabsf(jf - i_f), s * c1);
+    return ok ? t : NEG_FILL;
+}
+
+}  // namespace spn_attn

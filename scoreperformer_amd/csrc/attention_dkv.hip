@@ -1,0 +1,180 @@
+// dK / dV of the fused attention (see attention.hip).  grid (ceil(nk/128), kv_heads, b), 256 threads.
+// Wave w owns 32 keys (two 16-key blocks) j0 + 32w .. +31 and loops over all query tiles of all heads that share its K/V head
+// (multi-query attention: 8 heads), so dK/dV are reduced over heads in registers, without atomics.
+// Orientation S = Q K^T (lane = one key column): P and dS in C-layout are the B operands of dV^T = dO^T P and dK^T = Q^T dS.
+// 32 keys per wave halve the LDS fragment traffic per MFMA relative to 16 (each Q / dO fragment feeds two key blocks).
+#include "attention_common.h"
+
+namespace spn_attn {
+namespace {
+
+template <int CLS>
+__device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile, const char* do_tile, const char* dot_tile,
+                                         const float* nl2_s, const float* dl_s, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
+                                         f32x4 (&dk)[4][2], f32x4 (&dv)[4][2], const float (&jf)[2], const bool (&key_ok)[2],
+                                         int ioff, float c1, float slope2, bool causal, int lane, int g) {
+#pragma unroll
+for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
+        f32x4 p[2][2], ds[2][2];                // [qq][kb]
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int qb = 2 * u + qq;
+            const bf16x8 qa0 = frag_rows(q_tile, 16 * qb, 0, lane), qa1 = frag_rows(q_tile, 16 * qb, 1, lane);
+            const bf16x8 da0 = frag_rows(do_tile, 16 * qb, 0, lane), da1 = frag_rows(do_tile, 16 * qb, 1, lane);
+            const f32x4 n4 = *reinterpret_cast<const f32x4*>(nl2_s + 16 * qb + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 16 * qb + 4 * g);
+            const float ib = (float)(ioff + 16 * qb + 4 * g);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[kb][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[kb][1], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da0, vf[kb][0], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da1, vf[kb][1], acc2, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float i_f = ib + (float)r;
+                    float e;   // log2-domain score minus lse
+                    if (CLS == T_LEFT) e = fmaf(acc[r], c1, fmaf(slope2, jf[kb] - i_f, n4[r]));
+                    else if (CLS == T_RIGHT) e = fmaf(acc[r], c1, fmaf(-slope2, jf[kb] - i_f, n4[r]));
+                    else {
+                        const bool ok = key_ok[kb] && (!causal || jf[kb] <= i_f);
+                        const float t = fmaf(-slope2, fabsf(jf[kb] - i_f), acc[r] * c1);
+                        e = (ok ? t : NEG_FILL) + n4[r];
+                    }
+                    const float pv = fast_exp2(e);
+                    p[qq][kb][r] = pv;
+                    ds[qq][kb][r] = pv * (acc2[r] - d4[r]);
+                }
+            }
+        }
+        bf16x8 pf[2], dsf[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { pf[kb] = pack8(p[0][kb], p[1][kb]); dsf[kb] = pack8(ds[0][kb], ds[1][kb]); }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16x8 dot = frag_cols_t(dot_tile, 16 * db, u, lane);
+            const bf16x8 qt = frag_cols_t(qt_tile, 16 * db, u, lane);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                dv[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[kb], dv[db][kb], 0, 0, 0);
+                dk[db][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[kb], dk[db][kb], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
+    char* q_tile = smem;               // "a": A operand of S
+    char* qt_tile = smem + 8192;       // "t": Q^T A operand of dK^T
+    char* do_tile = smem + 16384;      // "a": A operand of dP
+    char* dot_tile = smem + 24576;     // "t": dO^T A operand of dV^T
+    float* nl2_s = reinterpret_cast<float*>(smem + 32768);   // -lse * log2e per row (NEG_FILL for dead rows: p = 0)
+    float* dl_s = nl2_s + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int bi = blockIdx.z, kh = blockIdx.y, j0 = blockIdx.x * 128;
+    const int off = a.nk - a.nq;
+    const int heads_per_kv = a.h / a.kvh;
+    const bf16_t* kp = a.k + bi * a.k_bs + kh * a.k_hs;
+    const bf16_t* vp = a.v + bi * a.v_bs + kh * a.v_hs;
+    const float c1 = a.scale * LOG2E;
+    int jcol[2];
+    float jf[2];
+    bool key_ok[2];
+    bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        jcol[kb] = j0 + 32 * w + 16 * kb + c;
+        jf[kb] = (float)jcol[kb];
+        key_ok[kb] = (jcol[kb] < a.nk) && (a.kmask ? a.kmask[(long)bi * a.nk + jcol[kb]] != 0 : true);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[kb][ks] = load_row_frag(kp, a.k_ns, jcol[kb], a.nk, ks, lane);
+            vf[kb][ks] = load_row_frag(vp, a.v_ns, jcol[kb], a.nk, ks, lane);
+        }
+    }
+    const bool keys_full = __all(key_ok[0] && key_ok[1]);
+    const int jw_lo = j0 + 32 * w, jw_hi = jw_lo + 31;
+
+    f32x4 dk[4][2], dv[4][2];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nqt = (a.nq + 63) / 64;
+    int t_first = 0;
+    if (a.causal) {  // query i sees key j iff j <= i + off  ->  first useful row i = j0 - off
+        const int i_min = j0 - off;
+        t_first = i_min <= 0 ? 0 : i_min / 64;
+    }
+    const int n_iter = (nqt - t_first) > 0 ? (nqt - t_first) * heads_per_kv : 0;
+
+    TileRegs qr, dor;
+    float lreg = 0.f, dreg = 0.f;
+    auto issue = [&](int it) {
+        const int hh = kh * heads_per_kv + it / (nqt - t_first);
+        const int i0 = (t_first + it % (nqt - t_first)) * 64;
+        qr.load(a.q + bi * a.q_bs + hh * a.q_hs, a.q_ns, i0, a.nq, tid);
+        dor.load(a.d_o + bi * a.o_bs + hh * a.o_hs, a.o_ns, i0, a.nq, tid);
+        if (tid < 64) {
+            const int i = i0 + tid;
+            const long si = ((long)bi * a.h + hh) * a.nq + i;
+            const float lse_i = i < a.nq ? a.lse[si] : NEG_FILL;
+            lreg = lse_i > -1e37f ? -lse_i * LOG2E : NEG_FILL;   // rows beyond nq / fully masked rows: p = exp2(t + NEG) = 0
+            dreg = i < a.nq ? a.delta[si] : 0.f;
+        }
+    };
+    if (n_iter > 0) issue(0);
+    for (int it = 0; it < n_iter; ++it) {
+        const int hh = kh * heads_per_kv + it / (nqt - t_first);
+        const int i0 = (t_first + it % (nqt - t_first)) * 64;
+        const float slope2 = a.slopes ? a.slopes[hh] * LOG2E : 0.f;
+        __syncthreads();
+        qr.store<false>(q_tile, tid);
+        qr.store<true>(qt_tile, tid);
+        dor.store<false>(do_tile, tid);
+        dor.store<true>(dot_tile, tid);
+        if (tid < 64) { nl2_s[tid] = lreg; dl_s[tid] = dreg; }
+        __syncthreads();
+        if (it + 1 < n_iter) issue(it + 1);
+
+        // tile class of this wave's 32 keys against the 64 rows (key coordinates i + off)
+        const int r_lo = i0 + off, r_hi = r_lo + 63;
+        int cls = T_GEN;
+        if (a.causal && jw_lo > r_hi) cls = T_SKIP;
+        else if (keys_full && jw_hi <= r_lo) cls = T_LEFT;              // j - i <= 0 everywhere
+        else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
+        if (cls == T_SKIP) continue;
+
+        if (cls == T_LEFT) dkv_tile<T_LEFT>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
+        else if (cls == T_RIGHT) dkv_tile<T_RIGHT>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
+        else dkv_tile<T_GEN>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (jcol[kb] >= a.nk) continue;
+        bf16_t* pk_ = a.dk + bi * a.dk_bs + (long)jcol[kb] * a.dk_ns + kh * a.dk_hs;
+        bf16_t* pv_ = a.dv + bi * a.dv_bs + (long)jcol[kb] * a.dv_ns + kh * a.dv_hs;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 x, y;
+            x.x = pack_bf2(dk[db][kb][0] * a.scale, dk[db][kb][1] * a.scale);
+            x.y = pack_bf2(dk[db][kb][2] * a.scale, dk[db][kb][3] * a.scale);
+            y.x = pack_bf2(dv[db][kb][0], dv[db][kb][1]); y.y = pack_bf2(dv[db][kb][2], dv[db][kb][3]);
+            *reinterpret_cast<uint2*>(pk_ + 16 * db + 4 * g) = x;
+            *reinterpret_cast<uint2*>(pv_ + 16 * db + 4 * g) = y;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_attn_dkv(const AttnArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
+    return 0;
+}
+
+}  // namespace spn_attn

@@ -14,13 +14,17 @@
 // operand ever needs a transposed copy in HBM.
 //
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
-// Global->register->LDS double buffering: tile t+1 is in flight in registers while tile t is multiplied.
+// Staging: interior tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
+// round trip and no ds_write, whose ~80 B/clk/CU is the first thing a register-staged 128^2 GEMM saturates).  The DMA writes
+// LDS linearly (wave base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE address.  Tiles that touch an M/N/K
+// edge take the register path with zero fill.  Two LDS stages: tile t+1 streams in while tile t is multiplied.
+// The MFMA is issued with operands swapped (D^T = B^T.A^T), which leaves each lane with 4 CONSECUTIVE output columns of one
+// row: the epilogue stores 8/16 bytes per lane instead of scattered 2/4-byte elements.
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, 16 KiB
+constexpr int BM = 128, BN = 128;   // BK = 64 (long K) or 32 (short K: smaller LDS footprint -> more resident blocks)
 
 struct GemmArgs {
     const bf16_t* A;
@@ -41,26 +45,53 @@ struct GemmArgs {
 
 // ---- LDS addressing -------------------------------------------------------------------------------------
 // K-contiguous tile: [128 rows][64 k] bf16, row = 128 B = 8 chunks of 16 B, chunk index XOR (row & 7).
-__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+template <int BK>
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & (BK / 8 - 1))) << 4); }
 // R-contiguous tile: [64 k][128 r] bf16, row = 256 B = 16 chunks; swizzle spreads the 4 k-rows of one
 // transpose-read (and the neighbouring lane group's 4 rows) over distinct 32-byte windows.
 __device__ __forceinline__ int rc_swz(int krow) { return (((krow & 3) | (((krow >> 3) & 1) << 2)) << 1); }
 __device__ __forceinline__ int rc_off(int krow, int chunk) { return krow * 256 + ((chunk ^ rc_swz(krow)) << 4); }
 
-template <bool T>
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// interior tile: 4 DMA instructions per wave; LDS chunk L = (wave*4+i)*64 + lane, source = inverse-swizzled global chunk
+template <bool T, int BK>
+__device__ __forceinline__ void dma_tile(const bf16_t* __restrict__ p, int ld, int row0, int k0, char* lds_tile, int wave, int lane) {
+    constexpr int PER_WAVE = BK / 16;   // 1 KiB pieces per wave: tile = 128*BK*2 bytes = BK/4 KiB over 4 waves
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int L = (wave * PER_WAVE + i) * 64 + lane;
+        const bf16_t* src;
+        if (!T) {
+            constexpr int CH = BK / 8;
+            const int row = L / CH, kc = (L % CH) ^ (row & (CH - 1));
+            src = p + (long)(row0 + row) * ld + k0 + kc * 8;
+        } else {
+            const int krow = L >> 4, rc = (L & 15) ^ rc_swz(krow);
+            src = p + (long)(k0 + krow) * ld + row0 + rc * 8;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + (wave * PER_WAVE + i) * 1024), 16, 0, 0);
+    }
+}
+
+// edge tile: registers with zero fill
+template <bool T, int BK>
 struct Stage {
-    uint4 r[4];
-    // operand tile origin: row0 = first m (or n) of the tile, k0 = first k
+    static constexpr int NR = BK / 16;   // 16-byte chunks per thread
+    uint4 r[NR];
     __device__ __forceinline__ void load(const bf16_t* __restrict__ p, int ld, int R, int K, int row0, int k0, int tid) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             uint4 v = make_uint4(0, 0, 0, 0);
+            const int c = tid + 256 * i;
             if (!T) {
-                const int row = (tid >> 3) + 32 * i, kc = tid & 7;
+                constexpr int CH = BK / 8;
+                const int row = c / CH, kc = c % CH;
                 const int gr = row0 + row, gk = k0 + kc * 8;
                 if (gr < R && gk < K) v = *reinterpret_cast<const uint4*>(p + (long)gr * ld + gk);
             } else {
-                const int krow = (tid >> 4) + 16 * i, rc = tid & 15;
+                const int krow = c >> 4, rc = c & 15;
                 const int gk = k0 + krow, gr = row0 + rc * 8;
                 if (gk < K && gr < R) v = *reinterpret_cast<const uint4*>(p + (long)gk * ld + gr);
             }
@@ -69,14 +100,14 @@ struct Stage {
     }
     __device__ __forceinline__ void store(char* lds, int tid) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
+            const int c = tid + 256 * i;
             int off;
             if (!T) {
-                const int row = (tid >> 3) + 32 * i, kc = tid & 7;
-                off = kc_off(row, kc);
+                constexpr int CH = BK / 8;
+                off = kc_off<BK>(c / CH, c % CH);
             } else {
-                const int krow = (tid >> 4) + 16 * i, rc = tid & 15;
-                off = rc_off(krow, rc);
+                off = rc_off(c >> 4, c & 15);
             }
             *reinterpret_cast<uint4*>(lds + off) = r[i];
         }
@@ -84,12 +115,12 @@ struct Stage {
 };
 
 // fragment for 16 rows starting at r_base, k-step ks (32 k each): lane l holds row r_base+(l&15), k = 32ks+(l>>4)*8+0..7
-template <bool T>
+template <bool T, int BK>
 __device__ __forceinline__ bf16x8 read_frag(const char* lds, int r_base, int ks, int lane) {
     if (!T) {
         const int row = r_base + (lane & 15);
         const int chunk = ks * 4 + (lane >> 4);
-        return *reinterpret_cast<const bf16x8*>(lds + kc_off(row, chunk));
+        return *reinterpret_cast<const bf16x8*>(lds + kc_off<BK>(row, chunk));
     } else {
         typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
         const int g = lane >> 4, p = lane & 15;
@@ -104,98 +135,139 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int r_base, int ks,
     }
 }
 
-template <bool TA, bool TB, typename OutT>
+template <bool TA, bool TB, typename OutT, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int TILE_BYTES = 128 * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // stage s: A tile at smem + s*2*TILE_BYTES, B tile right behind it
 #define LDS_A(s_) (smem + (s_) * 2 * TILE_BYTES)
 #define LDS_B(s_) (smem + (s_) * 2 * TILE_BYTES + TILE_BYTES)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order (speed only): workgroup id b runs on XCD b % 8, each with a private L2.  Re-number so that every
+    // XCD walks a CONTIGUOUS range of (m-tile, n-tile) pairs, n fastest: the n-tiles that share an A panel hit the same L2
+    // instead of fetching the panel once per XCD.  Bijective for any grid size.
+    int m0, n0;
+    {
+        const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        m0 = (wg / gridDim.x) * BM;
+        n0 = (wg % gridDim.x) * BN;
+    }
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
     const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4];   // acc[i][j]: rows (of C) m = 16i + (lane&15), cols n = 16j + (lane>>4)*4 + r   (swapped-operand layout)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Stage<TA> sa;
-    Stage<TB> sb;
     const int nt_all = (g.K + BK - 1) / BK;
     const int t_begin = split ? blockIdx.z * g.kt_per_split : 0;
     const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
     if (nt <= 0) return;
     const int kbase = t_begin * BK;
-    sa.load(A, g.lda, g.M, g.K, m0, kbase, tid);
-    sb.load(B, g.ldb, g.N, g.K, n0, kbase, tid);
-    sa.store(LDS_A(0), tid);
-    sb.store(LDS_B(0), tid);
+    const bool mn_interior = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+
+    Stage<TA, BK> sa;
+    Stage<TB, BK> sb;
+    auto stage_in = [&](int t, int buf) {   // bring K tile t (relative to kbase) into LDS stage buf
+        const int k0 = kbase + t * BK;
+        if (mn_interior && k0 + BK <= g.K) {
+            dma_tile<TA, BK>(A, g.lda, m0, k0, LDS_A(buf), wave, lane);
+            dma_tile<TB, BK>(B, g.ldb, n0, k0, LDS_B(buf), wave, lane);
+        } else {
+            sa.load(A, g.lda, g.M, g.K, m0, k0, tid);
+            sb.load(B, g.ldb, g.N, g.K, n0, k0, tid);
+            sa.store(LDS_A(buf), tid);
+            sb.store(LDS_B(buf), tid);
+        }
+    };
+    stage_in(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nt) {
-            sa.load(A, g.lda, g.M, g.K, m0, kbase + (t + 1) * BK, tid);
-            sb.load(B, g.ldb, g.N, g.K, n0, kbase + (t + 1) * BK, tid);
-        }
+        if (t + 1 < nt) stage_in(t + 1, cur ^ 1);   // stage cur^1 was last read in iteration t-1 (barrier passed)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA>(LDS_A(cur), wm * 64 + 16 * i, ks, lane);
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<TA, BK>(LDS_A(cur), wm * 64 + 16 * i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB>(LDS_B(cur), wn * 64 + 16 * j, ks, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<TB, BK>(LDS_B(cur), wn * 64 + 16 * j, ks, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nt) {
-            sa.store(LDS_A(cur ^ 1), tid);
-            sb.store(LDS_B(cur ^ 1), tid);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r -------------------
+    // ---- epilogue: lane owns row m = ..+(lane&15) and 4 consecutive columns n = ..+(lane>>4)*4 + 0..3 ----------
     OutT* C = reinterpret_cast<OutT*>(g.C) + (split ? 0 : (long)blockIdx.z * g.sC);
     const bool lead = !split || blockIdx.z == 0;   // bias / residual are added by the first K slice only
+    const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (!g.residual || g.ldr % 4 == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+        if (m >= g.M) continue;
+        const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 64 + 16 * i + (lane >> 4) * 4 + r;
-            if (m >= g.M) continue;
-            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + (lane >> 4) * 4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[i][j] * g.alpha;
+            const bool full4 = n + 4 <= g.N;
+            if (g.bias && lead) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + 16 * j + (lane & 15);
-                if (n >= g.N) continue;
-                float v = acc[i][j][r] * g.alpha;
-                if (g.bias && lead) v += g.bias[n];
-                v *= rs;
-                if (g.residual && lead) v += g.residual[(long)m * g.ldr + n];
-                OutT* dst = C + (long)m * g.ldc + n;
+                for (int r = 0; r < 4; ++r) if (n + r < g.N) v[r] += g.bias[n + r];
+            }
+            v *= rs;
+            OutT* dst = C + (long)m * g.ldc + n;
+            if (full4 && vec_ok) {
+                if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
                 if constexpr (sizeof(OutT) == 4) {
-                    if (split) { atomicAdd(dst, v); continue; }
-                    if (g.accumulate) v += *dst;
-                    *dst = v;
+                    if (split) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                    } else {
+                        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
                 } else {
-                    *dst = f2bf(v);
+                    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= g.N) continue;
+                    float x = v[r];
+                    if (g.residual && lead) x += g.residual[(long)m * g.ldr + n + r];
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (split) { atomicAdd(dst + r, x); continue; }
+                        if (g.accumulate) x += dst[r];
+                        dst[r] = x;
+                    } else {
+                        dst[r] = f2bf(x);
+                    }
                 }
             }
         }
     }
 }
 
-template <bool TA, bool TB, typename OutT>
-int launch(GemmArgs g, hipStream_t stream) {
+template <bool TA, bool TB, typename OutT, int BK>
+int launch_bk(GemmArgs g, hipStream_t stream) {
     // split-K for the weight-gradient shapes (tiny M x N, contraction over all tokens): fill the chip with K slices
     const int tiles = cdiv(g.N, BN) * cdiv(g.M, BM), nt = cdiv(g.K, BK);
     g.splitk = 1; g.kt_per_split = nt;
@@ -212,9 +284,17 @@ int launch(GemmArgs g, hipStream_t stream) {
         }
     }
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splitk > 1 ? g.splitk : g.batch);
-    hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT>), grid, dim3(256), 4 * TILE_BYTES, stream, g);
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK>), grid, dim3(256), 4 * 128 * BK * 2, stream, g);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
+}
+
+template <bool TA, bool TB, typename OutT>
+int launch(const GemmArgs& g, hipStream_t stream) {
+    // short contractions (K <= 1024: every projection with d_model = 512 on the input side) are latency-bound per block:
+    // BK = 32 halves the LDS footprint (32 KiB) so that 4 blocks stay resident per CU and hide each other's pipeline fill
+    if (g.K <= 1024) return launch_bk<TA, TB, OutT, 32>(g, stream);
+    return launch_bk<TA, TB, OutT, 64>(g, stream);
 }
 
 }  // namespace
