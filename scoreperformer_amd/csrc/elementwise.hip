@@ -132,6 +132,36 @@ __global__ void colsum_kernel(const TS* __restrict__ x, long ldx, float* __restr
     if (rg == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// bf16, N % 8 == 0, 16-byte aligned rows: each lane streams 8 columns (16 B) per row; block = 32 column groups x 8 row groups
+__global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ out, long T, int N,
+                                                            int rows_per_block) {
+    __shared__ float red[8][32][9];
+    const int cg = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int col = (blockIdx.x * 32 + cg) * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(T, r0 + rows_per_block);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < N)
+        for (long t = r0 + rg; t < r1; t += 8) {
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(x + t * ldx + col), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rg][cg][e] = acc[e];
+    __syncthreads();
+    const int c2 = threadIdx.x;          // 256 threads = 32 groups x 8 columns
+    const int g2 = c2 >> 3, e2 = c2 & 7;
+    const int ocol = (blockIdx.x * 32 + g2) * 8 + e2;
+    if (ocol < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += red[r][g2][e2];
+        atomicAdd(out + ocol, s);
+    }
+}
+
 __global__ void mish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = x[i];
@@ -224,6 +254,12 @@ extern "C" int spn_colsum(const void* x, int x_dtype, long ldx, float* out, long
     if (slabs > 512) slabs = 512;
     const int rpb = (int)((T + slabs - 1) / slabs);
     dim3 grid(cdiv(N, 64), cdiv(T, rpb));
+    if (x_dtype == 1 && N % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0) {
+        int rpb8 = ((rpb + 7) / 8) * 8;
+        hipLaunchKernelGGL(colsum_bf16x8_kernel, dim3(cdiv(N, 256), cdiv(T, rpb8)), dim3(256), 0, s, (const bf16_t*)x, ldx, out, T, N, rpb8);
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
     if (x_dtype == 0) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, out, T, N, rpb);
     else hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, T, N, rpb);
     SPN_LAUNCH_CHECK();

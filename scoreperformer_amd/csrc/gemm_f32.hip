@@ -4,6 +4,8 @@
 //   (modules/transformer/embeddings.py:202-213) and their backward contractions.
 // Arbitrary element strides:  A(m,k) = a[m*sam + k*sak],  B(k,n) = b[k*sbk + n*sbn],  C[m*ldc + n].
 // C = alpha * A.B + bias[n] (+ C if accumulate).  No alignment requirements.
+// Weight-gradient shapes (a handful of output tiles, contraction over every segment of the batch) are split along K
+// over blockIdx.z and reduced with fp32 atomics, otherwise 9 workgroups would walk 60k rows serially.
 #include "common.h"
 
 namespace {
@@ -13,25 +15,27 @@ constexpr int TM = 64, TN = 64, TK = 16;
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ a, long sam, long sak, const float* __restrict__ b,
                                                        long sbk, long sbn, float* __restrict__ c, long ldc,
                                                        const float* __restrict__ bias, int M, int N, int K, float alpha,
-                                                       int accumulate, const uint8_t* __restrict__ rowmask) {
+                                                       int accumulate, const uint8_t* __restrict__ rowmask, int k_per_split) {
     __shared__ float As[TK][TM + 4];
     __shared__ float Bs[TK][TN + 4];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const bool split = gridDim.z > 1;
+    const int k_begin = blockIdx.z * k_per_split, k_end = min(K, k_begin + k_per_split);
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += TK) {
+    for (int k0 = k_begin; k0 < k_end; k0 += TK) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i;        // 1024 elements per tile
-            {   // A tile: element (m = e % 64, k = e / 64) when A is m-contiguous friendly, else (m = e / 16, k = e % 16)
+            {   // walk the contiguous dimension of each operand with consecutive threads
                 const int m = (sam == 1) ? (e & 63) : (e >> 4), k = (sam == 1) ? (e >> 6) : (e & 15);
                 const int gm = m0 + m, gk = k0 + k;
-                As[k][m] = (gm < M && gk < K) ? a[gm * sam + gk * sak] : 0.f;
+                As[k][m] = (gm < M && gk < k_end) ? a[gm * sam + gk * sak] : 0.f;
             }
             {
                 const int n = (sbn == 1) ? (e & 63) : (e >> 4), k = (sbn == 1) ? (e >> 6) : (e & 15);
                 const int gn = n0 + n, gk = k0 + k;
-                Bs[k][n] = (gn < N && gk < K) ? b[gk * sbk + gn * sbn] : 0.f;
+                Bs[k][n] = (gn < N && gk < k_end) ? b[gk * sbk + gn * sbn] : 0.f;
             }
         }
         __syncthreads();
@@ -47,6 +51,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
         __syncthreads();
     }
+    const bool lead = blockIdx.z == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + ty * 4 + i;
@@ -56,8 +61,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tx * 4 + j;
             if (n >= N) continue;
-            float v = acc[i][j] * alpha + (bias ? bias[n] : 0.f);
+            float v = acc[i][j] * alpha + ((bias && lead) ? bias[n] : 0.f);
             v *= rs;
+            if (split) { atomicAdd(c + m * ldc + n, v); continue; }
             if (accumulate) v += c[m * ldc + n];
             c[m * ldc + n] = v;
         }
@@ -70,9 +76,23 @@ extern "C" int spn_gemm_f32(const float* a, long sam, long sak, const float* b, 
                             const float* bias, const uint8_t* rowmask, int M, int N, int K, float alpha, int accumulate,
                             hipStream_t stream) {
     SPN_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "spn_gemm_f32: bad arguments");
-    dim3 grid(cdiv(N, TN), cdiv(M, TM));
+    const int tiles = cdiv(N, TN) * cdiv(M, TM);
+    int splits = 1, k_per = K;
+    if (tiles < 128 && K >= 2048) {
+        splits = cdiv(512, tiles);
+        if (splits > K / 256) splits = K / 256;
+        if (splits > 1) {
+            k_per = cdiv(cdiv(K, splits), TK) * TK;
+            splits = cdiv(K, k_per);
+            if (!accumulate) {
+                if (ldc == N) hipMemsetAsync(c, 0, (size_t)M * N * 4, stream);
+                else hipMemset2DAsync(c, (size_t)ldc * 4, 0, (size_t)N * 4, M, stream);
+            }
+        } else { splits = 1; k_per = K; }
+    }
+    dim3 grid(cdiv(N, TN), cdiv(M, TM), splits);
     hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, a, sam, sak, b, sbk, sbn, c, ldc, bias, M, N, K, alpha,
-                       accumulate, rowmask);
+                       accumulate, rowmask, k_per);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -101,15 +101,17 @@ __global__ void seg_count_kernel(const long* __restrict__ seg, float* __restrict
 template <typename TX>
 __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, const long* __restrict__ seg,
                                const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out,
-                               int t, int S, int d) {
+                               int t, int S, int d, int t_chunk) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (c >= d) return;
     const TX* xb = x + (long)b * x_bs;
     const long* sb = seg + (long)b * t;
-    float acc = 0.f;
-    long cur = sb[0];
-    for (int i = 0; i < t; ++i) {
+    const int i_begin = blockIdx.z * t_chunk, i_end = min(t, i_begin + t_chunk);   // rows are split over blockIdx.z:
+    if (i_begin >= i_end) return;                                                  // a run cut by a chunk border is
+    float acc = 0.f;                                                               // completed by the atomics
+    long cur = sb[i_begin];
+    for (int i = i_begin; i < i_end; ++i) {
         const long s = sb[i];
         if (s != cur) {
             const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f;
@@ -286,9 +288,10 @@ extern "C" int spn_segment_count(const long* seg, float* counts, int b, int t, i
 extern "C" int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
                                const uint8_t* rowmask, float* out, int b, int t, int S, int d, hipStream_t s) {
     SPN_REQUIRE(x && seg && out && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_sum: bad arguments");
-    dim3 grid(cdiv(d, 64), b);
-    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d);
-    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d);
+    const int t_chunk = t > 256 ? 128 : t;
+    dim3 grid(cdiv(d, 64), b, cdiv(t, t_chunk));
+    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d, t_chunk);
+    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d, t_chunk);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
