@@ -21,6 +21,7 @@
 // The MFMA is issued with operands swapped (D^T = B^T.A^T), which leaves each lane with 4 CONSECUTIVE output columns of one
 // row: the epilogue stores 8/16 bytes per lane instead of scattered 2/4-byte elements.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -135,7 +136,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int r_base, int ks,
     }
 }
 
-template <bool TA, bool TB, typename OutT, int BK>
+template <bool TA, bool TB, typename OutT, int BK, int STAGES>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int TILE_BYTES = 128 * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -188,13 +189,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             sb.store(LDS_B(buf), tid);
         }
     };
-    stage_in(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    // STAGES-deep software pipeline: tiles t+1 .. t+STAGES-1 are in flight (LDS DMA) while tile t is multiplied.  Each wave waits
+    // only for ITS OWN pieces of tile t with a counted vmcnt (DMA instructions retire in order), then one raw s_barrier makes all
+    // waves' pieces visible and at the same time proves that everybody is done reading the stage that is refilled next.
+    // (__syncthreads() would drain vmcnt to 0 and serialise the pipeline on memory latency.)
+    constexpr int PER_TILE = 2 * (BK / 16);     // DMA instructions per wave per K tile (A + B)
+#pragma unroll
+    for (int s_ = 0; s_ < STAGES - 1; ++s_)
+        if (s_ < nt) stage_in(s_, s_);
     for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) stage_in(t + 1, cur ^ 1);   // stage cur^1 was last read in iteration t-1 (barrier passed)
+        const int cur = t % STAGES;
+        const int ahead = min(STAGES - 2, nt - 1 - t);   // younger tiles that may stay in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PER_TILE) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(PER_TILE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + STAGES - 1 < nt) stage_in(t + STAGES - 1, (t + STAGES - 1) % STAGES);   // refills the stage read in iteration t-1
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[4], bfr[4];
@@ -208,8 +219,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue: lane owns row m = ..+(lane&15) and 4 consecutive columns n = ..+(lane>>4)*4 + 0..3 ----------
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <bool TA, bool TB, typename OutT, int BK>
+template <bool TA, bool TB, typename OutT, int BK, int STAGES>
 int launch_bk(GemmArgs g, hipStream_t stream) {
     // split-K for the weight-gradient shapes (tiny M x N, contraction over all tokens): fill the chip with K slices
     const int tiles = cdiv(g.N, BN) * cdiv(g.M, BM), nt = cdiv(g.K, BK);
@@ -284,7 +293,16 @@ int launch_bk(GemmArgs g, hipStream_t stream) {
         }
     }
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splitk > 1 ? g.splitk : g.batch);
-    hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK>), grid, dim3(256), 4 * 128 * BK * 2, stream, g);
+    constexpr int LDS_BYTES = STAGES * 2 * 128 * BK * 2;
+    if (LDS_BYTES > 64 * 1024) {
+        static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
+        if (!attr_done) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OutT, BK, STAGES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_done = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK, STAGES>), grid, dim3(256), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -293,8 +311,17 @@ template <bool TA, bool TB, typename OutT>
 int launch(const GemmArgs& g, hipStream_t stream) {
     // short contractions (K <= 1024: every projection with d_model = 512 on the input side) are latency-bound per block:
     // BK = 32 halves the LDS footprint (32 KiB) so that 4 blocks stay resident per CU and hide each other's pipeline fill
-    if (g.K <= 1024) return launch_bk<TA, TB, OutT, 32>(g, stream);
-    return launch_bk<TA, TB, OutT, 64>(g, stream);
+    static const int variant = getenv("SPN_GEMM_VARIANT") ? atoi(getenv("SPN_GEMM_VARIANT")) : 0;   // tuning aid
+    if (variant == 1) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
+    if (variant == 2) return launch_bk<TA, TB, OutT, 64, 3>(g, stream);
+    if (variant == 3) return launch_bk<TA, TB, OutT, 32, 4>(g, stream);
+    if (variant == 4) return launch_bk<TA, TB, OutT, 32, 2>(g, stream);
+    if (variant == 5) return launch_bk<TA, TB, OutT, 64, 4>(g, stream);
+    if (variant == 6) return launch_bk<TA, TB, OutT, 32, 3>(g, stream);
+    // measured on MI355X (tools/bench_gemm.py): residency beats in-block pipelining -- two 16 KiB-per-operand stages with
+    // BK = 32 (32 KiB LDS, 4 blocks/CU) win everywhere except the long-K all-K-contiguous case
+    if (!TA && !TB && g.K >= 2048) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
+    return launch_bk<TA, TB, OutT, 32, 2>(g, stream);
 }
 
 }  // namespace
