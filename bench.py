@@ -32,6 +32,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=1024)
+    ap.add_argument("--dropout", type=float, default=0.1, help="attention / FFN dropout (recipes/scoreperformer/base.yaml:167,176)")
     return ap.parse_args()
 
 
@@ -69,7 +70,7 @@ def main():
     from scoreperformer_amd.synthetic import model_config, synthetic_batch
 
     torch.manual_seed(1234)  # identical initial replicas on every rank
-    cfg = model_config(args.preset, max_seq_len=max(args.seq, 256))
+    cfg = model_config(args.preset, max_seq_len=max(args.seq, 256), dropout=args.dropout)
     model = ScorePerformer.init(cfg)
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
     arena = ParamArena(model, dev)
@@ -117,7 +118,7 @@ def main():
         "unit": "note-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"C3 ScorePerformer train step: 6/6/6 layers d=512 h=8 MQA GLU-SiLUx4, MMD-VAE style encoder, "
-                               f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, dropout=0 (fused dropout not yet implemented)",
+                               f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss,
                    "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},

@@ -44,11 +44,13 @@ int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, l
  *      modules/transformer/embeddings.py:294-315).  head dim 64; q [b,nq,h,64], k/v [b,nk,kvh,64] through strides;
  *      kvh = 1 is multi-query.  strides: {q_bs,q_ns,q_hs, k_.., v_.., o_..} (+ {dq_.., dk_.., dv_..} for bwd). */
 int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const float* slopes,
-                 int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, spn_stream_t stream);
-/* delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
+                 int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, float p_drop,
+                 unsigned seed, spn_stream_t stream);
+/* p_drop > 0: attention dropout (attend.py:122); the mask is a pure function of (seed, b, h, i, j), recomputed in backward.
+ * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
-                 int nq, int nk, int causal, float scale, const long* strides, spn_stream_t stream);
+                 int nq, int nk, int causal, float scale, const long* strides, float p_drop, unsigned seed, spn_stream_t stream);
 
 /* ---- LayerNorm / AdaptiveLayerNorm (modules/transformer/transformer.py:106,123-125,192-193,217;
  *      modules/layers.py:31-47).  gb = [T,2D] fp32 per-token (gamma|beta).  bwd: dy bf16; dgamma/dbeta ACCUMULATED. */
@@ -59,9 +61,11 @@ int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long
                       long lddx, float* dgamma, float* dbeta, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
 
 /* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
-int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, spn_stream_t s);
-int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act, int glu,
+/* p_drop > 0: nn.Dropout on the activation output (feedforward.py:57-60); the mask is a pure function of (seed, index) */
+int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, float p_drop, unsigned seed,
                 spn_stream_t s);
+int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act, int glu,
+                float p_drop, unsigned seed, spn_stream_t s);
 int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dtype, long y_bs, long y_ts,
              const uint8_t* rowmask, long B, long t_len, int D, spn_stream_t s);
 int spn_colsum(const void* x, int x_dtype, long ldx, float* out /* ACCUMULATED */, long T, int N, spn_stream_t s);

@@ -33,10 +33,10 @@ using namespace spn_attn;
 // ==========================================================================================================
 // forward: grid (ceil(nq/128), h, b), 256 threads; wave w owns query rows q0 + 32w .. +31
 // ==========================================================================================================
-template <int MODE>
+template <int MODE, bool DROP>
 __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], float (&m_run)[2], float (&l_run)[2],
                                             const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
-                                            bool causal) {
+                                            bool causal, const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8) {
     uint32_t mbits[4] = {0, 0, 0, 0};
     if (MODE == T_GEN) {
 #pragma unroll
@@ -77,10 +77,22 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
                 s[kb][qb][r] = p;
                 psum += p;
             }
-        l_run[qb] += psum;
+        l_run[qb] += psum;   // the softmax normaliser is that of the un-dropped probabilities
+        if (DROP) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const int jh = (j0 + 16 * kb + 4 * g) >> 1;
+                const uint32_t b0 = drop_bits(rowc[qb], jh), b1 = drop_bits(rowc[qb], jh + 1);
+                if (!drop_keep(b0, i_odd, 0, thr8)) s[kb][qb][0] = 0.f;
+                if (!drop_keep(b0, i_odd, 1, thr8)) s[kb][qb][1] = 0.f;
+                if (!drop_keep(b1, i_odd, 0, thr8)) s[kb][qb][2] = 0.f;
+                if (!drop_keep(b1, i_odd, 1, thr8)) s[kb][qb][3] = 0.f;
+            }
+        }
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 64 + 16];
     char* k_tile = smem;            // "a" layout
@@ -108,6 +120,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = load_row_frag(qp, a.q_ns, q0 + 32 * w + 16 * qb + c, a.nq, ks, lane);
     }
     const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
+    uint32_t rowc[2] = {0, 0};
+    const int i_odd = c & 1;   // (q0 + 32w + 16qb + c) & 1
+    if (DROP) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+            rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, (a.nq + 1) >> 1, (q0 + 32 * w + 16 * qb + c) >> 1);
+    }
 
     f32x4 o[4][2];
 #pragma unroll
@@ -162,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         const float j0f = (float)j0;
-        if (cls == T_LEFT) fwd_softmax<T_LEFT>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal);
-        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal);
-        else fwd_softmax<T_GEN>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal);
+        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
+        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
+        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
 
         // O^T += V^T P^T
 #pragma unroll
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int qb = 0; qb < 2; ++qb) {
         const int i = q0 + 32 * w + 16 * qb + c;
         const float l = group_sum(l_run[qb]);
-        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const float inv = (l > 0.f ? 1.f / l : 0.f) * (DROP ? a.inv_keep : 1.f);
         if (i < a.nq) {
             bf16_t* op = a.o + bi * a.o_bs + (long)i * a.o_ns + hi * a.o_hs;
 #pragma unroll
@@ -233,10 +252,11 @@ __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
 // d slope_h = sum_ij dS_ij * (-|j - i - off|).  delta is computed from the bf16-rounded O, so each row's dS carries a
 // common error -P_ij * eps_i; since sum_j dS_ij must be 0, the measured row sum r_i = -eps_i gives the exact
 // correction  + r_i * sum_j P_ij |d_ij|  (otherwise the error is amplified by the mean attended distance).
-template <int MODE, bool SLOPE_GRAD>
+template <int MODE, bool SLOPE_GRAD, bool DROP>
 __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (&dp)[2][2], const float (&l2)[2], const float (&dl)[2],
                                           const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
-                                          bool causal, float (&acc_d)[2], float (&acc_r)[2], float (&acc_p)[2]) {
+                                          bool causal, float (&acc_d)[2], float (&acc_r)[2], float (&acc_p)[2],
+                                          const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8, float inv_keep) {
     uint32_t mbits[2] = {0, 0};
     if (MODE == T_GEN) {
 #pragma unroll
@@ -248,7 +268,12 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
         const float uo = MODE == T_LEFT ? -slope2 * i_f[qb] : (MODE == T_RIGHT ? slope2 * i_f[qb] : 0.f);
         const float mm = l2[qb] - uo;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
+        for (int k2 = 0; k2 < 2; ++k2) {
+            uint32_t b0 = 0, b1 = 0;
+            if (DROP) {
+                const int jh = (j0 + 16 * (2 * u + k2) + 4 * g) >> 1;
+                b0 = drop_bits(rowc[qb], jh); b1 = drop_bits(rowc[qb], jh + 1);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float jc = (float)(16 * (2 * u + k2) + r);
@@ -256,16 +281,20 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
                 const bool ok = MODE != T_GEN || ((((mbits[k2] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
                 const float t = score<MODE>(s[k2][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
                 const float p = fast_exp2(t - mm);
-                const float ds = p * (dp[k2][qb][r] - dl[qb]);
+                float dpv = dp[k2][qb][r];
+                if (DROP) dpv = drop_keep(r < 2 ? b0 : b1, i_odd, r & 1, thr8) ? dpv * inv_keep : 0.f;
+                const float ds = p * (dpv - dl[qb]);
                 if (SLOPE_GRAD) {
                     const float ad = fabsf(jf - i_f[qb]);
                     acc_d[qb] = fmaf(ds, ad, acc_d[qb]); acc_r[qb] += ds; acc_p[qb] = fmaf(p, ad, acc_p[qb]);
                 }
                 s[k2][qb][r] = ds;
             }
+        }
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 8192 + 64 + 16];
     char* k_tile = smem;              // "a": A operand of S^T
@@ -306,6 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         dl[qb] = i < a.nq ? a.delta[si] : 0.f;
     }
     const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
+    uint32_t rowc[2] = {0, 0};
+    const int i_odd = c & 1;
+    if (DROP) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+            rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, (a.nq + 1) >> 1, (q0 + 32 * w + 16 * qb + c) >> 1);
+    }
     f32x4 dq[4][2];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -370,13 +406,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
             if (slope_grad) {
-                if (cls == T_LEFT) dq_scores<T_LEFT, true>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, true>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
-                else dq_scores<T_GEN, true>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
+                if (cls == T_LEFT) dq_scores<T_LEFT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                else if (cls == T_RIGHT) dq_scores<T_RIGHT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                else dq_scores<T_GEN, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
             } else {
-                if (cls == T_LEFT) dq_scores<T_LEFT, false>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, false>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
-                else dq_scores<T_GEN, false>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p);
+                if (cls == T_LEFT) dq_scores<T_LEFT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                else if (cls == T_RIGHT) dq_scores<T_RIGHT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                else dq_scores<T_GEN, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
             }
             bf16x8 dsf[2];
 #pragma unroll
@@ -417,6 +453,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
+void set_dropout(AttnArgs& a, float p_drop, unsigned seed) {
+    const float t = p_drop * 256.f;
+    a.thr8 = t <= 0.f ? 0u : (t >= 255.f ? 255u : (uint32_t)(t + 0.5f));
+    a.seed = seed;
+    a.inv_keep = 1.f / (1.f - (float)a.thr8 / 256.f);
+}
+
 int check_common(const AttnArgs& a) {
     SPN_REQUIRE(a.q && a.k && a.v, "spn_attn: null q/k/v");
     SPN_REQUIRE(a.b > 0 && a.h > 0 && a.nq > 0 && a.nk > 0, "spn_attn: empty problem");
@@ -433,9 +476,10 @@ int check_common(const AttnArgs& a) {
 // strides: 12 longs = {q_bs,q_ns,q_hs, k_bs,k_ns,k_hs, v_bs,v_ns,v_hs, o_bs,o_ns,o_hs} in elements; head dim 64.
 extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                             const float* slopes, int b, int h, int kvh, int nq, int nk, int causal, float scale,
-                            const long* strides, hipStream_t stream) {
+                            const long* strides, float p_drop, unsigned seed, hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
+    set_dropout(a, p_drop, seed);
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
     a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk; a.causal = causal;
     a.scale = scale;
@@ -448,7 +492,8 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     SPN_REQUIRE(o && lse, "spn_attn_fwd: null output");
     SPN_REQUIRE((a.o_ns % 4) == 0 && (a.o_hs % 4) == 0 && (a.o_bs % 4) == 0, "spn_attn_fwd: o strides must be multiples of 4");
     dim3 grid(cdiv(nq, 128), h, b);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, stream, a);
+    if (a.thr8) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -458,9 +503,10 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
 extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                             const float* lse, float* delta, void* dq, void* dk, void* dv, float* dslope,
                             const uint8_t* kmask, const float* slopes, int b, int h, int kvh, int nq, int nk,
-                            int causal, float scale, const long* strides, hipStream_t stream) {
+                            int causal, float scale, const long* strides, float p_drop, unsigned seed, hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
+    set_dropout(a, p_drop, seed);
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.d_o = (const bf16_t*)d_o;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.dslope = dslope; a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk;
@@ -480,7 +526,8 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     const long total = (long)b * nq * h;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, delta);
     launch_attn_dkv(a, stream);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -25,6 +25,9 @@ struct AttnArgs {
     long dk_bs, dk_ns, dk_hs;
     long dv_bs, dv_ns, dv_hs;
     float scale;
+    // attention dropout (attend.py:122 `dropout_p`): keep iff the 8-bit field of hash(seed, b, h, i>>1, j>>1) selected by
+    // (i&1, j&1) is >= thr8;  kept probabilities are scaled by inv_keep = 1 / (1 - thr8/256).  thr8 == 0: no dropout.
+    uint32_t thr8, seed; float inv_keep;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -98,6 +101,15 @@ __device__ __forceinline__ float group_max(float v) {  // across the 4 lane grou
 __device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
+}
+
+// dropout bits of the 2x2 block (i>>1, j>>1): `row_const` = drop_row_const(...) of the row pair, `j_half` = j >> 1
+__device__ __forceinline__ uint32_t drop_row_const(uint32_t seed, int bh, int nq_half, int i_half) {
+    return ((uint32_t)(bh * nq_half + i_half)) * 0x9E3779B1u + seed;
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t row_const, int j_half) { return spn_hash32(row_const + (uint32_t)j_half * 0x85EBCA77u); }
+__device__ __forceinline__ bool drop_keep(uint32_t bits, int i_odd, int j_odd, uint32_t thr8) {
+    return ((bits >> (8 * (2 * i_odd + j_odd))) & 0xffu) >= thr8;
 }
 
 // Causal work per query tile grows linearly with its index, and consecutive blockIdx.x land on consecutive XCDs

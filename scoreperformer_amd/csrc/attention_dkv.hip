@@ -8,11 +8,12 @@
 namespace spn_attn {
 namespace {
 
-template <int CLS>
+template <int CLS, bool DROP>
 __device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile, const char* do_tile, const char* dot_tile,
                                          const float* nl2_s, const float* dl_s, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
                                          f32x4 (&dk)[4][2], f32x4 (&dv)[4][2], const float (&jf)[2], const bool (&key_ok)[2],
-                                         int ioff, float c1, float slope2, bool causal, int lane, int g) {
+                                         int ioff, float c1, float slope2, bool causal, int lane, int g,
+                                         uint32_t seed, int bh, int nq_half, int i0, const int (&jcol)[2], uint32_t thr8, float inv_keep) {
 #pragma unroll
 for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
         f32x4 p[2][2], ds[2][2];                // [qq][kb]
@@ -26,6 +27,12 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
             const float ib = (float)(ioff + 16 * qb + 4 * g);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+                uint32_t b0 = 0, b1 = 0;
+                if (DROP) {   // rows i0 + 16qb + 4g + r: pairs (r=0,1) and (r=2,3) share a 2x2 block row
+                    const int ih = (i0 + 16 * qb + 4 * g) >> 1;
+                    b0 = drop_bits(drop_row_const(seed, bh, nq_half, ih), jcol[kb] >> 1);
+                    b1 = drop_bits(drop_row_const(seed, bh, nq_half, ih + 1), jcol[kb] >> 1);
+                }
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[kb][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[kb][1], acc, 0, 0, 0);
@@ -43,8 +50,14 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
                         e = (ok ? t : NEG_FILL) + n4[r];
                     }
                     const float pv = fast_exp2(e);
-                    p[qq][kb][r] = pv;
-                    ds[qq][kb][r] = pv * (acc2[r] - d4[r]);
+                    if (DROP) {
+                        const bool keep = drop_keep(r < 2 ? b0 : b1, r & 1, jcol[kb] & 1, thr8);
+                        p[qq][kb][r] = keep ? pv * inv_keep : 0.f;                      // P_dropped feeds dV
+                        ds[qq][kb][r] = pv * ((keep ? acc2[r] * inv_keep : 0.f) - d4[r]);
+                    } else {
+                        p[qq][kb][r] = pv;
+                        ds[qq][kb][r] = pv * (acc2[r] - d4[r]);
+                    }
                 }
             }
         }
@@ -64,6 +77,7 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
     char* q_tile = smem;               // "a": A operand of S
@@ -149,9 +163,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
         if (cls == T_SKIP) continue;
 
-        if (cls == T_LEFT) dkv_tile<T_LEFT>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
-        else if (cls == T_RIGHT) dkv_tile<T_RIGHT>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
-        else dkv_tile<T_GEN>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g);
+        if (cls == T_LEFT) dkv_tile<T_LEFT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
+        else if (cls == T_RIGHT) dkv_tile<T_RIGHT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
+        else dkv_tile<T_GEN, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -173,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }  // namespace
 
 int launch_attn_dkv(const AttnArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
+    if (a.thr8) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
     return 0;
 }
 

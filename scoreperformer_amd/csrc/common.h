@@ -46,6 +46,13 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// counter-based random bits for dropout masks (murmur3 finaliser): the same (seed, counter) gives the same bits in the
+// forward and in every backward kernel, so masks are recomputed instead of stored
+__device__ __forceinline__ uint32_t spn_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

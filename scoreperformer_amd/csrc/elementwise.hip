@@ -35,8 +35,20 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
 }
 
 // out[t, i] = u[t, i] * act(u[t, I + i])     (GLU) ;  GLU=false: out[t,i] = act(u[t,i])
+// dropout of the activation output (nn.Dropout between activation and out-projection, feedforward.py:57-60): element e of
+// chunk idx is kept iff the e-th 16-bit field of hash(seed, 4*idx + e/2) >= thr16; kept values are scaled by 1/(1-p)
+__device__ __forceinline__ void drop8(float* o, long idx, uint32_t seed, uint32_t thr16, float keep_scale) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t h = spn_hash32(((uint32_t)idx * 4u + q) * 0x9E3779B1u + seed);
+        o[2 * q] = (h & 0xffffu) >= thr16 ? o[2 * q] * keep_scale : 0.f;
+        o[2 * q + 1] = (h >> 16) >= thr16 ? o[2 * q + 1] * keep_scale : 0.f;
+    }
+}
+
 template <int ACT, bool GLU>
-__global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* __restrict__ out, long ldo, long T, int I) {
+__global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* __restrict__ out, long ldo, long T, int I,
+                               uint32_t thr16, float keep_scale, uint32_t seed) {
     const int chunks = I / 8;
     const long total = T * chunks;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -53,13 +65,14 @@ __global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* _
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = act_f<ACT>(g[e]);
         }
+        if (thr16) drop8(o, idx, seed, thr16, keep_scale);
         *reinterpret_cast<uint4*>(out + t * ldo + c) = pack8f(o);
     }
 }
 
 template <int ACT, bool GLU>
 __global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf16_t* __restrict__ dout, long lddo,
-                               bf16_t* __restrict__ du, long lddu, long T, int I) {
+                               bf16_t* __restrict__ du, long lddu, long T, int I, uint32_t thr16, float keep_scale, uint32_t seed) {
     const int chunks = I / 8;
     const long total = T * chunks;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -67,6 +80,7 @@ __global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf1
         const int c = (idx % chunks) * 8;
         float a[8], g[8], d[8], da[8], dg[8];
         unpack8(*reinterpret_cast<const uint4*>(dout + t * lddo + c), d);
+        if (thr16) drop8(d, idx, seed, thr16, keep_scale);
         if (GLU) {
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), a);
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + I + c), g);
@@ -207,28 +221,36 @@ inline int grid_for(long total, int block = 256) { long g = (total + block - 1) 
 }  // namespace
 
 // act: 0 = SiLU, 1 = GELU(erf).  glu != 0: u is [T, 2I] (value | gate), out [T, I];  glu == 0: u [T, I].
-extern "C" int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, hipStream_t s) {
+static inline uint32_t thr16_of(float p) { const float t = p * 65536.f; return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)(t + 0.5f)); }
+
+// p_drop > 0: dropout of the output with keep probability 1 - round(p*65536)/65536 and mask bits from (seed, element index)
+extern "C" int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, float p_drop,
+                           unsigned seed, hipStream_t s) {
     SPN_REQUIRE(u && out && T > 0 && I > 0 && I % 8 == 0 && ldu % 8 == 0 && ldo % 8 == 0, "spn_act_fwd: bad arguments (I, ld multiples of 8)");
     const int g = grid_for(T * (I / 8));
     const bf16_t* up = (const bf16_t*)u; bf16_t* op = (bf16_t*)out;
-    if (act == 0 && glu) hipLaunchKernelGGL((act_fwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
-    else if (act == 0) hipLaunchKernelGGL((act_fwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
-    else if (glu) hipLaunchKernelGGL((act_fwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
-    else hipLaunchKernelGGL((act_fwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I);
+    const uint32_t thr = thr16_of(p_drop);
+    const float ks = 1.f / (1.f - (float)thr / 65536.f);
+    if (act == 0 && glu) hipLaunchKernelGGL((act_fwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I, thr, ks, seed);
+    else if (act == 0) hipLaunchKernelGGL((act_fwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I, thr, ks, seed);
+    else if (glu) hipLaunchKernelGGL((act_fwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I, thr, ks, seed);
+    else hipLaunchKernelGGL((act_fwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, op, ldo, T, I, thr, ks, seed);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
 
 extern "C" int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act,
-                           int glu, hipStream_t s) {
+                           int glu, float p_drop, unsigned seed, hipStream_t s) {
     SPN_REQUIRE(u && dout && du && T > 0 && I > 0 && I % 8 == 0 && ldu % 8 == 0 && lddo % 8 == 0 && lddu % 8 == 0,
                 "spn_act_bwd: bad arguments (I, ld multiples of 8)");
     const int g = grid_for(T * (I / 8));
     const bf16_t* up = (const bf16_t*)u; const bf16_t* dp = (const bf16_t*)dout; bf16_t* op = (bf16_t*)du;
-    if (act == 0 && glu) hipLaunchKernelGGL((act_bwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
-    else if (act == 0) hipLaunchKernelGGL((act_bwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
-    else if (glu) hipLaunchKernelGGL((act_bwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
-    else hipLaunchKernelGGL((act_bwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I);
+    const uint32_t thr = thr16_of(p_drop);
+    const float ks = 1.f / (1.f - (float)thr / 65536.f);
+    if (act == 0 && glu) hipLaunchKernelGGL((act_bwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
+    else if (act == 0) hipLaunchKernelGGL((act_bwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
+    else if (glu) hipLaunchKernelGGL((act_bwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
+    else hipLaunchKernelGGL((act_bwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

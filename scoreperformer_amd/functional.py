@@ -16,6 +16,21 @@ from .ops import BF16, F32
 
 ACT_SILU, ACT_GELU = 0, 1
 
+_seed_state = {"base": None, "counter": 0}
+
+
+def next_seed() -> int:
+    """32-bit seed for a dropout site: deterministic under torch.manual_seed, host-side only (no device sync)."""
+    base = torch.initial_seed()
+    if _seed_state["base"] != base:
+        _seed_state["base"], _seed_state["counter"] = base, 0
+    _seed_state["counter"] += 1
+    x = (base * 0x9E3779B97F4A7C15 + _seed_state["counter"] * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    return (x * 0x94D049BB133111EB >> 32) & 0xFFFFFFFF
+
+
+
 
 # ---------------------------------------------------------------------------------------------------------
 # bf16 compute copies of fp32 master weights
@@ -235,22 +250,23 @@ class SelfAttnFn(Function):
     """qkv: [b, n, (h + 2*kvh)*64] bf16 fused projection (q | k | v);  returns o [b, n, h*64] bf16."""
 
     @staticmethod
-    def forward(ctx, qkv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float):
+    def forward(ctx, qkv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0):
         b, n, _ = qkv.shape
         q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
         k = qkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
         v = qkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
-        o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale)
+        seed = next_seed() if p_drop > 0 else 0
+        o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
         ctx.save_for_backward(qkv, o, lse, sl, kmask)
-        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None)
+        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, n, heads * 64)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_o):
         qkv, o, lse, sl, kmask = ctx.saved_tensors
-        heads, kv_heads, causal, scale, sshape = ctx.cfg
+        heads, kv_heads, causal, scale, sshape, p_drop, seed = ctx.cfg
         b, n, _ = qkv.shape
         q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
         k = qkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
@@ -261,30 +277,31 @@ class SelfAttnFn(Function):
         dv = dqkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, n, heads, 64)
         dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=sl, causal=causal, scale=scale,
-                           want_dslope=sl is not None and ctx.needs_input_grad[1])
-        return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None
+                           want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, seed=seed)
+        return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 
 class CrossAttnFn(Function):
     """q: [b, nq, h*64]; kv: [b, nk, 2*kvh*64] (k | v) fused projection of the context."""
 
     @staticmethod
-    def forward(ctx, q, kv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float):
+    def forward(ctx, q, kv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0):
         b, nq, _ = q.shape
         q4 = q.unflatten(-1, (heads, 64))
         k = kv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
         v = kv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
-        o, lse = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale)
+        seed = next_seed() if p_drop > 0 else 0
+        o, lse = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
         ctx.save_for_backward(q, kv, o, lse, sl, kmask)
-        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None)
+        ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, nq, heads * 64)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_o):
         q, kv, o, lse, sl, kmask = ctx.saved_tensors
-        heads, kv_heads, causal, scale, sshape = ctx.cfg
+        heads, kv_heads, causal, scale, sshape, p_drop, seed = ctx.cfg
         b, nq, _ = q.shape
         q4 = q.unflatten(-1, (heads, 64))
         k = kv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
@@ -295,8 +312,9 @@ class CrossAttnFn(Function):
         dv = dkv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, nq, heads, 64)
         dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, slopes=sl,
-                           causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2])
-        return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None
+                           causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2], p_drop=p_drop,
+                           seed=seed)
+        return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -304,24 +322,26 @@ class CrossAttnFn(Function):
 # ---------------------------------------------------------------------------------------------------------
 
 class ActFn(Function):
+    """GLU / activation, with the FFN's nn.Dropout fused behind it (mask recomputed in backward from the seed)."""
+
     @staticmethod
-    def forward(ctx, u, act: int, glu: bool):
+    def forward(ctx, u, act: int, glu: bool, p_drop: float, seed: int):
         ctx.save_for_backward(u)
-        ctx.cfg = (act, glu)
-        out = ops.act_fwd(u, act=act, glu=glu)
+        ctx.cfg = (act, glu, p_drop, seed)
+        out = ops.act_fwd(u, act=act, glu=glu, p_drop=p_drop, seed=seed)
         return out.view(*u.shape[:-1], out.shape[-1])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
         (u,) = ctx.saved_tensors
-        act, glu = ctx.cfg
-        du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu)
-        return du.view(u.shape), None, None
+        act, glu, p_drop, seed = ctx.cfg
+        du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu, p_drop=p_drop, seed=seed)
+        return du.view(u.shape), None, None, None, None
 
 
-def glu_act(u, *, act=ACT_SILU, glu=True):
-    return ActFn.apply(u, act, glu)
+def glu_act(u, *, act=ACT_SILU, glu=True, p_drop: float = 0.0):
+    return ActFn.apply(u, act, glu, float(p_drop), next_seed() if p_drop > 0 else 0)
 
 
 # ---------------------------------------------------------------------------------------------------------

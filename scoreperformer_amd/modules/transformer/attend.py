@@ -50,8 +50,6 @@ class Attend(nn.Module):
         assert prev_attn is None, 'residual attention not compatible with efficient attention'
         if attn_bias is not None:
             raise NotImplementedError("pass ALiBi as per-head `slopes`; a materialised attn_bias is never built here")
-        if self.training and self.dropout > 0:
-            warn_dropout_once("Attend")
         b, h, n, d = q.shape
         if mask is not None and mask.ndim == 4:
             if mask.shape[1] != 1 or mask.shape[2] != 1:
@@ -64,5 +62,5 @@ class Attend(nn.Module):
         vb = vb.unsqueeze(2) if vb.ndim == 3 else vb.permute(0, 2, 1, 3)
         kv = torch.cat([kb, vb], dim=-2).flatten(-2)               # b j (2*kvh*d)   (stand-alone path only)
         out = F_.CrossAttnFn.apply(qb.reshape(b, n, h * d), kv, slopes, mask, h, kb.shape[2], self.causal,
-                                   self.scale if self.scale is not None else d ** -0.5)
+                                   self.scale if self.scale is not None else d ** -0.5, self.dropout if self.training else 0.0)
         return out.view(b, n, h, d).permute(0, 2, 1, 3), AttentionIntermediates(keys=k, values=v)

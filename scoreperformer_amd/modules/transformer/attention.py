@@ -14,7 +14,7 @@ from torch import Tensor
 from ... import functional as F_
 from ...utils import default
 from ..constructor import Constructor, ModuleConfig
-from .attend import AttentionIntermediates, Attend, warn_dropout_once
+from .attend import AttentionIntermediates, Attend
 from .embeddings import ALiBiPositionalBias, LearnedALiBiPositionalBias
 
 
@@ -91,14 +91,13 @@ class Attention(nn.Module, Constructor):
         assert not (has_context and has_cache), 'cache is not compatible with context yet'
         if has_mem or attn_mask is not None or prev_attn is not None:
             raise NotImplementedError("mem / attn_mask / prev_attn are not reachable from the ScorePerformer models")
-        if self.training and self.attend.dropout > 0:
-            warn_dropout_once("Attention")
+        p_drop = self.attend.dropout if self.training else 0.0
         slopes = self.rel_pos.padded_slopes() if self.rel_pos is not None else None
         key_mask = mask if context_mask is None else context_mask
 
         if not has_context and not has_cache:
             qkv = F_.linear(x, self._fused("_w_qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight)))
-            o = F_.SelfAttnFn.apply(qkv, slopes, key_mask, h, kvh, self.causal, self.scale)
+            o = F_.SelfAttnFn.apply(qkv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop)
             k_view, v_view = qkv[..., h * 64:(h + kvh) * 64], qkv[..., (h + kvh) * 64:]
         else:
             q = F_.linear(x, self.to_q.weight)
@@ -107,7 +106,7 @@ class Attention(nn.Module, Constructor):
                 ck = cache.keys if cache.keys.ndim == 3 else cache.keys.permute(0, 2, 1, 3).flatten(-2)
                 cv = cache.values if cache.values.ndim == 3 else cache.values.permute(0, 2, 1, 3).flatten(-2)
                 kv = torch.cat([torch.cat([ck, kv[..., :kvh * 64]], dim=1), torch.cat([cv, kv[..., kvh * 64:]], dim=1)], dim=-1)
-            o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale)
+            o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop)
             k_view, v_view = kv[..., :kvh * 64], kv[..., kvh * 64:]
 
         qmask = mask

@@ -5,7 +5,6 @@ import torch.nn as nn
 
 from ... import functional as F_
 from ..constructor import Constructor, ModuleConfig
-from .attend import warn_dropout_once
 
 
 class GLU(nn.Module):
@@ -14,9 +13,9 @@ class GLU(nn.Module):
         self.act = activation
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
-    def forward(self, x):
+    def forward(self, x, p_drop: float = 0.0):
         u = F_.linear(x, self.proj.weight, self.proj.bias)
-        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True)
+        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True, p_drop=p_drop)
 
 
 @dataclass
@@ -43,14 +42,16 @@ class FeedForward(nn.Module, Constructor):
         self.glu, self.act_code, self.dropout = glu, (F_.ACT_SILU if swish else F_.ACT_GELU), dropout
 
     def forward(self, x, residual=None):
-        if self.training and self.dropout > 0:
-            warn_dropout_once("FeedForward")
+        p = self.dropout if self.training else 0.0
+        has_ln = isinstance(self.ff[1], nn.LayerNorm)
+        if has_ln and p > 0:
+            raise NotImplementedError("post_act_ln together with dropout (not used by any recipe)")
         if self.glu:
-            g = self.ff[0](x)
+            g = self.ff[0](x, p_drop=p)
         else:
             lin = self.ff[0][0]
-            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False)
-        if isinstance(self.ff[1], nn.LayerNorm):
+            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p)
+        if has_ln:
             g = F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps)
         out = self.ff[3]
         return F_.linear(g, out.weight, out.bias, residual=residual, out_fp32=residual is not None)

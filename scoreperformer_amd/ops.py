@@ -138,7 +138,7 @@ def _mask_u8(m: Optional[torch.Tensor]):
     return m.view(torch.uint8) if m.dtype == torch.bool else m
 
 
-def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None):
+def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0):
     """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq]."""
     require_gpu(q, k, v)
     b, nq, h, dh = q.shape
@@ -152,11 +152,12 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None):
     kmask = _mask_u8(kmask)
     call("spn_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh),
          c_int(nq), c_int(nk), c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides,
-         stream_ptr())
+         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
     return o, lse
 
 
-def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False):
+def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
+             p_drop: float = 0.0, seed: int = 0):
     """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None."""
     b, nq, h, dh = q.shape
     nk, kvh = k.shape[1], k.shape[2]
@@ -173,7 +174,8 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
     kmask = _mask_u8(kmask)
     call("spn_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
          ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
-         c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, stream_ptr())
+         c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, c_float(p_drop),
+         ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
     return dslope
 
 
@@ -214,23 +216,23 @@ def cast(x: torch.Tensor, dtype, *, rowmask: Optional[torch.Tensor] = None, out:
     return out
 
 
-def act_fwd(u: torch.Tensor, *, act: int, glu: bool) -> torch.Tensor:
+def act_fwd(u: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
     u2 = _rows2d(u)
     T, W = u2.shape
     I = W // 2 if glu else W
     out = torch.empty((T, I), device=u.device, dtype=BF16)
     call("spn_act_fwd", ptr(u2), c_long(u2.stride(0)), ptr(out), c_long(I), c_long(T), c_int(I), c_int(act), c_int(int(glu)),
-         stream_ptr())
+         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
     return out
 
 
-def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool) -> torch.Tensor:
+def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
     u2, d2 = _rows2d(u), _rows2d(dout)
     T, W = u2.shape
     I = W // 2 if glu else W
     du = torch.empty((T, W), device=u.device, dtype=BF16)
     call("spn_act_bwd", ptr(u2), c_long(u2.stride(0)), ptr(d2), c_long(d2.stride(0)), ptr(du), c_long(W), c_long(T), c_int(I),
-         c_int(act), c_int(int(glu)), stream_ptr())
+         c_int(act), c_int(int(glu)), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
     return du
 
 

@@ -208,3 +208,76 @@ def test_attention_fast_paths_and_rescale(dev, causal, use_slopes, use_mask):
     assert rel_err(dv, vr.grad) < 3e-2
     if use_slopes:
         assert rel_err(dslope, sr.grad) < 3e-2
+
+
+def test_ffn_dropout_mask_is_consistent_and_unbiased(dev):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    T, I, p, seed = 512, 256, 0.1, 12345
+    u = torch.randn(T, 2 * I, generator=g).to(dev).bfloat16()
+    dout = torch.randn(T, I, generator=g).to(dev).bfloat16()
+    out0 = ops.act_fwd(u, act=0, glu=True).float()
+    out1 = ops.act_fwd(u, act=0, glu=True, p_drop=p, seed=seed).float()
+    keep = out1 != 0
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01
+    assert rel_err(out1[keep], out0[keep] / (1 - p)) < 2e-2          # kept values scaled by 1/(1-p)
+    assert (out1[~keep] == 0).all()
+    again = ops.act_fwd(u, act=0, glu=True, p_drop=p, seed=seed).float()
+    assert torch.equal(again, out1)                                  # same seed -> same mask
+    other = ops.act_fwd(u, act=0, glu=True, p_drop=p, seed=seed + 1).float()
+    assert (other != out1).float().mean().item() > 0.1
+    du0 = ops.act_bwd(u, dout, act=0, glu=True).float()
+    du1 = ops.act_bwd(u, dout, act=0, glu=True, p_drop=p, seed=seed).float()
+    m2 = torch.cat([keep, keep], dim=1)
+    assert rel_err(du1[m2], du0[m2] / (1 - p)) < 3e-2                # backward uses the same mask
+    assert (du1[~m2] == 0).all()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
+    """The mask is a pure function of (seed, b, h, i, j): extract it with one-hot V, then check forward and all three
+    backward kernels against an fp32 reference that uses exactly that mask."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(31 + int(causal))
+    b, h, nq, nk, p, seed = 2, 2, 160, 192, 0.25, 777
+    q = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+    k = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
+    v = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
+    slopes = torch.tensor([0.3, 0.05], device=dev)
+    scale = 64 ** -0.5
+    # 1. reveal P_dropped column block by column block
+    pd = torch.zeros(b, h, nq, nk, device=dev)
+    for t in range(nk // 64):
+        vi = torch.zeros(b, nk, 1, 64, device=dev)
+        vi[:, 64 * t:64 * (t + 1), 0] = torch.eye(64, device=dev)
+        o, _ = ops.attn_fwd(q, k, vi.bfloat16(), slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+        pd[..., 64 * t:64 * (t + 1)] = o.float().permute(0, 2, 1, 3)
+    qf, kf = q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3).expand(b, h, nk, 64)
+    dist = torch.arange(nk, device=dev)[None, :] - (torch.arange(nq, device=dev)[:, None] + nk - nq)
+    dots = qf @ kf.transpose(-1, -2) * scale - slopes.view(1, h, 1, 1) * dist.abs().float()
+    if causal:
+        dots = dots.masked_fill(dist > 0, -1.7014118e38)
+    p0 = dots.softmax(-1)
+    visible = p0 > 1e-3
+    mask = (pd > 0)
+    thr = round(p * 256) / 256
+    assert abs(mask[visible].float().mean().item() - (1 - thr)) < 0.02
+    assert rel_err(pd[mask & visible], (p0 / (1 - thr))[mask & visible]) < 3e-2
+    # 2. forward + backward with random V against the reference using the extracted mask
+    mfull = torch.where(visible, mask, torch.ones_like(mask)).float()   # invisible entries: contribution ~ 0 either way
+    qr, kr, vr = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    dots_r = (qr.permute(0, 2, 1, 3) @ kr.permute(0, 2, 1, 3).expand(b, h, nk, 64).transpose(-1, -2)) * scale \
+        - slopes.view(1, h, 1, 1) * dist.abs().float()
+    if causal:
+        dots_r = dots_r.masked_fill(dist > 0, -1.7014118e38)
+    ref = ((dots_r.softmax(-1) * mfull / (1 - thr)) @ vr.permute(0, 2, 1, 3).expand(b, h, nk, 64)).permute(0, 2, 1, 3)
+    d_o = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+    ref.backward(d_o.float())
+    o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+    assert rel_err(o, ref) < 3e-2
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+    assert rel_err(dq, qr.grad) < 4e-2
+    assert rel_err(dk, kr.grad) < 4e-2
+    assert rel_err(dv, vr.grad) < 4e-2
