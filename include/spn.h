@@ -113,6 +113,22 @@ int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf
                    float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                    int step, spn_stream_t s);
 
+/* ---- decode, b = 1 (per-note body of ScorePerformerMixedLMWrapper.unmask_tokens, models/scoreperformer/wrappers.py:325-407;
+ *      cache protocol modules/transformer/transformer.py:159-181,219-221; attention.py:155-156; sampling.py:28-59).
+ *      fp32; `pos` is a DEVICE int: row addressing = base + (*pos + off) * ld, so one captured hipGraph step is replayed per note. */
+int spn_dec_gemv(const float* W, long ldw, const float* x, long x_ld, int x_off, const float* bias, const float* residual, float* y,
+                 long y_ld, int y_off, const int* pos, int N, int K, int kn_layout, spn_stream_t s);
+int spn_dec_embed(int nkeys, const float* const* tables, const int* E, const long* tokens, long tok_ld, int row_off, const int* pos,
+                  const float* gamma, const float* beta, float* y, float eps, spn_stream_t s);
+int spn_dec_copy_row(const float* src, long src_ld, int src_off, float* dst, long dst_ld, int dst_off, const int* pos, int D,
+                     spn_stream_t s);
+int spn_dec_glu(const float* u, float* out, int I, int act, int glu, spn_stream_t s);
+int spn_dec_attn(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, int h, int kvh,
+                 float scale, spn_stream_t s);
+int spn_dec_argmax_write(const float* logits, int V, unsigned ban_mask, long* tokens, long tok_ld, int dim, int mask_id, const int* pos,
+                         spn_stream_t s);
+int spn_dec_add_pos(int* pos, int delta, spn_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

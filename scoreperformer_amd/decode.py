@@ -1,0 +1,204 @@
+"""Greedy render engine (b = 1): static caches, device-resident position, one hipGraph-captured decoder step per note.
+
+Semantics = `ScorePerformerMixedLMWrapper.unmask_tokens` with `filter_logits_fn=top_k, k=1` (wrappers.py:325-407): for every
+position idx that still holds MASK tokens, run the shifted decoder on the prefix, take the LM-head logits of position idx-1 for
+the masked dims, ban PAD/MASK ids, write the arg-max.  Differences in *how*: the reference re-runs Python modules per note with
+`torch.cat`-grown caches and reads tokens back to the host every step; here every note is one replay of a captured graph of
+fp32 kernels over preallocated [L, .] caches, and tokens stay on the device until the end.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .models.scoreperformer.embeddings import build_tables, TupleTokenTiedLMHead, TupleTokenLMHead
+from .modules.layers import AdaptiveLayerNorm
+from .modules.transformer.attend import AttentionIntermediates
+from .modules.transformer.transformer import TransformerIntermediates
+
+F32 = torch.float32
+
+
+class GreedyDecoder:
+    def __init__(self, decoder, max_len: int, use_graph: bool = True):
+        """decoder: the TupleTransformer wrapped by the MixedLM wrapper (`model.perf_decoder.model`)."""
+        self.m = m = decoder
+        self.max_len, self.use_graph = max_len, use_graph
+        tr = m.transformer
+        if any(t != ('a', 'f')[i % 2] for i, t in enumerate(tr.layer_types)) or not tr.pre_norm:
+            raise NotImplementedError("decode engine: pre-norm self-attention decoder only (context_emb_mode='cat')")
+        if getattr(m.token_emb, "multiseq_mode", None) != "post-cat" or m.pos_emb is not None:
+            raise NotImplementedError("decode engine: multi-seq post-cat token embeddings without absolute positions")
+        self.dev = next(m.parameters()).device
+        self.dim = m.dim
+        self.ada = tr.ada_norm
+        self.graph = None
+
+    # -- buffers -------------------------------------------------------------------------------------------
+    def _alloc(self, L):
+        m, dev, d = self.m, self.dev, self.dim
+        te = m.token_emb
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=F32)
+        self.pos = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.e_cat = z(te.total_emb_dim)
+        self.proj_cat = z(2 * d)
+        self.tok_emb = z(L, d)
+        width = d + (m.context_emb_dim if m.context_emb_mode == "cat" else 0) + (m.style_emb_dim if m.style_emb_mode == "cat" else 0)
+        self.xcat = z(width)
+        self.x, self.h, self.o = z(d), z(d), z(d)
+        att0 = m.transformer.layers[0][1]
+        self.heads, self.kvh = att0.heads, att0.kv_heads
+        self.qkv = z((self.heads + 2 * self.kvh) * 64)
+        inner2 = m.transformer.layers[1][1].ff[0].proj.weight.shape[0] if m.transformer.layers[1][1].glu else \
+            m.transformer.layers[1][1].ff[0][0].weight.shape[0]
+        self.u = z(inner2)
+        self.g = z(inner2 // 2 if m.transformer.layers[1][1].glu else inner2)
+        self.gb = z(2 * d)
+        n_attn = m.transformer.num_attn_layers
+        self.kc = [z(L, self.kvh * 64) for _ in range(n_attn)]
+        self.vc = [z(L, self.kvh * 64) for _ in range(n_attn)]
+        self.hid = [z(L, d) for _ in range(n_attn + 1)]
+        self.e_head = z(te.total_emb_dim)
+        self.e_head_n = z(te.total_emb_dim)
+        self.logits = z(max(te.num_tokens.values()) + 8)
+        self.stats = z(2)
+
+    # -- one decoder step at position t = *pos (predicts the MASKed dims of position t + 1) -----------------
+    def _ln(self, x, norm, out, cond_row: bool):
+        if self.ada and isinstance(norm, AdaptiveLayerNorm):
+            ops.dec_gemv(norm.linear.weight.data, self.style2d, self.gb, bias=norm.linear.bias.data, pos=self.pos,
+                         x_ld=self.style2d.stride(0), x_off=1)
+            ops.layernorm_fwd(x.view(1, -1), None, None, self.gb.view(1, -1), out_dtype=F32, eps=norm.eps, out=out.view(1, -1))
+        else:
+            ops.layernorm_fwd(x.view(1, -1), norm.weight.data, norm.bias.data, None, out_dtype=F32, eps=norm.eps, out=out.view(1, -1))
+
+    def _step(self, dims: List[int]):
+        m, d, pos = self.m, self.dim, self.pos
+        te = m.token_emb
+        has_norm = isinstance(te.norm, nn.LayerNorm)
+        gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
+        for si, (toks, off) in enumerate(((self.seq2d, 0), (self.masked2d, 1))):
+            ops.dec_embed(self.tables, toks, pos, self.e_cat, row_off=off, gamma=gam, beta=bet, eps=eps)
+            ops.dec_gemv(te.project_emb.weight.data, self.e_cat, self.proj_cat[si * d:(si + 1) * d], bias=te.project_emb.bias.data)
+        ops.dec_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x, bias=te.project_multiemb.bias.data)
+        ops.dec_copy_row(self.x, self.tok_emb, pos, d, dst_ld=d)
+        if isinstance(m.emb_norm, nn.LayerNorm):
+            ops.layernorm_fwd(self.x.view(1, -1), m.emb_norm.weight.data, m.emb_norm.bias.data, None, out_dtype=F32,
+                              eps=m.emb_norm.eps, out=self.xcat[:d].view(1, -1))
+        else:
+            ops.dec_copy_row(self.x, self.xcat, pos, d)
+        col = d
+        if m.context_emb_mode == "cat" and self.ctx2d is not None:
+            ops.dec_copy_row(self.ctx2d, self.xcat[col:], pos, m.context_emb_dim, src_ld=self.ctx2d.stride(0), src_off=1)
+            col += m.context_emb_dim
+        if m.style_emb_mode == "cat" and self.style2d is not None:
+            ops.dec_copy_row(self.style2d, self.xcat[col:], pos, m.style_emb_dim, src_ld=self.style2d.stride(0), src_off=1)
+        if isinstance(m.project_emb, nn.Linear):
+            ops.dec_gemv(m.project_emb.weight.data, self.xcat, self.x, bias=m.project_emb.bias.data)
+        else:
+            ops.dec_copy_row(self.xcat, self.x, pos, d)
+        ai = 0
+        for lt, (norms, block, _res) in zip(m.transformer.layer_types, m.transformer.layers):
+            if lt == 'a':
+                ops.dec_copy_row(self.x, self.hid[ai], pos, d, dst_ld=d)
+                self._ln(self.x, norms[0], self.h, True)
+                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
+                ops.dec_gemv(wqkv, self.h, self.qkv)
+                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+                ops.dec_attn(self.qkv, self.kc[ai], self.vc[ai], slopes, pos, self.o, h=self.heads, kvh=self.kvh, scale=block.scale)
+                ops.dec_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+                ai += 1
+            else:
+                self._ln(self.x, norms[0], self.h, True)
+                if block.glu:
+                    lin = block.ff[0].proj
+                else:
+                    lin = block.ff[0][0]
+                ops.dec_gemv(lin.weight.data, self.h, self.u, bias=lin.bias.data if lin.bias is not None else None)
+                ops.dec_glu(self.u, self.g, self.g.numel(), act=block.act_code, glu=block.glu)
+                if isinstance(block.ff[1], nn.LayerNorm):
+                    ops.layernorm_fwd(self.g.view(1, -1), block.ff[1].weight.data, block.ff[1].bias.data, None, out_dtype=F32,
+                                      eps=block.ff[1].eps, out=self.g.view(1, -1))
+                out = block.ff[3]
+                ops.dec_gemv(out.weight.data, self.g, self.x, bias=out.bias.data if out.bias is not None else None, residual=self.x)
+        fn = m.transformer.final_norm
+        if not isinstance(fn, nn.Identity):
+            self._ln(self.x, fn, self.h, True)
+        else:
+            ops.dec_copy_row(self.x, self.h, pos, d)
+        ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
+        # LM head on this position for the candidate dims, arg-max written where the next position holds MASK
+        head = m.lm_head
+        keys = list(te.embs.keys())
+        if isinstance(head, TupleTokenTiedLMHead):
+            if head.reuse_projection:
+                ops.dec_gemv(head.project_emb.weight.data, self.h, self.e_head, kn_layout=True)
+            else:
+                ops.dec_gemv(head.project_emb.weight.data, self.h, self.e_head)
+            ops.layernorm_fwd(self.e_head.view(1, -1), head.norm.weight.data, head.norm.bias.data, None, out_dtype=F32,
+                              eps=head.norm.eps, out=self.e_head_n.view(1, -1))
+            offs = [0]
+            for w in head.split_dims:
+                offs.append(offs[-1] + w)
+            for dim in dims:
+                tab = self.tables[dim]
+                ops.dec_gemv(tab, self.e_head_n[offs[dim]:offs[dim + 1]], self.logits)
+                ops.dec_argmax_write(self.logits, tab.shape[0], self.seq2d, dim, pos)
+        elif isinstance(head, TupleTokenLMHead):
+            for dim in dims:
+                lin = head.heads[keys[dim]]
+                ops.dec_gemv(lin.weight.data, self.h, self.logits, bias=lin.bias.data)
+                ops.dec_argmax_write(self.logits, lin.weight.shape[0], self.seq2d, dim, pos)
+        else:
+            raise NotImplementedError("decode engine: lm / lm-tied heads")
+        ops.dec_add_pos(pos, 1)
+
+    # -- public ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, tokens: torch.Tensor, tokens_masked: torch.Tensor, context: Optional[torch.Tensor],
+            style: Optional[torch.Tensor], mask_token_id: int = 1):
+        """tokens / tokens_masked: [1, L, K] int64 on the GPU; returns (filled tokens, number of decoded positions)."""
+        m = self.m
+        L = tokens.shape[1]
+        self._alloc(L)
+        self.seq2d = tokens[0].clone().contiguous()
+        self.masked2d = tokens_masked[0].contiguous()
+        self.ctx2d = context[0].float().contiguous() if context is not None else None
+        self.style2d = style[0].float().contiguous() if style is not None else None
+        unmask = (self.seq2d == mask_token_id)
+        rows = unmask.any(dim=1).nonzero().flatten()
+        if rows.numel() == 0:
+            return self.seq2d[None], 0
+        dims = unmask.any(dim=0).nonzero().flatten().tolist()
+        last = int(rows.max())                      # one host read for the whole window
+        with torch.no_grad():
+            self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
+        n_steps = last                              # positions t = 0 .. last-1 (predicting t+1)
+        self.pos.zero_()
+        if self.use_graph and n_steps > 2:
+            self._step(dims)                        # warm-up (also position 0), eager
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step(dims)                    # recorded, not executed; every replay reads *pos on the device
+            for _ in range(n_steps - 1):
+                g.replay()
+            self.graph = g
+        else:
+            for _ in range(n_steps):
+                self._step(dims)
+        self.n_steps = n_steps
+        return self.seq2d[None], n_steps
+
+    def caches(self):
+        """Caches in the reference's layout (TupleTransformerCaches fields) for the decoded prefix."""
+        from .models.scoreperformer.transformer import TupleTransformerCaches
+        n = self.n_steps
+        att = [AttentionIntermediates(keys=k[None, :n] if self.kvh == 1 else k[:n].view(1, n, self.kvh, 64).permute(0, 2, 1, 3),
+                                      values=v[None, :n] if self.kvh == 1 else v[:n].view(1, n, self.kvh, 64).permute(0, 2, 1, 3))
+               for k, v in zip(self.kc, self.vc)]
+        return TupleTransformerCaches(token_emb=self.tok_emb[None, :n],
+                                      transformer=TransformerIntermediates(hiddens=[h[None, :n] for h in self.hid], attention=att))

@@ -233,6 +233,20 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         mask = kwargs.pop('mask', None)
         if mask is None:
             mask = torch.full_like(out[..., 0], True, dtype=torch.bool, device=out.device)
+        # fast path: greedy, one sequence, fresh caches -> hipGraph-replayed fp32 decode engine (decode.py)
+        if (out.is_cuda and out.shape[0] == 1 and caches is None and not filter_key_ids and is_greedy(filter_logits_fn, filter_kwargs)
+                and bool(mask.all()) and getattr(self, "use_decode_engine", True)):
+            try:
+                from ...decode import GreedyDecoder
+                eng = GreedyDecoder(self.model, out.shape[1])
+            except NotImplementedError:
+                eng = None
+            if eng is not None:
+                res, _ = eng.run(out, tokens_masked, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id)
+                res = res.squeeze(0) if num_dims == 2 else res
+                if was_training:
+                    self.model.train(was_training)
+                return (res, eng.caches()) if return_caches else res
         filter_key_ids = filter_key_ids or dict()
         unmask_mask = out == self.mask_token_id
         # one host read of the mask layout for the whole window (the reference reads it per step: wrappers.py:385-390)

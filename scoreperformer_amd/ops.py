@@ -567,3 +567,46 @@ def attn_bwd(q, k, v, o, d_o, lse, **kw):  # noqa: F811
     fl = 10.0 * b_ * h * nq * k.shape[1] * dh * (0.5 if kw.get("causal") else 1.0)
     return PROFILE.wrap("attn_bwd", fl, f"b{b_} h{h} nq{nq} nk{k.shape[1]} causal{int(bool(kw.get('causal')))}",
                         lambda: _attn_bwd_raw(q, k, v, o, d_o, lse, **kw))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# decode (b = 1) kernels: fp32, position read from a device scalar so that one captured step can be replayed
+# ---------------------------------------------------------------------------------------------------------
+
+def dec_gemv(W, x, y, *, bias=None, residual=None, pos=None, x_ld=0, x_off=0, y_ld=0, y_off=0, kn_layout=False):
+    N, K = (W.shape[1], W.shape[0]) if kn_layout else (W.shape[0], W.shape[1])
+    call("spn_dec_gemv", ptr(W), c_long(W.stride(0)), ptr(x), c_long(x_ld), c_int(x_off), ptr(bias), ptr(residual), ptr(y),
+         c_long(y_ld), c_int(y_off), ptr(pos), c_int(N), c_int(K), c_int(int(kn_layout)), stream_ptr())
+    return y
+
+
+def dec_embed(tables, tokens2d, pos, y, *, row_off=0, gamma=None, beta=None, eps=1e-5):
+    E = [t.shape[1] for t in tables]
+    call("spn_dec_embed", c_int(len(tables)), _ptr_array(tables), _int_array(E), ptr(tokens2d), c_long(tokens2d.stride(0)),
+         c_int(row_off), ptr(pos), ptr(gamma), ptr(beta), ptr(y), c_float(eps), stream_ptr())
+    return y
+
+
+def dec_copy_row(src, dst, pos, D, *, src_ld=0, src_off=0, dst_ld=0, dst_off=0):
+    call("spn_dec_copy_row", ptr(src), c_long(src_ld), c_int(src_off), ptr(dst), c_long(dst_ld), c_int(dst_off), ptr(pos), c_int(D),
+         stream_ptr())
+
+
+def dec_glu(u, out, I, *, act=0, glu=True):
+    call("spn_dec_glu", ptr(u), ptr(out), c_int(I), c_int(act), c_int(int(glu)), stream_ptr())
+    return out
+
+
+def dec_attn(qkv, kcache, vcache, slopes, pos, o, *, h, kvh, scale):
+    call("spn_dec_attn", ptr(qkv), ptr(kcache), ptr(vcache), ptr(slopes), ptr(pos), ptr(o), c_int(h), c_int(kvh), c_float(scale),
+         stream_ptr())
+    return o
+
+
+def dec_argmax_write(logits, V, tokens2d, dim, pos, *, ban_mask=0b11, mask_id=1):
+    call("spn_dec_argmax_write", ptr(logits), c_int(V), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)), c_int(dim),
+         c_int(mask_id), ptr(pos), stream_ptr())
+
+
+def dec_add_pos(pos, delta=1):
+    call("spn_dec_add_pos", ptr(pos), c_int(delta), stream_ptr())

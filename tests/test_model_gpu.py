@@ -150,3 +150,38 @@ def test_greedy_render_matches_reference_tokens(dev):
     assert len(mism) <= 0.03 * (want != fix["in/tokens"]).sum(), f"{len(mism)} tokens differ"
     assert tuple(caches.token_emb.shape) == tuple(fix["cache/token_emb_shape"])
     assert len(caches.transformer.hiddens) == int(fix["cache/n_hiddens"])
+
+
+def test_decode_engine_matches_reference_and_module_path(dev):
+    """The hipGraph-replayed fp32 decode engine: tokens equal to the reference's cached decode (fixture) bit for bit, and its
+    caches equal to the module path's caches."""
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.modules.sampling import top_k
+    from scoreperformer_amd.synthetic import model_config
+    fix = dict(np.load(os.path.join(GOLD, "tiny_greedy.npz"), allow_pickle=False))
+    model = ScorePerformer.init(model_config(preset="tiny", num_tokens=SMALL_VOCAB))
+    model.load_state_dict(filled_state_dict(model, seed=3))
+    ParamArena(model, dev)
+    model.eval()
+    tokens = torch.from_numpy(fix["in/tokens"]).to(dev)
+    masked = torch.from_numpy(fix["in/masked_perf"]).to(dev)
+    # feed the REFERENCE encoder outputs so that only the decode path is under test
+    ctx = torch.from_numpy(fix["out/score_embeddings"]).to(dev)
+    sty = torch.from_numpy(fix["out/perf_embeddings"]).to(dev)
+    dec = model.perf_decoder
+    out_e, caches_e = dec.unmask_tokens(tokens, masked, context=ctx, style_embeddings=sty, filter_logits_fn=top_k,
+                                        filter_kwargs={"k": 1}, return_caches=True, disable_tqdm=True)
+    assert int((out_e.cpu().numpy() != fix["out/tokens"]).sum()) == 0          # bit-exact greedy tokens
+    assert tuple(caches_e.token_emb.shape) == tuple(fix["cache/token_emb_shape"])
+    assert len(caches_e.transformer.hiddens) == int(fix["cache/n_hiddens"])
+    assert tuple(caches_e.transformer.attention[0].keys.shape) == tuple(fix["cache/keys0_shape"])
+    dec.use_decode_engine = False
+    out_m, caches_m = dec.unmask_tokens(tokens, masked, context=ctx, style_embeddings=sty, filter_logits_fn=top_k,
+                                        filter_kwargs={"k": 1}, return_caches=True, disable_tqdm=True)
+    same = (out_m == out_e).float().mean().item()
+    assert same > 0.97
+    if same == 1.0:
+        for a, b_ in zip(caches_e.transformer.hiddens, caches_m.transformer.hiddens):
+            assert (a - b_.float()).abs().max().item() <= 0.05 * b_.float().abs().max().item()
