@@ -129,7 +129,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         result["roofline"] = roofline_leg(ops, step, args)
     if rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args)
+        result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args, model, dev)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -166,7 +166,7 @@ def roofline_leg(ops, step, args):
             "attention_tflops": (sum(r[1] for r in attn) / (sum(r[2] for r in attn) * 1e-3) / 1e12) if attn else None}
 
 
-def cpu_baseline_leg(cfg, cpu_state, args):
+def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
     """The CPU oracle (parity-pinned port of the reference, oracle/ref_cpu.py) timed on this host's cores: forward+backward
     of ONE sequence of `cpu_seq` notes of the same model (bounded sample), fp32."""
     from oracle import ref_cpu
@@ -182,7 +182,23 @@ def cpu_baseline_leg(cfg, cpu_state, args):
     out = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
     out["loss"].backward()
     dt = time.perf_counter() - t0
-    return {"value": args.cpu_batch * n / dt, "unit": "note-tokens/s", "cores": threads, "kind": "port",
+    parity = None
+    if model is not None:   # same batch, same initial weights, same MMD samples through the HIP path (dropout off): loss parity
+        sd_now = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(cpu_state)     # (the arena's load hook refreshes the bf16 compute copies)
+        model.eval()
+        bounds = model.perf_encoder.segment_bounds
+        model.perf_encoder.segment_bounds = None
+        model.perf_encoder._z_override = [t.to(dev) for t in z]
+        with torch.no_grad():
+            g = model(**{k: v.to(dev) for k, v in batch.items()})
+        gl = float(g.loss)
+        parity = {"gpu_loss": gl, "cpu_loss": float(out["loss"].detach()), "abs_diff": abs(gl - float(out["loss"].detach())),
+                  "per_key": {k: [float(g.losses[k]), float(out["losses"][k].detach())] for k in out["losses"] if k in g.losses}}
+        model.perf_encoder._z_override, model.perf_encoder.segment_bounds = None, bounds
+        model.load_state_dict(sd_now)
+        model.train()
+    return {"value": args.cpu_batch * n / dt, "unit": "note-tokens/s", "cores": threads, "kind": "port", "parity": parity,
             "sample": f"{args.cpu_batch} sequences x {n} notes of the same C3 model, forward+backward (no optimizer), fp32, torch "
                       f"{torch.__version__} CPU with {threads} threads (host has {os.cpu_count()} cores), {dt:.1f} s wall",
             "cpu_loss": float(out["loss"].detach())}

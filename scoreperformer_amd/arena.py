@@ -62,8 +62,10 @@ class ParamArena:
             for bname, buf in list(mod._buffers.items()):
                 if buf is not None and buf.device != device:
                     mod._buffers[bname] = buf.to(device)
-        self.refresh_shadow()
         self._bind_fused_groups()
+        self.refresh_shadow()
+        # weights written behind the optimizer's back (load_state_dict / Model.load) invalidate the bf16 compute copy
+        model.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.refresh_shadow())
 
     # -- bf16 compute copies ---------------------------------------------------------------------------------
     def refresh_shadow(self):
@@ -71,6 +73,11 @@ class ParamArena:
         ops.cast(self.params.view(1, -1), BF16, out=self.shadow.view(1, -1))
         for p in self.param_list:
             p._spn_shadow_version = p._version
+        for mod in self.model.modules():
+            for attr in getattr(mod, "_spn_fuse_groups", {}) or {}:
+                fused = getattr(mod, attr, None)
+                if fused is not None and hasattr(fused, "_spn_parts"):
+                    fused._spn_shadow_version = tuple(p._version for p in fused._spn_parts)
 
     def _bind_fused_groups(self):
         by_id = {id(p): off for p, off in zip(self.param_list, self.offsets)}
@@ -99,8 +106,8 @@ class ParamArena:
                 fused = self.params[offs[0]:offs[0] + n].view(shape).detach().requires_grad_(True)
                 fused._spn_main_grad = self.grads[offs[0]:offs[0] + n].view(shape)
                 fused._spn_shadow = self.shadow[offs[0]:offs[0] + n].view(shape)
-                fused._spn_shadow_version = fused._version
                 fused._spn_parts = ps
+                fused._spn_shadow_version = tuple(p._version for p in ps)
                 setattr(mod, attr, fused)
 
     # -- training step -----------------------------------------------------------------------------------------

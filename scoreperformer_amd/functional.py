@@ -42,7 +42,8 @@ def bf16_weight(w: torch.Tensor) -> torch.Tensor:
     if w.dtype == BF16:
         return w
     shadow = getattr(w, "_spn_shadow", None)
-    ver = w._version
+    parts = getattr(w, "_spn_parts", None)   # fused arena view (e.g. q|k|v): stale when any constituent parameter changed
+    ver = w._version if parts is None else tuple(p._version for p in parts)
     if shadow is not None and shadow.device == w.device:
         if getattr(w, "_spn_shadow_version", None) != ver:
             ops.cast(w.detach().reshape(-1, w.shape[-1]) if w.ndim > 1 else w.detach().view(1, -1), BF16,

@@ -185,3 +185,19 @@ def test_decode_engine_matches_reference_and_module_path(dev):
     if same == 1.0:
         for a, b_ in zip(caches_e.transformer.hiddens, caches_m.transformer.hiddens):
             assert (a - b_.float()).abs().max().item() <= 0.05 * b_.float().abs().max().item()
+
+
+def test_load_state_dict_refreshes_bf16_copies(dev):
+    """Weights written behind the optimizer's back must reach the bf16 compute copies, including the fused q|k|v views."""
+    model, arena, sd = build("tiny_mixlm", dev)
+    att = model.perf_decoder.model.transformer.layers[0][1]
+    assert att._w_qkv is not None
+    sd2 = {k: (v * 1.5 if k.endswith("to_q.weight") else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd2)
+    from scoreperformer_amd import functional as F_
+    wq = F_.bf16_weight(att._w_qkv)[:att.to_q.weight.shape[0]].float()
+    assert (wq - att.to_q.weight.detach()).abs().max().item() <= 2 ** -7 * att.to_q.weight.abs().max().item()
+    with torch.no_grad():
+        att.to_k.weight.mul_(2.0)            # in-place edit of one constituent
+    wk = F_.bf16_weight(att._w_qkv)[att.to_q.weight.shape[0]:att.to_q.weight.shape[0] + att.to_k.weight.shape[0]].float()
+    assert (wk - att.to_k.weight.detach()).abs().max().item() <= 2 ** -7 * att.to_k.weight.abs().max().item()
