@@ -1,0 +1,102 @@
+"""GPU: remaining API surface of the mirrored modules/models, each against fp32 PyTorch math or the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny(dev, **kw):
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    cfg = model_config("tiny", **kw)
+    model = ScorePerformer.init(model_config("tiny", **kw))
+    sd = filled_state_dict(model, seed=2)
+    model.load_state_dict(sd)
+    arena = ParamArena(model, dev)
+    return cfg, model, arena, sd
+
+
+def test_evaluator_matches_torch_metrics(dev):
+    from scoreperformer_amd.models import ScorePerformerEvaluator
+    from scoreperformer_amd.synthetic import synthetic_batch
+    cfg, model, arena, sd = _tiny(dev)
+    model.train()
+    batch = synthetic_batch(2, 48, seed=4, ragged=True, device=dev)
+    out = model(**batch)
+    ignore = ["Bar", "Position", "Pitch", "Duration", "TimeSig", "PositionShift", "NotesInOnset", "PositionInOnset"]
+    tv = {k: torch.linspace(0, 1, v).tolist() for k, v in cfg["num_tokens"].items()}
+    ev = ScorePerformerEvaluator(model, ignore_keys=ignore, weighted_distance=True, token_values=tv)
+    metrics = ev(batch, out)
+    labels = batch["labels"][:, 1:]
+    keys = list(out.perf_decoder.logits.keys())
+    preds = torch.stack([out.perf_decoder.logits[k].float().argmax(-1) for k in keys], -1)
+    m = labels != -100
+    assert abs(float(metrics["accuracy"]) - float((preds[m] == labels[m]).float().mean())) < 1e-6
+    i = keys.index("Velocity")
+    mi = labels[..., i] != -100
+    assert abs(float(metrics["accuracy/Velocity"]) - float((preds[..., i][mi] == labels[..., i][mi]).float().mean())) < 1e-6
+    assert "accuracy/Bar" not in metrics and "distance/Tempo" in metrics
+    probs = out.perf_decoder.logits["Tempo"].float().softmax(-1)[labels[..., keys.index("Tempo")] != -100]
+    assert torch.isfinite(metrics["distance/Tempo"]) and probs.shape[0] > 0
+
+
+def test_untied_lm_head_variant_matches_oracle(dev):
+    from oracle import ref_cpu
+    from scoreperformer_amd.synthetic import synthetic_batch
+    cfg, model, arena, sd = _tiny(dev, lm_head="lm")
+    model.train()
+    batch = synthetic_batch(2, 40, seed=6, ragged=True)
+    z = [torch.randn(256, d, generator=torch.Generator().manual_seed(i)) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
+    model.perf_encoder._z_override = [t.to(dev) for t in z]
+    out = model(**{k: v.to(dev) for k, v in batch.items()})
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v) for k, v in sd.items()}
+    ref = ref_cpu.score_performer_forward(sdg, cfg, batch, z, training=True)
+    assert abs(float(out.loss) - float(ref["loss"])) <= 2e-2 * float(ref["loss"])
+    arena.zero_grad()
+    out.loss.backward()
+    ref["loss"].backward()
+    k = "perf_decoder.model.lm_head.heads.Velocity.weight"
+    g = dict(model.named_parameters())[k].grad.float().cpu()
+    assert (g - sdg[k].grad).abs().max() <= 0.06 * sdg[k].grad.abs().max() + 1e-5
+
+
+def test_clm_wrapper_forward_and_generate(dev):
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import Performer
+    from scoreperformer_amd.modules.sampling import top_k
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch, PERFORMANCE_VOCAB
+    from scoreperformer_amd.utils.config import OmegaConf
+    cfg = model_config("tiny", context_emb_mode="attention")
+    dec = dict(cfg["perf_decoder"], num_tokens=dict(PERFORMANCE_VOCAB), dim=128, style_emb_dim=None, style_emb_mode="cat")
+    dec["token_embeddings"] = dict(dec["token_embeddings"], _target_="simple")
+    p = Performer.init(OmegaConf.create({"transformer": dec, "mode": "clm"}))
+    ParamArena(p, dev)
+    batch = synthetic_batch(2, 32, seed=8, device=dev)
+    p.train()
+    out = p(batch["perf"], mask=batch["perf_mask"], labels=batch["perf"].clone())
+    assert torch.isfinite(out.loss) and len(out.losses) == 12
+    out.loss.backward()
+    p.eval()
+    gen = p.transformer.generate(batch["perf"][:1, :4], seq_len=12, filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+    assert gen.shape[-1] == 12 and gen.shape[-2] >= 1
+    assert int(gen.min()) >= 2        # PAD / MASK are banned (wrappers.py:257)
+
+
+def test_mlm_single_run_unmask(dev):
+    cfg, model, arena, sd = _tiny(dev)
+    from scoreperformer_amd.models.scoreperformer.wrappers import ScorePerformerMLMWrapper
+    from scoreperformer_amd.synthetic import synthetic_batch
+    model.eval()
+    batch = synthetic_batch(1, 24, seed=9, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    mlm = ScorePerformerMLMWrapper(model.perf_decoder.model)
+    tokens = batch["masked_perf"].clone()
+    with pytest.warns(UserWarning):
+        out = mlm.unmask_tokens(tokens, single_run=True, x_extra=batch["masked_perf"], context=enc.score_embeddings,
+                                style_embeddings=enc.perf_embeddings)
+    assert int((out == 1).sum()) == 0 and (out[tokens != 1] == tokens[tokens != 1]).all()
