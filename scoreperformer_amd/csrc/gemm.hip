@@ -41,7 +41,10 @@ struct GemmArgs {
     int batch;                // blockIdx.z (batched) ...
     long sA, sB, sC;          // batch strides in elements
     int splitk;               // ... or, when > 1, blockIdx.z = K slice: partial products are atomically added into fp32 C
-    int kt_per_split;         // K tiles (of 64) per slice
+    int kt_per_split;         // K tiles per slice
+#ifdef SPN_GEMM_TIMING
+    long long* dbg;
+#endif
 };
 
 // ---- LDS addressing -------------------------------------------------------------------------------------
@@ -275,6 +278,299 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+#ifdef SPN_GEMM_TIMING
+static long long* g_dbg = nullptr;   // tuning aid (tools/gemm_timing.py): per-segment s_memtime sums of block 0, waves 0 and 4
+#define TSTAMP(k_) do { const long long t__ = __builtin_amdgcn_s_memtime(); seg[k_] += t__ - tprev; tprev = t__; } while (0)
+#else
+#define TSTAMP(k_) do {} while (0)
+#endif
+
+// ---- 256x256 ping-pong kernel ------------------------------------------------------------------------------
+// The two-barrier loop above tops out near 0.9 PFLOP/s: every K step each wave stages, waits, reads and multiplies in lockstep,
+// so the matrix pipe idles through the staging part.  This kernel splits the 8 waves of a 256x256 tile into two groups
+// (waves 0-3 / 4-7: one wave of each group per SIMD) that run ONE BARRIER APART: while one group issues its MFMAs the other one
+// reads fragments and issues LDS DMA, and they swap at every barrier.
+//   * K tile 64 (128-byte rows: every DMA lane group fetches whole cache lines).  A wave owns 128x64 of C = 2x2 quadrants of 64x32;
+//     phase 4t+p multiplies one quadrant over K tile t:  p0 (A0,B0)  p1 (A0,B1)  p2 (A1,B1)  p3 (A1,B0), Ah = the wave's rows
+//     64h..64h+63, Bh = its columns 32h..32h+31.  Reads per phase: A0+B0 / B1 / A1 / none (B0 stays in registers).
+//   * the operands are staged as 16 KiB half-tiles: AX = the A0 rows of both row groups, AY = the A1 rows, BX / BY alike for the
+//     four column groups.  Stream S = AX(0) BX(0) BY(0) AY(0) AX(1) ...: exactly the order of first use.  Each kind has 2 slots
+//     (K tile parity): 8 x 16 KiB = 128 KiB.
+//   * the read part of phase p issues S[p+6] (2 DMA instructions per wave) and then waits with vmcnt(8): S[<= p+2] has landed
+//     (this wave's pieces; 4 half-tiles stay in flight), the barrier publishes it, and it is read in phase p+1 or later
+//     (AX(t) = S[4t], BX(t) = S[4t+1] first read in phase 4t, BY(t) = S[4t+2] in 4t+1, AY(t) = S[4t+3] in 4t+2)
+//   * S[p+6] overwrites a slot last read in phase <= p-2: both groups have retired those reads (lgkmcnt(0) right after the barrier
+//     that starts their MFMA part) at least one barrier before either group issues the refill
+// Interior tiles only (M, N multiples of 256, K of 64): the launcher routes everything else to the kernel above.
+constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_LEAD = 6;
+constexpr int PP_HALF = 128 * PP_BK * 2;   // bytes of one half-tile (128 rows x 64 k)
+
+// LDS addressing of the ping-pong kernel (32-row fragments of v_mfma_f32_32x32x16_bf16).
+// K-contiguous half-tile [128 rows][64 k]: row = 128 B = 8 chunks of 16 B; two rows share a 256-byte bank window and the XOR key is the
+// window index, so the 16 rows of one ds_read_b128 lane group (rows {0-3,12-15,20-27} / {4-11,16-19,28-31}) hit 16 distinct slots.
+__device__ __forceinline__ int pp_kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// R-contiguous half-tile [64 k][128 r]: row = 256 B = 16 chunks.  One transpose-read half (32 lanes) covers 4 k-rows x 2 adjacent
+// 32-byte column windows; XOR-ing the window index with 2*(krow & 3) puts the 8 pieces on 8 distinct windows.
+__device__ __forceinline__ int pp_rc_swz(int krow) { return (krow & 3) << 2; }
+__device__ __forceinline__ int pp_rc_off(int krow, int chunk) { return krow * 256 + ((chunk ^ pp_rc_swz(krow)) << 4); }
+
+// fragment of v_mfma_f32_32x32x16_bf16 for 32 rows starting at r_base, k-step ks (16 k each):
+// lane l holds row r_base + (l & 31), k = 16 ks + (l >> 5) * 8 + 0..7
+template <bool T>
+__device__ __forceinline__ bf16x8 pp_read_frag(const char* lds, int r_base, int ks, int lane) {
+    if (!T) {
+        return *reinterpret_cast<const bf16x8*>(lds + pp_kc_off(r_base + (lane & 31), ks * 2 + (lane >> 5)));
+    } else {
+        // ds_read_b64_tr_b16: within a 16-lane group lane p addresses k-row p/4, columns 4(p%4)..+3 and receives column p
+        typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+        const int g = lane >> 4, p = lane & 15;
+        const int col_byte = (r_base + 16 * (g & 1) + 4 * (p & 3)) * 2;
+        const int chunk = col_byte >> 4, within = col_byte & 15;
+        const int k0 = ks * 16 + (g >> 1) * 8 + (p >> 2);
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + pp_rc_off(k0, chunk) + within));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + pp_rc_off(k0 + 4, chunk) + within));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+// half-tile row x (0..127) -> row of the 256-row block tile.  A: x = 64*group + r -> 128*group + 64*h + r  (2 row groups);
+// B: x = 32*group + r -> 64*group + 32*h + r  (4 column groups).  Multiples of 8 stay contiguous.
+template <int SUB> __device__ __forceinline__ int pp_row(int x, int h) { return (x / SUB) * (2 * SUB) + SUB * h + (x % SUB); }
+
+// one half-tile = 16 pieces of 1 KiB, 2 per wave; LDS image linear, swizzle applied on the source address
+template <bool T, int SUB>
+__device__ __forceinline__ void pp_dma(const bf16_t* __restrict__ p, int ld, int row0, int k0, int h, char* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wave * 2 + i) * 64 + lane;
+        const bf16_t* src;
+        if (!T) {
+            const int x = L >> 3, kc = (L & 7) ^ ((x >> 1) & 7);
+            src = p + (long)(row0 + pp_row<SUB>(x, h)) * ld + k0 + kc * 8;
+        } else {
+            const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
+            src = p + (long)(k0 + krow) * ld + row0 + pp_row<SUB>(rc * 8, h);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+}
+
+template <bool TA, bool TB, typename OutT>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // slot of half-tile kind c (0 AX, 1 BX, 2 BY, 3 AY) of K tile t
+#define PP_SLOT(c_, t_) (smem + ((c_) * 2 + ((t_) & 1)) * PP_HALF)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int m0, n0;
+    {
+        const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        m0 = (wg / gridDim.x) * PP_BM;
+        n0 = (wg % gridDim.x) * PP_BN;
+    }
+    const bool split = g.splitk > 1;
+    const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
+    const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
+    const int nt_all = g.K / PP_BK;
+    const int t_begin = split ? blockIdx.z * g.kt_per_split : 0;
+    const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
+    if (nt <= 0) return;
+    const int kbase = t_begin * PP_BK;
+    const int total = 4 * nt;   // half-tiles in the stream
+
+    f32x16 acc[4][2];   // acc[2h + i][j]: rows 64h + 32i.., columns 32j..
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int c, int t) {   // c is a compile-time constant at every call site
+        const int k0 = kbase + t * PP_BK;
+        if (c == 0) pp_dma<TA, 64>(A, g.lda, m0, k0, 0, PP_SLOT(0, t), wave, lane);
+        else if (c == 1) pp_dma<TB, 32>(B, g.ldb, n0, k0, 0, PP_SLOT(1, t), wave, lane);
+        else if (c == 2) pp_dma<TB, 32>(B, g.ldb, n0, k0, 1, PP_SLOT(2, t), wave, lane);
+        else pp_dma<TA, 64>(A, g.lda, m0, k0, 1, PP_SLOT(3, t), wave, lane);
+    };
+    // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
+    auto wait_landed = [&](int p) {
+        const int younger = min(p + PP_LEAD + 1, total) - (p + 3);
+        if (younger >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#define PP_SYNC_MFMA_BEGIN()                                   \
+    TSTAMP(2);                                                  \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    __builtin_amdgcn_s_barrier();                               \
+    TSTAMP(3);                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    TSTAMP(4);                                                  \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    __builtin_amdgcn_s_setprio(1)
+#define PP_SYNC_MFMA_END()                                     \
+    __builtin_amdgcn_s_setprio(0);                              \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    TSTAMP(5);                                                  \
+    __builtin_amdgcn_s_barrier();                               \
+    TSTAMP(6)
+
+    // prologue: S[0..5] = K tile 0 and AX, BX of K tile 1
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    if (nt > 1) { issue(0, 1); issue(1, 1); }
+    wait_landed(-1);
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind the first
+
+#ifdef SPN_GEMM_TIMING
+    long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memtime();
+#endif
+    for (int t = 0; t < nt; ++t) {
+        bf16x8 af[2][4], b0[4], b1[4];
+        // ---- p0: reads A0, B0; issues BY(t+1) = S[4t+6] ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b0[ks] = pp_read_frag<TB>(PP_SLOT(1, t), wc * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[i][ks] = pp_read_frag<TA>(PP_SLOT(0, t), wr * 64 + 32 * i, ks, lane);
+        TSTAMP(0);
+        if (t + 1 < nt) issue(2, t + 1);
+        TSTAMP(1);
+        wait_landed(4 * t);
+        PP_SYNC_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[ks], af[i][ks], acc[i][0], 0, 0, 0);
+        }
+        PP_SYNC_MFMA_END();
+        // ---- p1: reads B1; issues AY(t+1) = S[4t+7] ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) b1[ks] = pp_read_frag<TB>(PP_SLOT(2, t), wc * 32, ks, lane);
+        TSTAMP(0);
+        if (t + 1 < nt) issue(3, t + 1);
+        TSTAMP(1);
+        wait_landed(4 * t + 1);
+        PP_SYNC_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[ks], af[i][ks], acc[i][1], 0, 0, 0);
+        }
+        PP_SYNC_MFMA_END();
+        // ---- p2: reads A1; issues AX(t+2) = S[4t+8] ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) af[i][ks] = pp_read_frag<TA>(PP_SLOT(3, t), wr * 64 + 32 * i, ks, lane);
+        TSTAMP(0);
+        if (t + 2 < nt) issue(0, t + 2);
+        TSTAMP(1);
+        wait_landed(4 * t + 2);
+        PP_SYNC_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[ks], af[i][ks], acc[2 + i][1], 0, 0, 0);
+        }
+        PP_SYNC_MFMA_END();
+        // ---- p3: no reads (B0 is still in registers); issues BX(t+2) = S[4t+9] ----
+        TSTAMP(0);
+        if (t + 2 < nt) issue(1, t + 2);
+        TSTAMP(1);
+        wait_landed(4 * t + 3);
+        PP_SYNC_MFMA_BEGIN();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[ks], af[i][ks], acc[2 + i][0], 0, 0, 0);
+        }
+        PP_SYNC_MFMA_END();
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();   // balances the second group's extra barrier
+#ifdef SPN_GEMM_TIMING
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4) && lane == 0)
+        for (int k = 0; k < 8; ++k) g.dbg[(wave >> 2) * 8 + k] = seg[k];
+#endif
+#undef PP_SYNC_MFMA_BEGIN
+#undef PP_SYNC_MFMA_END
+#undef PP_SLOT
+
+    // ---- epilogue (same lane layout as gemm_kernel: row m = ..+(lane&31), 4 consecutive columns per accumulator quad) ----
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (split ? 0 : (long)blockIdx.z * g.sC);
+    const bool lead = !split || blockIdx.z == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 128 + 32 * i + (lane & 31);
+        const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int jq = 0; jq < 8; ++jq) {
+            const int j = jq >> 2, q = jq & 3;
+            const int n = n0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
+            f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha;
+            if (g.bias && lead) v += *reinterpret_cast<const f32x4*>(g.bias + n);
+            v *= rs;
+            if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+            OutT* dst = C + (long)m * g.ldc + n;
+            if constexpr (sizeof(OutT) == 4) {
+                if (split) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
+                } else {
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            } else {
+                uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            }
+        }
+    }
+}
+
+// shapes the ping-pong kernel takes: whole 256x256x64 tiles, vector-aligned epilogue operands
+static bool pp_eligible(const GemmArgs& g) {
+    return g.M % PP_BM == 0 && g.N % PP_BN == 0 && g.K % PP_BK == 0 && g.K >= 4 * PP_BK && g.ldc % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.residual || (g.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)) &&
+           (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) && (g.sC % 4 == 0);
+}
+
+template <bool TA, bool TB, typename OutT>
+int launch_pp(GemmArgs g, hipStream_t stream) {
+    const int tiles = (g.N / PP_BN) * (g.M / PP_BM), nt = g.K / PP_BK;
+    g.splitk = 1; g.kt_per_split = nt;
+    if (sizeof(OutT) == 4 && g.batch == 1 && tiles < 192 && nt >= 64) {
+        int want = cdiv(512, tiles);
+        if (want > nt / 16) want = nt / 16;
+        if (want > 1) {
+            g.kt_per_split = cdiv(nt, want);
+            g.splitk = cdiv(nt, g.kt_per_split);
+            if (!g.accumulate) {
+                if (g.ldc == g.N) hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, stream);
+                else hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream);
+            }
+        }
+    }
+    constexpr int LDS_BYTES = 8 * PP_HALF;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    dim3 grid(g.N / PP_BN, g.M / PP_BM, g.splitk > 1 ? g.splitk : g.batch);
+    hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 template <bool TA, bool TB, typename OutT, int BK, int STAGES>
 int launch_bk(GemmArgs g, hipStream_t stream) {
     // split-K for the weight-gradient shapes (tiny M x N, contraction over all tokens): fill the chip with K slices
@@ -318,6 +614,8 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     if (variant == 4) return launch_bk<TA, TB, OutT, 32, 2>(g, stream);
     if (variant == 5) return launch_bk<TA, TB, OutT, 64, 4>(g, stream);
     if (variant == 6) return launch_bk<TA, TB, OutT, 32, 3>(g, stream);
+    if (variant == 9 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
+    if (variant == 0 && !TA && g.K >= 1024 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
     // measured on MI355X (tools/bench_gemm.py): residency beats in-block pipelining -- two 16 KiB-per-operand stages with
     // BK = 32 (32 KiB LDS, 4 blocks/CU) win everywhere except the long-K all-K-contiguous case
     if (!TA && !TB && g.K >= 2048) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
@@ -346,6 +644,9 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.residual = residual; g.rowmask = rowmask;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+#ifdef SPN_GEMM_TIMING
+    g.dbg = g_dbg;
+#endif
     if (f32) {
         if (!ta && !tb) return launch<false, false, float>(g, stream);
         if (!ta && tb) return launch<false, true, float>(g, stream);
@@ -358,3 +659,7 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
         return launch<true, true, bf16_t>(g, stream);
     }
 }
+
+#ifdef SPN_GEMM_TIMING
+extern "C" void spn_gemm_set_debug(void* p) { g_dbg = (long long*)p; }
+#endif

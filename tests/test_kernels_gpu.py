@@ -16,7 +16,8 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1000, 264, 520), (264, 1000, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1000, 264, 520), (264, 1000, 2048),
+                                   (512, 256, 256), (256, 768, 1088), (1024, 512, 64 * 37)])   # last three: whole 256x256x64 tiles
 def test_gemm_layouts(dev, ta, tb, M, N, K):
     from scoreperformer_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
@@ -52,6 +53,33 @@ def test_gemm_epilogue(dev):
     ops.gemm(wide[:, K:2 * K], w, out=outw[:, N:])
     assert rel_err(outw[:, N:], wide[:, K:2 * K].float() @ w.float().t()) < 1e-2
     assert outw[:, :N].abs().max().item() == 0
+
+
+def test_gemm_big_tile_epilogue_and_splitk(dev):
+    """Shapes that take the 256x256 ping-pong kernel: fused epilogue, accumulate, and the split-K weight-gradient form."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 768, 512, 320
+    a = torch.randn(M, K, generator=g).to(dev).bfloat16()
+    w = torch.randn(N, K, generator=g).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) > 0.3).to(dev)
+    ref = res + mask[:, None] * (0.5 * (a.float() @ w.float().t()) + bias)
+    out = ops.gemm(a, w, out_dtype=torch.float32, bias=bias, residual=res, rowmask=mask, alpha=0.5)
+    assert rel_err(out, ref) < 2e-3
+    out16 = ops.gemm(a, w, out_dtype=torch.bfloat16, bias=bias)
+    assert rel_err(out16, a.float() @ w.float().t() + bias) < 1e-2
+    # dW = dY^T X over many tokens (split-K with atomics), accumulated onto an existing gradient
+    T = 16384
+    dy = torch.randn(T, 512, generator=g).to(dev).bfloat16()
+    x = torch.randn(T, 256, generator=g).to(dev).bfloat16()
+    ref = dy.float().t() @ x.float()
+    dw = ops.gemm(dy, x, ta=True, tb=True, out_dtype=torch.float32)
+    assert rel_err(dw, ref) < 2e-3
+    acc = torch.ones(512, 256, device=dev)
+    ops.gemm(dy, x, ta=True, tb=True, out=acc, accumulate=True)
+    assert rel_err(acc, 1 + ref) < 2e-3
 
 
 @pytest.mark.parametrize("D", [128, 320, 512, 1280, 1536])

@@ -16,7 +16,15 @@ def run(M, N, K, ta, tb, f32, reps=10):
         ops.gemm(a, b, ta=ta, tb=tb, out=out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"M={M:6d} N={N:5d} K={K:6d} {'T' if ta else 'N'}{'T' if tb else 'N'} {'f32' if f32 else 'bf16'}: {dt*1e3:7.3f} ms  {2.0*M*N*K/dt/1e12:6.0f} TF/s")
+    am, bm = (a.t() if ta else a), (b if tb else b.t())
+    o2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    torch.matmul(am, bm, out=o2); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        torch.matmul(am, bm, out=o2)
+    torch.cuda.synchronize()
+    dl = (time.perf_counter() - t0) / reps
+    print(f"M={M:6d} N={N:5d} K={K:6d} {'T' if ta else 'N'}{'T' if tb else 'N'} {'f32' if f32 else 'bf16'}: {dt*1e3:7.3f} ms  {2.0*M*N*K/dt/1e12:6.0f} TF/s   | hipBLASLt (bf16 out) {dl*1e3:7.3f} ms {2.0*M*N*K/dl/1e12:6.0f} TF/s")
 
 T = 131072
 for shape in [(T, 4096, 512, False, False, False), (T, 512, 2048, False, False, True), (T, 640, 512, False, False, False),

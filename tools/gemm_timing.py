@@ -1,0 +1,36 @@
+"""Tuning aid: per-segment s_memtime sums of the ping-pong GEMM (needs libspn_timing.so built with -DSPN_GEMM_TIMING)."""
+import ctypes, os, sys, torch
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(root, "tools/_bin", os.environ.get("LIB", "libspn_timing.so")))
+E = lambda k, d: int(os.environ.get(k, d))
+M, N, K = E("M", 8192), E("N", 8192), E("K", 8192)
+dev = torch.device("cuda")
+LDA, LDB = E("LDA", K), E("LDB", K)
+a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
+c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+dbg = torch.zeros(16, device=dev, dtype=torch.int64)
+if hasattr(lib, "spn_gemm_set_debug"):
+    lib.spn_gemm_set_debug(ctypes.c_void_p(dbg.data_ptr()))
+P = ctypes.c_void_p
+for _ in range(2):
+    rc = lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
+                           ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
+                      ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+if LDA == K and LDB == K:
+    ref = a[:512].float() @ b.float().t()
+    err = ((c[:512].float() - ref).abs().max() / ref.abs().max()).item()
+    ref2 = a[-256:].float() @ b[-256:].float().t()
+    err2 = ((c[-256:, -256:].float() - ref2).abs().max() / ref2.abs().max()).item()
+    print("relerr", f"{err:.2e} {err2:.2e}", "OK" if max(err, err2) < 1e-2 else "WRONG")
+print(f"{os.environ.get('LIB', '')} M={M} N={N} K={K}: {ms:.3f} ms {2.0*M*N*K/ms/1e9:.0f} TF/s")
+names = ["ds_read issue", "dma issue", "vmcnt wait", "barrier A", "lgkm wait", "mfma", "barrier B", "-"]
+d = dbg.cpu().tolist(); ph = 4 * K // 64
+for g in range(2):
+    print(f"group {g}: " + "  ".join(f"{names[k]}={d[g*8+k]/ph:.0f}" for k in range(7)), " total/phase", sum(d[g*8:g*8+7]) / ph)
