@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, cons
 }
 
 // backward pass 2: grid (chunks, keys).  Each block owns one key's table copy in LDS (if it fits) and a slab of rows.
-__global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+// A wave takes 64 rows at a time: lane r fetches row r's token and LayerNorm statistics (one latency for 64 rows instead of a
+// dependent token -> table-row chain per row), then the rows are walked with wave-uniform broadcasts; every lane owns a column pair.
+// Few fat blocks (one per CU): the final flush is V*E global atomics PER BLOCK, which dominated with ~1000 thin blocks.
+__global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
                                                                 const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ s1, const float* __restrict__ s2, int T,
@@ -245,30 +248,48 @@ __global__ __launch_bounds__(256) void embed_bwd_scatter_kernel(GatherDesc d, co
     const int kk = blockIdx.y, E = d.width[kk], V = d.rows[kk], c0 = d.col0[kk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (use_lds) {
-        for (int i = threadIdx.x; i < V * E; i += 256) acc[i] = 0.f;
+        for (int i = threadIdx.x; i < V * E; i += 512) acc[i] = 0.f;
         __syncthreads();
     }
     const float* tab = d.table[kk];
     float* dtab = d.dtable[kk];
+    float* dst = use_lds ? acc : dtab;
     const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
-    for (int row = row_begin + w; row < row_end; row += 4) {
-        const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
-        if (tok == padding_idx) continue;
-        float mu = 0.f, rs = 1.f, a1 = 0.f, a2 = 0.f;
-        if (gamma) { mu = mean[row]; rs = rstd[row]; a1 = s1[row]; a2 = s2[row]; }
-        for (int c = lane; c < E; c += 64) {
-            float g = bf2f(dy[(long)row * lddy + c0 + c]);
-            if (gamma) {
-                const float xh = (tab[tok * E + c] - mu) * rs;
-                g = rs * (g * gamma[c0 + c] - a1 - xh * a2);
+    for (int base = row_begin + w * 64; base < row_end; base += 8 * 64) {
+        const int myrow = base + lane;
+        int tok_l = padding_idx;
+        float mu_l = 0.f, rs_l = 1.f, a1_l = 0.f, a2_l = 0.f;
+        if (myrow < row_end) {
+            tok_l = (int)tokens[(long)(myrow / t_len) * tok_bs + (long)(myrow % t_len) * tok_ts + kk];
+            if (gamma) { mu_l = mean[myrow]; rs_l = rstd[myrow]; a1_l = s1[myrow]; a2_l = s2[myrow]; }
+        }
+        const int cnt = min(64, row_end - base);
+#pragma unroll 4
+        for (int r = 0; r < cnt; ++r) {
+            const int tok = __shfl(tok_l, r, 64);
+            const float mu = __shfl(mu_l, r, 64), rs = __shfl(rs_l, r, 64), a1 = __shfl(a1_l, r, 64), a2 = __shfl(a2_l, r, 64);
+            const bool live = tok != padding_idx;
+            const bf16_t* dyr = dy + (long)(base + r) * lddy + c0;
+            const float* tr = tab + (long)(live ? tok : 0) * E;
+            for (int c = 2 * lane; c < E; c += 128) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(dyr + c);
+                float g0 = bf2f(u & 0xffff), g1 = bf2f(u >> 16);
+                if (gamma) {
+                    const float2 x = *reinterpret_cast<const float2*>(tr + c);
+                    const float2 ga = *reinterpret_cast<const float2*>(gamma + c0 + c);
+                    g0 = rs * (g0 * ga.x - a1 - (x.x - mu) * rs * a2);
+                    g1 = rs * (g1 * ga.y - a1 - (x.y - mu) * rs * a2);
+                }
+                if (live) {
+                    atomicAdd(dst + (long)tok * E + c, g0);
+                    atomicAdd(dst + (long)tok * E + c + 1, g1);
+                }
             }
-            if (use_lds) atomicAdd(&acc[tok * E + c], g);
-            else atomicAdd(dtab + tok * E + c, g);
         }
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < V * E; i += 256) {
+        for (int i = threadIdx.x; i < V * E; i += 512) {
             const float v = acc[i];
             if (v != 0.f) atomicAdd(dtab + i, v);
         }
@@ -383,12 +404,13 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
         hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    int chunks = 1024 / nkeys;
-    if (chunks > cdiv(T, 64)) chunks = cdiv(T, 64);
+    // one block per CU when the table copy fills the LDS, a few more when it is small
+    int chunks = (lds_bytes > 72 * 1024 ? 256 : 512) / nkeys;
+    if (chunks > cdiv(T, 512)) chunks = cdiv(T, 512);
     if (chunks < 1) chunks = 1;
-    int rpb = cdiv(T, chunks); rpb = ((rpb + 3) / 4) * 4;
+    int rpb = cdiv(T, chunks); rpb = ((rpb + 63) / 64) * 64;
     dim3 grid(cdiv(T, rpb), nkeys);
-    hipLaunchKernelGGL(embed_bwd_scatter_kernel, grid, dim3(256), use_lds ? lds_bytes : 0, stream, d, tokens, tok_bs, tok_ts, t_len,
+    hipLaunchKernelGGL(embed_bwd_scatter_kernel, grid, dim3(512), use_lds ? lds_bytes : 0, stream, d, tokens, tok_bs, tok_ts, t_len,
                        (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, T, rpb, padding_idx, use_lds);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

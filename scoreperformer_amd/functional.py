@@ -158,8 +158,11 @@ def linear(x, weight, bias=None, *, residual=None, rowmask=None, out_fp32=False,
 # ---------------------------------------------------------------------------------------------------------
 
 class LayerNormFn(Function):
+    """`fork=True` also returns x itself (the residual branch of a pre-norm block): the backward then receives both branch
+    gradients and the kernel adds them (dx = d_residual + LN backward) instead of autograd launching a separate add."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, out_fp32: bool, eps: float):
+    def forward(ctx, x, gamma, beta, out_fp32: bool, eps: float, fork: bool = False):
         y, mean, rstd = ops.layernorm_fwd(x, gamma.detach() if gamma is not None else None,
                                           beta.detach() if beta is not None else None, None,
                                           out_dtype=F32 if out_fp32 else BF16, eps=eps)
@@ -168,14 +171,17 @@ class LayerNormFn(Function):
         for p in (gamma, beta):
             if p is not None and p.requires_grad:
                 _pend(p)
-        return y.view(x.shape)
+        return (y.view(x.shape), x.view_as(x)) if fork else y.view(x.shape)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.gamma_ref, ctx.beta_ref
         D = x.shape[-1]
+        if dy is None:   # only the residual branch was used
+            return dres, None, None, None, None, None
+        dres = _fork_grad(dres, x)
         dyb = to_bf16(dy.reshape(-1, D))
         dgamma = dbeta = None
         g_main = getattr(gamma, "_spn_main_grad", None) if gamma is not None else None
@@ -184,7 +190,7 @@ class LayerNormFn(Function):
         if gamma is not None:
             dgamma = g_main if fused else torch.zeros(D, device=x.device, dtype=F32)
             dbeta = b_main if fused else torch.zeros(D, device=x.device, dtype=F32)
-        dx, _ = ops.layernorm_bwd(x, dyb, gamma.detach() if gamma is not None else None, None, mean, rstd,
+        dx, _ = ops.layernorm_bwd(x, dyb, gamma.detach() if gamma is not None else None, None, mean, rstd, dres=dres,
                                   dx_dtype=x.dtype, dgamma=dgamma, dbeta=dbeta)
         if fused:
             for p in (gamma, beta):
@@ -192,18 +198,63 @@ class LayerNormFn(Function):
                 if hook is not None:
                     hook()
             dgamma = dbeta = None
-        return dx.view(x.shape), dgamma, dbeta, None, None
+        return dx.view(x.shape), dgamma, dbeta, None, None, None
 
 
-def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5):
-    return LayerNormFn.apply(x, gamma, beta, out_fp32, eps)
+def _fork_grad(dres, x):
+    """Residual-branch gradient in the form the LayerNorm backward kernel adds: fp32, row-major, or None."""
+    if dres is None:
+        return None
+    dres = dres.reshape(-1, x.shape[-1])
+    if dres.dtype != F32:
+        dres = dres.float()
+    return dres if dres.stride(-1) == 1 else dres.contiguous()
+
+
+class SplitColsFn(Function):
+    """x[..., off_i : off_i + w_i] for consecutive widths, as ONE autograd node: the backward packs the slice gradients into a
+    single buffer (one strided copy per slice) instead of autograd's zero-filled full-width tensor plus an add per slice."""
+
+    @staticmethod
+    def forward(ctx, x, *widths):
+        ctx.widths, ctx.shape, ctx.dt = widths, x.shape, x.dtype
+        outs, off = [], 0
+        for w in widths:
+            outs.append(x.narrow(-1, off, w))
+            off += w
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        dx = torch.empty(ctx.shape, device=grads[0].device if grads[0] is not None else next(g for g in grads if g is not None).device,
+                         dtype=ctx.dt)
+        off = 0
+        for w, g in zip(ctx.widths, grads):
+            dst = dx.narrow(-1, off, w)
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+            off += w
+        if off < ctx.shape[-1]:
+            dx.narrow(-1, off, ctx.shape[-1] - off).zero_()
+        return (dx,) + (None,) * len(ctx.widths)
+
+
+def split_cols(x, widths):
+    return SplitColsFn.apply(x, *widths)
+
+
+def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5, fork=False):
+    return LayerNormFn.apply(x, gamma, beta, out_fp32, eps, fork)
 
 
 class AdaLayerNormFn(Function):
     """y = gamma_t * LN(x) + beta_t,  (gamma_t | beta_t) = cond @ W^T + b   (modules/layers.py:31-47)."""
 
     @staticmethod
-    def forward(ctx, x, cond, weight, bias, out_fp32: bool, eps: float):
+    def forward(ctx, x, cond, weight, bias, out_fp32: bool, eps: float, fork: bool = False):
         D = x.shape[-1]
         cb = to_bf16(cond)
         c2 = cb.reshape(-1, cb.shape[-1])
@@ -212,16 +263,18 @@ class AdaLayerNormFn(Function):
         ctx.save_for_backward(x, c2, gb, mean, rstd)
         ctx.weight_ref, ctx.bias_ref, ctx.cond_shape, ctx.cond_dtype = weight, bias, cond.shape, cond.dtype
         _pend(weight); _pend(bias)
-        return y.view(x.shape)
+        return (y.view(x.shape), x.view_as(x)) if fork else y.view(x.shape)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, c2, gb, mean, rstd = ctx.saved_tensors
         weight, bias = ctx.weight_ref, ctx.bias_ref
         D = x.shape[-1]
+        if dy is None:
+            dy = torch.zeros(x.shape, device=x.device, dtype=BF16)
         dyb = to_bf16(dy.reshape(-1, D))
-        dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dx_dtype=x.dtype, want_dgb=True)
+        dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dres=_fork_grad(dres, x), dx_dtype=x.dtype, want_dgb=True)
         dcond = None
         if ctx.needs_input_grad[1]:
             dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
@@ -236,11 +289,11 @@ class AdaLayerNormFn(Function):
                 hook()
         else:
             db = ops.colsum(dgb)
-        return dx.view(x.shape), dcond, dw, db, None, None
+        return dx.view(x.shape), dcond, dw, db, None, None, None
 
 
-def ada_layer_norm(x, cond, weight, bias, *, out_fp32=False, eps=1e-5):
-    return AdaLayerNormFn.apply(x, cond, weight, bias, out_fp32, eps)
+def ada_layer_norm(x, cond, weight, bias, *, out_fp32=False, eps=1e-5, fork=False):
+    return AdaLayerNormFn.apply(x, cond, weight, bias, out_fp32, eps, fork)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -297,12 +297,8 @@ class TupleTokenTiedLMHead(_HeadBase, Constructor):
             e = F_.linear(x, self.project_emb.weight)
         e = self.norm(e)
         tables = build_tables(list(self.embs.values()))
-        items, off = [], 0
-        for i, key in enumerate(self.embs.keys()):
-            w = self.split_dims[i]
-            if _wanted(i, key, keys):
-                items.append((i, key, e[..., off:off + w], tables[i], None))
-            off += w
+        parts = F_.split_cols(e, self.split_dims) if e.requires_grad else torch.split(e, self.split_dims, dim=-1)
+        items = [(i, key, parts[i], tables[i], None) for i, key in enumerate(self.embs.keys()) if _wanted(i, key, keys)]
         logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
         return (logits, sums, argmax) if labels is not None or want_argmax else logits
 

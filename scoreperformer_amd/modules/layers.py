@@ -31,8 +31,9 @@ class Residual(nn.Module):
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters (same state_dict keys), HIP forward/backward; returns bf16 unless `out_fp32`."""
 
-    def forward(self, x: Tensor, out_fp32: bool = False):
-        return F_.layer_norm(x, self.weight, self.bias, out_fp32=out_fp32, eps=self.eps)
+    def forward(self, x: Tensor, out_fp32: bool = False, fork: bool = False):
+        """`fork=True` returns (norm(x), x): the pair a pre-norm residual block consumes, with one fused backward."""
+        return F_.layer_norm(x, self.weight, self.bias, out_fp32=out_fp32, eps=self.eps, fork=fork)
 
 
 class AdaptiveLayerNorm(nn.Module):
@@ -45,11 +46,11 @@ class AdaptiveLayerNorm(nn.Module):
         self.linear.bias.data[:dim] = 1
         self.linear.bias.data[dim:] = 0
 
-    def forward(self, x: Tensor, condition: Optional[Tensor] = None, out_fp32: bool = False):
+    def forward(self, x: Tensor, condition: Optional[Tensor] = None, out_fp32: bool = False, fork: bool = False):
         if condition is None:  # gamma = 1, beta = 0
-            return F_.layer_norm(x, None, None, out_fp32=out_fp32, eps=self.eps)
+            return F_.layer_norm(x, None, None, out_fp32=out_fp32, eps=self.eps, fork=fork)
         if condition.ndim == 2:
             condition = condition.unsqueeze(1)
         if condition.shape[1] != x.shape[1]:
             condition = condition.expand(-1, x.shape[1], -1)
-        return F_.ada_layer_norm(x, condition, self.linear.weight, self.linear.bias, out_fp32=out_fp32, eps=self.eps)
+        return F_.ada_layer_norm(x, condition, self.linear.weight, self.linear.bias, out_fp32=out_fp32, eps=self.eps, fork=fork)

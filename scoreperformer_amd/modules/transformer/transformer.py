@@ -81,10 +81,10 @@ class Transformer(nn.Module, Constructor):
             norms = nn.ModuleList([norm_fn() if pre_norm else None, None, norm_fn() if not pre_norm else None])
             self.layers.append(nn.ModuleList([norms, layer, Residual(dim)]))
 
-    def _norm(self, norm, x, style, out_fp32=False):
+    def _norm(self, norm, x, style, out_fp32=False, fork=False):
         if self.ada_norm:
-            return norm(x, condition=style, out_fp32=out_fp32)
-        return norm(x, out_fp32=out_fp32)
+            return norm(x, condition=style, out_fp32=out_fp32, fork=fork)
+        return norm(x, out_fp32=out_fp32, fork=fork)
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None,
@@ -119,7 +119,11 @@ class Transformer(nn.Module, Constructor):
                 cache = intermediates_cache.attention.pop(0)
             residual = x
             pre_norm, post_branch_norm, post_main_norm = norm
-            h = self._norm(pre_norm, x, style_embeddings) if pre_norm is not None else F_.cast(x, torch.bfloat16)
+            if pre_norm is not None and x.dtype == torch.float32 and x.requires_grad:
+                # (norm(x), x) from one autograd node: its backward adds the two branch gradients inside the LayerNorm kernel
+                h, residual = self._norm(pre_norm, x, style_embeddings, fork=True)
+            else:
+                h = self._norm(pre_norm, x, style_embeddings) if pre_norm is not None else F_.cast(x, torch.bfloat16)
             fuse = residual_fn.is_plain
             res_arg = residual if fuse else None
             if layer_type == 'a':
