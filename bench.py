@@ -30,6 +30,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the bucketed RCCL all-reduce path on a one-rank group")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048)
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -55,10 +56,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from scoreperformer_amd import build as spn_build
     if rank == 0:
@@ -79,7 +82,7 @@ def main():
     model.train()
     model.sync_free = True
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
-    sync = GradSync(arena, dist.group.WORLD if dist is not None else None)
+    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp)
     batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
     # segment-slot counts are known to the (host-side) input pipeline: pass them as python ints, no device read-back
     model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in

@@ -14,14 +14,16 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, arena, group=None, bucket_mb: float = 32.0):
+    def __init__(self, arena, group=None, bucket_mb: float = 32.0, force: bool = False):
+        """`force=True` keeps the bucketed all-reduce path active on a one-rank group (single-GPU tests of the RCCL path)."""
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if group is not None else 1
+        self.active = self.world > 1 or (force and group is not None)
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
         self.pending: List[int] = []
-        if self.world == 1:
+        if not self.active:
             return
         # buckets in REVERSE arena order (decoder parameters come last in the arena and first in backward)
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -96,7 +98,7 @@ class GradSync:
         self.handles.append(dist.all_reduce(self.arena.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_step(self):
-        if self.world == 1:
+        if not self.active:
             return
         self.handles, self.done, self.launched = [], set(), set()
         self.counts = [0] * len(self.arena.param_list)
@@ -107,7 +109,7 @@ class GradSync:
 
     def finish(self):
         """After backward: reduce whatever has not been launched yet (parameters that got no gradient), wait for all."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):
             if b not in self.launched:

@@ -1,0 +1,52 @@
+"""GPU: the bucketed RCCL all-reduce path (GradSync) on a one-rank nccl group gives the same step as no sync at all."""
+import os
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gradsync_nccl_single_rank_matches_plain_step(dev):
+    import torch.distributed as dist
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena, FusedAdamW
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.parallel import GradSync
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        batch = synthetic_batch(2, 64, seed=3, ragged=True, device=dev)
+        results = []
+        for use_sync in (False, True):
+            model = ScorePerformer.init(model_config("tiny", dropout=0.0))
+            model.load_state_dict(filled_state_dict(model, seed=5))
+            arena = ParamArena(model, dev)
+            model.train()
+            opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+            sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, force=True) if use_sync else None
+            torch.manual_seed(11)
+            first = None
+            for it in range(2):
+                if sync:
+                    sync.begin_step()
+                arena.zero_grad()
+                out = model(**batch)
+                out.loss.backward()
+                if sync:
+                    sync.finish()
+                    assert len(sync.buckets) >= 3 and len(sync.launched) == len(sync.buckets)
+                grads = arena.grads.clone()
+                first = grads if it == 0 else first
+                opt.step()
+            torch.cuda.synchronize()
+            results.append((float(out.loss.detach()), first, grads, arena.params.clone()))
+        (l0, f0, g0, p0), (l1, f1, g1, p1) = results
+        # split-K weight gradients add with fp32 atomics: equal up to summation order on the first step, and up to that noise
+        # carried through one optimizer step on the second
+        assert (f0 - f1).abs().max() <= 2e-5 * f0.abs().max()
+        assert abs(l0 - l1) < 1e-3
+        assert (g0 - g1).abs().max() <= 5e-3 * g0.abs().max() and (p0 - p1).abs().max() <= 1e-4
+    finally:
+        dist.destroy_process_group()
