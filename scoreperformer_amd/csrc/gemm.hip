@@ -40,7 +40,7 @@ struct GemmArgs {
     int accumulate;           // C += (fp32 C only)
     int batch;                // blockIdx.z (batched) ...
     long sA, sB, sC;          // batch strides in elements
-    int splitk;               // ... or, when > 1, blockIdx.z = K slice: partial products are atomically added into fp32 C
+    int splitk;               // ... or, when > 1, blockIdx.z = K slice writing its partial product to C + z*sC (a workspace)
     int kt_per_split;         // K tiles per slice
 #ifdef SPN_GEMM_TIMING
     long long* dbg;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane owns row m = ..+(lane&15) and 4 consecutive columns n = ..+(lane>>4)*4 + 0..3 ----------
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (split ? 0 : (long)blockIdx.z * g.sC);
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
     const bool lead = !split || blockIdx.z == 0;   // bias / residual are added by the first K slice only
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (!g.residual || g.ldr % 4 == 0);
 #pragma unroll
@@ -248,13 +248,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             if (full4 && vec_ok) {
                 if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
                 if constexpr (sizeof(OutT) == 4) {
-                    if (split) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                    } else {
-                        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                        *reinterpret_cast<f32x4*>(dst) = v;
-                    }
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
                     uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
                     *reinterpret_cast<uint2*>(dst) = pk;
@@ -266,7 +261,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
                     float x = v[r];
                     if (g.residual && lead) x += g.residual[(long)m * g.ldr + n + r];
                     if constexpr (sizeof(OutT) == 4) {
-                        if (split) { atomicAdd(dst + r, x); continue; }
                         if (g.accumulate) x += dst[r];
                         dst[r] = x;
                     } else {
@@ -505,7 +499,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #undef PP_SLOT
 
     // ---- epilogue (same lane layout as gemm_kernel: row m = ..+(lane&31), 4 consecutive columns per accumulator quad) ----
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (split ? 0 : (long)blockIdx.z * g.sC);
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
     const bool lead = !split || blockIdx.z == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -521,19 +515,82 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
             OutT* dst = C + (long)m * g.ldc + n;
             if constexpr (sizeof(OutT) == 4) {
-                if (split) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(dst + r, v[r]);
-                } else {
-                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                }
+                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                *reinterpret_cast<f32x4*>(dst) = v;
             } else {
                 uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(dst) = pk;
             }
         }
     }
+}
+
+// ---- split-K plumbing -------------------------------------------------------------------------------------
+// K slices write their partial products to a workspace [splits][M][N] with plain stores and one small kernel sums them into C
+// (deterministic; fp32 atomics into C cost up to half of the weight-gradient GEMMs: ~16K atomics per block through L2).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long slice, float* __restrict__ C,
+                                                            int ldc, int N, long total4, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const long e = i * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + e);
+        for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + z * slice + e);
+        float* dst = C + (e / N) * ldc + (e % N);
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
+}
+
+// grow-only workspace.  Reuse is ordered by the stream; a call from another stream waits for the previous user's reduce.
+struct SplitWorkspace {
+    float* ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+    float* get(size_t need, hipStream_t stream) {
+        if (!done) hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (need > bytes) {
+            if (ptr) { hipDeviceSynchronize(); hipFree(ptr); }
+            bytes = need + need / 4;
+            if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; bytes = 0; return nullptr; }
+            used = false;
+        }
+        if (used && last != stream) hipStreamWaitEvent(stream, done, 0);
+        return ptr;
+    }
+    void release(hipStream_t stream) { hipEventRecord(done, stream); last = stream; used = true; }
+};
+static SplitWorkspace g_split_ws[16];   // per device
+
+// decide the K split of a tiny-MxN / long-K product, redirect the kernel's output to the workspace; returns the final C description
+struct SplitPlan { float* C; int ldc; int accumulate; float* ws; };
+static int plan_split(GemmArgs& g, int tiles, int nt, int max_tiles, int want_blocks, int min_kt, hipStream_t stream, SplitPlan& plan) {
+    g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
+    if (g.batch != 1 || tiles >= max_tiles || nt < 4 * min_kt || g.N % 4 != 0 || g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0)
+        return SPN_OK;
+    int want = cdiv(want_blocks, tiles);
+    if (want > nt / min_kt) want = nt / min_kt;
+    if (want <= 1) return SPN_OK;
+    g.kt_per_split = cdiv(nt, want);
+    g.splitk = cdiv(nt, g.kt_per_split);
+    int dev = 0;
+    hipGetDevice(&dev);
+    float* ws = g_split_ws[dev & 15].get((size_t)g.splitk * g.M * g.N * 4, stream);
+    if (!ws) { spn_set_error("spn_gemm_bf16: split-K workspace allocation failed"); return SPN_ERR_HIP; }
+    plan = SplitPlan{reinterpret_cast<float*>(g.C), g.ldc, g.accumulate, ws};
+    g.C = ws; g.ldc = g.N; g.sC = (long)g.M * g.N; g.accumulate = 0;
+    return SPN_OK;
+}
+static void finish_split(const GemmArgs& g, const SplitPlan& plan, hipStream_t stream) {
+    if (!plan.ws) return;
+    const long total4 = (long)g.M * g.N / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, plan.ws, g.splitk, (long)g.M * g.N, plan.C, plan.ldc, g.N,
+                       total4, plan.accumulate);
+    int dev = 0;
+    hipGetDevice(&dev);
+    g_split_ws[dev & 15].release(stream);
 }
 
 // shapes the ping-pong kernel takes: whole 256x256x64 tiles, vector-aligned epilogue operands
@@ -546,18 +603,12 @@ static bool pp_eligible(const GemmArgs& g) {
 template <bool TA, bool TB, typename OutT>
 int launch_pp(GemmArgs g, hipStream_t stream) {
     const int tiles = (g.N / PP_BN) * (g.M / PP_BM), nt = g.K / PP_BK;
-    g.splitk = 1; g.kt_per_split = nt;
-    if (sizeof(OutT) == 4 && g.batch == 1 && tiles < 192 && nt >= 64) {
-        int want = cdiv(512, tiles);
-        if (want > nt / 16) want = nt / 16;
-        if (want > 1) {
-            g.kt_per_split = cdiv(nt, want);
-            g.splitk = cdiv(nt, g.kt_per_split);
-            if (!g.accumulate) {
-                if (g.ldc == g.N) hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, stream);
-                else hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream);
-            }
-        }
+    SplitPlan plan;
+    if (sizeof(OutT) == 4) {
+        const int rc = plan_split(g, tiles, nt, 192, 512, 16, stream, plan);
+        if (rc != SPN_OK) return rc;
+    } else {
+        g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
     constexpr int LDS_BYTES = 8 * PP_HALF;
     static bool attr_done = false;
@@ -568,6 +619,8 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     dim3 grid(g.N / PP_BN, g.M / PP_BM, g.splitk > 1 ? g.splitk : g.batch);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
+    finish_split(g, plan, stream);
+    SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
 
@@ -575,18 +628,12 @@ template <bool TA, bool TB, typename OutT, int BK, int STAGES>
 int launch_bk(GemmArgs g, hipStream_t stream) {
     // split-K for the weight-gradient shapes (tiny M x N, contraction over all tokens): fill the chip with K slices
     const int tiles = cdiv(g.N, BN) * cdiv(g.M, BM), nt = cdiv(g.K, BK);
-    g.splitk = 1; g.kt_per_split = nt;
-    if (sizeof(OutT) == 4 && g.batch == 1 && tiles < 384 && nt >= 32) {
-        int want = cdiv(768, tiles);
-        if (want > nt / 8) want = nt / 8;
-        if (want > 1) {
-            g.kt_per_split = cdiv(nt, want);
-            g.splitk = cdiv(nt, g.kt_per_split);
-            if (!g.accumulate) {   // slices add atomically: C must start from zero (stream-ordered memset)
-                if (g.ldc == g.N) hipMemsetAsync(g.C, 0, (size_t)g.M * g.N * 4, stream);
-                else hipMemset2DAsync(g.C, (size_t)g.ldc * 4, 0, (size_t)g.N * 4, g.M, stream);
-            }
-        }
+    SplitPlan plan;
+    if (sizeof(OutT) == 4) {
+        const int rc = plan_split(g, tiles, nt, 384, 768, 8, stream, plan);
+        if (rc != SPN_OK) return rc;
+    } else {
+        g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splitk > 1 ? g.splitk : g.batch);
     constexpr int LDS_BYTES = STAGES * 2 * 128 * BK * 2;
@@ -599,6 +646,8 @@ int launch_bk(GemmArgs g, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK, STAGES>), grid, dim3(256), LDS_BYTES, stream, g);
+    SPN_LAUNCH_CHECK();
+    finish_split(g, plan, stream);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
