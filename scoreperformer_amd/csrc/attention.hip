@@ -36,7 +36,8 @@ using namespace spn_attn;
 template <int MODE, bool DROP>
 __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], float (&m_run)[2], float (&l_run)[2],
                                             const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
-                                            bool causal, const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8) {
+                                            bool causal, const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8,
+                                            uint16_t* bitp, long bstride) {
     uint32_t mbits[4] = {0, 0, 0, 0};
     if (MODE == T_GEN) {
 #pragma unroll
@@ -79,15 +80,20 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
             }
         l_run[qb] += psum;   // the softmax normaliser is that of the un-dropped probabilities
         if (DROP) {
+            uint32_t kw = 0;   // keep bits of this lane's 16 scores, bit 4*kb + r
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const int jh = (j0 + 16 * kb + 4 * g) >> 1;
-                const uint32_t b0 = drop_bits(rowc[qb], jh), b1 = drop_bits(rowc[qb], jh + 1);
-                if (!drop_keep(b0, i_odd, 0, thr8)) s[kb][qb][0] = 0.f;
-                if (!drop_keep(b0, i_odd, 1, thr8)) s[kb][qb][1] = 0.f;
-                if (!drop_keep(b1, i_odd, 0, thr8)) s[kb][qb][2] = 0.f;
-                if (!drop_keep(b1, i_odd, 1, thr8)) s[kb][qb][3] = 0.f;
+                const uint32_t mine = drop_bits(rowc[qb], jh + i_odd), other = lane_swap1(mine);   // lane parity == i_odd
+                const uint32_t b0 = i_odd ? other : mine, b1 = i_odd ? mine : other;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool keep = drop_keep(r < 2 ? b0 : b1, i_odd, r & 1, thr8);
+                    if (!keep) s[kb][qb][r] = 0.f;
+                    kw |= keep ? (1u << (4 * kb + r)) : 0u;
+                }
             }
+            bitp[qb * bstride] = (uint16_t)kw;
         }
     }
 }
@@ -127,6 +133,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int qb = 0; qb < 2; ++qb)
             rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, (a.nq + 1) >> 1, (q0 + 32 * w + 16 * qb + c) >> 1);
     }
+
+    const long bstride = (long)a.nkt64 * 64;   // keep-bit words between consecutive 16-query tiles
+    uint16_t* bitbase = DROP ? a.dropbits + ((long)(bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * bstride + lane : nullptr;
 
     f32x4 o[4][2];
 #pragma unroll
@@ -181,9 +190,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         const float j0f = (float)j0;
-        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
-        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
-        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8);
+        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
+        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
+        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
 
         // O^T += V^T P^T
 #pragma unroll
@@ -256,7 +265,7 @@ template <int MODE, bool SLOPE_GRAD, bool DROP>
 __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (&dp)[2][2], const float (&l2)[2], const float (&dl)[2],
                                           const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
                                           bool causal, float (&acc_d)[2], float (&acc_r)[2], float (&acc_p)[2],
-                                          const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8, float inv_keep) {
+                                          const uint32_t (&kw)[2], float inv_keep) {
     uint32_t mbits[2] = {0, 0};
     if (MODE == T_GEN) {
 #pragma unroll
@@ -269,11 +278,6 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
         const float mm = l2[qb] - uo;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            uint32_t b0 = 0, b1 = 0;
-            if (DROP) {
-                const int jh = (j0 + 16 * (2 * u + k2) + 4 * g) >> 1;
-                b0 = drop_bits(rowc[qb], jh); b1 = drop_bits(rowc[qb], jh + 1);
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float jc = (float)(16 * (2 * u + k2) + r);
@@ -281,9 +285,14 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
                 const bool ok = MODE != T_GEN || ((((mbits[k2] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
                 const float t = score<MODE>(s[k2][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
                 const float p = fast_exp2(t - mm);
-                float dpv = dp[k2][qb][r];
-                if (DROP) dpv = drop_keep(r < 2 ? b0 : b1, i_odd, r & 1, thr8) ? dpv * inv_keep : 0.f;
-                const float ds = p * (dpv - dl[qb]);
+                float ds;
+                if (DROP) {   // keep bit 4*kb + r of the forward's word -> all-ones / zero mask
+                    const int keepm = __builtin_amdgcn_sbfe((int)kw[qb], 4 * (2 * u + k2) + r, 1);
+                    const float dpm = __uint_as_float(__float_as_uint(dp[k2][qb][r]) & (uint32_t)keepm);
+                    ds = p * fmaf(dpm, inv_keep, -dl[qb]);
+                } else {
+                    ds = p * (dp[k2][qb][r] - dl[qb]);
+                }
                 if (SLOPE_GRAD) {
                     const float ad = fabsf(jf - i_f[qb]);
                     acc_d[qb] = fmaf(ds, ad, acc_d[qb]); acc_r[qb] += ds; acc_p[qb] = fmaf(p, ad, acc_p[qb]);
@@ -335,13 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         dl[qb] = i < a.nq ? a.delta[si] : 0.f;
     }
     const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
-    uint32_t rowc[2] = {0, 0};
-    const int i_odd = c & 1;
-    if (DROP) {
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-            rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, (a.nq + 1) >> 1, (q0 + 32 * w + 16 * qb + c) >> 1);
-    }
+    const long bstride = (long)a.nkt64 * 64;
+    const uint16_t* bitbase = DROP ? a.dropbits + ((long)(bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * bstride + lane : nullptr;
+    uint32_t kw[2] = {0, 0}, kwn[2] = {0, 0};   // keep-bit words of the current / next key tile
     f32x4 dq[4][2];
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -360,10 +365,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         kr.load(kp, a.k_ns, 0, a.nk, tid);
         vr.load(vp, a.v_ns, 0, a.nk, tid);
         if (tid < 64) mreg = (tid < a.nk) ? (mp ? mp[tid] : 1) : 0;
+        if (DROP) { kwn[0] = bitbase[0]; kwn[1] = bitbase[bstride]; }
     }
     for (int t = 0; t < nt; ++t) {
         const int j0 = t * 64;
         __syncthreads();
+        kw[0] = kwn[0]; kw[1] = kwn[1];
         kr.store<false>(k_tile, tid);
         kr.store<true>(kt_tile, tid);
         vr.store<false>(v_tile, tid);
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             kr.load(kp, a.k_ns, j0 + 64, a.nk, tid);
             vr.load(vp, a.v_ns, j0 + 64, a.nk, tid);
             if (tid < 64) { const int j = j0 + 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
+            if (DROP) { kwn[0] = bitbase[(t + 1) * 64]; kwn[1] = bitbase[bstride + (t + 1) * 64]; }
         }
         // rows beyond nq hold zero fragments and are never written; the last q block may straddle nq: use the general path
         const bool rows_ok = q0 + 32 * w + 31 < a.nq;
@@ -406,13 +414,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
             if (slope_grad) {
-                if (cls == T_LEFT) dq_scores<T_LEFT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
-                else dq_scores<T_GEN, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                if (cls == T_LEFT) dq_scores<T_LEFT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
+                else if (cls == T_RIGHT) dq_scores<T_RIGHT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
+                else dq_scores<T_GEN, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
             } else {
-                if (cls == T_LEFT) dq_scores<T_LEFT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
-                else dq_scores<T_GEN, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, rowc, i_odd, j0, a.thr8, a.inv_keep);
+                if (cls == T_LEFT) dq_scores<T_LEFT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
+                else if (cls == T_RIGHT) dq_scores<T_RIGHT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
+                else dq_scores<T_GEN, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
             }
             bf16x8 dsf[2];
 #pragma unroll
@@ -453,11 +461,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
-void set_dropout(AttnArgs& a, float p_drop, unsigned seed) {
+void set_dropout(AttnArgs& a, float p_drop, unsigned seed, void* dropbits, int nq, int nk) {
     const float t = p_drop * 256.f;
     a.thr8 = t <= 0.f ? 0u : (t >= 255.f ? 255u : (uint32_t)(t + 0.5f));
     a.seed = seed;
     a.inv_keep = 1.f / (1.f - (float)a.thr8 / 256.f);
+    a.dropbits = (uint16_t*)dropbits;
+    a.nqt16 = dropbits_nqt16(nq);
+    a.nkt64 = dropbits_nkt64(nk);
 }
 
 int check_common(const AttnArgs& a) {
@@ -474,12 +485,18 @@ int check_common(const AttnArgs& a) {
 }  // namespace
 
 // strides: 12 longs = {q_bs,q_ns,q_hs, k_bs,k_ns,k_hs, v_bs,v_ns,v_hs, o_bs,o_ns,o_hs} in elements; head dim 64.
+// uint16 words of the dropout keep-bit buffer for a [b, h, nq, nk] attention (1 bit per score, whole 128x128 blocks)
+extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {
+    return (long)b * h * dropbits_nqt16(nq) * dropbits_nkt64(nk) * 64;
+}
+
 extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                             const float* slopes, int b, int h, int kvh, int nq, int nk, int causal, float scale,
-                            const long* strides, float p_drop, unsigned seed, hipStream_t stream) {
+                            const long* strides, float p_drop, unsigned seed, void* dropbits, hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    set_dropout(a, p_drop, seed);
+    set_dropout(a, p_drop, seed, dropbits, nq, nk);
+    SPN_REQUIRE(a.thr8 == 0 || dropbits, "spn_attn_fwd: dropout needs the keep-bit buffer (spn_attn_dropbits_elems uint16 words)");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
     a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk; a.causal = causal;
     a.scale = scale;
@@ -503,10 +520,11 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
 extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                             const float* lse, float* delta, void* dq, void* dk, void* dv, float* dslope,
                             const uint8_t* kmask, const float* slopes, int b, int h, int kvh, int nq, int nk,
-                            int causal, float scale, const long* strides, float p_drop, unsigned seed, hipStream_t stream) {
+                            int causal, float scale, const long* strides, float p_drop, const void* dropbits, hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    set_dropout(a, p_drop, seed);
+    set_dropout(a, p_drop, 0, const_cast<void*>(dropbits), nq, nk);
+    SPN_REQUIRE(a.thr8 == 0 || dropbits, "spn_attn_bwd: dropout needs the keep bits written by spn_attn_fwd");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.d_o = (const bf16_t*)d_o;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.dslope = dslope; a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk;

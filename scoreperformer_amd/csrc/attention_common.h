@@ -27,8 +27,17 @@ struct AttnArgs {
     float scale;
     // attention dropout (attend.py:122 `dropout_p`): keep iff the 8-bit field of hash(seed, b, h, i>>1, j>>1) selected by
     // (i&1, j&1) is >= thr8;  kept probabilities are scaled by inv_keep = 1 / (1 - thr8/256).  thr8 == 0: no dropout.
+    // The forward hashes and ALSO writes the keep bits (1 bit per score, dropbits_elems() uint16 words); both backward kernels
+    // read them back instead of re-hashing (they are VALU-bound; a bit test is 3x cheaper per element than hash + compare).
+    // Word [bh][query tile of 16][key tile of 64][forward lane]: bit 4*kb + r = key 16*kb + 4*(lane>>4) + r of query lane&15,
+    // i.e. exactly the forward's (and dQ's) S^T register layout.
     uint32_t thr8, seed; float inv_keep;
+    uint16_t* dropbits; int nqt16, nkt64;
 };
+
+// geometry of the keep-bit buffer: whole 128-query blocks and 128-key blocks, so no kernel needs bounds checks
+__host__ __device__ inline int dropbits_nqt16(int nq) { return 8 * ((nq + 127) / 128); }
+__host__ __device__ inline int dropbits_nkt64(int nk) { return 2 * ((nk + 127) / 128); }
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -107,7 +116,18 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ uint32_t drop_row_const(uint32_t seed, int bh, int nq_half, int i_half) {
     return ((uint32_t)(bh * nq_half + i_half)) * 0x9E3779B1u + seed;
 }
-__device__ __forceinline__ uint32_t drop_bits(uint32_t row_const, int j_half) { return spn_hash32(row_const + (uint32_t)j_half * 0x85EBCA77u); }
+// Mixer built from full-rate VALU ops only (v_mul_u32_u24 / v_mad_u32_u24; v_mul_lo_u32 is quarter rate): two rounds of
+// fold + 24-bit multiply-add, final fold.  Checked offline on the (row_const, j_half) lattice: per-byte chi^2 ~ 1, keep-rate and
+// field / row / column / diagonal correlations at sampling noise, avalanche 0.49-0.51.
+__device__ __forceinline__ uint32_t drop_hash(uint32_t x) {
+    x ^= x >> 11; x = __umul24(x, 0xD35A2Du) + (x >> 8);
+    x ^= x >> 13; x = __umul24(x, 0x9E3B35u) + (x >> 9);
+    return x ^ (x >> 15);
+}
+__device__ __forceinline__ uint32_t drop_bits(uint32_t row_const, int j_half) { return drop_hash(row_const + __umul24((uint32_t)j_half, 0xEBCA77u)); }
+// Lanes l and l^1 hold neighbouring rows (or columns) of the same 2x2 blocks and need the same two hashes: each computes one
+// and they swap through DPP (quad_perm [1,0,3,2]), halving the hash count.
+__device__ __forceinline__ uint32_t lane_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ bool drop_keep(uint32_t bits, int i_odd, int j_odd, uint32_t thr8) {
     return ((bits >> (8 * (2 * i_odd + j_odd))) & 0xffu) >= thr8;
 }

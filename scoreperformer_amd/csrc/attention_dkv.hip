@@ -13,7 +13,7 @@ __device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile
                                          const float* nl2_s, const float* dl_s, const bf16x8 (&kf)[2][2], const bf16x8 (&vf)[2][2],
                                          f32x4 (&dk)[4][2], f32x4 (&dv)[4][2], const float (&jf)[2], const bool (&key_ok)[2],
                                          int ioff, float c1, float slope2, bool causal, int lane, int g,
-                                         uint32_t seed, int bh, int nq_half, int i0, const int (&jcol)[2], uint32_t thr8, float inv_keep) {
+                                         const uint2 (&bw)[4], const int (&boff)[2], float log2_inv_keep, float keep_prob) {
 #pragma unroll
 for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
         f32x4 p[2][2], ds[2][2];                // [qq][kb]
@@ -22,17 +22,13 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
             const int qb = 2 * u + qq;
             const bf16x8 qa0 = frag_rows(q_tile, 16 * qb, 0, lane), qa1 = frag_rows(q_tile, 16 * qb, 1, lane);
             const bf16x8 da0 = frag_rows(do_tile, 16 * qb, 0, lane), da1 = frag_rows(do_tile, 16 * qb, 1, lane);
-            const f32x4 n4 = *reinterpret_cast<const f32x4*>(nl2_s + 16 * qb + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 16 * qb + 4 * g);
+            // dropout: P' = P / keep_prob (the log2 shift rides on -lse), dS = P' * (keep * dP - delta * keep_prob)
+            f32x4 n4 = *reinterpret_cast<const f32x4*>(nl2_s + 16 * qb + 4 * g);
+            f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 16 * qb + 4 * g);
+            if (DROP) { n4 += log2_inv_keep; d4 *= keep_prob; }
             const float ib = (float)(ioff + 16 * qb + 4 * g);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                uint32_t b0 = 0, b1 = 0;
-                if (DROP) {   // rows i0 + 16qb + 4g + r: pairs (r=0,1) and (r=2,3) share a 2x2 block row
-                    const int ih = (i0 + 16 * qb + 4 * g) >> 1;
-                    b0 = drop_bits(drop_row_const(seed, bh, nq_half, ih), jcol[kb] >> 1);
-                    b1 = drop_bits(drop_row_const(seed, bh, nq_half, ih + 1), jcol[kb] >> 1);
-                }
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa0, kf[kb][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa1, kf[kb][1], acc, 0, 0, 0);
@@ -50,10 +46,10 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
                         e = (ok ? t : NEG_FILL) + n4[r];
                     }
                     const float pv = fast_exp2(e);
-                    if (DROP) {
-                        const bool keep = drop_keep(r < 2 ? b0 : b1, r & 1, jcol[kb] & 1, thr8);
-                        p[qq][kb][r] = keep ? pv * inv_keep : 0.f;                      // P_dropped feeds dV
-                        ds[qq][kb][r] = pv * ((keep ? acc2[r] * inv_keep : 0.f) - d4[r]);
+                    if (DROP) {   // row r of this lane's key column: halfword r of bw[qb], bit boff[kb] (see attention_common.h)
+                        const uint32_t keepm = (uint32_t)__builtin_amdgcn_sbfe((int)(r < 2 ? bw[qb].x : bw[qb].y), boff[kb] + 16 * (r & 1), 1);
+                        p[qq][kb][r] = __uint_as_float(__float_as_uint(pv) & keepm);                      // P_dropped feeds dV
+                        ds[qq][kb][r] = pv * (__uint_as_float(__float_as_uint(acc2[r]) & keepm) - d4[r]);
                     } else {
                         p[qq][kb][r] = pv;
                         ds[qq][kb][r] = pv * (acc2[r] - d4[r]);
@@ -126,11 +122,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     const int n_iter = (nqt - t_first) > 0 ? (nqt - t_first) * heads_per_kv : 0;
 
+    // keep bits of the forward: this lane's key column c of key block kb sits in forward lanes (c>>2)*16 + 4g + r (r = its 4 rows),
+    // bit 4*kb_f + (c&3) with kb_f = the 16-key block index inside the forward's 64-key tile
+    const long bstride = (long)a.nkt64 * 64;
+    const int boff[2] = {4 * (2 * (w & 1)) + (c & 3), 4 * (2 * (w & 1) + 1) + (c & 3)};
+    const long bit_lane = (long)((j0 + 32 * w) / 64) * 64 + (c >> 2) * 16 + 4 * g;
+    const float log2_inv_keep = DROP ? __builtin_log2f(a.inv_keep) : 0.f, keep_prob = DROP ? 1.f / a.inv_keep : 1.f;
+    uint2 bw[4], bwn[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) { bw[qb] = make_uint2(0, 0); bwn[qb] = make_uint2(0, 0); }
+
     TileRegs qr, dor;
     float lreg = 0.f, dreg = 0.f;
     auto issue = [&](int it) {
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
+        if (DROP) {
+            const uint16_t* bp = a.dropbits + ((long)(bi * a.h + hh) * a.nqt16 + i0 / 16) * bstride + bit_lane;
+#pragma unroll
+            for (int qb = 0; qb < 4; ++qb) bwn[qb] = *reinterpret_cast<const uint2*>(bp + qb * bstride);
+        }
         qr.load(a.q + bi * a.q_bs + hh * a.q_hs, a.q_ns, i0, a.nq, tid);
         dor.load(a.d_o + bi * a.o_bs + hh * a.o_hs, a.o_ns, i0, a.nq, tid);
         if (tid < 64) {
@@ -152,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         dor.store<false>(do_tile, tid);
         dor.store<true>(dot_tile, tid);
         if (tid < 64) { nl2_s[tid] = lreg; dl_s[tid] = dreg; }
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) bw[qb] = bwn[qb];
         __syncthreads();
         if (it + 1 < n_iter) issue(it + 1);
 
@@ -163,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
         if (cls == T_SKIP) continue;
 
-        if (cls == T_LEFT) dkv_tile<T_LEFT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
-        else if (cls == T_RIGHT) dkv_tile<T_RIGHT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
-        else dkv_tile<T_GEN, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, a.seed, bi * a.h + hh, (a.nq + 1) >> 1, i0, jcol, a.thr8, a.inv_keep);
+        if (cls == T_LEFT) dkv_tile<T_LEFT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
+        else if (cls == T_RIGHT) dkv_tile<T_RIGHT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
+        else dkv_tile<T_GEN, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

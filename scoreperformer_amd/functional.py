@@ -311,7 +311,8 @@ class SelfAttnFn(Function):
         v = qkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
-        o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        o, lse, *bits = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        ctx.dropbits = bits[0] if bits else None
         ctx.save_for_backward(qkv, o, lse, sl, kmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, n, heads * 64)
@@ -331,7 +332,7 @@ class SelfAttnFn(Function):
         dv = dqkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, n, heads, 64)
         dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=sl, causal=causal, scale=scale,
-                           want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, seed=seed)
+                           want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, dropbits=ctx.dropbits)
         return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 
@@ -346,7 +347,8 @@ class CrossAttnFn(Function):
         v = kv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
-        o, lse = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        o, lse, *bits = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        ctx.dropbits = bits[0] if bits else None
         ctx.save_for_backward(q, kv, o, lse, sl, kmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, nq, heads * 64)
@@ -367,7 +369,7 @@ class CrossAttnFn(Function):
         d_o = to_bf16(d_o).contiguous().view(b, nq, heads, 64)
         dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, slopes=sl,
                            causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2], p_drop=p_drop,
-                           seed=seed)
+                           dropbits=ctx.dropbits)
         return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 

@@ -32,6 +32,7 @@ def load() -> ctypes.CDLL:
                            f"(the HIP extension is mandatory; there is no fallback path)")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.spn_last_error.restype = ctypes.c_char_p
+        _lib.spn_attn_dropbits_elems.restype = ctypes.c_long
     return _lib
 
 

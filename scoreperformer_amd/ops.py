@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .lib import call, ptr, stream_ptr, require_gpu, c_int, c_long, c_float, SpnError
+from .lib import load,  call, ptr, stream_ptr, require_gpu, c_int, c_long, c_float, SpnError
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -139,7 +139,9 @@ def _mask_u8(m: Optional[torch.Tensor]):
 
 
 def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0):
-    """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq]."""
+    """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq].
+
+    With p_drop > 0 a third value is returned: the dropout keep bits (int16 words, 1 bit per score) that `attn_bwd` needs."""
     require_gpu(q, k, v)
     b, nq, h, dh = q.shape
     nk, kvh = k.shape[1], k.shape[2]
@@ -150,15 +152,21 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_dr
         ks, vs = (ks[0], ks[1], 0), (vs[0], vs[1], 0)
     strides = (c_long * 12)(*_bnhd_strides(q), *ks, *vs, *_bnhd_strides(o))
     kmask = _mask_u8(kmask)
+    bits = None
+    if p_drop > 0:
+        bits = torch.empty(load().spn_attn_dropbits_elems(c_int(b), c_int(h), c_int(nq), c_int(nk)), device=q.device, dtype=torch.int16)
     call("spn_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh),
          c_int(nq), c_int(nk), c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides,
-         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
-    return o, lse
+         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(bits), stream_ptr())
+    return (o, lse) if bits is None else (o, lse, bits)
 
 
 def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
-             p_drop: float = 0.0, seed: int = 0):
-    """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None."""
+             p_drop: float = 0.0, dropbits=None):
+    """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None.
+    `dropbits`: the keep bits returned by `attn_fwd` when p_drop > 0."""
+    if p_drop > 0 and dropbits is None:
+        raise SpnError("attn_bwd: p_drop > 0 needs the keep bits of the forward")
     b, nq, h, dh = q.shape
     nk, kvh = k.shape[1], k.shape[2]
     ks, vs, dks, dvs = _bnhd_strides(k), _bnhd_strides(v), _bnhd_strides(dk), _bnhd_strides(dv)
@@ -175,7 +183,7 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
     call("spn_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
          ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
          c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, c_float(p_drop),
-         ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
+         ptr(dropbits), stream_ptr())
     return dslope
 
 

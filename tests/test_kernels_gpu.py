@@ -279,7 +279,7 @@ def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
     for t in range(nk // 64):
         vi = torch.zeros(b, nk, 1, 64, device=dev)
         vi[:, 64 * t:64 * (t + 1), 0] = torch.eye(64, device=dev)
-        o, _ = ops.attn_fwd(q, k, vi.bfloat16(), slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+        o, _, _ = ops.attn_fwd(q, k, vi.bfloat16(), slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
         pd[..., 64 * t:64 * (t + 1)] = o.float().permute(0, 2, 1, 3)
     qf, kf = q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3).expand(b, h, nk, 64)
     dist = torch.arange(nk, device=dev)[None, :] - (torch.arange(nq, device=dev)[:, None] + nk - nq)
@@ -302,10 +302,10 @@ def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
     ref = ((dots_r.softmax(-1) * mfull / (1 - thr)) @ vr.permute(0, 2, 1, 3).expand(b, h, nk, 64)).permute(0, 2, 1, 3)
     d_o = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
     ref.backward(d_o.float())
-    o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+    o, lse, bits = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
     assert rel_err(o, ref) < 3e-2
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
-    ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, scale=scale, p_drop=p, seed=seed)
+    ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, scale=scale, p_drop=p, dropbits=bits)
     assert rel_err(dq, qr.grad) < 4e-2
     assert rel_err(dk, kr.grad) < 4e-2
     assert rel_err(dv, vr.grad) < 4e-2
