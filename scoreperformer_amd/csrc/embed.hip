@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, cons
 
 // backward pass 2: grid (chunks, keys).  Each block owns one key's table copy in LDS (if it fits) and a slab of rows.
 // A wave takes 64 rows at a time: lane r fetches row r's token and LayerNorm statistics (one latency for 64 rows instead of a
-// dependent token -> table-row chain per row), then the rows are walked with wave-uniform broadcasts; every lane owns a column pair.
+// dependent token -> table-row chain per row), then the rows are walked four at a time with lane-group broadcasts.
 // Few fat blocks (one per CU): the final flush is V*E global atomics PER BLOCK, which dominated with ~1000 thin blocks.
 __global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
                                                                 const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ gamma,
@@ -255,6 +255,8 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, co
     float* dtab = d.dtable[kk];
     float* dst = use_lds ? acc : dtab;
     const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
+    // 32 lanes x 4 columns per row, 2 rows per wave step, 4 steps in flight: 8-byte gradient loads instead of a row-per-wave walk
+    const int q = lane >> 5, c4 = (lane & 31) * 4;
     for (int base = row_begin + w * 64; base < row_end; base += 8 * 64) {
         const int myrow = base + lane;
         int tok_l = padding_idx;
@@ -265,24 +267,24 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, co
         }
         const int cnt = min(64, row_end - base);
 #pragma unroll 4
-        for (int r = 0; r < cnt; ++r) {
+        for (int r2 = 0; r2 < cnt; r2 += 2) {
+            const int r = r2 + q;
             const int tok = __shfl(tok_l, r, 64);
             const float mu = __shfl(mu_l, r, 64), rs = __shfl(rs_l, r, 64), a1 = __shfl(a1_l, r, 64), a2 = __shfl(a2_l, r, 64);
-            const bool live = tok != padding_idx;
-            const bf16_t* dyr = dy + (long)(base + r) * lddy + c0;
+            const bool live = r < cnt && tok != padding_idx;
+            const bf16_t* dyr = dy + (long)(base + (r < cnt ? r : 0)) * lddy + c0;
             const float* tr = tab + (long)(live ? tok : 0) * E;
-            for (int c = 2 * lane; c < E; c += 128) {
-                const uint32_t u = *reinterpret_cast<const uint32_t*>(dyr + c);
-                float g0 = bf2f(u & 0xffff), g1 = bf2f(u >> 16);
+            for (int c = c4; c < E; c += 128) {
+                const uint2 u = *reinterpret_cast<const uint2*>(dyr + c);
+                f32x4 g = f32x4{bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
                 if (gamma) {
-                    const float2 x = *reinterpret_cast<const float2*>(tr + c);
-                    const float2 ga = *reinterpret_cast<const float2*>(gamma + c0 + c);
-                    g0 = rs * (g0 * ga.x - a1 - (x.x - mu) * rs * a2);
-                    g1 = rs * (g1 * ga.y - a1 - (x.y - mu) * rs * a2);
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(tr + c);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0 + c);
+                    g = rs * (g * ga - a1 - (x - mu) * (rs * a2));
                 }
                 if (live) {
-                    atomicAdd(dst + (long)tok * E + c, g0);
-                    atomicAdd(dst + (long)tok * E + c + 1, g1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(dst + (long)tok * E + c + e, g[e]);
                 }
             }
         }

@@ -228,6 +228,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
     const bool lead = !split || blockIdx.z == 0;   // bias / residual are added by the first K slice only
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (!g.residual || g.ldr % 4 == 0);
+    if (mn_interior && vec_ok && (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0)) {
+        // whole tile inside C: no bounds checks; the bias vectors of the wave's four column blocks are fetched once
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            bv[j] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + 16 * j + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * j + (lane >> 4) * 4;
+                f32x4 v = (acc[i][j] * g.alpha + bv[j]) * rs;
+                if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                OutT* dst = C + (long)m * g.ldc + n;
+                if constexpr (sizeof(OutT) == 4) {
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + 16 * i + (lane & 15);
