@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logi
                                                      long T, int V) {
     __shared__ float blk[2][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long row = (long)blockIdx.x * 4 + w;
     float loss = 0.f, cnt = 0.f;
-    if (row < T) {
+    // a wave walks rows with a grid stride: one pair of (same-address) atomics per BLOCK at the end, not per 4 rows
+    for (long row = (long)blockIdx.x * 4 + w; row < T; row += (long)gridDim.x * 4) {
         const TL* lr = logits + row * ld;
         float m = -INFINITY;
         int am = 0;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logi
             lse[row] = l;
             if (argmax) argmax[row] = am;
             const long lab = labels[(row / t_len) * lab_bs + (row % t_len) * lab_ts];
-            if (lab != ignore_index) { loss = l - ld_logit(lr + lab); cnt = 1.f; }
+            if (lab != ignore_index) { loss += l - ld_logit(lr + lab); cnt += 1.f; }
         }
     }
     if (lane == 0) { blk[0][w] = loss; blk[1][w] = cnt; }
@@ -259,7 +259,7 @@ inline int grid_for(long total, int block = 256) { long g = (total + block - 1) 
 extern "C" int spn_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index, float* lse,
                           float* sums, int* argmax, long T, int V, hipStream_t s) {
     SPN_REQUIRE(logits && labels && lse && sums && T > 0 && V > 0, "spn_ce_fwd: bad arguments");
-    dim3 grid(cdiv(T, 4));
+    dim3 grid(cdiv(T, 4) < 2048 ? cdiv(T, 4) : 2048);
     if (dtype == 0) hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
     else hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
     SPN_LAUNCH_CHECK();

@@ -229,14 +229,67 @@ def _wanted(i, key, keys):
     return keys is None or i in keys or key in keys
 
 
+class LazyLogits(dict):
+    """{key: logits} in the reference's key order.  Keys whose label column holds no valid label contribute nothing to the
+    training loss, so their logits GEMM is deferred until somebody actually reads the entry."""
+    _PENDING = object()
+
+    def defer(self, key, thunk):
+        dict.__setitem__(self, key, LazyLogits._PENDING)
+        self.__dict__.setdefault("_thunks", {})[key] = thunk
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is LazyLogits._PENDING:
+            v = self._thunks.pop(key)()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def _force(self):
+        for key in list(getattr(self, "_thunks", {})):
+            self[key]
+
+    def items(self):
+        self._force()
+        return dict.items(self)
+
+    def values(self):
+        self._force()
+        return dict.values(self)
+
+    def copy(self):
+        self._force()
+        return dict(self)
+
+
 class _HeadBase(nn.Module):
     """`forward(x, keys=None)` -> {key: logits}.  With `labels` (int64 [b, n, K] view, -100 = ignore) the per-key
-    cross-entropy is fused behind the logits GEMM: returns (logits, sums) with sums[key] = (loss_sum, valid_count)."""
+    cross-entropy is fused behind the logits GEMM: returns (logits, sums) with sums[key] = (loss_sum, valid_count).
+    `label_counts` = (pinned int32 [K] valid-label counts, event) issued by the LM wrapper before the decoder ran: keys
+    with a zero count skip their GEMM + cross-entropy in forward AND backward (the reference drops them from the loss,
+    wrappers.py:56)."""
 
-    def _per_key(self, items, labels, ignore_index, want_argmax):
-        logits, sums, argmax = {}, {}, {}
+    def _per_key(self, items, labels, ignore_index, want_argmax, label_counts=None):
+        logits, sums, argmax = LazyLogits(), {}, {}
         self.ce_state = {"active": None}
+        counts = None
+        if label_counts is not None and labels is not None:
+            buf, ev = label_counts
+            ev.synchronize()   # recorded before the decoder layers were enqueued: long complete, no pipeline bubble
+            counts = buf.tolist()
+            self.ce_state["active"] = {key for i, key, *_ in items if counts[i] > 0}
+            self.ce_state["counts"] = counts
         for i, key, e, table, bias in items:
+            if counts is not None and counts[i] == 0 and not want_argmax:
+                def thunk(e=e, table=table, bias=bias):
+                    lg, _, _ = F_.HeadCEFn.apply(e, table, bias, None, ignore_index, False, None, None)
+                    return lg.view(*e.shape[:-1], lg.shape[-1])
+                logits.defer(key, thunk)
+                sums[key] = torch.zeros(2, device=e.device, dtype=torch.float32)
+                continue
             lab = labels[..., i] if labels is not None else None
             lg, sm, am = F_.HeadCEFn.apply(e, table, bias, lab, ignore_index, want_argmax, self.ce_state, key)
             logits[key] = lg.view(*e.shape[:-1], lg.shape[-1])
@@ -257,11 +310,12 @@ class TupleTokenLMHead(_HeadBase, Constructor):
         self.heads = nn.ModuleDict({key: nn.Linear(dim, num) for key, num in num_tokens.items()
                                     if not filter_keys or key in filter_keys})
 
-    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
+                label_counts=None):
         xb = F_.cast(x, torch.bfloat16)
         items = [(i, key, xb, head.weight, head.bias) for i, (key, head) in enumerate(self.heads.items())
                  if _wanted(i, key, keys)]
-        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax, label_counts)
         return (logits, sums, argmax) if labels is not None or want_argmax else logits
 
 
@@ -289,7 +343,8 @@ class TupleTokenTiedLMHead(_HeadBase, Constructor):
         self.norm = LayerNorm(self.total_emb_dim)
         self.reuse_projection = reuse_projection
 
-    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
+                label_counts=None):
         # `x @ project_emb.weight` uses the [dim, total] weight UNtransposed (embeddings.py:346)
         if self.reuse_projection:
             e = F_.linear(x, self.project_emb.weight, kn_layout=True)
@@ -299,7 +354,7 @@ class TupleTokenTiedLMHead(_HeadBase, Constructor):
         tables = build_tables(list(self.embs.values()))
         parts = F_.split_cols(e, self.split_dims) if e.requires_grad else torch.split(e, self.split_dims, dim=-1)
         items = [(i, key, parts[i], tables[i], None) for i, key in enumerate(self.embs.keys()) if _wanted(i, key, keys)]
-        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax, label_counts)
         return (logits, sums, argmax) if labels is not None or want_argmax else logits
 
 
@@ -321,14 +376,15 @@ class TupleTokenTiedSplitLMHead(_HeadBase, Constructor):
         self.to_embs = nn.ModuleDict(to_embs)
         self.embs = embeddings.embs
 
-    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False):
+    def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
+                label_counts=None):
         tables = build_tables(list(self.embs.values()))
         items = []
         for i, key in enumerate(self.embs.keys()):
             if _wanted(i, key, keys):
                 lin, ln = self.to_embs[key]
                 items.append((i, key, ln(F_.linear(x, lin.weight, lin.bias)), tables[i], None))
-        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax)
+        logits, sums, argmax = self._per_key(items, labels, ignore_index, want_argmax, label_counts)
         return (logits, sums, argmax) if labels is not None or want_argmax else logits
 
 

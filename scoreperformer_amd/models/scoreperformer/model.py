@@ -12,7 +12,7 @@ from ..base import Model
 from .embeddings import TupleTokenLMHeadConfig, shared_tables
 from .mmd_transformer import MMDTupleTransformer, MMDTupleTransformerOutput
 from .transformer import TupleTransformerConfig, TupleTransformerOutput, TupleTransformer
-from .wrappers import LMWrapper, ScorePerformerLMModes, ScorePerformerLMWrappers, finalize_lm_losses
+from .wrappers import LMWrapper, ScorePerformerLMModes, ScorePerformerLMWrappers, finalize_lm_losses, mark_inputs_ready
 
 
 def _get(inputs, *path):
@@ -168,6 +168,8 @@ class ScorePerformer(_LMModeMixin, Model):
 
     def forward(self, perf: Tensor, perf_mask=None, score=None, score_mask=None, noisy_perf=None, noisy_perf_mask=None,
                 masked_perf=None, labels=None, bars=None, beats=None, onsets=None, directions=None, deadpan_mask=None):
+        if labels is not None and labels.is_cuda:
+            mark_inputs_ready()
         with shared_tables():
             enc_out = self.forward_encoders(
                 perf=default(noisy_perf, perf), perf_mask=default(noisy_perf_mask, perf_mask), score=score,

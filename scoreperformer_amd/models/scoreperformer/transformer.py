@@ -112,7 +112,7 @@ class TupleTransformer(nn.Module, Constructor):
                 context: Optional[Tensor] = None, context_mask: Optional[Tensor] = None,
                 caches: Optional[TupleTransformerCaches] = None, logits_keys: Optional[List] = None,
                 return_embeddings: bool = False, return_attn: bool = False, return_caches: bool = False,
-                labels: Optional[Tensor] = None, want_argmax: bool = False, **kwargs):
+                labels: Optional[Tensor] = None, want_argmax: bool = False, label_counts=None, **kwargs):
         token_emb_cache = caches.token_emb if caches is not None else None
         if hasattr(self.token_emb, "multiseq_mode") and x_extra is not None:
             x_extra = [x_extra] if isinstance(x_extra, Tensor) else x_extra
@@ -145,7 +145,7 @@ class TupleTransformer(nn.Module, Constructor):
 
         logits = ce_sums = argmax = None
         if not return_embeddings and self.lm_head is not None:
-            res = self.lm_head(out, keys=logits_keys, labels=labels, want_argmax=want_argmax)
+            res = self.lm_head(out, keys=logits_keys, labels=labels, want_argmax=want_argmax, label_counts=label_counts)
             if isinstance(res, tuple):
                 logits, ce_sums, argmax = res
             else:

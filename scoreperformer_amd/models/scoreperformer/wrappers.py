@@ -30,6 +30,42 @@ class ScorePerformerLMOutput(TupleTransformerOutput):
     losses: Optional[Dict[str, Tensor]] = None
 
 
+_inputs_ready = {"event": None}
+_side_streams = {}
+
+
+def mark_inputs_ready():
+    """Called by the model when its forward starts: everything enqueued so far (i.e. the previous step) precedes this point,
+    the batch tensors are complete.  Lets the label count below run beside the forward instead of behind it."""
+    ev = torch.cuda.Event()
+    ev.record()
+    _inputs_ready["event"] = ev
+
+
+def _count_labels_async(labels: Tensor, ignore_index: int):
+    """Valid-label count per key, on a side stream, copied to pinned memory: (buffer, event).  The LM head reads it on the
+    host to skip keys that carry no loss at all (wrappers.py:56) -- by then the copy finished long ago, so neither the host
+    nor the GPU waits."""
+    dev = labels.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    ready = _inputs_ready["event"]
+    if ready is None:
+        ready = torch.cuda.Event()
+        ready.record()
+    _inputs_ready["event"] = None
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        cnt = (labels != ignore_index).sum(dim=(0, 1), dtype=torch.int32)
+        buf = torch.empty(cnt.shape, dtype=torch.int32, pin_memory=True)
+        buf.copy_(cnt, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    labels.record_stream(side)
+    return buf, ev
+
+
 def finalize_lm_losses(out, host_counts: Optional[List[float]] = None):
     """Drop the per-key losses without any valid label, like the `torch.any(labels != ignore)` guard of
     `wrappers.py:56`, given the per-key valid counts on the host; also lets backward skip those keys."""
@@ -49,6 +85,8 @@ class ScorePerformerLMWrapper(LMWrapper):
         self.ignore_index = ignore_index
 
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, _defer_sync: bool = False, **kwargs):
+        if exists(labels) and labels.is_cuda and labels.ndim == 3:
+            kwargs["label_counts"] = _count_labels_async(labels, self.ignore_index)
         out = self.model(seq, labels=labels, **kwargs)
         loss = losses = None
         res = ScorePerformerLMOutput(loss=None, losses=None, **out.__dict__)
