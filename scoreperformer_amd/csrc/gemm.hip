@@ -42,6 +42,7 @@ struct GemmArgs {
     long sA, sB, sC;          // batch strides in elements
     int splitk;               // ... or, when > 1, blockIdx.z = K slice writing its partial product to C + z*sC (a workspace)
     int kt_per_split;         // K tiles per slice
+    int ngroup;               // n-tiles per column group of the tile order
 #ifdef SPN_GEMM_TIMING
     long long* dbg;
 #endif
@@ -158,8 +159,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        m0 = (wg / gridDim.x) * BM;
-        n0 = (wg % gridDim.x) * BN;
+        // within that order: column groups of `ngroup` n-tiles, m-tiles down each group, n fastest inside.  The tiles an XCD
+        // runs together then share few B panels AND few A panels (wide N: all of B no longer cycles through the 4 MiB L2 per
+        // m-row)
+        const int G = g.ngroup, mt = gridDim.y, per = G * mt;
+        const int c = wg / per, within = wg - c * per;
+        const int gw = min(G, (int)gridDim.x - c * G);   // width of this (possibly last, narrower) group
+        m0 = (within / gw) * BM;
+        n0 = (c * G + within % gw) * BN;
     }
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
@@ -229,27 +236,53 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const bool lead = !split || blockIdx.z == 0;   // bias / residual are added by the first K slice only
     const bool vec_ok = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && (!g.residual || g.ldr % 4 == 0);
     if (mn_interior && vec_ok && (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0)) {
-        // whole tile inside C: no bounds checks; the bias vectors of the wave's four column blocks are fetched once
+        // Whole tile inside C.  The accumulator layout gives every store instruction 32-byte (bf16) / 64-byte (fp32) pieces of
+        // 16 different rows; partial-line writes make the L2 fetch each 128-byte line of C from HBM first (measured: FETCH_SIZE
+        // ~ size of C on the 131072x4096x512 product).  So the wave's 64x64 block goes through its own LDS slab (the operand
+        // stages are dead by now) and leaves as whole 128-byte row segments, 16 bytes per lane.
+        __syncthreads();   // every wave is done reading the operand stages
+        constexpr int ES = sizeof(OutT), ROWB = 64 * ES, CPR = ROWB / 16;   // bytes per row, 16-byte chunks per row
+        constexpr int RPP = 8192 / ROWB, NPASS = 64 / RPP;                   // rows per 8 KiB pass (64 bf16 / 32 fp32)
+        char* stg = smem + wave * 8192;
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             bv[j] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + n0 + wn * 64 + 16 * j + (lane >> 4) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + 16 * i + (lane & 15);
-            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+        for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + 16 * j + (lane >> 4) * 4;
-                f32x4 v = (acc[i][j] * g.alpha + bv[j]) * rs;
-                if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
-                OutT* dst = C + (long)m * g.ldc + n;
-                if constexpr (sizeof(OutT) == 4) {
+            for (int ii = 0; ii < RPP / 16; ++ii) {
+                const int i = pass * (RPP / 16) + ii;
+                const int row = 16 * ii + (lane & 15);
+                const int m = m0 + wm * 64 + 16 * i + (lane & 15);
+                const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + 16 * j + (lane >> 4) * 4;
+                    f32x4 v = (acc[i][j] * g.alpha + bv[j]) * rs;
+                    if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                    const int colb = (16 * j + (lane >> 4) * 4) * ES;
+                    char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
+                    if constexpr (ES == 4) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+                        uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                }
+            }
+            // the slab is private to the wave and DS operations of one wave complete in order: no barrier
+#pragma unroll
+            for (int it = 0; it < RPP * CPR / 64; ++it) {
+                const int row = it * (64 / CPR) + lane / CPR, chunk = lane % CPR;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + row * ROWB + (((chunk ^ row) & (CPR - 1)) << 4));
+                OutT* dst = C + (long)(m0 + wm * 64 + pass * RPP + row) * g.ldc + n0 + wn * 64 + chunk * (16 / ES);
+                if constexpr (ES == 4) {
+                    f32x4 v = __builtin_bit_cast(f32x4, val);
                     if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
-                    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
+                    *reinterpret_cast<uint4*>(dst) = val;
                 }
             }
         }
@@ -672,6 +705,9 @@ int launch_bk(GemmArgs g, hipStream_t stream) {
             attr_done = true;
         }
     }
+    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
+    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK, STAGES>), grid, dim3(256), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);
