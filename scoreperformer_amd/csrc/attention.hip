@@ -44,21 +44,46 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
         for (int kb = 0; kb < 4; ++kb) mbits[kb] = *reinterpret_cast<const uint32_t*>(m_tile + 16 * kb + 4 * g);
     }
     const float sj0 = slope2 * (j0f + (float)(4 * g));
+    // linear-bias tiles: the per-key bias of this lane's 16 keys, as pairs for the packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32:
+    // two scores per VALU slot -- the kernel is VALU-bound at head dim 64).  Shared by both query blocks.
+    f32x2 kbias[4][2];
+    if (MODE != T_GEN) {
+        const float sg = MODE == T_LEFT ? 1.f : -1.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 jc = f32x2{(float)(16 * kb + 2 * hh), (float)(16 * kb + 2 * hh + 1)};
+                kbias[kb][hh] = (jc * slope2 + sj0) * sg;
+            }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float u = MODE == T_LEFT ? -slope2 * i_f[qb] : (MODE == T_RIGHT ? slope2 * i_f[qb] : 0.f);
         float tmax = NEG_FILL;
+        if (MODE != T_GEN) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float jc = (float)(16 * kb + r);
-                const float jf = j0f + (float)(4 * g) + jc;
-                const bool ok = MODE != T_GEN || ((((mbits[kb] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
-                const float t = score<MODE>(s[kb][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
-                s[kb][qb][r] = t;
-                tmax = fmaxf(tmax, t);
-            }
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2 sv = f32x2{s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]};
+                    const f32x2 t = sv * c1 + kbias[kb][hh];
+                    s[kb][qb][2 * hh] = t.x; s[kb][qb][2 * hh + 1] = t.y;
+                    tmax = fmaxf(fmaxf(tmax, t.x), t.y);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float jc = (float)(16 * kb + r);
+                    const float jf = j0f + (float)(4 * g) + jc;
+                    const bool ok = ((((mbits[kb] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
+                    const float t = score<MODE>(s[kb][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
+                    s[kb][qb][r] = t;
+                    tmax = fmaxf(tmax, t);
+                }
+        }
         tmax = group_max(tmax) + u;
         if (__any(tmax > m_run[qb] + RESCALE_THR)) {   // wave-uniform: rescale only when some row's max really grew
             const float m_new = fmaxf(m_run[qb], tmax);
@@ -69,16 +94,17 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
             for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
         }
         const float mm = m_run[qb] - u;
-        float psum = 0.f;
+        f32x2 psum2 = f32x2{0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = fast_exp2(s[kb][qb][r] - mm);
-                s[kb][qb][r] = p;
-                psum += p;
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x2 a = f32x2{s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]} - mm;
+                const f32x2 p = f32x2{fast_exp2(a.x), fast_exp2(a.y)};
+                s[kb][qb][2 * hh] = p.x; s[kb][qb][2 * hh + 1] = p.y;
+                psum2 += p;
             }
-        l_run[qb] += psum;   // the softmax normaliser is that of the un-dropped probabilities
+        l_run[qb] += psum2.x + psum2.y;   // the softmax normaliser is that of the un-dropped probabilities
         if (DROP) {
             uint32_t kw = 0;   // keep bits of this lane's 16 scores, bit 4*kb + r
 #pragma unroll
