@@ -50,6 +50,9 @@ int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * it as keep bits (1 bit per score) into `dropbits` (spn_attn_dropbits_elems() uint16 words), which the backward reads back.
  * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
 long spn_attn_dropbits_elems(int b, int h, int nq, int nk);
+/* ALiBi band skipping: key tiles whose probabilities are provably below 2^-log2_threshold of the row maximum (Cauchy-Schwarz
+ * bound on q.k plus the linear distance penalty) are not visited, forward and backward alike.  Default 40; 0 = visit all. */
+void spn_attn_set_band(float log2_threshold);
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
                  int nq, int nk, int causal, float scale, const long* strides, float p_drop, const void* dropbits,

@@ -170,20 +170,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int qb = 0; qb < 2; ++qb) o[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {NEG_FILL, NEG_FILL}, l_run[2] = {0.f, 0.f};
 
-    int nt = (a.nk + 63) / 64;
+    int nt = (a.nk + 63) / 64, t_lo = 0;
     if (a.causal) {
         const int last = q0 + 127 + off;  // largest key index any row of this block may see
         nt = last < 0 ? 0 : min(nt, last / 64 + 1);
     }
+    {   // ALiBi band: key tiles further than the reach of this block's 128 rows contribute < 2^-band_log2 per probability
+        const float reach = band_reach(a, bi, hi, kh, q0 / 64, 2, c1, slope2);
+        if (reach < 1.0e9f) {
+            const int d = (int)reach + 1;
+            t_lo = max(0, q0 + off - d) / 64;
+            nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
+        }
+    }
 
     TileRegs kr, vr;
     uint8_t mreg = 1;
-    if (nt > 0) {
-        kr.load(kp, a.k_ns, 0, a.nk, tid);
-        vr.load(vp, a.v_ns, 0, a.nk, tid);
-        if (tid < 64) mreg = (tid < a.nk) ? (mp ? mp[tid] : 1) : 0;
+    if (nt > t_lo) {
+        kr.load(kp, a.k_ns, t_lo * 64, a.nk, tid);
+        vr.load(vp, a.v_ns, t_lo * 64, a.nk, tid);
+        if (tid < 64) { const int j = t_lo * 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
     }
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_lo; t < nt; ++t) {
         const int j0 = t * 64;
         __syncthreads();
         kr.store<false>(k_tile, tid);
@@ -380,20 +388,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float acc_d[2] = {0.f, 0.f}, acc_r[2] = {0.f, 0.f}, acc_p[2] = {0.f, 0.f};
 
-    int nt = (a.nk + 63) / 64;
+    int nt = (a.nk + 63) / 64, t_lo = 0;
     if (a.causal) {
         const int last = q0 + 127 + off;
         nt = last < 0 ? 0 : min(nt, last / 64 + 1);
     }
+    {   // same ALiBi band as the forward (same bound inputs, same arithmetic)
+        const float reach = band_reach(a, bi, hi, kh, q0 / 64, 2, c1, slope2);
+        if (reach < 1.0e9f) {
+            const int d = (int)reach + 1;
+            t_lo = max(0, q0 + off - d) / 64;
+            nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
+        }
+    }
     TileRegs kr, vr;
     uint8_t mreg = 1;
-    if (nt > 0) {
-        kr.load(kp, a.k_ns, 0, a.nk, tid);
-        vr.load(vp, a.v_ns, 0, a.nk, tid);
-        if (tid < 64) mreg = (tid < a.nk) ? (mp ? mp[tid] : 1) : 0;
-        if (DROP) { kwn[0] = bitbase[0]; kwn[1] = bitbase[bstride]; }
+    if (nt > t_lo) {
+        kr.load(kp, a.k_ns, t_lo * 64, a.nk, tid);
+        vr.load(vp, a.v_ns, t_lo * 64, a.nk, tid);
+        if (tid < 64) { const int j = t_lo * 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
+        if (DROP) { kwn[0] = bitbase[t_lo * 64]; kwn[1] = bitbase[bstride + t_lo * 64]; }
     }
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_lo; t < nt; ++t) {
         const int j0 = t * 64;
         __syncthreads();
         kw[0] = kwn[0]; kw[1] = kwn[1];
@@ -487,6 +503,85 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     }
 }
 
+// ==========================================================================================================
+// ALiBi band skipping.  ALiBi subtracts slope*|i - j| from the score, so for the steep heads everything far from the diagonal
+// is numerically dead: with B >= |q.k|*scale*log2e the probability of key j relative to the row's largest one is at most
+// 2^(2B - slope2*|d|) (attention_common.h, band_reach).  Tiles where that is < 2^-band_log2 (default 40: 2048 such terms sum to
+// < 2^-29 of the row normaliser, below fp32 resolution) are not visited -- in the forward AND in both backward kernels, from
+// the same bound, so the three stay consistent.  The bound B comes from this pre-pass: max ||q||^2 per 64-row tile and max ||k||^2
+// per (batch, kv head) (Cauchy-Schwarz).  A query tile containing a row whose own diagonal key is masked or out of range has no
+// such lower bound on its row maximum and is marked +inf = never skipped.  Learned slopes <= 0 disable skipping for that head.
+// ==========================================================================================================
+__global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __restrict__ band) {
+    const int lane = threadIdx.x, bi = blockIdx.z, hi = blockIdx.y, x = blockIdx.x;
+    const int off = a.nk - a.nq;
+    const bool is_q = x < a.nqt64;
+    if (!is_q && hi >= a.kvh) return;
+    const int row = (is_q ? x : x - a.nqt64) * 64 + lane;
+    const int n = is_q ? a.nq : a.nk;
+    float v = 0.f;
+    if (row < n) {
+        const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const uint4 u = *reinterpret_cast<const uint4*>(p + ch * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float lo = bf2f(w[e] & 0xffff), hi_ = bf2f(w[e] >> 16); v = fmaf(lo, lo, fmaf(hi_, hi_, v)); }
+        }
+        if (is_q) {
+            const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
+            if (jd < 0 || jd >= a.nk || (a.kmask && a.kmask[(long)bi * a.nk + jd] == 0)) v = __builtin_inff();
+        }
+    }
+    v = wave_max(v);
+    if (lane == 0) {
+        if (is_q) band[((long)(bi * a.h + hi)) * a.nqt64 + x] = v;
+        else atomicMax(reinterpret_cast<unsigned int*>(band + (long)a.b * a.h * a.nqt64 + bi * a.kvh + hi), __float_as_uint(v));   // v >= 0
+    }
+}
+
+// grow-only scratch for the band bounds; reuse is ordered by the stream, a different stream waits for the previous user
+struct BandWorkspace {
+    float* ptr = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false;
+    float* get(size_t need, hipStream_t stream) {
+        if (!done) hipEventCreateWithFlags(&done, hipEventDisableTiming);
+        if (need > bytes) {
+            if (ptr) { hipDeviceSynchronize(); hipFree(ptr); }
+            bytes = need * 2;
+            if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; bytes = 0; return nullptr; }
+            used = false;
+        }
+        if (used && last != stream) hipStreamWaitEvent(stream, done, 0);
+        return ptr;
+    }
+    void release(hipStream_t stream) { hipEventRecord(done, stream); last = stream; used = true; }
+};
+BandWorkspace g_band_ws[16];
+float g_band_log2 = -1.f;   // < 0: not initialised (SPN_ATTN_BAND env, default 40); 0: off
+
+// fills a.band for this problem (no-op without ALiBi slopes); call release_band() after the consuming kernels are enqueued
+int prepare_band(AttnArgs& a, hipStream_t stream) {
+    if (g_band_log2 < 0.f) g_band_log2 = getenv("SPN_ATTN_BAND") ? (float)atof(getenv("SPN_ATTN_BAND")) : 40.f;
+    a.band = nullptr; a.band_log2 = g_band_log2; a.nqt64 = (a.nq + 63) / 64;
+    if (!a.slopes || g_band_log2 <= 0.f) return SPN_OK;
+    int dev = 0;
+    hipGetDevice(&dev);
+    const size_t nq_part = (size_t)a.b * a.h * a.nqt64, n = nq_part + (size_t)a.b * a.kvh;
+    float* ws = g_band_ws[dev & 15].get(n * 4, stream);
+    if (!ws) { spn_set_error("spn_attn: band workspace allocation failed"); return SPN_ERR_HIP; }
+    hipMemsetAsync(ws + nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
+    hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, ws);
+    a.band = ws;
+    return SPN_OK;
+}
+void release_band(const AttnArgs& a, hipStream_t stream) {
+    if (!a.band) return;
+    int dev = 0;
+    hipGetDevice(&dev);
+    g_band_ws[dev & 15].release(stream);
+}
+
 void set_dropout(AttnArgs& a, float p_drop, unsigned seed, void* dropbits, int nq, int nk) {
     const float t = p_drop * 256.f;
     a.thr8 = t <= 0.f ? 0u : (t >= 255.f ? 255u : (uint32_t)(t + 0.5f));
@@ -511,6 +606,10 @@ int check_common(const AttnArgs& a) {
 }  // namespace
 
 // strides: 12 longs = {q_bs,q_ns,q_hs, k_bs,k_ns,k_hs, v_bs,v_ns,v_hs, o_bs,o_ns,o_hs} in elements; head dim 64.
+// probabilities below 2^-log2_threshold of their row's largest one may be skipped by the ALiBi band (0 = visit everything).
+// Default 40, or the SPN_ATTN_BAND environment variable.  Process-wide; meant for tests and ablations.
+extern "C" void spn_attn_set_band(float log2_threshold) { g_band_log2 = log2_threshold < 0.f ? 0.f : log2_threshold; }
+
 // uint16 words of the dropout keep-bit buffer for a [b, h, nq, nk] attention (1 bit per score, whole 128x128 blocks)
 extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {
     return (long)b * h * dropbits_nqt16(nq) * dropbits_nkt64(nk) * 64;
@@ -534,9 +633,12 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     if (rc) return rc;
     SPN_REQUIRE(o && lse, "spn_attn_fwd: null output");
     SPN_REQUIRE((a.o_ns % 4) == 0 && (a.o_hs % 4) == 0 && (a.o_bs % 4) == 0, "spn_attn_fwd: o strides must be multiples of 4");
+    rc = prepare_band(a, stream);
+    if (rc) return rc;
     dim3 grid(cdiv(nq, 128), h, b);
     if (a.thr8) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
+    release_band(a, stream);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -567,11 +669,14 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE(o && d_o && lse && delta && dq && dk && dv, "spn_attn_bwd: null tensor");
     SPN_REQUIRE((a.o_ns % 8) == 0 && (a.o_hs % 8) == 0 && (a.o_bs % 8) == 0, "spn_attn_bwd: o/dO strides must be multiples of 8");
     SPN_REQUIRE((((uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "spn_attn_bwd: o/dO must be 16-byte aligned");
+    rc = prepare_band(a, stream);
+    if (rc) return rc;
     const long total = (long)b * nq * h;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, delta);
     launch_attn_dkv(a, stream);
     if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    release_band(a, stream);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

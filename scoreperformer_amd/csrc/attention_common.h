@@ -33,7 +33,23 @@ struct AttnArgs {
     // i.e. exactly the forward's (and dQ's) S^T register layout.
     uint32_t thr8, seed; float inv_keep;
     uint16_t* dropbits; int nqt16, nkt64;
+    // ALiBi band (attention.hip, "band skipping"): band[(b*h + head)*nqt64 + i/64] = max ||q_i||^2 over the 64-row tile (+inf if
+    // the tile must never be skipped), then band[b*h*nqt64 + b_*kvh + kv_head] = max ||k_j||^2.  null / band_log2 <= 0: off.
+    const float* band; int nqt64; float band_log2;
 };
+
+// Largest |j - i - off| that can still matter for a query tile: with |q.k * scale * log2e| <= B every score obeys
+// t_ij <= B - slope2*|d| while the row maximum is at least its diagonal score >= -B, so  t_ij - m_i <= 2B - slope2*|d|.
+// Beyond D = (band_log2 + 2B) / slope2 every probability is below 2^-band_log2 of the row's largest one.
+__device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, int kh, int qtile64, int ntiles, float c1, float slope2) {
+    if (!a.band || !(slope2 > 0.f)) return 3.0e38f;
+    const float* qt = a.band + ((long)(bi * a.h + hi)) * a.nqt64 + qtile64;
+    float qm = qt[0];
+    for (int t = 1; t < ntiles; ++t) if (qtile64 + t < a.nqt64) qm = fmaxf(qm, qt[t]);
+    const float km = a.band[(long)a.b * a.h * a.nqt64 + bi * a.kvh + kh];
+    const float D = (a.band_log2 + 2.f * c1 * sqrtf(qm * km)) / slope2;
+    return D < 1.0e9f ? D : 3.0e38f;   // inf / nan (never-skip tiles) -> unbounded
+}
 
 // geometry of the keep-bit buffer: whole 128-query blocks and 128-key blocks, so no kernel needs bounds checks
 __host__ __device__ inline int dropbits_nqt16(int nq) { return 8 * ((nq + 127) / 128); }

@@ -152,8 +152,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             dreg = i < a.nq ? a.delta[si] : 0.f;
         }
     };
-    if (n_iter > 0) issue(0);
-    for (int it = 0; it < n_iter; ++it) {
+    // ALiBi band (attention.hip): a (head, query tile) whose reach ends before this block's 128 keys is not visited
+    auto next_live = [&](int it) {
+        for (; it < n_iter; ++it) {
+            const int hh = kh * heads_per_kv + it / (nqt - t_first);
+            const int i0 = (t_first + it % (nqt - t_first)) * 64;
+            const float reach = band_reach(a, bi, hh, kh, i0 / 64, 1, c1, a.slopes ? a.slopes[hh] * LOG2E : 0.f);
+            if (!(reach < 1.0e9f)) break;
+            const float r_lo = (float)(i0 + off), r_hi = r_lo + 63.f;
+            if ((float)j0 <= r_hi + reach && (float)(j0 + 127) >= r_lo - reach) break;
+        }
+        return it;
+    };
+    int it = next_live(0);
+    if (it < n_iter) issue(it);
+    while (it < n_iter) {
+        const int it_next = next_live(it + 1);
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
         const float slope2 = a.slopes ? a.slopes[hh] * LOG2E : 0.f;
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) bw[qb] = bwn[qb];
         __syncthreads();
-        if (it + 1 < n_iter) issue(it + 1);
+        if (it_next < n_iter) issue(it_next);
 
         // tile class of this wave's 32 keys against the 64 rows (key coordinates i + off)
         const int r_lo = i0 + off, r_hi = r_lo + 63;
@@ -174,11 +188,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (a.causal && jw_lo > r_hi) cls = T_SKIP;
         else if (keys_full && jw_hi <= r_lo) cls = T_LEFT;              // j - i <= 0 everywhere
         else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
-        if (cls == T_SKIP) continue;
+        if (cls == T_SKIP) { it = it_next; continue; }
 
         if (cls == T_LEFT) dkv_tile<T_LEFT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
         else if (cls == T_RIGHT) dkv_tile<T_RIGHT, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
         else dkv_tile<T_GEN, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
+        it = it_next;
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

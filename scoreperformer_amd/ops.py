@@ -161,6 +161,11 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_dr
     return (o, lse) if bits is None else (o, lse, bits)
 
 
+def attn_set_band(log2_threshold: float) -> None:
+    """ALiBi band skipping threshold (log2 of the smallest probability ratio still visited); 0 disables (tests, ablations)."""
+    load().spn_attn_set_band(c_float(log2_threshold))
+
+
 def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
              p_drop: float = 0.0, dropbits=None):
     """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None.

@@ -238,6 +238,42 @@ def test_attention_fast_paths_and_rescale(dev, causal, use_slopes, use_mask):
         assert rel_err(dslope, sr.grad) < 3e-2
 
 
+@pytest.mark.parametrize("causal,masked", [(False, False), (True, False), (False, True)])
+def test_attention_alibi_band_skipping_is_invisible(dev, causal, masked):
+    """Tiles outside the ALiBi reach are skipped (forward, dQ, dK/dV): the result must equal the visit-everything run."""
+    from scoreperformer_amd import ops
+    b, n, h = 2, 1024, 8
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(b, n, (h + 2) * 64, generator=g) * 1.5).to(dev).bfloat16()
+    q, k, v = (qkv[..., :h * 64].unflatten(-1, (h, 64)), qkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)),
+               qkv[..., (h + 1) * 64:].unflatten(-1, (1, 64)))
+    slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(h)], device=dev)
+    kmask = None
+    if masked:
+        kmask = torch.ones(b, n, dtype=torch.bool, device=dev)
+        kmask[0, 700:] = False
+        kmask[1, 333:] = False
+    d_o = torch.randn(b, n, h, 64, generator=g).to(dev).bfloat16()
+    res = []
+    try:
+        for thr in (0.0, 40.0):
+            ops.attn_set_band(thr)
+            o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=slopes, causal=causal)
+            dqkv = torch.zeros_like(qkv)
+            dq, dk, dv = (dqkv[..., :h * 64].unflatten(-1, (h, 64)), dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)),
+                          dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64)))
+            dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=slopes, causal=causal, want_dslope=True)
+            res.append((o.float(), lse, dqkv.float(), dsl))
+    finally:
+        ops.attn_set_band(40.0)
+    (o0, l0, d0, s0), (o1, l1, d1, s1) = res
+    valid = slice(None) if kmask is None else kmask   # rows at padded positions are don't-care in the model, but checked too
+    assert (o0 - o1).abs().max() <= 1e-6 * o0.abs().max()
+    assert (l0 - l1).abs().max() <= 1e-5
+    assert (d0 - d1).abs().max() <= 1e-6 * d0.abs().max()
+    assert (s0 - s1).abs().max() <= 1e-5 * s0.abs().max()
+
+
 def test_ffn_dropout_mask_is_consistent_and_unbiased(dev):
     from scoreperformer_amd import ops
     g = torch.Generator().manual_seed(5)
