@@ -558,28 +558,53 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #undef PP_SYNC_MFMA_END
 #undef PP_SLOT
 
-    // ---- epilogue (same lane layout as gemm_kernel: row m = ..+(lane&31), 4 consecutive columns per accumulator quad) ----
+    // ---- epilogue: through the wave's own 16 KiB LDS slab, so that C leaves as whole 128-byte row segments (see gemm_kernel) ----
     OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
     const bool lead = !split || blockIdx.z == 0;
+    __syncthreads();   // every wave is done with the operand ring
+    constexpr int ES = sizeof(OutT), ROWB = 64 * ES, CPR = ROWB / 16;    // bytes per row of the wave's 128x64 block, chunks per row
+    constexpr int RPP = 16384 / ROWB, NPASS = 128 / RPP;                  // rows per pass: 128 (bf16) / 64 (fp32)
+    char* stg = smem + wave * 16384;
+    f32x4 bv[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 128 + 32 * i + (lane & 31);
-        const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+    for (int jq = 0; jq < 8; ++jq)
+        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-            const int j = jq >> 2, q = jq & 3;
-            const int n = n0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
-            f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha;
-            if (g.bias && lead) v += *reinterpret_cast<const f32x4*>(g.bias + n);
-            v *= rs;
-            if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
-            OutT* dst = C + (long)m * g.ldc + n;
-            if constexpr (sizeof(OutT) == 4) {
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+        for (int ii = 0; ii < RPP / 32; ++ii) {
+            const int i = pass * (RPP / 32) + ii;
+            const int row = 32 * ii + (lane & 31);
+            const int m = m0 + wr * 128 + 32 * i + (lane & 31);
+            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+            for (int jq = 0; jq < 8; ++jq) {
+                const int j = jq >> 2, q = jq & 3;
+                const int n = n0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
+                f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[jq]) * rs;
+                if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                const int colb = (32 * j + 8 * q + (lane >> 5) * 4) * ES;
+                char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
+                if constexpr (ES == 4) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < RPP * CPR / 64; ++it) {
+            const int row = it * (64 / CPR) + lane / CPR, chunk = lane % CPR;
+            const uint4 val = *reinterpret_cast<const uint4*>(stg + row * ROWB + (((chunk ^ row) & (CPR - 1)) << 4));
+            OutT* dst = C + (long)(m0 + wr * 128 + pass * RPP + row) * g.ldc + n0 + wc * 64 + chunk * (16 / ES);
+            if constexpr (ES == 4) {
+                f32x4 v = __builtin_bit_cast(f32x4, val);
                 if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
-                uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(dst) = pk;
+                *reinterpret_cast<uint4*>(dst) = val;
             }
         }
     }
@@ -727,7 +752,8 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     if (variant == 5) return launch_bk<TA, TB, OutT, 64, 4>(g, stream);
     if (variant == 6) return launch_bk<TA, TB, OutT, 32, 3>(g, stream);
     if (variant == 9 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
-    if (variant == 0 && !TA && g.K >= 1024 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
+    // measured (tools/bench_gemm.py): with the LDS-staged epilogue the 256x256 ping-pong kernel wins on every shape it can take
+    if (variant == 0 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
     // measured on MI355X (tools/bench_gemm.py): residency beats in-block pipelining -- two 16 KiB-per-operand stages with
     // BK = 32 (32 KiB LDS, 4 blocks/CU) win everywhere except the long-K all-K-contiguous case
     if (!TA && !TB && g.K >= 2048) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
