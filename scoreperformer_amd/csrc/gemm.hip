@@ -355,7 +355,7 @@ static long long* g_dbg = nullptr;   // tuning aid (tools/gemm_timing.py): per-s
 //     (AX(t) = S[4t], BX(t) = S[4t+1] first read in phase 4t, BY(t) = S[4t+2] in 4t+1, AY(t) = S[4t+3] in 4t+2)
 //   * S[p+6] overwrites a slot last read in phase <= p-2: both groups have retired those reads (lgkmcnt(0) right after the barrier
 //     that starts their MFMA part) at least one barrier before either group issues the refill
-// Interior tiles only (M, N multiples of 256, K of 64): the launcher routes everything else to the kernel above.
+// M / N edges: clamped loads + guarded stores.  K must be whole 64-tiles and >= 256; other shapes take the kernel above.
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_LEAD = 6;
 constexpr int PP_HALF = 128 * PP_BK * 2;   // bytes of one half-tile (128 rows x 64 k)
 
@@ -392,18 +392,20 @@ __device__ __forceinline__ bf16x8 pp_read_frag(const char* lds, int r_base, int 
 template <int SUB> __device__ __forceinline__ int pp_row(int x, int h) { return (x / SUB) * (2 * SUB) + SUB * h + (x % SUB); }
 
 // one half-tile = 16 pieces of 1 KiB, 2 per wave; LDS image linear, swizzle applied on the source address
+// R = rows (A: M, B: N) of the operand: tiles that hang over the edge re-read the last row (last 8-row group when the rows
+// are the contiguous dimension) -- valid memory, and the epilogue never stores what was computed from it.
 template <bool T, int SUB>
-__device__ __forceinline__ void pp_dma(const bf16_t* __restrict__ p, int ld, int row0, int k0, int h, char* lds, int wave, int lane) {
+__device__ __forceinline__ void pp_dma(const bf16_t* __restrict__ p, int ld, int row0, int R, int k0, int h, char* lds, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int L = (wave * 2 + i) * 64 + lane;
         const bf16_t* src;
         if (!T) {
             const int x = L >> 3, kc = (L & 7) ^ ((x >> 1) & 7);
-            src = p + (long)(row0 + pp_row<SUB>(x, h)) * ld + k0 + kc * 8;
+            src = p + (long)min(row0 + pp_row<SUB>(x, h), R - 1) * ld + k0 + kc * 8;
         } else {
             const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
-            src = p + (long)(k0 + krow) * ld + row0 + pp_row<SUB>(rc * 8, h);
+            src = p + (long)(k0 + krow) * ld + min(row0 + pp_row<SUB>(rc * 8, h), R - 8);
         }
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (wave * 2 + i) * 1024), 16, 0, 0);
     }
@@ -445,10 +447,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 
     auto issue = [&](int c, int t) {   // c is a compile-time constant at every call site
         const int k0 = kbase + t * PP_BK;
-        if (c == 0) pp_dma<TA, 64>(A, g.lda, m0, k0, 0, PP_SLOT(0, t), wave, lane);
-        else if (c == 1) pp_dma<TB, 32>(B, g.ldb, n0, k0, 0, PP_SLOT(1, t), wave, lane);
-        else if (c == 2) pp_dma<TB, 32>(B, g.ldb, n0, k0, 1, PP_SLOT(2, t), wave, lane);
-        else pp_dma<TA, 64>(A, g.lda, m0, k0, 1, PP_SLOT(3, t), wave, lane);
+        if (c == 0) pp_dma<TA, 64>(A, g.lda, m0, g.M, k0, 0, PP_SLOT(0, t), wave, lane);
+        else if (c == 1) pp_dma<TB, 32>(B, g.ldb, n0, g.N, k0, 0, PP_SLOT(1, t), wave, lane);
+        else if (c == 2) pp_dma<TB, 32>(B, g.ldb, n0, g.N, k0, 1, PP_SLOT(2, t), wave, lane);
+        else pp_dma<TA, 64>(A, g.lda, m0, g.M, k0, 1, PP_SLOT(3, t), wave, lane);
     };
     // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
     auto wait_landed = [&](int p) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     f32x4 bv[8];
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq)
-        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4)
+        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4))
                                   : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -577,13 +579,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             const int i = pass * (RPP / 32) + ii;
             const int row = 32 * ii + (lane & 31);
             const int m = m0 + wr * 128 + 32 * i + (lane & 31);
-            const float rs = g.rowmask ? (g.rowmask[m] ? 1.f : 0.f) : 1.f;
+            const float rs = g.rowmask ? (g.rowmask[min(m, g.M - 1)] ? 1.f : 0.f) : 1.f;
 #pragma unroll
             for (int jq = 0; jq < 8; ++jq) {
                 const int j = jq >> 2, q = jq & 3;
                 const int n = n0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
                 f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[jq]) * rs;
-                if (g.residual && lead) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
                 const int colb = (32 * j + 8 * q + (lane >> 5) * 4) * ES;
                 char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
                 if constexpr (ES == 4) {
@@ -598,7 +600,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         for (int it = 0; it < RPP * CPR / 64; ++it) {
             const int row = it * (64 / CPR) + lane / CPR, chunk = lane % CPR;
             const uint4 val = *reinterpret_cast<const uint4*>(stg + row * ROWB + (((chunk ^ row) & (CPR - 1)) << 4));
-            OutT* dst = C + (long)(m0 + wr * 128 + pass * RPP + row) * g.ldc + n0 + wc * 64 + chunk * (16 / ES);
+            const int mo = m0 + wr * 128 + pass * RPP + row, no = n0 + wc * 64 + chunk * (16 / ES);
+            if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
+            OutT* dst = C + (long)mo * g.ldc + no;
             if constexpr (ES == 4) {
                 f32x4 v = __builtin_bit_cast(f32x4, val);
                 if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
@@ -678,16 +682,17 @@ static void finish_split(const GemmArgs& g, const SplitPlan& plan, hipStream_t s
     g_split_ws[dev & 15].release(stream);
 }
 
-// shapes the ping-pong kernel takes: whole 256x256x64 tiles, vector-aligned epilogue operands
+// shapes the ping-pong kernel takes: K in whole 64-tiles, rows in multiples of 8, vector-aligned epilogue operands
 static bool pp_eligible(const GemmArgs& g) {
-    return g.M % PP_BM == 0 && g.N % PP_BN == 0 && g.K % PP_BK == 0 && g.K >= 4 * PP_BK && g.ldc % 4 == 0 &&
+    // edge tiles in M and N are fine (clamped loads, guarded stores); K must be whole 64-tiles
+    return g.M >= 128 && g.N >= 128 && g.M % 8 == 0 && g.N % 8 == 0 && g.K % PP_BK == 0 && g.K >= 4 * PP_BK && g.ldc % 8 == 0 &&
            (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.residual || (g.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)) &&
            (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) && (g.sC % 4 == 0);
 }
 
 template <bool TA, bool TB, typename OutT>
 int launch_pp(GemmArgs g, hipStream_t stream) {
-    const int tiles = (g.N / PP_BN) * (g.M / PP_BM), nt = g.K / PP_BK;
+    const int tiles = cdiv(g.N, PP_BN) * cdiv(g.M, PP_BM), nt = g.K / PP_BK;
     SplitPlan plan;
     if (sizeof(OutT) == 4) {
         const int rc = plan_split(g, tiles, nt, 192, 512, 16, stream, plan);
@@ -701,7 +706,7 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
-    dim3 grid(g.N / PP_BN, g.M / PP_BM, g.splitk > 1 ? g.splitk : g.batch);
+    dim3 grid(cdiv(g.N, PP_BN), cdiv(g.M, PP_BM), g.splitk > 1 ? g.splitk : g.batch);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);

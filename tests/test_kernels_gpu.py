@@ -17,7 +17,8 @@ def rel_err(a, b):
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1000, 264, 520), (264, 1000, 2048),
-                                   (512, 256, 256), (256, 768, 1088), (1024, 512, 64 * 37)])   # last three: whole 256x256x64 tiles
+                                   (512, 256, 256), (256, 768, 1088), (1024, 512, 64 * 37),   # whole 256x256x64 tiles
+                                   (4088, 640, 512), (392, 648, 320), (136, 1160, 256)])      # ping-pong kernel with M / N edge tiles
 def test_gemm_layouts(dev, ta, tb, M, N, K):
     from scoreperformer_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
