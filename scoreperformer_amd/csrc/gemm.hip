@@ -657,7 +657,7 @@ static int plan_split(GemmArgs& g, int tiles, int nt, int max_tiles, int want_bl
     g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     if (g.batch != 1 || tiles >= max_tiles || nt < 4 * min_kt || g.N % 4 != 0 || g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0)
         return SPN_OK;
-    int want = cdiv(want_blocks, tiles);
+    int want = want_blocks < 0 ? (-want_blocks) / tiles : cdiv(want_blocks, tiles);   // negative target: round down
     if (want > nt / min_kt) want = nt / min_kt;
     if (want <= 1) return SPN_OK;
     g.kt_per_split = cdiv(nt, want);
@@ -695,7 +695,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     const int tiles = cdiv(g.N, PP_BN) * cdiv(g.M, PP_BM), nt = g.K / PP_BK;
     SplitPlan plan;
     if (sizeof(OutT) == 4) {
-        const int rc = plan_split(g, tiles, nt, 192, 512, 16, stream, plan);
+        static const int want_env = getenv("SPN_GEMM_PP_SPLIT_BLOCKS") ? atoi(getenv("SPN_GEMM_PP_SPLIT_BLOCKS")) : 0;   // tuning aid
+        // one block per CU: aim for ONE full round of 256 blocks (floor, so that no second, nearly empty round appears)
+        const int rc = plan_split(g, tiles, nt, 192, want_env > 0 ? want_env : -256, 16, stream, plan);
         if (rc != SPN_OK) return rc;
     } else {
         g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
