@@ -157,12 +157,28 @@ def roofline_leg(ops, step, args):
         a = by_shape.setdefault(tag, [0, 0.0, 0.0])
         a[0] += 1; a[1] += f; a[2] += t
     top = sorted(by_shape.items(), key=lambda kv: -kv[1][2])[:6]
+    # per template instantiation, i.e. per kernel NAME in the rocprofv3 summary (profiles/): <A M-contiguous, B N-contiguous, C type>
+    by_inst = {}
+    for name, f, t, tag in gemm:
+        _, lay, dt = tag.split(":")
+        a = by_inst.setdefault(f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
+                               f"{'float' if dt == 'f32' else 'unsigned short'}>", [0, 0.0, 0.0])
+        a[0] += 1; a[1] += f; a[2] += t
     attn = [r for r in recs if r[0].startswith("attn")]
-    return {"bound": "mfma", "kernel": "gemm_kernel<bf16, 128x128x64, v_mfma_f32_16x16x32_bf16> (all launches of a step)",
+    traffic, traffic_note = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("note")
+    return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
+                                       "of a step, a split-K launch includes its reduce kernel)",
             "achieved": flops / (ms * 1e-3) / 1e12 if ms else None, "peak": 2500.0, "unit": "TFLOP/s",
-            "frac": (flops / (ms * 1e-3) / 1e12 / 2500.0) if ms else None, "traffic": None,
+            "frac": (flops / (ms * 1e-3) / 1e12 / 2500.0) if ms else None, "traffic": traffic, "traffic_note": traffic_note,
             "launches_per_step": len(gemm) // 2, "avg_launch_ms": ms / max(len(gemm), 1),
             "gemm_ms_per_step": ms / 2,
+            "per_kernel": [{"kernel": k, "launches": v[0] // 2, "avg_launch_ms": v[2] / v[0], "ms_per_step": v[2] / 2,
+                            "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in sorted(by_inst.items(), key=lambda kv: -kv[1][2])],
             "top_shapes": [{"MNK_layout": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2,
                             "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in top],
             "attention_ms_per_step": sum(r[2] for r in attn) / 2,

@@ -424,8 +424,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        m0 = (wg / gridDim.x) * PP_BM;
-        n0 = (wg % gridDim.x) * PP_BN;
+        // column groups of `ngroup` n-tiles, m-tiles down each group (see gemm_kernel): the 32 tiles an XCD runs together share
+        // few B panels and few A panels
+        const int G = g.ngroup, mt = gridDim.y, per = G * mt;
+        const int c = wg / per, within = wg - c * per;
+        const int gw = min(G, (int)gridDim.x - c * G);
+        m0 = (within / gw) * PP_BM;
+        n0 = (c * G + within % gw) * PP_BN;
     }
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
@@ -709,6 +714,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
         attr_done = true;
     }
     dim3 grid(cdiv(g.N, PP_BN), cdiv(g.M, PP_BM), g.splitk > 1 ? g.splitk : g.batch);
+    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
+    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);

@@ -560,7 +560,9 @@ def gemm(a, b, *, ta=False, tb=False, **kw):  # noqa: F811
     a2, b2 = _rows2d(a), _rows2d(b)
     M, K = (a2.shape[1], a2.shape[0]) if ta else (a2.shape[0], a2.shape[1])
     N = b2.shape[1] if tb else b2.shape[0]
-    return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:{'T' if ta else 'N'}{'T' if tb else 'N'}",
+    out = kw.get("out")
+    f32 = (out.dtype if out is not None else kw.get("out_dtype", BF16)) == F32
+    return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:{'T' if ta else 'N'}{'T' if tb else 'N'}:{'f32' if f32 else 'bf16'}",
                         lambda: _gemm_raw(a, b, ta=ta, tb=tb, **kw))
 
 
