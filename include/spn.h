@@ -64,7 +64,8 @@ int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, 
                       void* y, int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps, spn_stream_t stream);
 int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma, const float* gb,
                       long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,
-                      long lddx, float* dgamma, float* dbeta, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
+                      long lddx, void* dx16 /* optional bf16 copy of dx */, long lddx16, float* dgamma, float* dbeta, void* dgb,
+                      long lddgb, int T, int D, spn_stream_t stream);
 
 /* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
 /* p_drop > 0: nn.Dropout on the activation output (feedforward.py:57-60); the mask is a pure function of (seed, index) */

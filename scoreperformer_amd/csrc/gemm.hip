@@ -459,7 +459,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     };
     // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
     auto wait_landed = [&](int p) {
+#ifdef PP_WAIT_ALTERNATE
+        // variant: wait only in even phases (and the prologue), one half-tile deeper, so that the following odd phase needs none
+        if (p >= 0 && (p & 1)) return;
+        const int younger = min(p + PP_LEAD + 1, total) - (p + 4);
+#else
         const int younger = min(p + PP_LEAD + 1, total) - (p + 3);
+#endif
         if (younger >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
                                                      const float* __restrict__ gamma, const float* __restrict__ gb, long ldgb,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, long lddres, TDx* __restrict__ dx, long lddx,
+                                                     bf16_t* __restrict__ dx16, long lddx16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      bf16_t* __restrict__ dgb, long lddgb, int T, int D, int rows_per_block) {
     __shared__ float red[4][64 * NV * 4 + 4];
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
             for (int e = 0; e < 4; ++e) o[e] = rs * (gq[i][e] - s1 - xh[i][e] * s2);
             if (dres) o += *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col);
             IO<TDx>::store4(dx + (long)row * lddx + col, o);
+            if (dx16) IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);   // bf16 copy = the next backward GEMM's operand
         }
     }
     if (dgamma && !dgb) {
@@ -170,11 +172,11 @@ int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const 
 template <typename TIn, typename TDx>
 int launch_bwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const void* dy, long lddy, const float* gamma,
                const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx,
-               long lddx, float* dgamma, float* dbeta, bf16_t* dgb, long lddgb, int T, int D, int rpb) {
+               long lddx, bf16_t* dx16, long lddx16, float* dgamma, float* dbeta, bf16_t* dgb, long lddgb, int T, int D, int rpb) {
 #define CASE(NV_)                                                                                                        \
     case NV_:                                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<TIn, TDx, NV_>), grid, dim3(256), 0, s, (const TIn*)x, ldx, (const bf16_t*)dy, \
-                           lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, (TDx*)dx, lddx, dgamma, dbeta, dgb, lddgb, T, D, \
+                           lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, (TDx*)dx, lddx, dx16, lddx16, dgamma, dbeta, dgb, lddgb, T, D, \
                            rpb);                                                                                         \
         break;
     switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
@@ -206,23 +208,23 @@ extern "C" int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const flo
 }
 
 // dx[T,D] (fp32 or bf16) = (dres or 0) + LN backward; dy is bf16.  Affine: dgamma/dbeta [D] fp32 are ACCUMULATED
-// (atomics; zero them first).  Adaptive: dgb [T,2D] bf16 rows are written.
+// (atomics; zero them first).  Adaptive: dgb [T,2D] bf16 rows are written.  dx16 (optional): bf16 copy of dx, row stride lddx16.
 extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma,
                                  const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres,
-                                 long lddres, void* dx, int dx_dtype, long lddx, float* dgamma, float* dbeta, void* dgb,
-                                 long lddgb, int T, int D, hipStream_t stream) {
+                                 long lddres, void* dx, int dx_dtype, long lddx, void* dx16, long lddx16, float* dgamma,
+                                 float* dbeta, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
     SPN_REQUIRE(x && dy && mean && rstd && dx && T > 0 && D > 0, "spn_layernorm_bwd: bad arguments");
     SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldgb % 4 == 0 && lddgb % 4 == 0 &&
-                lddres % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
+                lddres % 4 == 0 && lddx16 % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
     const int nv = round_nv((D + 255) / 256);
     int rpb = cdiv(T, 2048);  // <= 2048 blocks
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));
     int rc;
-    if (x_dtype == 0 && dx_dtype == 0) rc = launch_bwd<float, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else if (x_dtype == 0 && dx_dtype == 1) rc = launch_bwd<float, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else if (x_dtype == 1 && dx_dtype == 0) rc = launch_bwd<bf16_t, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else rc = launch_bwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    if (x_dtype == 0 && dx_dtype == 0) rc = launch_bwd<float, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else if (x_dtype == 0 && dx_dtype == 1) rc = launch_bwd<float, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else if (x_dtype == 1 && dx_dtype == 0) rc = launch_bwd<bf16_t, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+    else rc = launch_bwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
     if (rc) { spn_set_error("spn_layernorm_bwd: unsupported width"); return rc; }
     SPN_LAUNCH_CHECK();
     return SPN_OK;

@@ -69,6 +69,23 @@ def to_bf16(x: torch.Tensor, rowmask: Optional[torch.Tensor] = None) -> torch.Te
     return ops.cast(x, BF16, rowmask=rowmask)
 
 
+def _bf16_grad(dy: torch.Tensor, n: int, rowmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[T, n] bf16 operand of a backward GEMM.  A LayerNorm backward that produced `dy` in fp32 also wrote its bf16 copy
+    (`dy._spn_bf16`, set on the very tensor object autograd hands on): use it instead of a cast pass."""
+    shadow = getattr(dy, "_spn_bf16", None) if rowmask is None else None
+    if shadow is not None and shadow.numel() == dy.numel():
+        return shadow.reshape(-1, n)
+    return to_bf16(dy.reshape(-1, n), rowmask=rowmask)
+
+
+def _with_shadow(dx: torch.Tensor, shape) -> torch.Tensor:
+    out = dx.view(shape)
+    shadow = getattr(dx, "_spn_bf16", None)
+    if shadow is not None:
+        out._spn_bf16 = shadow
+    return out
+
+
 def _accumulate_wgrad(w: torch.Tensor, compute, shape):
     """Weight gradient: accumulate straight into the arena's fp32 grad view when there is one (returns None to
     autograd), else return a fresh fp32 gradient."""
@@ -124,7 +141,7 @@ class LinearFn(Function):
         weight = ctx.weight_ref
         N = weight.shape[1] if ctx.kn else weight.shape[0]
         d_res = dy if ctx.has_res else None
-        dyb = to_bf16(dy.reshape(-1, N), rowmask=rowmask)
+        dyb = _bf16_grad(dy, N, rowmask)
         wb = bf16_weight(weight)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -191,14 +208,14 @@ class LayerNormFn(Function):
             dgamma = g_main if fused else torch.zeros(D, device=x.device, dtype=F32)
             dbeta = b_main if fused else torch.zeros(D, device=x.device, dtype=F32)
         dx, _ = ops.layernorm_bwd(x, dyb, gamma.detach() if gamma is not None else None, None, mean, rstd, dres=dres,
-                                  dx_dtype=x.dtype, dgamma=dgamma, dbeta=dbeta)
+                                  dx_dtype=x.dtype, dgamma=dgamma, dbeta=dbeta, want_dx16=True)
         if fused:
             for p in (gamma, beta):
                 hook = getattr(p, "_spn_grad_ready", None)
                 if hook is not None:
                     hook()
             dgamma = dbeta = None
-        return dx.view(x.shape), dgamma, dbeta, None, None, None
+        return _with_shadow(dx, x.shape), dgamma, dbeta, None, None, None
 
 
 def _fork_grad(dres, x):
@@ -274,7 +291,8 @@ class AdaLayerNormFn(Function):
         if dy is None:
             dy = torch.zeros(x.shape, device=x.device, dtype=BF16)
         dyb = to_bf16(dy.reshape(-1, D))
-        dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dres=_fork_grad(dres, x), dx_dtype=x.dtype, want_dgb=True)
+        dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dres=_fork_grad(dres, x), dx_dtype=x.dtype, want_dgb=True,
+                                    want_dx16=True)
         dcond = None
         if ctx.needs_input_grad[1]:
             dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
@@ -289,7 +307,7 @@ class AdaLayerNormFn(Function):
                 hook()
         else:
             db = ops.colsum(dgb)
-        return dx.view(x.shape), dcond, dw, db, None, None, None
+        return _with_shadow(dx, x.shape), dcond, dw, db, None, None, None
 
 
 def ada_layer_norm(x, cond, weight, bias, *, out_fp32=False, eps=1e-5, fork=False):

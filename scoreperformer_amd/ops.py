@@ -101,22 +101,27 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
 
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tensor], gb: Optional[torch.Tensor],
                   mean: torch.Tensor, rstd: torch.Tensor, *, dres: Optional[torch.Tensor] = None, dx_dtype=F32,
-                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, want_dgb: bool = False):
-    """Returns (dx, dgb).  dgamma/dbeta (fp32 [D]) are accumulated in place when given."""
+                  dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, want_dgb: bool = False,
+                  want_dx16: bool = False):
+    """Returns (dx, dgb).  dgamma/dbeta (fp32 [D]) are accumulated in place when given.  `want_dx16`: the kernel also writes
+    a bf16 copy of an fp32 dx, attached as `dx._spn_bf16` (the operand of the next backward GEMM; saves its cast pass)."""
     x2, dy2 = _rows2d(x), _rows2d(dy)
     if dy2.dtype != BF16:
         raise SpnError("layernorm_bwd: dy must be bf16")
     T, D = x2.shape
     dx = torch.empty((T, D), device=x.device, dtype=dx_dtype)
     dgb = torch.empty((T, 2 * D), device=x.device, dtype=BF16) if want_dgb else None
+    dx16 = torch.empty((T, D), device=x.device, dtype=BF16) if (want_dx16 and dx_dtype == F32) else None
     if gb is not None:
         gb = _rows2d(gb)
     if dres is not None:
         dres = _rows2d(dres)
     call("spn_layernorm_bwd", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gamma),
          ptr(gb), c_long(gb.stride(0) if gb is not None else 0), ptr(mean), ptr(rstd), ptr(dres),
-         c_long(dres.stride(0) if dres is not None else 0), ptr(dx), c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dgamma),
-         ptr(dbeta), ptr(dgb), c_long(2 * D), c_int(T), c_int(D), stream_ptr())
+         c_long(dres.stride(0) if dres is not None else 0), ptr(dx), c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D),
+         ptr(dgamma), ptr(dbeta), ptr(dgb), c_long(2 * D), c_int(T), c_int(D), stream_ptr())
+    if dx16 is not None:
+        dx._spn_bf16 = dx16
     return dx, dgb
 
 
