@@ -77,7 +77,7 @@ def main():
     torch.manual_seed(1234)  # identical initial replicas on every rank
     cfg = model_config(args.preset, max_seq_len=max(args.seq, 256), dropout=args.dropout)
     model = ScorePerformer.init(cfg)
-    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 and not args.no_cpu_baseline else None
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     arena = ParamArena(model, dev)
     model.train()
     model.sync_free = True
@@ -129,9 +129,12 @@ def main():
                    "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},
     }
 
-    if rank == 0 and not args.no_roofline:
-        result["roofline"] = roofline_leg(ops, step, args)
-    if rank == 0 and not args.no_cpu_baseline:
+    if not args.no_roofline:
+        # every rank runs the instrumented steps (they contain the gradient all-reduce); rank 0 reports its own launches
+        roof = roofline_leg(ops, step, args)
+        if rank == 0:
+            result["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 measurement
         result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args, model, dev)
     if dist is not None:
         dist.barrier()
