@@ -13,13 +13,19 @@
 // M/N-contiguous tiles are staged [64][rows] and read with ds_read_b64_tr_b16 (hardware transpose), so no
 // operand ever needs a transposed copy in HBM.
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 accumulators.
-// Staging: interior tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
-// round trip and no ds_write, whose ~80 B/clk/CU is the first thing a register-staged 128^2 GEMM saturates).  The DMA writes
-// LDS linearly (wave base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE address.  Tiles that touch an M/N/K
-// edge take the register path with zero fill.  Two LDS stages: tile t+1 streams in while tile t is multiplied.
-// The MFMA is issued with operands swapped (D^T = B^T.A^T), which leaves each lane with 4 CONSECUTIVE output columns of one
-// row: the epilogue stores 8/16 bytes per lane instead of scattered 2/4-byte elements.
+// Two kernels (dispatch in launch<>):
+//  * gemm_pp_kernel: 256x256x64 tiles, 8 waves in two groups one barrier apart (one multiplies with v_mfma_f32_32x32x16_bf16 while
+//    the other reads fragments and issues LDS DMA), 8-slot half-tile ring in 128 KiB LDS.  Takes every shape whose K is a
+//    multiple of 64 (>= 256) and whose M, N are multiples of 8 -- M / N edge tiles included.  See the comment above the kernel.
+//  * gemm_kernel: 128x128x{32,64} tiles, 4 waves (2x2) x (4x4) v_mfma_f32_16x16x32_bf16, two LDS stages; everything else
+//    (ragged K, tiny problems).  Tiles that touch an M/N/K edge take a register path with zero fill.
+// Common to both: interior tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
+// round trip and no ds_write); the DMA writes LDS linearly (wave base + lane*16), so the XOR swizzle is applied on the per-lane
+// SOURCE address.  The MFMA is issued with operands swapped (D^T = B^T.A^T), which leaves each lane with 4 CONSECUTIVE output
+// columns of one row.  The epilogue (alpha, bias, row mask, fp32 residual, accumulate) stages the wave's block through its own LDS
+// slab and stores whole 128-byte row segments: partial-line writes make the L2 fetch every line of C first.  Weight-gradient
+// shapes (tiny MxN, K = all tokens) split K over blocks that write fp32 partials to a workspace; one small kernel reduces them.
+// Tile order: XCD-contiguous (workgroup id % 8 = XCD), column groups of 8 n-tiles, m-tiles down each group.
 #include "common.h"
 #include <stdlib.h>
 
