@@ -49,6 +49,7 @@ struct GemmArgs {
     int splitk;               // ... or, when > 1, blockIdx.z = K slice writing its partial product to C + z*sC (a workspace)
     int kt_per_split;         // K tiles per slice
     int ngroup;               // n-tiles per column group of the tile order
+    int pp_addr_ok;           // both operands span < 2^31 bytes (the ping-pong kernel addresses them with 32-bit offsets)
 #ifdef SPN_GEMM_TIMING
     long long* dbg;
 #endif
@@ -400,20 +401,19 @@ template <int SUB> __device__ __forceinline__ int pp_row(int x, int h) { return 
 // one half-tile = 16 pieces of 1 KiB, 2 per wave; LDS image linear, swizzle applied on the source address
 // R = rows (A: M, B: N) of the operand: tiles that hang over the edge re-read the last row (last 8-row group when the rows
 // are the contiguous dimension) -- valid memory, and the epilogue never stores what was computed from it.
+// One half-tile = 16 pieces of 1 KiB, 2 per wave; the LDS image is linear, the swizzle is applied on the source address.
+// The per-lane part of the address is loop-invariant (one 32-bit VGPR per piece, computed once), the K-tile part is a scalar offset,
+// the base sits in an SGPR buffer resource: buffer_load_dwordx4 ... offen lds with NO vector address arithmetic inside the K loop
+// (+10% over flat global_load_lds with 64-bit per-lane addresses on the long-K shapes).
 template <bool T, int SUB>
-__device__ __forceinline__ void pp_dma(const bf16_t* __restrict__ p, int ld, int row0, int R, int k0, int h, char* lds, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int L = (wave * 2 + i) * 64 + lane;
-        const bf16_t* src;
-        if (!T) {
-            const int x = L >> 3, kc = (L & 7) ^ ((x >> 1) & 7);
-            src = p + (long)min(row0 + pp_row<SUB>(x, h), R - 1) * ld + k0 + kc * 8;
-        } else {
-            const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
-            src = p + (long)(k0 + krow) * ld + min(row0 + pp_row<SUB>(rc * 8, h), R - 8);
-        }
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + (wave * 2 + i) * 1024), 16, 0, 0);
+__device__ __forceinline__ uint32_t pp_voffset(int ld, int row0, int R, int h, int wave, int lane, int i) {
+    const int L = (wave * 2 + i) * 64 + lane;
+    if (!T) {
+        const int x = L >> 3, kc = (L & 7) ^ ((x >> 1) & 7);
+        return (uint32_t)(((long)min(row0 + pp_row<SUB>(x, h), R - 1) * ld + kc * 8) * 2);
+    } else {
+        const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
+        return (uint32_t)(((long)krow * ld + min(row0 + pp_row<SUB>(rc * 8, h), R - 8)) * 2);
     }
 }
 
@@ -456,12 +456,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    uint32_t vo[4][2];   // [kind][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vo[0][i] = pp_voffset<TA, 64>(g.lda, m0, g.M, 0, wave, lane, i);
+        vo[1][i] = pp_voffset<TB, 32>(g.ldb, n0, g.N, 0, wave, lane, i);
+        vo[2][i] = pp_voffset<TB, 32>(g.ldb, n0, g.N, 1, wave, lane, i);
+        vo[3][i] = pp_voffset<TA, 64>(g.lda, m0, g.M, 1, wave, lane, i);
+    }
     auto issue = [&](int c, int t) {   // c is a compile-time constant at every call site
         const int k0 = kbase + t * PP_BK;
-        if (c == 0) pp_dma<TA, 64>(A, g.lda, m0, g.M, k0, 0, PP_SLOT(0, t), wave, lane);
-        else if (c == 1) pp_dma<TB, 32>(B, g.ldb, n0, g.N, k0, 0, PP_SLOT(1, t), wave, lane);
-        else if (c == 2) pp_dma<TB, 32>(B, g.ldb, n0, g.N, k0, 1, PP_SLOT(2, t), wave, lane);
-        else pp_dma<TA, 64>(A, g.lda, m0, g.M, k0, 1, PP_SLOT(3, t), wave, lane);
+        const bool isA = (c == 0 || c == 3);
+        const uint32_t soff = isA ? (TA ? (uint32_t)k0 * g.lda * 2u : (uint32_t)k0 * 2u) : (TB ? (uint32_t)k0 * g.ldb * 2u : (uint32_t)k0 * 2u);
+        char* dst = PP_SLOT(c, t) + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(dst + i * 1024), 16, vo[c][i], soff, 0, 0);
     };
     // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
     auto wait_landed = [&](int p) {
@@ -702,7 +714,9 @@ static void finish_split(const GemmArgs& g, const SplitPlan& plan, hipStream_t s
 // shapes the ping-pong kernel takes: K in whole 64-tiles, rows in multiples of 8, vector-aligned epilogue operands
 static bool pp_eligible(const GemmArgs& g) {
     // edge tiles in M and N are fine (clamped loads, guarded stores); K must be whole 64-tiles
+    // operands are addressed with 32-bit byte offsets from their base
     return g.M >= 128 && g.N >= 128 && g.M % 8 == 0 && g.N % 8 == 0 && g.K % PP_BK == 0 && g.K >= 4 * PP_BK && g.ldc % 8 == 0 &&
+           g.pp_addr_ok &&
            (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (!g.residual || (g.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)) &&
            (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) && (g.sC % 4 == 0);
 }
@@ -809,6 +823,10 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.residual = residual; g.rowmask = rowmask;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    {
+        const long a_span = (long)(ta ? K : M) * lda * 2, b_span = (long)(tb ? K : N) * ldb * 2;
+        g.pp_addr_ok = (a_span < (1L << 31) && b_span < (1L << 31)) ? 1 : 0;
+    }
 #ifdef SPN_GEMM_TIMING
     g.dbg = g_dbg;
 #endif
