@@ -151,3 +151,43 @@ class FusedAdamW:
         if zero_grad:
             self.arena.zero_grad()
         return norm
+
+    # -- checkpoint / resume in torch.optim.AdamW's own format (what the reference's checkpoints hold under "optimizer":
+    #    experiments/optimizers.py wraps torch.optim.AdamW over model.parameters(), i.e. the arena's parameter order) ------------
+    def state_dict(self):
+        a = self.arena
+        state = {}
+        if a.step_count > 0:
+            for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(a.step_count)),
+                            "exp_avg": a.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": a.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(a.param_list)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(a.param_list):
+            raise ValueError("optimizer state does not match the model: expected one param group with "
+                             f"{len(a.param_list)} parameters")
+        g = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        a.exp_avg.zero_(); a.exp_avg_sq.zero_()
+        steps = set()
+        for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
+            st = sd["state"].get(g["params"][i])
+            if st is None:
+                continue
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {a.names[i]} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+            a.exp_avg[off:off + n].view(p.shape).copy_(st["exp_avg"])
+            a.exp_avg_sq[off:off + n].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the fused update keeps one step counter")
+        a.step_count = steps.pop() if steps else 0

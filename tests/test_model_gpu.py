@@ -201,3 +201,46 @@ def test_load_state_dict_refreshes_bf16_copies(dev):
         att.to_k.weight.mul_(2.0)            # in-place edit of one constituent
     wk = F_.bf16_weight(att._w_qkv)[att.to_q.weight.shape[0]:att.to_q.weight.shape[0] + att.to_k.weight.shape[0]].float()
     assert (wk - att.to_k.weight.detach()).abs().max().item() <= 2 ** -7 * att.to_k.weight.abs().max().item()
+
+
+def test_optimizer_state_dict_round_trips_through_torch_adamw_format(dev):
+    """FusedAdamW.state_dict() is torch.optim.AdamW's format (reference checkpoints' "optimizer" entry): a torch AdamW loaded
+    from it continues exactly like the fused optimizer, and a fresh arena resumed from it does too."""
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena, FusedAdamW
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    cfg = model_config("tiny", dropout=0.0)
+    batch = synthetic_batch(2, 48, seed=2, ragged=True, device=dev)
+
+    def make():
+        m = ScorePerformer.init(model_config("tiny", dropout=0.0))
+        m.load_state_dict(filled_state_dict(m, seed=9))
+        a = ParamArena(m, dev)
+        m.train()
+        return m, a, FusedAdamW(a, lr=1e-3, weight_decay=1e-2, grad_clip=None)
+
+    def run(m, a, o, n):
+        for _ in range(n):
+            torch.manual_seed(5)
+            a.zero_grad()
+            m(**batch).loss.backward()
+            o.step()
+
+    m1, a1, o1 = make()
+    run(m1, a1, o1, 2)
+    sd_model = {k: v.clone() for k, v in m1.state_dict().items()}
+    sd_opt = o1.state_dict()
+    # torch's own AdamW accepts the dict
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in a1.param_list]
+    topt = torch.optim.AdamW(ref_params, lr=1.0)
+    topt.load_state_dict(sd_opt)
+    assert topt.param_groups[0]["lr"] == 1e-3 and int(topt.state[ref_params[0]]["step"]) == 2
+    # resume in a fresh arena and continue: same parameters as the uninterrupted run (up to summation-order noise)
+    m2, a2, o2 = make()
+    m2.load_state_dict(sd_model)
+    o2.load_state_dict(sd_opt)
+    run(m1, a1, o1, 1)
+    run(m2, a2, o2, 1)
+    assert a2.step_count == 3
+    assert (a1.params - a2.params).abs().max() <= 2e-5
