@@ -72,7 +72,8 @@ int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long
 int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, float p_drop, unsigned seed,
                 spn_stream_t s);
 int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act, int glu,
-                float p_drop, unsigned seed, spn_stream_t s);
+                float p_drop, unsigned seed, float* colsum /* optional: += column sums of du (bias gradient) */,
+                float* colsum_ws /* scratch, 4096 * width floats, required with colsum */, spn_stream_t s);
 int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dtype, long y_bs, long y_ts,
              const uint8_t* rowmask, long B, long t_len, int D, spn_stream_t s);
 int spn_colsum(const void* x, int x_dtype, long ldx, float* out /* ACCUMULATED */, long T, int N, spn_stream_t s);

@@ -72,9 +72,14 @@ __global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* _
 
 template <int ACT, bool GLU>
 __global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf16_t* __restrict__ dout, long lddo,
-                               bf16_t* __restrict__ du, long lddu, long T, int I, uint32_t thr16, float keep_scale, uint32_t seed) {
+                               bf16_t* __restrict__ du, long lddu, long T, int I, uint32_t thr16, float keep_scale, uint32_t seed,
+                               float* __restrict__ colsum) {
     const int chunks = I / 8;
     const long total = T * chunks;
+    // colsum != null (the launcher guarantees grid stride % chunks == 0, so a thread always sees the same 8 columns): every block
+    // leaves the column sums of the du rows it produced in row blockIdx.x of `colsum` [gridDim.x, W]; the launcher adds the rows
+    // up = the bias gradient of the Linear in front, without re-reading du (1 GB for the C3 FFN)
+    float sa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long t = idx / chunks;
         const int c = (idx % chunks) * 8;
@@ -86,13 +91,52 @@ __global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf1
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + I + c), g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { da[e] = d[e] * act_f<ACT>(g[e]); dg[e] = d[e] * a[e] * act_g<ACT>(g[e]); }
-            *reinterpret_cast<uint4*>(du + t * lddu + c) = pack8f(da);
-            *reinterpret_cast<uint4*>(du + t * lddu + I + c) = pack8f(dg);
+            const uint4 pa = pack8f(da), pg = pack8f(dg);
+            *reinterpret_cast<uint4*>(du + t * lddu + c) = pa;
+            *reinterpret_cast<uint4*>(du + t * lddu + I + c) = pg;
+            if (colsum) {   // sum what the consumer GEMMs will see: the bf16-rounded values
+                float ra[8], rg[8];
+                unpack8(pa, ra); unpack8(pg, rg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sa[e] += ra[e]; sg[e] += rg[e]; }
+            }
         } else {
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) dg[e] = d[e] * act_g<ACT>(g[e]);
-            *reinterpret_cast<uint4*>(du + t * lddu + c) = pack8f(dg);
+            const uint4 pg = pack8f(dg);
+            *reinterpret_cast<uint4*>(du + t * lddu + c) = pg;
+            if (colsum) {
+                float rg[8];
+                unpack8(pg, rg);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sg[e] += rg[e];
+            }
+        }
+    }
+    if (colsum) {
+        const int W = GLU ? 2 * I : I;
+        const int c = (int)((((long)blockIdx.x * blockDim.x + threadIdx.x) % chunks) * 8);
+        float* row = colsum + (long)blockIdx.x * W;   // blocks with fewer than `chunks` live threads leave zeros (buffer pre-zeroed)
+        if ((long)blockIdx.x * blockDim.x + threadIdx.x < total) {
+            // several threads of one block share a column chunk when chunks < 256: their partials meet in the block's row
+            if (256 % chunks == 0 && chunks < 256) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (GLU) { atomicAdd(row + c + e, sa[e]); atomicAdd(row + I + c + e, sg[e]); }
+                    else atomicAdd(row + c + e, sg[e]);
+                }
+            } else {
+                if (GLU) {
+                    *reinterpret_cast<f32x4*>(row + c) = f32x4{sa[0], sa[1], sa[2], sa[3]};
+                    *reinterpret_cast<f32x4*>(row + c + 4) = f32x4{sa[4], sa[5], sa[6], sa[7]};
+                    *reinterpret_cast<f32x4*>(row + I + c) = f32x4{sg[0], sg[1], sg[2], sg[3]};
+                    *reinterpret_cast<f32x4*>(row + I + c + 4) = f32x4{sg[4], sg[5], sg[6], sg[7]};
+                } else {
+                    *reinterpret_cast<f32x4*>(row + c) = f32x4{sg[0], sg[1], sg[2], sg[3]};
+                    *reinterpret_cast<f32x4*>(row + c + 4) = f32x4{sg[4], sg[5], sg[6], sg[7]};
+                }
+            }
         }
     }
 }
@@ -239,18 +283,36 @@ extern "C" int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T,
     return SPN_OK;
 }
 
+// colsum (optional, fp32 [W], W = 2I for GLU / I): column sums of du are ACCUMULATED into it (bias gradient of the producing
+// Linear); needs colsum_ws = scratch of 4096 * W floats (per-block partial rows, reduced here)
 extern "C" int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act,
-                           int glu, float p_drop, unsigned seed, hipStream_t s) {
+                           int glu, float p_drop, unsigned seed, float* colsum, float* colsum_ws, hipStream_t s) {
     SPN_REQUIRE(u && dout && du && T > 0 && I > 0 && I % 8 == 0 && ldu % 8 == 0 && lddo % 8 == 0 && lddu % 8 == 0,
                 "spn_act_bwd: bad arguments (I, ld multiples of 8)");
-    const int g = grid_for(T * (I / 8));
+    int g = grid_for(T * (I / 8));
+    const int W = glu ? 2 * I : I;
+    float* partial = nullptr;
+    if (colsum) {   // a grid stride that keeps thread <-> column chunk fixed
+        const int chunks = I / 8;
+        SPN_REQUIRE(colsum_ws, "spn_act_bwd: fused column sums need the scratch buffer");
+        SPN_REQUIRE(chunks % 256 == 0 || 256 % chunks == 0, "spn_act_bwd: fused column sums need I/8 to divide or be a multiple of 256");
+        if (g > 1024) g = 1024;   // 4 blocks per CU still stream at full rate; 4x fewer partial rows to reduce
+        if (chunks > 256) { const int per = chunks / 256; g = (g / per) * per; if (g < per) g = per; }
+        partial = colsum_ws;
+        hipMemsetAsync(partial, 0, (size_t)g * W * 4, s);
+    }
     const bf16_t* up = (const bf16_t*)u; const bf16_t* dp = (const bf16_t*)dout; bf16_t* op = (bf16_t*)du;
     const uint32_t thr = thr16_of(p_drop);
     const float ks = 1.f / (1.f - (float)thr / 65536.f);
-    if (act == 0 && glu) hipLaunchKernelGGL((act_bwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
-    else if (act == 0) hipLaunchKernelGGL((act_bwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
-    else if (glu) hipLaunchKernelGGL((act_bwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
-    else hipLaunchKernelGGL((act_bwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed);
+    if (act == 0 && glu) hipLaunchKernelGGL((act_bwd_kernel<0, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed, partial);
+    else if (act == 0) hipLaunchKernelGGL((act_bwd_kernel<0, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed, partial);
+    else if (glu) hipLaunchKernelGGL((act_bwd_kernel<1, true>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed, partial);
+    else hipLaunchKernelGGL((act_bwd_kernel<1, false>), dim3(g), dim3(256), 0, s, up, ldu, dp, lddo, op, lddu, T, I, thr, ks, seed, partial);
+    if (partial) {   // colsum += sum over the g partial rows
+        int slabs = (g + 63) / 64;   // W/64 x g/64 blocks: enough of them to stream the partial rows at full rate
+        const int rpb = (g + slabs - 1) / slabs;
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(cdiv(W, 64), cdiv(g, rpb)), dim3(256), 0, s, partial, (long)W, colsum, (long)g, W, rpb);
+    }
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

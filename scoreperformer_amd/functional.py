@@ -157,7 +157,8 @@ class LinearFn(Function):
             bias = ctx.bias_ref
             main = getattr(bias, "_spn_main_grad", None)
             if main is not None:
-                ops.colsum(dyb, out=main)
+                if not getattr(dy, "_spn_bias_done", False):   # else: the activation backward that produced dy summed it already
+                    ops.colsum(dyb, out=main)
                 hook = getattr(bias, "_spn_grad_ready", None)
                 if hook is not None:
                     hook()
@@ -399,9 +400,12 @@ class ActFn(Function):
     """GLU / activation, with the FFN's nn.Dropout fused behind it (mask recomputed in backward from the seed)."""
 
     @staticmethod
-    def forward(ctx, u, act: int, glu: bool, p_drop: float, seed: int):
+    def forward(ctx, u, act: int, glu: bool, p_drop: float, seed: int, bias=None):
+        # `bias`: the bias parameter of the Linear that produced u; its gradient (column sums of du) is then accumulated by the
+        # backward kernel itself and the Linear's backward skips its own column-sum pass
         ctx.save_for_backward(u)
         ctx.cfg = (act, glu, p_drop, seed)
+        ctx.bias_ref = bias
         out = ops.act_fwd(u, act=act, glu=glu, p_drop=p_drop, seed=seed)
         return out.view(*u.shape[:-1], out.shape[-1])
 
@@ -410,12 +414,19 @@ class ActFn(Function):
     def backward(ctx, dout):
         (u,) = ctx.saved_tensors
         act, glu, p_drop, seed = ctx.cfg
-        du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu, p_drop=p_drop, seed=seed)
-        return du.view(u.shape), None, None, None, None
+        bias = ctx.bias_ref
+        main = getattr(bias, "_spn_main_grad", None) if bias is not None and bias.requires_grad else None
+        if main is not None and not ops.act_bwd_can_fuse_colsum(u.shape[-1], glu):
+            main = None
+        du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu, p_drop=p_drop, seed=seed, colsum=main)
+        du = du.view(u.shape)
+        if main is not None:
+            du._spn_bias_done = True
+        return du, None, None, None, None, None
 
 
-def glu_act(u, *, act=ACT_SILU, glu=True, p_drop: float = 0.0):
-    return ActFn.apply(u, act, glu, float(p_drop), next_seed() if p_drop > 0 else 0)
+def glu_act(u, *, act=ACT_SILU, glu=True, p_drop: float = 0.0, bias=None):
+    return ActFn.apply(u, act, glu, float(p_drop), next_seed() if p_drop > 0 else 0, bias)
 
 
 # ---------------------------------------------------------------------------------------------------------

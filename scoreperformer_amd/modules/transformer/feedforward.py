@@ -15,7 +15,8 @@ class GLU(nn.Module):
 
     def forward(self, x, p_drop: float = 0.0):
         u = F_.linear(x, self.proj.weight, self.proj.bias)
-        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True, p_drop=p_drop)
+        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True, p_drop=p_drop,
+                          bias=self.proj.bias)
 
 
 @dataclass
@@ -50,7 +51,7 @@ class FeedForward(nn.Module, Constructor):
             g = self.ff[0](x, p_drop=p)
         else:
             lin = self.ff[0][0]
-            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p)
+            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p, bias=lin.bias)
         if has_ln:
             g = F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps)
         out = self.ff[3]

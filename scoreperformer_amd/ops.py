@@ -244,14 +244,22 @@ def act_fwd(u: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: 
     return out
 
 
-def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0,
+            colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`colsum` (fp32 [W]): the column sums of the result are accumulated into it (bias gradient of the Linear that produced u)."""
     u2, d2 = _rows2d(u), _rows2d(dout)
     T, W = u2.shape
     I = W // 2 if glu else W
     du = torch.empty((T, W), device=u.device, dtype=BF16)
+    ws = torch.empty(4096 * W, device=u.device, dtype=F32) if colsum is not None else None   # per-block partial rows
     call("spn_act_bwd", ptr(u2), c_long(u2.stride(0)), ptr(d2), c_long(d2.stride(0)), ptr(du), c_long(W), c_long(T), c_int(I),
-         c_int(act), c_int(int(glu)), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
+         c_int(act), c_int(int(glu)), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(colsum), ptr(ws), stream_ptr())
     return du
+
+
+def act_bwd_can_fuse_colsum(width: int, glu: bool) -> bool:
+    chunks = (width // 2 if glu else width) // 8
+    return chunks > 0 and (chunks % 256 == 0 or 256 % chunks == 0)
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
