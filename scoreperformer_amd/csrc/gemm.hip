@@ -425,19 +425,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    int m0, n0;
-    {
-        const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        // column groups of `ngroup` n-tiles, m-tiles down each group (see gemm_kernel): the 32 tiles an XCD runs together share
-        // few B panels and few A panels
+#ifdef SPN_GEMM_TIMING
+    const long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    // workgroup id -> tile: XCD-contiguous (id % 8 = XCD), then column groups of `ngroup` n-tiles, m-tiles down each group (see
+    // gemm_kernel): the 32 tiles an XCD runs together share few B panels and few A panels
+    const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    auto tile_of = [&](int id, int& tm, int& tn) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
         const int G = g.ngroup, mt = gridDim.y, per = G * mt;
         const int c = wg / per, within = wg - c * per;
         const int gw = min(G, (int)gridDim.x - c * G);
-        m0 = (within / gw) * PP_BM;
-        n0 = (c * G + within % gw) * PP_BN;
-    }
+        tm = (within / gw) * PP_BM;
+        tn = (c * G + within % gw) * PP_BN;
+    };
+    int m0, n0;
+    tile_of(bid, m0, n0);
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
     const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
@@ -582,6 +586,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();   // balances the second group's extra barrier
 #ifdef SPN_GEMM_TIMING
+    const long long t_loop_end = __builtin_amdgcn_s_memtime();
     if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4) && lane == 0)
         for (int k = 0; k < 8; ++k) g.dbg[(wave >> 2) * 8 + k] = seg[k];
 #endif
@@ -641,6 +646,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             }
         }
     }
+#ifdef SPN_GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
+    const long long t_end = __builtin_amdgcn_s_memtime();
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && wave == 0 && lane == 0) {
+        g.dbg[16] = t_loop_end - t_start;   // prologue + main loop
+        g.dbg[17] = t_end - t_loop_end;     // epilogue until the stores are acknowledged
+    }
+#endif
 }
 
 // ---- split-K plumbing -------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ dev = torch.device("cuda")
 LDA, LDB = E("LDA", K), E("LDB", K)
 a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
 c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-dbg = torch.zeros(16, device=dev, dtype=torch.int64)
+dbg = torch.zeros(32, device=dev, dtype=torch.int64)
 if hasattr(lib, "spn_gemm_set_debug"):
     lib.spn_gemm_set_debug(ctypes.c_void_p(dbg.data_ptr()))
 P = ctypes.c_void_p
@@ -32,5 +32,6 @@ if LDA == K and LDB == K:
 print(f"{os.environ.get('LIB', '')} M={M} N={N} K={K}: {ms:.3f} ms {2.0*M*N*K/ms/1e9:.0f} TF/s")
 names = ["ds_read issue", "dma issue", "vmcnt wait", "barrier A", "lgkm wait", "mfma", "barrier B", "-"]
 d = dbg.cpu().tolist(); ph = 4 * K // 64
+print(f"block (0,0): prologue + main loop {d[16]} cycles, epilogue (stores acknowledged) {d[17]} cycles")
 for g in range(2):
     print(f"group {g}: " + "  ".join(f"{names[k]}={d[g*8+k]/ph:.0f}" for k in range(7)), " total/phase", sum(d[g*8:g*8+7]) / ph)
