@@ -136,6 +136,19 @@ int spn_dec_attn(const float* qkv, float* kcache, float* vcache, const float* sl
 int spn_dec_argmax_write(const float* logits, int V, unsigned ban_mask, long* tokens, long tok_ld, int dim, int mask_id, const int* pos,
                          spn_stream_t s);
 int spn_dec_add_pos(int* pos, int delta, spn_stream_t s);
+/* fused step kernels (a decode step is launch-latency bound): LayerNorm/AdaLN prologue + GEMV + GLU/bias/residual epilogue (+ cache
+ * row mirror); (LN(x) | context row | style row) concatenation; split-key single-query attention with the ALiBi reach and a running
+ * max |k|^2; LM head (LayerNorm + per-dim logits + banned ids + arg-max write) for all candidate dims in one launch */
+int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const float* x, long x_ld, int x_off, int norm, const float* gamma,
+                       const float* beta, float eps, const float* bias, const float* residual, float* y, long y_ld, int y_off, float* y2,
+                       long y2_ld, int y2_off, float* xn_out, long xn_ld, int xn_off, int glu, int act, const int* pos, spn_stream_t s);
+int spn_dec_cat(const float* x, int d, const float* gamma, const float* beta, float eps, const float* ctx, long ctx_ld, int ctx_w,
+                const float* style, long style_ld, int style_w, const int* pos, float* out, spn_stream_t s);
+int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part, int* counter,
+                  float* kmax2, int h, int kvh, float scale, int splits, spn_stream_t s);
+int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
+                 const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
+                 const int* pos, spn_stream_t s);
 
 #ifdef __cplusplus
 }

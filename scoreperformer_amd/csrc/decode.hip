@@ -189,6 +189,254 @@ __global__ __launch_bounds__(256) void dec_argmax_write_kernel(const float* __re
 
 __global__ void dec_add_pos_kernel(int* pos, int delta) { if (threadIdx.x == 0 && blockIdx.x == 0) *pos += delta; }
 
+// ---- fused step kernels (fewer, fatter launches: a decode step is launch-latency bound) -----------------------------------
+// y[n] = [GLU]( W[n,:] . LN?(x) + bias[n] ) + residual[n], optionally mirrored into a second (cache) row.
+//   norm: 0 none, 1 affine LayerNorm(gamma, beta), 2 adaptive (gamma | beta = gb[0:K] | gb[K:2K])   -- done in the prologue by
+//         every block on its own LDS copy of x (K <= 2048 floats: cheaper than a separate launch + round trip)
+//   glu : W has 2N rows (values | gates), y[n] = v_n * act(g_n)
+//   xn_out: block 0 also stores the normalised x (the reference caches the final-norm output)
+struct DecGemvArgs {
+    const float* W; long ldw; int N, K;
+    const float* x; long x_ld; int x_off;
+    int norm; const float* gamma; const float* beta; float eps;
+    const float* bias; const float* residual;
+    float* y; long y_ld; int y_off;
+    float* y2; long y2_ld; int y2_off;
+    float* xn_out; long xn_ld; int xn_off;
+    int glu, act;
+    const int* pos;
+};
+__device__ __forceinline__ float dec_act(float g, int act) {
+    return act == 0 ? g / (1.f + __expf(-g)) : 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+}
+__global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
+    __shared__ __attribute__((aligned(16))) float xs[2048];
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int p = a.pos ? *a.pos : 0;
+    const float* x = a.x + (long)(p + a.x_off) * a.x_ld;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < a.K; k += 256) { const float v = x[k]; xs[k] = v; s += v; }
+    if (a.norm) {
+        s = wave_sum(s);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.K;
+        float q2 = 0.f;
+        for (int k = threadIdx.x; k < a.K; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+        q2 = wave_sum(q2);
+        if (lane == 0) red[4 + w] = q2;
+        __syncthreads();
+        const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.K + a.eps);
+        const float* gam = a.gamma;
+        const float* bet = a.norm == 2 ? a.gamma + a.K : a.beta;
+        for (int k = threadIdx.x; k < a.K; k += 256) {
+            float v = (xs[k] - mu) * rs;
+            if (gam) v = v * gam[k] + bet[k];
+            xs[k] = v;
+            if (a.xn_out && blockIdx.x == 0) a.xn_out[(long)(p + a.xn_off) * a.xn_ld + k] = v;
+        }
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + w;
+    if (n >= a.N) return;
+    const float* wv_ = a.W + (long)n * a.ldw;
+    const float* wg_ = a.W + (long)(n + a.N) * a.ldw;
+    float acc = 0.f, accg = 0.f;
+    if ((a.K & 3) == 0 && (a.ldw & 3) == 0) {
+        for (int k = lane * 4; k < a.K; k += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wv_ + k);
+            acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            if (a.glu) {
+                const f32x4 wg = *reinterpret_cast<const f32x4*>(wg_ + k);
+                accg += wg[0] * xv[0] + wg[1] * xv[1] + wg[2] * xv[2] + wg[3] * xv[3];
+            }
+        }
+    } else {
+        for (int k = lane; k < a.K; k += 64) { acc = fmaf(wv_[k], xs[k], acc); if (a.glu) accg = fmaf(wg_[k], xs[k], accg); }
+    }
+    acc = wave_sum(acc);
+    if (a.glu) accg = wave_sum(accg);
+    if (lane == 0) {
+        if (a.bias) { acc += a.bias[n]; if (a.glu) accg += a.bias[n + a.N]; }
+        if (a.glu) acc = acc * dec_act(accg, a.act);
+        else if (a.act >= 0 && a.glu < 0) acc = dec_act(acc, a.act);   // plain activation (glu = -1)
+        if (a.residual) acc += a.residual[n];
+        a.y[(long)(p + a.y_off) * a.y_ld + n] = acc;
+        if (a.y2) a.y2[(long)(p + a.y2_off) * a.y2_ld + n] = acc;
+    }
+}
+
+// out = ( LN?(x) | ctx[pos + 1] | style[pos + 1] )   (transformer.py:160-176: the decoder's concatenated input of one position)
+__global__ __launch_bounds__(256) void dec_cat_kernel(const float* __restrict__ x, int d, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, const float* __restrict__ ctx, long ctx_ld,
+                                                      int ctx_w, const float* __restrict__ style, long style_ld, int style_w,
+                                                      const int* __restrict__ pos, float* __restrict__ out) {
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, p = *pos;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < d; k += 256) s += x[k];
+    float mu = 0.f, rs = 1.f;
+    if (gamma) {
+        s = wave_sum(s);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+        float q2 = 0.f;
+        for (int k = threadIdx.x; k < d; k += 256) { const float t = x[k] - mu; q2 += t * t; }
+        q2 = wave_sum(q2);
+        if (lane == 0) red[4 + w] = q2;
+        __syncthreads();
+        rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d + eps);
+    }
+    for (int k = threadIdx.x; k < d; k += 256) out[k] = gamma ? (x[k] - mu) * rs * gamma[k] + beta[k] : x[k];
+    if (ctx) for (int k = threadIdx.x; k < ctx_w; k += 256) out[d + k] = ctx[(long)(p + 1) * ctx_ld + k];
+    if (style) for (int k = threadIdx.x; k < style_w; k += 256) out[d + (ctx ? ctx_w : 0) + k] = style[(long)(p + 1) * style_ld + k];
+}
+
+// Single-query attention, keys split over blocks (grid = h x S), 16 lanes per key (4 dims each: one 16-byte load), online softmax per
+// lane group, partials merged by the last block of each head.  ALiBi reach: with B = scale*|q|*max|k| every weight further than
+// D = (104 + 2B)/slope from the query is below exp(-104) of the largest one -- exactly 0 or one denormal ulp in the fp32 reference
+// as well -- so those keys are not read.  kmax2[0] = running max |k|^2 of this layer's cache (MQA: one kv head; else per kv head).
+__global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict__ qkv, float* __restrict__ kcache, float* __restrict__ vcache,
+                                                        const float* __restrict__ slopes, const int* __restrict__ pos, float* __restrict__ o,
+                                                        float* __restrict__ part, int* __restrict__ counter, float* __restrict__ kmax2,
+                                                        int h, int kvh, float scale) {
+    __shared__ float sm[16], sl[16];
+    __shared__ __attribute__((aligned(16))) float so[16][64];
+    __shared__ int is_last;
+    const int hi = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, l16 = lane & 15;
+    const int kh = kvh == 1 ? 0 : hi;
+    const int t = *pos;
+    const long cw = (long)kvh * 64;
+    const float* knew = qkv + h * 64 + kh * 64;
+    const float* vnew = qkv + h * 64 + kvh * 64 + kh * 64;
+    // |k_new|^2, |q|^2 (every block; 64-lane reductions)
+    float kn2 = knew[lane] * knew[lane], qn2 = qkv[hi * 64 + lane] * qkv[hi * 64 + lane];
+    kn2 = wave_sum(kn2); qn2 = wave_sum(qn2);
+    if (sp == 0 && w == 0) {   // append (blocks sharing a kv head write the same values: benign)
+        kcache[t * cw + kh * 64 + lane] = knew[lane];
+        vcache[t * cw + kh * 64 + lane] = vnew[lane];
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(kmax2 + kh), __float_as_uint(kn2));
+    }
+    const float slope = slopes ? slopes[hi] : 0.f;
+    int j_lo = 0;
+    if (slope > 0.f) {
+        const float km = fmaxf(kmax2[kh], kn2);
+        const float reach = (104.f + 2.f * scale * sqrtf(qn2 * km)) / slope;
+        if (reach < (float)t) j_lo = t - (int)reach - 1;
+    }
+    const int total = t + 1 - j_lo;
+    const int chunk = (total + S - 1) / S;
+    const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qkv + hi * 64 + l16 * 4) * scale;
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = j0 + w * 4 + grp; j < j1; j += 16) {
+        const float* kr = (j == t) ? knew : kcache + j * cw + kh * 64;
+        const float* vr = (j == t) ? vnew : vcache + j * cw + kh * 64;
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + l16 * 4);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + l16 * 4);
+        float sc = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+        sc -= slope * (float)(t - j);
+        const float m_new = fmaxf(m, sc);
+        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
+        l = l * alpha + pj;
+        acc = acc * alpha + v4 * pj;
+        m = m_new;
+    }
+    const int gi = w * 4 + grp;
+    if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
+    *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+    __syncthreads();
+    // block result -> partial (m, l, o[64]) of (head, split)
+    float* mine = part + ((long)hi * S + sp) * 66;
+    if (tid < 64) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
+            num += so[q][tid] * f; den += sl[q] * f;
+        }
+        mine[2 + tid] = num;
+        if (tid == 0) { mine[0] = mm; mine[1] = den; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(counter + hi, 1) == S - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid < 64) {
+        const float* ph = part + (long)hi * S * 66;
+        float mm = -INFINITY;
+        for (int q = 0; q < S; ++q) mm = fmaxf(mm, ph[q * 66]);
+        float num = 0.f, den = 0.f;
+        for (int q = 0; q < S; ++q) {
+            const float mq = ph[q * 66];
+            const float f = (mq == -INFINITY) ? 0.f : __expf(mq - mm);
+            num += ph[q * 66 + 2 + tid] * f; den += ph[q * 66 + 1] * f;
+        }
+        o[hi * 64 + tid] = num / den;
+        if (tid == 0) counter[hi] = 0;   // ready for the next step
+    }
+}
+
+// LM head of one position for all candidate dims in one launch (grid = dims): LayerNorm(e) slice . table_dim^T -> arg-max with
+// banned ids -> written where the next position holds MASK.  e: [D] head embedding (models/scoreperformer/embeddings.py:345-353).
+struct DecHeadDesc {
+    const float* table[16];   // [V, width] fp32
+    int V[16], width[16], col0[16], dim[16];
+    int n, D;
+};
+__global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const float* __restrict__ e, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, unsigned ban_mask,
+                                                       long* __restrict__ tokens, long tok_ld, int mask_id, const int* __restrict__ pos) {
+    __shared__ __attribute__((aligned(16))) float xs[2048];
+    __shared__ float red[8];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < d.D; k += 256) { const float v = e[k]; xs[k] = v; s += v; }
+    s = wave_sum(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
+    float q2 = 0.f;
+    for (int k = threadIdx.x; k < d.D; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+    q2 = wave_sum(q2);
+    if (lane == 0) red[4 + w] = q2;
+    __syncthreads();
+    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+    const int c0 = d.col0[q], W = d.width[q], V = d.V[q];
+    for (int k = threadIdx.x; k < W; k += 256) xs[c0 + k] = (xs[c0 + k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
+    __syncthreads();
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int v = w; v < V; v += 4) {
+        const float* row = d.table[q] + (long)v * W;
+        float acc = 0.f;
+        for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
+        acc = wave_sum(acc);
+        if (v < 32 && ((ban_mask >> v) & 1u)) acc = -INFINITY;
+        if (acc > best || (acc == best && v < idx)) { best = acc; idx = v; }
+    }
+    if (lane == 0) { bv[w] = best; bi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int r = 1; r < 4; ++r) if (bv[r] > best || (bv[r] == best && bi[r] < idx)) { best = bv[r]; idx = bi[r]; }
+        long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
+        if (*cell == mask_id) *cell = idx;
+    }
+}
+
 }  // namespace
 
 extern "C" int spn_dec_gemv(const float* W, long ldw, const float* x, long x_ld, int x_off, const float* bias, const float* residual,
@@ -252,6 +500,51 @@ extern "C" int spn_dec_argmax_write(const float* logits, int V, unsigned ban_mas
 extern "C" int spn_dec_add_pos(int* pos, int delta, hipStream_t s) {
     SPN_REQUIRE(pos, "spn_dec_add_pos: bad arguments");
     hipLaunchKernelGGL(dec_add_pos_kernel, dim3(1), dim3(64), 0, s, pos, delta);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// ---- fused entry points -------------------------------------------------------------------------------------------------
+extern "C" int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const float* x, long x_ld, int x_off, int norm,
+                                  const float* gamma, const float* beta, float eps, const float* bias, const float* residual, float* y,
+                                  long y_ld, int y_off, float* y2, long y2_ld, int y2_off, float* xn_out, long xn_ld, int xn_off, int glu,
+                                  int act, const int* pos, hipStream_t s) {
+    SPN_REQUIRE(W && x && y && N > 0 && K > 0 && K <= 2048, "spn_dec_fused_gemv: bad arguments (K <= 2048)");
+    SPN_REQUIRE(norm >= 0 && norm <= 2 && (norm != 2 || gamma), "spn_dec_fused_gemv: bad norm mode");
+    DecGemvArgs a{W, ldw, N, K, x, x_ld, x_off, norm, gamma, beta, eps, bias, residual, y, y_ld, y_off, y2, y2_ld, y2_off,
+                  xn_out, xn_ld, xn_off, glu, act, pos};
+    hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_dec_cat(const float* x, int d, const float* gamma, const float* beta, float eps, const float* ctx, long ctx_ld, int ctx_w,
+                           const float* style, long style_ld, int style_w, const int* pos, float* out, hipStream_t s) {
+    SPN_REQUIRE(x && out && pos && d > 0, "spn_dec_cat: bad arguments");
+    hipLaunchKernelGGL(dec_cat_kernel, dim3(1), dim3(256), 0, s, x, d, gamma, beta, eps, ctx, ctx_ld, ctx_w, style, style_ld, style_w, pos, out);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// part: h * splits * 66 floats scratch; counter: h ints, zero before the first step (the kernel resets it); kmax2: kvh floats, zero at start
+extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part,
+                             int* counter, float* kmax2, int h, int kvh, float scale, int splits, hipStream_t s) {
+    SPN_REQUIRE(qkv && kcache && vcache && pos && o && part && counter && kmax2 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
+                "spn_dec_attn2: bad arguments");
+    hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(256), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
+                            const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld,
+                            int mask_id, const int* pos, hipStream_t s) {
+    SPN_REQUIRE(n > 0 && n <= 16 && tables && e && gamma && beta && tokens && pos && D > 0 && D <= 2048, "spn_dec_head: bad arguments");
+    DecHeadDesc d;
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < n; ++i) { d.table[i] = tables[i]; d.V[i] = V[i]; d.width[i] = width[i]; d.col0[i] = col0[i]; d.dim[i] = dim[i]; }
+    d.n = n; d.D = D;
+    hipLaunchKernelGGL(dec_head_kernel, dim3(n), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

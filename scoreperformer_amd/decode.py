@@ -23,10 +23,12 @@ F32 = torch.float32
 
 
 class GreedyDecoder:
-    def __init__(self, decoder, max_len: int, use_graph: bool = True):
-        """decoder: the TupleTransformer wrapped by the MixedLM wrapper (`model.perf_decoder.model`)."""
+    def __init__(self, decoder, max_len: int, use_graph: bool = True, fused: bool = True, attn_splits: int = 8):
+        """decoder: the TupleTransformer wrapped by the MixedLM wrapper (`model.perf_decoder.model`).
+        fused: ~40 fused launches per note (LayerNorm inside the GEMVs, GLU epilogue, split-key attention, one LM-head launch)
+        instead of ~110 small ones; same arithmetic, same tokens."""
         self.m = m = decoder
-        self.max_len, self.use_graph = max_len, use_graph
+        self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
         tr = m.transformer
         if any(t != ('a', 'f')[i % 2] for i, t in enumerate(tr.layer_types)) or not tr.pre_norm:
             raise NotImplementedError("decode engine: pre-norm self-attention decoder only (context_emb_mode='cat')")
@@ -65,6 +67,24 @@ class GreedyDecoder:
         self.e_head_n = z(te.total_emb_dim)
         self.logits = z(max(te.num_tokens.values()) + 8)
         self.stats = z(2)
+        # fused path: split-attention scratch, running max |k|^2 per layer, all AdaLN (gamma|beta) rows of a step in one GEMV
+        S = self.attn_splits
+        self.att_part = z(self.heads * S * 66)
+        self.att_counter = torch.zeros(self.heads, device=dev, dtype=torch.int32)
+        self.kmax2 = [z(self.kvh) for _ in range(n_attn)]
+        tr = m.transformer
+        self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
+        self.ada_rows = {}
+        if self.ada:
+            ada = [n for n in self.norm_list if isinstance(n, AdaptiveLayerNorm)]
+            if ada:
+                self.ada_W = torch.cat([n.linear.weight.data.float() for n in ada], 0).contiguous()
+                self.ada_b = torch.cat([n.linear.bias.data.float() for n in ada], 0).contiguous()
+                self.gb_all = z(len(ada), 2 * d)
+                self.ada_rows = {id(n): i for i, n in enumerate(ada)}
+        head = m.lm_head
+        if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection:
+            self.head_Wt = head.project_emb.weight.data.float().t().contiguous()   # [total_emb, d]: row-major GEMV operand
 
     # -- one decoder step at position t = *pos (predicts the MASKed dims of position t + 1) -----------------
     def _ln(self, x, norm, out, cond_row: bool):
@@ -130,6 +150,11 @@ class GreedyDecoder:
         else:
             ops.dec_copy_row(self.x, self.h, pos, d)
         ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
+        self._head_tail(dims)
+
+    def _head_tail(self, dims: List[int]):
+        m, pos = self.m, self.pos
+        te = m.token_emb
         # LM head on this position for the candidate dims, arg-max written where the next position holds MASK
         head = m.lm_head
         keys = list(te.embs.keys())
@@ -156,6 +181,80 @@ class GreedyDecoder:
             raise NotImplementedError("decode engine: lm / lm-tied heads")
         ops.dec_add_pos(pos, 1)
 
+    # -- the same step in ~40 fused launches -----------------------------------------------------------------------
+    def _norm_args(self, norm):
+        """(norm mode, gamma-or-gb-row, beta, eps) of a pre-norm for the fused GEMV prologue."""
+        if self.ada and isinstance(norm, AdaptiveLayerNorm):
+            return 2, self.gb_all[self.ada_rows[id(norm)]], None, norm.eps
+        if isinstance(norm, AdaptiveLayerNorm):
+            return 1, None, None, norm.eps          # no condition: plain normalisation (gamma = 1, beta = 0)
+        return 1, norm.weight.data, norm.bias.data, norm.eps
+
+    def _step_fused(self, dims: List[int]):
+        m, d, pos = self.m, self.dim, self.pos
+        te, tr = m.token_emb, m.transformer
+        has_norm = isinstance(te.norm, nn.LayerNorm)
+        gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
+        for si, (toks, off) in enumerate(((self.seq2d, 0), (self.masked2d, 1))):
+            ops.dec_embed(self.tables, toks, pos, self.e_cat, row_off=off, gamma=gam, beta=bet, eps=eps)
+            ops.dec_gemv(te.project_emb.weight.data, self.e_cat, self.proj_cat[si * d:(si + 1) * d], bias=te.project_emb.bias.data)
+        ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x, bias=te.project_multiemb.bias.data, pos=pos,
+                           y2=self.tok_emb, y2_ld=d)
+        en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
+        ops.dec_cat(self.x, d, self.xcat, pos, gamma=en.weight.data if en is not None else None,
+                    beta=en.bias.data if en is not None else None, eps=en.eps if en is not None else 1e-5,
+                    ctx=self.ctx2d if m.context_emb_mode == "cat" else None, style=self.style2d if m.style_emb_mode == "cat" else None)
+        if self.ada_rows:   # every AdaLN (gamma | beta) row of this step: one GEMV over the stacked condition projections
+            ops.dec_gemv(self.ada_W, self.style2d, self.gb_all.view(-1), bias=self.ada_b, pos=pos, x_ld=self.style2d.stride(0), x_off=1)
+        if isinstance(m.project_emb, nn.Linear):
+            ops.dec_fused_gemv(m.project_emb.weight.data, self.xcat, self.x, bias=m.project_emb.bias.data, pos=pos, y2=self.hid[0], y2_ld=d)
+        else:
+            ops.dec_copy_row(self.xcat, self.x, pos, d)
+            ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
+        ai = 0
+        n_layers = len(tr.layers)
+        for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
+            mode, g_, b_, eps_ = self._norm_args(norms[0])
+            if lt == 'a':
+                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
+                ops.dec_fused_gemv(wqkv, self.x, self.qkv, norm=mode, gamma=g_, beta=b_, eps=eps_)
+                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+                ops.dec_attn2(self.qkv, self.kc[ai], self.vc[ai], slopes, pos, self.o, self.att_part, self.att_counter, self.kmax2[ai],
+                              h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
+                ops.dec_fused_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+                ai += 1
+            else:
+                lin = block.ff[0].proj if block.glu else block.ff[0][0]
+                ops.dec_fused_gemv(lin.weight.data, self.x, self.g, norm=mode, gamma=g_, beta=b_, eps=eps_,
+                                   bias=lin.bias.data if lin.bias is not None else None, glu=1 if block.glu else -1, act=block.act_code)
+                if isinstance(block.ff[1], nn.LayerNorm):
+                    ops.layernorm_fwd(self.g.view(1, -1), block.ff[1].weight.data, block.ff[1].bias.data, None, out_dtype=F32,
+                                      eps=block.ff[1].eps, out=self.g.view(1, -1))
+                out = block.ff[3]
+                nxt_attn = li + 1 < n_layers
+                ops.dec_fused_gemv(out.weight.data, self.g, self.x, bias=out.bias.data if out.bias is not None else None, residual=self.x,
+                                   pos=pos, y2=self.hid[ai] if nxt_attn else None, y2_ld=d if nxt_attn else 0)
+        head = m.lm_head
+        fn = tr.final_norm
+        if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity):
+            mode, g_, b_, eps_ = self._norm_args(fn)
+            ops.dec_fused_gemv(self.head_Wt, self.x, self.e_head, norm=mode, gamma=g_, beta=b_, eps=eps_, pos=pos,
+                               xn_out=self.hid[-1], xn_ld=d)
+            offs = [0]
+            for w in head.split_dims:
+                offs.append(offs[-1] + w)
+            ops.dec_head([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
+                         head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos)
+            ops.dec_add_pos(pos, 1)
+            return
+        # other head / norm combinations: the unfused tail
+        if not isinstance(fn, nn.Identity):
+            self._ln(self.x, fn, self.h, True)
+        else:
+            ops.dec_copy_row(self.x, self.h, pos, d)
+        ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
+        self._head_tail(dims)
+
     # -- public ----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, tokens: torch.Tensor, tokens_masked: torch.Tensor, context: Optional[torch.Tensor],
@@ -177,19 +276,20 @@ class GreedyDecoder:
         with torch.no_grad():
             self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
         n_steps = last                              # positions t = 0 .. last-1 (predicting t+1)
+        step = self._step_fused if self.fused else self._step
         self.pos.zero_()
         if self.use_graph and n_steps > 2:
-            self._step(dims)                        # warm-up (also position 0), eager
+            step(dims)                              # warm-up (also position 0), eager
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._step(dims)                    # recorded, not executed; every replay reads *pos on the device
+                step(dims)                          # recorded, not executed; every replay reads *pos on the device
             for _ in range(n_steps - 1):
                 g.replay()
             self.graph = g
         else:
             for _ in range(n_steps):
-                self._step(dims)
+                step(dims)
         self.n_steps = n_steps
         return self.seq2d[None], n_steps
 

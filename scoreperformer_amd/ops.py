@@ -636,5 +636,38 @@ def dec_argmax_write(logits, V, tokens2d, dim, pos, *, ban_mask=0b11, mask_id=1)
          c_int(mask_id), ptr(pos), stream_ptr())
 
 
+def dec_fused_gemv(W, x, y, *, N=None, pos=None, x_ld=0, x_off=0, norm=0, gamma=None, beta=None, eps=1e-5, bias=None, residual=None,
+                   y_ld=0, y_off=0, y2=None, y2_ld=0, y2_off=0, xn_out=None, xn_ld=0, xn_off=0, glu=0, act=-1):
+    """y = [GLU](W . LN?(x) + bias) + residual in one launch (decode.hip).  norm: 0 none, 1 affine (gamma, beta), 2 adaptive
+    (gamma = the (gamma|beta) row).  glu=1: W holds values|gates (2N rows); glu=-1 with act>=0: plain activation."""
+    K = W.shape[1]
+    N = N if N is not None else (W.shape[0] // 2 if glu == 1 else W.shape[0])
+    call("spn_dec_fused_gemv", ptr(W), c_long(W.stride(0)), c_int(N), c_int(K), ptr(x), c_long(x_ld), c_int(x_off), c_int(norm),
+         ptr(gamma), ptr(beta), c_float(eps), ptr(bias), ptr(residual), ptr(y), c_long(y_ld), c_int(y_off), ptr(y2), c_long(y2_ld),
+         c_int(y2_off), ptr(xn_out), c_long(xn_ld), c_int(xn_off), c_int(glu), c_int(act), ptr(pos), stream_ptr())
+    return y
+
+
+def dec_cat(x, d, out, pos, *, gamma=None, beta=None, eps=1e-5, ctx=None, style=None):
+    call("spn_dec_cat", ptr(x), c_int(d), ptr(gamma), ptr(beta), c_float(eps), ptr(ctx), c_long(ctx.stride(0) if ctx is not None else 0),
+         c_int(ctx.shape[1] if ctx is not None else 0), ptr(style), c_long(style.stride(0) if style is not None else 0),
+         c_int(style.shape[1] if style is not None else 0), ptr(pos), ptr(out), stream_ptr())
+    return out
+
+
+def dec_attn2(qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, *, h, kvh, scale, splits):
+    call("spn_dec_attn2", ptr(qkv), ptr(kcache), ptr(vcache), ptr(slopes), ptr(pos), ptr(o), ptr(part), ptr(counter), ptr(kmax2),
+         c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
+    return o
+
+
+def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, *, ban_mask=0b11, mask_id=1):
+    V = [t.shape[0] for t in tables]
+    W = [t.shape[1] for t in tables]
+    call("spn_dec_head", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(W), _int_array(col0), _int_array(dims), c_int(D),
+         ptr(e), ptr(gamma), ptr(beta), c_float(eps), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)), c_int(mask_id),
+         ptr(pos), stream_ptr())
+
+
 def dec_add_pos(pos, delta=1):
     call("spn_dec_add_pos", ptr(pos), c_int(delta), stream_ptr())

@@ -19,18 +19,28 @@ def main():
     tokens = batch["masked_perf"].clone(); tokens[:, 0] = batch["perf"][:, 0]
     dec = model.perf_decoder
     res = {}
-    for name, use in (("engine_hipgraph_fp32", True), ("module_path_bf16_torchcat", False)):
+    import scoreperformer_amd.decode as dmod
+    orig_init = dmod.GreedyDecoder.__init__
+    for name, use in (("engine_fused_hipgraph_fp32", True), ("engine_unfused_hipgraph_fp32", "unfused"), ("module_path_bf16_torchcat", False)):
+        dmod.GreedyDecoder.__init__ = (lambda self, dec_, L_, **kw: orig_init(self, dec_, L_, fused=False, **kw)) if use == "unfused" else orig_init
+        tok_ref = None
         if not use and L > 1024 and not os.environ.get("FULL"):
             Lm = 512
             t_in, m_in, ctx, sty = tokens[:, :Lm], batch["masked_perf"][:, :Lm], enc.score_embeddings[:, :Lm], enc.perf_embeddings[:, :Lm]
         else:
             Lm = L
             t_in, m_in, ctx, sty = tokens, batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings
-        dec.use_decode_engine = use
+        dec.use_decode_engine = bool(use)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = dec.unmask_tokens(t_in, m_in, context=ctx, style_embeddings=sty, filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         res[name] = {"notes": Lm - 1, "seconds": dt, "notes_per_s": (Lm - 1) / dt, "us_per_note": dt / (Lm - 1) * 1e6,
                      "masks_left": int((out == 1).sum())}
+        res[name]["tokens_checksum"] = int(out[:, :Lm].sum())
+        if name.startswith("engine"):
+            res.setdefault("_engine_tokens", []).append(out.clone())
+    eng = res.pop("_engine_tokens", [])
+    if len(eng) == 2:
+        res["fused_equals_unfused"] = bool(torch.equal(eng[0], eng[1]))
     print(json.dumps({"decode_c5": res, "seq": L}))
 main()
