@@ -148,7 +148,7 @@ int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* s
                   float* kmax2, int h, int kvh, float scale, int splits, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
-                 const int* pos, spn_stream_t s);
+                 const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);
 
 #ifdef __cplusplus
 }

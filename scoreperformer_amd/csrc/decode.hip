@@ -397,7 +397,8 @@ struct DecHeadDesc {
 };
 __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const float* __restrict__ e, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, unsigned ban_mask,
-                                                       long* __restrict__ tokens, long tok_ld, int mask_id, const int* __restrict__ pos) {
+                                                       long* __restrict__ tokens, long tok_ld, int mask_id, const int* __restrict__ pos,
+                                                       float* __restrict__ part, int* __restrict__ counter) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float bv[4];
@@ -420,7 +421,9 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
     __syncthreads();
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int v = w; v < V; v += 4) {
+    // rows of this dim are split over gridDim.y slabs (4 rows per slab step); the last slab to finish picks the winner
+    const int nsl = gridDim.y, sl = blockIdx.y;
+    for (int v = sl * 4 + w; v < V; v += 4 * nsl) {
         const float* row = d.table[q] + (long)v * W;
         float acc = 0.f;
         for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
@@ -432,8 +435,20 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int r = 1; r < 4; ++r) if (bv[r] > best || (bv[r] == best && bi[r] < idx)) { best = bv[r]; idx = bi[r]; }
-        long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
-        if (*cell == mask_id) *cell = idx;
+        float* mine = part + ((long)q * nsl + sl) * 2;
+        mine[0] = best; mine[1] = __int_as_float(idx);
+        __threadfence();
+        if (atomicAdd(counter + q, 1) == nsl - 1) {
+            __threadfence();
+            for (int r = 0; r < nsl; ++r) {
+                const float bvv = part[((long)q * nsl + r) * 2];
+                const int bii = __float_as_int(part[((long)q * nsl + r) * 2 + 1]);
+                if (r == 0 || bvv > best || (bvv == best && bii < idx)) { best = bvv; idx = bii; }
+            }
+            long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
+            if (*cell == mask_id) *cell = idx;
+            counter[q] = 0;
+        }
     }
 }
 
@@ -538,13 +553,15 @@ extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, con
 
 extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
                             const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld,
-                            int mask_id, const int* pos, hipStream_t s) {
+                            int mask_id, const int* pos, float* part, int* counter, int slabs, hipStream_t s) {
     SPN_REQUIRE(n > 0 && n <= 16 && tables && e && gamma && beta && tokens && pos && D > 0 && D <= 2048, "spn_dec_head: bad arguments");
+    SPN_REQUIRE(part && counter && slabs > 0 && slabs <= 64, "spn_dec_head: scratch (n*slabs*2 floats, n zeroed ints) required");
     DecHeadDesc d;
     memset(&d, 0, sizeof(d));
     for (int i = 0; i < n; ++i) { d.table[i] = tables[i]; d.V[i] = V[i]; d.width[i] = width[i]; d.col0[i] = col0[i]; d.dim[i] = dim[i]; }
     d.n = n; d.D = D;
-    hipLaunchKernelGGL(dec_head_kernel, dim3(n), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos);
+    hipLaunchKernelGGL(dec_head_kernel, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
+                       counter);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -23,11 +23,14 @@ F32 = torch.float32
 
 
 class GreedyDecoder:
-    def __init__(self, decoder, max_len: int, use_graph: bool = True, fused: bool = True, attn_splits: int = 8):
+    def __init__(self, decoder, max_len: int, use_graph: bool = True, fused: bool = True, attn_splits: int = 16):
         """decoder: the TupleTransformer wrapped by the MixedLM wrapper (`model.perf_decoder.model`).
         fused: ~40 fused launches per note (LayerNorm inside the GEMVs, GLU epilogue, split-key attention, one LM-head launch)
         instead of ~110 small ones; same arithmetic, same tokens."""
         self.m = m = decoder
+        import os
+        attn_splits = int(os.environ.get("SPN_DEC_SPLITS", attn_splits))   # tuning aid
+        self.head_slabs = int(os.environ.get("SPN_DEC_HEAD_SLABS", 8))
         self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
         tr = m.transformer
         if any(t != ('a', 'f')[i % 2] for i, t in enumerate(tr.layer_types)) or not tr.pre_norm:
@@ -71,6 +74,8 @@ class GreedyDecoder:
         S = self.attn_splits
         self.att_part = z(self.heads * S * 66)
         self.att_counter = torch.zeros(self.heads, device=dev, dtype=torch.int32)
+        self.head_part = z(16 * 8 * 2)
+        self.head_counter = torch.zeros(16, device=dev, dtype=torch.int32)
         self.kmax2 = [z(self.kvh) for _ in range(n_attn)]
         tr = m.transformer
         self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
@@ -244,7 +249,7 @@ class GreedyDecoder:
             for w in head.split_dims:
                 offs.append(offs[-1] + w)
             ops.dec_head([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
-                         head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos)
+                         head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part, self.head_counter, slabs=self.head_slabs)
             ops.dec_add_pos(pos, 1)
             return
         # other head / norm combinations: the unfused tail

@@ -661,12 +661,12 @@ def dec_attn2(qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, *, h, k
     return o
 
 
-def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, *, ban_mask=0b11, mask_id=1):
+def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1):
     V = [t.shape[0] for t in tables]
     W = [t.shape[1] for t in tables]
     call("spn_dec_head", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(W), _int_array(col0), _int_array(dims), c_int(D),
          ptr(e), ptr(gamma), ptr(beta), c_float(eps), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)), c_int(mask_id),
-         ptr(pos), stream_ptr())
+         ptr(pos), ptr(part), ptr(counter), c_int(slabs), stream_ptr())
 
 
 def dec_add_pos(pos, delta=1):

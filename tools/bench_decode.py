@@ -10,6 +10,7 @@ from scoreperformer_amd.synthetic import model_config, synthetic_batch
 def main():
     L = int(os.environ.get("L", 4096))
     dev = torch.device("cuda")
+    torch.manual_seed(int(os.environ.get("SEED", 0)))
     model = ScorePerformer.init(model_config("c5", max_seq_len=L)); ParamArena(model, dev); model.eval()
     batch = synthetic_batch(1, L, seed=7, device=dev)
     with torch.no_grad():
@@ -42,5 +43,8 @@ def main():
     eng = res.pop("_engine_tokens", [])
     if len(eng) == 2:
         res["fused_equals_unfused"] = bool(torch.equal(eng[0], eng[1]))
+        if not res["fused_equals_unfused"]:
+            diff = (eng[0] != eng[1]).any(-1)[0].nonzero().flatten()
+            res["first_diff_position"] = int(diff[0]); res["positions_differing"] = int(diff.numel())
     print(json.dumps({"decode_c5": res, "seq": L}))
 main()
