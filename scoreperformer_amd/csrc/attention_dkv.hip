@@ -14,8 +14,9 @@ __device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile
                                          f32x4 (&dk)[4][2], f32x4 (&dv)[4][2], const float (&jf)[2], const bool (&key_ok)[2],
                                          int ioff, float c1, float slope2, bool causal, int lane, int g,
                                          const uint2 (&bw)[4], const int (&boff)[2], float log2_inv_keep, float keep_prob) {
+    const float sjf[2] = {slope2 * jf[0], slope2 * jf[1]};
 #pragma unroll
-for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
+    for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
         f32x4 p[2][2], ds[2][2];                // [qq][kb]
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -27,6 +28,11 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
             f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 16 * qb + 4 * g);
             if (DROP) { n4 += log2_inv_keep; d4 *= keep_prob; }
             const float ib = (float)(ioff + 16 * qb + 4 * g);
+            // linear-bias tiles: slope2*(j - i) - lse = [slope2*j] + [-slope2*i - lse]: the row part once per 4 rows (shared by both
+            // key blocks), the key part once per lane -- one add per score instead of a subtract and an fma
+            f32x4 rowt = n4;
+            if (CLS == T_LEFT) rowt -= slope2 * (ib + f32x4{0.f, 1.f, 2.f, 3.f});
+            else if (CLS == T_RIGHT) rowt += slope2 * (ib + f32x4{0.f, 1.f, 2.f, 3.f});
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -38,8 +44,8 @@ for (int u = 0; u < 2; ++u) {               // two halves of 32 query rows
                 for (int r = 0; r < 4; ++r) {
                     const float i_f = ib + (float)r;
                     float e;   // log2-domain score minus lse
-                    if (CLS == T_LEFT) e = fmaf(acc[r], c1, fmaf(slope2, jf[kb] - i_f, n4[r]));
-                    else if (CLS == T_RIGHT) e = fmaf(acc[r], c1, fmaf(-slope2, jf[kb] - i_f, n4[r]));
+                    if (CLS == T_LEFT) e = fmaf(acc[r], c1, sjf[kb] + rowt[r]);
+                    else if (CLS == T_RIGHT) e = fmaf(acc[r], c1, rowt[r] - sjf[kb]);
                     else {
                         const bool ok = key_ok[kb] && (!causal || jf[kb] <= i_f);
                         const float t = fmaf(-slope2, fabsf(jf[kb] - i_f), acc[r] * c1);
