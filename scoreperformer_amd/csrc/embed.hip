@@ -135,14 +135,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(GatherDesc d, const long
     if (row >= T) return;
     f32x4 v[NV];
     float sum = 0.f;
+    // the row's token tuple: one load by the first nkeys lanes, broadcast (instead of a token load in front of every table load)
+    const int tok_l = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (lane + 64 * i) * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int kk = 0;
+        for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
+        const long tok = __shfl(tok_l, kk, 64);
         if (col < d.D) {
-            int kk = 0;
-            for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
-            const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
             v[i] = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
         }
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
