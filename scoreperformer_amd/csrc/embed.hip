@@ -241,25 +241,28 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, cons
 // A wave takes 64 rows at a time: lane r fetches row r's token and LayerNorm statistics (one latency for 64 rows instead of a
 // dependent token -> table-row chain per row), then the rows are walked four at a time with lane-group broadcasts.
 // Few fat blocks (one per CU): the final flush is V*E global atomics PER BLOCK, which dominated with ~1000 thin blocks.
-__global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+template <bool USE_LDS>
+__global__ __launch_bounds__(1024) void embed_bwd_scatter_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
                                                                 const bf16_t* __restrict__ dy, long lddy, const float* __restrict__ gamma,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ s1, const float* __restrict__ s2, int T,
-                                                                int rows_per_block, int padding_idx, int use_lds) {
+                                                                int rows_per_block, int padding_idx) {
+    // USE_LDS is a template parameter on purpose: with a run-time choice between the LDS copy and the global table the pointer is
+    // generic and every add becomes a flat_atomic_add_f32 through the LDS aperture (4x slower than ds_add_f32 here)
+    constexpr bool use_lds = USE_LDS;
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int kk = blockIdx.y, E = d.width[kk], V = d.rows[kk], c0 = d.col0[kk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (use_lds) {
-        for (int i = threadIdx.x; i < V * E; i += 512) acc[i] = 0.f;
+        for (int i = threadIdx.x; i < V * E; i += 1024) acc[i] = 0.f;
         __syncthreads();
     }
     const float* tab = d.table[kk];
     float* dtab = d.dtable[kk];
-    float* dst = use_lds ? acc : dtab;
     const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
     // 32 lanes x 4 columns per row, 2 rows per wave step, 4 steps in flight: 8-byte gradient loads instead of a row-per-wave walk
     const int q = lane >> 5, c4 = (lane & 31) * 4;
-    for (int base = row_begin + w * 64; base < row_end; base += 8 * 64) {
+    for (int base = row_begin + w * 64; base < row_end; base += 16 * 64) {
         const int myrow = base + lane;
         int tok_l = padding_idx;
         float mu_l = 0.f, rs_l = 1.f, a1_l = 0.f, a2_l = 0.f;
@@ -286,14 +289,17 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_kernel(GatherDesc d, co
                 }
                 if (live) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(dst + (long)tok * E + c + e, g[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        if (USE_LDS) atomicAdd(&acc[tok * E + c + e], g[e]);
+                        else atomicAdd(dtab + (long)tok * E + c + e, g[e]);
+                    }
                 }
             }
         }
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < V * E; i += 512) {
+        for (int i = threadIdx.x; i < V * E; i += 1024) {
             const float v = acc[i];
             if (v != 0.f) atomicAdd(dtab + i, v);
         }
@@ -405,17 +411,19 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
     const int use_lds = lds_bytes <= 150 * 1024;
     static bool attr_set = false;
     if (use_lds && !attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // one block per CU when the table copy fills the LDS, a few more when it is small
     int chunks = (lds_bytes > 72 * 1024 ? 256 : 512) / nkeys;
     if (chunks > cdiv(T, 512)) chunks = cdiv(T, 512);
     if (chunks < 1) chunks = 1;
-    int rpb = cdiv(T, chunks); rpb = ((rpb + 63) / 64) * 64;
+    int rpb = cdiv(T, chunks); rpb = ((rpb + 63) / 64) * 64;   // 16 waves per block: twice the loads in flight of 8
     dim3 grid(cdiv(T, rpb), nkeys);
-    hipLaunchKernelGGL(embed_bwd_scatter_kernel, grid, dim3(512), use_lds ? lds_bytes : 0, stream, d, tokens, tok_bs, tok_ts, t_len,
-                       (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, T, rpb, padding_idx, use_lds);
+    if (use_lds) hipLaunchKernelGGL(embed_bwd_scatter_kernel<true>, grid, dim3(1024), lds_bytes, stream, d, tokens, tok_bs, tok_ts, t_len,
+                                    (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, T, rpb, padding_idx);
+    else hipLaunchKernelGGL(embed_bwd_scatter_kernel<false>, grid, dim3(1024), 0, stream, d, tokens, tok_bs, tok_ts, t_len,
+                            (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, T, rpb, padding_idx);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
