@@ -204,12 +204,13 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, cons
     for (int row = row_begin + w; row < row_end; row += 4) {
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
+        const int tok_l = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (lane + 64 * i) * 4;
-            if (col >= d.D) continue;
             const int kk = key_of[i];
-            const long tok = tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + kk];
+            const long tok = __shfl(tok_l, kk, 64);   // one token-tuple load per row, broadcast
+            if (col >= d.D) continue;
             const f32x4 xv = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
             const uint2 u = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + col);
             const float dyv[4] = {bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16)};
@@ -248,7 +249,10 @@ __global__ __launch_bounds__(1024) void embed_bwd_scatter_kernel(GatherDesc d, c
                                                                 const float* __restrict__ s1, const float* __restrict__ s2, int T,
                                                                 int rows_per_block, int padding_idx) {
     // USE_LDS is a template parameter on purpose: with a run-time choice between the LDS copy and the global table the pointer is
-    // generic and every add becomes a flat_atomic_add_f32 through the LDS aperture (4x slower than ds_add_f32 here)
+    // generic and every add becomes a flat_atomic_add_f32 through the LDS aperture.  Even as ds_add_f32 the LDS float atomics are
+    // what this kernel spends its time on (~120 cycles per wave-instruction: 0.8 of 1.07 ms; bank-conflict-free column orders do
+    // not change that).  Tried and slower: one owner wave per token id (mod 16) with plain read-modify-writes -- small vocabularies
+    // (16 NotesInOnset ids) serialise a wave on one table row.
     constexpr bool use_lds = USE_LDS;
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int kk = blockIdx.y, E = d.width[kk], V = d.rows[kk], c0 = d.col0[kk];
