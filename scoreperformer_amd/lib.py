@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspn.so")
+LIB_PATH = os.environ.get("SPN_LIB") or os.path.join(_HERE, "libspn.so")   # SPN_LIB: A/B a variant build (tools/)
 _lib: Optional[ctypes.CDLL] = None
 
 c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
