@@ -150,6 +150,17 @@ int spn_dec_head(int n, const float* const* tables, const int* V, const int* wid
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);
 
+/* ---- device-side batch builder (scoreperformer/data/collators/score_performance.py:35-115,186-234; performance.py:18-92,100-115,
+ *      213-247): raw ragged int32 tokens (samples concatenated, row offsets [b+1]) -> every tensor the MixedLM collator returns:
+ *      padded int64 tokens, bool masks, lengths, bar/beat/onset ids (seg_flat = [3, sum_s] or null), deadpan flags, masked_perf, labels.
+ *      ignore_ids: host array (<= 16 ids; pad is always ignored); ignore_dims: bit k = token dim k is never masked. */
+int spn_collate_mixlm(const int32_t* score_flat, const int32_t* perf_flat, const int32_t* seg_flat, const int32_t* score_off,
+                      const int32_t* perf_off, const uint8_t* deadpan, int b, int Ks, int Kp, int Ls, int Lp, long sum_s, int pad_id,
+                      int mask_id, int label_pad_id, const int* ignore_ids, int n_ignore, unsigned ignore_dims, int label_pad_ignored_dims,
+                      long long* score, uint8_t* score_mask, long long* score_len, long long* perf, uint8_t* perf_mask, long long* perf_len,
+                      long long* masked_perf, long long* labels, long long* bar, long long* beat, long long* onset, uint8_t* deadpan_mask,
+                      spn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

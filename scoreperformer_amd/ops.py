@@ -671,3 +671,39 @@ def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, co
 
 def dec_add_pos(pos, delta=1):
     call("spn_dec_add_pos", ptr(pos), c_int(delta), stream_ptr())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device-side batch builder (collate.hip)
+# ---------------------------------------------------------------------------------------------------------
+
+def collate_mixlm(score_flat, perf_flat, seg_flat, score_off, perf_off, deadpan, *, b, Ks, Kp, Ls, Lp, pad_id=0, mask_id=1,
+                  label_pad_id=-100, ignore_ids=(), ignore_dims=0, label_pad_ignored_dims=True):
+    """Raw ragged int32 device buffers -> dict of the padded tensors the reference's MixedLM collator returns."""
+    require_gpu(score_flat, perf_flat, score_off, perf_off)
+    for t in (score_flat, perf_flat, seg_flat, score_off, perf_off):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise SpnError("collate_mixlm: inputs must be contiguous int32")
+    if deadpan is not None and deadpan.dtype not in (torch.uint8, torch.bool):
+        raise SpnError("collate_mixlm: deadpan flags must be uint8/bool")
+    dev = score_flat.device
+    sum_s = score_flat.numel() // Ks
+    i64 = dict(device=dev, dtype=torch.int64)
+    out = {
+        "score": torch.empty((b, Ls, Ks), **i64), "score_mask": torch.empty((b, Ls), device=dev, dtype=torch.bool),
+        "score_len": torch.empty(b, **i64),
+        "perf": torch.empty((b, Lp, Kp), **i64), "perf_mask": torch.empty((b, Lp), device=dev, dtype=torch.bool),
+        "perf_len": torch.empty(b, **i64),
+        "masked_perf": torch.empty((b, Lp, Kp), **i64), "labels": torch.empty((b, Lp, Kp), **i64),
+        "deadpan_mask": torch.empty(b, device=dev, dtype=torch.bool),
+    }
+    if seg_flat is not None:
+        for name in ("bar", "beat", "onset"):
+            out[name] = torch.empty((b, Ls), **i64)
+    ids = [int(t) for t in ignore_ids]
+    call("spn_collate_mixlm", ptr(score_flat), ptr(perf_flat), ptr(seg_flat), ptr(score_off), ptr(perf_off), ptr(deadpan), c_int(b), c_int(Ks),
+         c_int(Kp), c_int(Ls), c_int(Lp), c_long(sum_s), c_int(pad_id), c_int(mask_id), c_int(label_pad_id), _int_array(ids), c_int(len(ids)),
+         ctypes.c_uint(ignore_dims), c_int(int(label_pad_ignored_dims)), ptr(out["score"]), ptr(out["score_mask"]), ptr(out["score_len"]),
+         ptr(out["perf"]), ptr(out["perf_mask"]), ptr(out["perf_len"]), ptr(out["masked_perf"]), ptr(out["labels"]), ptr(out.get("bar")),
+         ptr(out.get("beat")), ptr(out.get("onset")), ptr(out["deadpan_mask"]), stream_ptr())
+    return out

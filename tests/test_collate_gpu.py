@@ -1,0 +1,134 @@
+"""GPU: the device-side collator (spn_collate_mixlm through scoreperformer_amd.data) -- bit-exact against the reference collator's
+golden outputs and against the CPU oracle on ragged seeded batches."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from test_collate_cpu import CASES
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = {
+    "score": lambda d: d.scores.tokens, "score_mask": lambda d: d.scores.mask, "score_len": lambda d: d.scores.lengths,
+    "perf": lambda d: d.performances.tokens, "perf_mask": lambda d: d.performances.mask, "perf_len": lambda d: d.performances.lengths,
+    "masked_perf": lambda d: d.masked_performances.tokens, "labels": lambda d: d.labels.tokens, "labels_mask": lambda d: d.labels.mask,
+    "bar": lambda d: d.segments.bar, "beat": lambda d: d.segments.beat, "onset": lambda d: d.segments.onset,
+    "deadpan_mask": lambda d: d.deadpan_mask,
+}
+
+
+def samples_of(ins, with_segments=True):
+    out = []
+    for i in range(len(ins["perfs"])):
+        seg = SimpleNamespace(**ins["segments"][i]) if with_segments and ins["segments"] is not None else None
+        out.append(SimpleNamespace(score=ins["scores"][i], perf=ins["perfs"][i], noisy_perf=None, directions=None, segments=seg,
+                                   is_deadpan=bool(ins["deadpan"][i])))
+    return out
+
+
+def check(data, want, keys=None):
+    for key in (keys or want):
+        have = FIELDS[key](data)
+        assert have.is_cuda
+        have = have.cpu().numpy()
+        ref = want["perf_mask"] if key == "labels_mask" and key not in want else want[key]
+        assert have.shape == ref.shape and have.dtype == ref.dtype, (key, have.shape, ref.shape, have.dtype, ref.dtype)
+        assert np.array_equal(have, ref), key
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_collator_matches_reference_golden(name):
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    kw, ins, ref = CASES[name]
+    kw = dict(kw)
+    inference = kw.pop("inference")
+    data = MixedLMScorePerformanceCollator(**kw)(samples_of(ins), inference=inference)
+    check(data, ref)
+
+
+def ragged(rng, b, lo, hi, ks, kp, vocab=300, equal=False):
+    scores, perfs, segs, dead = [], [], [], []
+    for _ in range(b):
+        ns = int(rng.integers(lo, hi + 1))
+        np_ = ns if equal else int(rng.integers(lo, hi + 1))
+        scores.append(rng.integers(0, vocab, size=(ns, ks)).astype(np.int64))
+        perfs.append(rng.integers(0, vocab, size=(np_, kp)).astype(np.int64))
+        segs.append({k: np.cumsum(rng.integers(0, 2, size=ns)).astype(np.int64) for k in ("bar", "beat", "onset")})
+        dead.append(bool(rng.integers(0, 2)))
+    return dict(scores=scores, perfs=perfs, segments=segs, deadpan=dead)
+
+
+RANDOM = [
+    # b, lo, hi, ks, kp, kwargs, inference, segments
+    (1, 1, 1, 10, 12, dict(), False, True),                                                         # one sample of one note
+    (7, 1, 9, 10, 12, dict(pad_to_multiple_of=4, mask_ignore_token_ids=[0, 1, 2, 3], mask_ignore_token_dims=[0, 5, -1]), False, True),
+    (5, 3, 70, 4, 1, dict(mask_ignore_token_ids=[5]), False, False),                                # one token dim, no segments
+    (16, 100, 600, 10, 12, dict(pad_to_multiple_of=64, mask_ignore_token_ids=list(range(16)), mask_ignore_token_dims=list(range(12)),
+                                label_pad_ignored_dims=False, label_pad_token_id=-1, mask_token_id=299), True, True),
+    (64, 1500, 2048, 10, 12, dict(pad_to_multiple_of=128, mask_ignore_token_ids=[0, 1, 2, 3],      # BASELINE config 3's batch shape
+                                  mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9]), False, True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(RANDOM)))
+def test_device_collator_matches_oracle_on_ragged_batches(case):
+    from oracle.collate_cpu import collate_mixlm
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    b, lo, hi, ks, kp, kw, inference, with_seg = RANDOM[case]
+    ins = ragged(np.random.default_rng(100 + case), b, lo, hi, ks, kp)
+    want = collate_mixlm(ins["scores"], ins["perfs"], ins["segments"] if with_seg else None, ins["deadpan"], inference=inference, **kw)
+    coll = MixedLMScorePerformanceCollator(**kw)
+    data = coll(samples_of(ins, with_seg), inference=inference)
+    check(data, want, keys=list(want) + ["labels_mask"])
+    if not with_seg:
+        assert data.segments is None
+    # the staging buffer is reused: a second, different batch through the same collator must not be disturbed by the first
+    ins2 = ragged(np.random.default_rng(900 + case), max(1, b // 2), lo, hi, ks, kp)
+    want2 = collate_mixlm(ins2["scores"], ins2["perfs"], ins2["segments"] if with_seg else None, ins2["deadpan"], inference=inference, **kw)
+    check(coll(samples_of(ins2, with_seg), inference=inference), want2, keys=list(want2))
+    check(data, want, keys=list(want))
+
+
+def test_device_collator_refuses_unsupported_fields():
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    ins = ragged(np.random.default_rng(1), 2, 4, 8, 10, 12)
+    smp = samples_of(ins)
+    smp[1].noisy_perf = smp[1].perf
+    with pytest.raises(NotImplementedError):
+        MixedLMScorePerformanceCollator()(smp)
+
+
+def test_device_batch_drives_the_model():
+    """Collator output -> prepare_inputs -> forward: same loss as the same batch built on the host by the oracle."""
+    from oracle.collate_cpu import collate_mixlm
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, PERFORMANCE_VOCAB
+    dev = torch.device("cuda")
+    model = ScorePerformer.init(model_config("tiny", dropout=0.0))
+    model.load_state_dict(filled_state_dict(model, seed=9))
+    arena = ParamArena(model, dev)   # noqa: F841  (moves the parameters into the device arena)
+    model.eval()
+    sizes_p = list(PERFORMANCE_VOCAB.values())
+    sizes_s = sizes_p[:10]
+    rng = np.random.default_rng(5)
+    ins = dict(scores=[], perfs=[], segments=[], deadpan=[])
+    for n in (40, 64, 17):
+        ins["scores"].append(np.stack([rng.integers(4, v, size=n) for v in sizes_s], -1).astype(np.int64))
+        ins["perfs"].append(np.stack([rng.integers(4, v, size=n) for v in sizes_p], -1).astype(np.int64))
+        ins["segments"].append({k: (np.arange(n) // d + 1).astype(np.int64) for k, d in (("bar", 8), ("beat", 4), ("onset", 2))})
+        ins["deadpan"].append(False)
+    kw = dict(pad_to_multiple_of=64, mask_ignore_token_ids=[0, 1, 2, 3], mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
+    data = MixedLMScorePerformanceCollator(**kw)(samples_of(ins))
+    want = collate_mixlm(ins["scores"], ins["perfs"], ins["segments"], ins["deadpan"], **kw)
+    host = dict(perf=want["perf"], perf_mask=want["perf_mask"], score=want["score"], score_mask=want["score_mask"], labels=want["labels"],
+                masked_perf=want["masked_perf"], bars=want["bar"], beats=want["beat"], onsets=want["onset"], deadpan_mask=want["deadpan_mask"])
+    host = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    with torch.no_grad():
+        a = model(**model.allocate_inputs(model.prepare_inputs(data), torch.device("cuda")))
+        b = model(**host)
+    assert torch.equal(a.loss, b.loss)

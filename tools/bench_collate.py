@@ -1,0 +1,110 @@
+"""Measure the device-side collator (N2): kernel time vs the HBM roofline, whole call (host concat + one H2D + kernel), and the host
+flow it replaces (CPU collate by the oracle + H2D of the derived tensors) on the same ragged batch.
+
+    python tools/bench_collate.py [--batch 64] [--len 2048] [--reps 50] [--out gpurun_out/collate.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.collate_cpu import collate_mixlm          # noqa: E402  (the CPU baseline leg)
+from scoreperformer_amd import ops                     # noqa: E402
+from scoreperformer_amd.data import MixedLMScorePerformanceCollator  # noqa: E402
+from scoreperformer_amd.synthetic import PERFORMANCE_VOCAB            # noqa: E402
+
+KW = dict(pad_token_id=0, pad_to_multiple_of=1, mask_token_id=1, mask_ignore_token_ids=[0, 1, 2, 3],
+          mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])           # recipes/scoreperformer/base.yaml:60-66
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--len", type=int, default=2048)
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    rng = np.random.default_rng(0)
+    sizes = list(PERFORMANCE_VOCAB.values())
+    samples, lens = [], []
+    for i in range(a.batch):
+        n = a.len if i == 0 else int(rng.integers(3 * a.len // 4, a.len + 1))
+        perf = np.stack([rng.integers(4, v, size=n) for v in sizes], -1).astype(np.int64)
+        seg = SimpleNamespace(**{k: (np.arange(n) // d + 4).astype(np.int64) for k, d in (("bar", 16), ("beat", 4), ("onset", 2))})
+        samples.append(SimpleNamespace(score=perf[:, :10].copy(), perf=perf, noisy_perf=None, directions=None, segments=seg, is_deadpan=False))
+        lens.append(n)
+    b, L, Ks, Kp = a.batch, a.len, 10, 12
+    sum_n = sum(lens)
+    alg_bytes = 4 * (sum_n * Ks + sum_n * Kp + 3 * sum_n) + 8 * (b * L * (Ks + 3) + 3 * b * L * Kp) + 2 * b * L
+
+    coll = MixedLMScorePerformanceCollator(**KW)
+    for _ in range(3):
+        data = coll(samples)
+    torch.cuda.synchronize()
+    # (1) whole device-collator call, wall clock
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        data = coll(samples)
+    torch.cuda.synchronize()
+    call_ms = (time.perf_counter() - t0) / a.reps * 1e3
+
+    # (2) the kernel alone, inputs resident, HIP events on the launch stream
+    dev = torch.device("cuda")
+    sf = torch.from_numpy(np.concatenate([s.score for s in samples]).astype(np.int32)).to(dev)
+    pf = torch.from_numpy(np.concatenate([s.perf for s in samples]).astype(np.int32)).to(dev)
+    sg = torch.from_numpy(np.stack([np.concatenate([getattr(s.segments, k) for s in samples]) for k in ("bar", "beat", "onset")]).astype(np.int32)).to(dev)
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).to(dev)
+    dead = torch.zeros(b, dtype=torch.uint8, device=dev)
+    run = lambda: ops.collate_mixlm(sf.view(-1), pf.view(-1), sg.view(-1), off, off, dead, b=b, Ks=Ks, Kp=Kp, Ls=L, Lp=L, ignore_ids=[1, 2, 3],
+                                    ignore_dims=sum(1 << d for d in KW["mask_ignore_token_dims"]))
+    for _ in range(5):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / a.reps
+
+    # (3) the host flow it replaces: CPU collate (numpy oracle) + H2D of every derived tensor (trainer.py:449-452 allocate_inputs)
+    reps_cpu = max(2, a.reps // 10)
+    scores, perfs = [s.score for s in samples], [s.perf for s in samples]
+    segs = [dict(bar=s.segments.bar, beat=s.segments.beat, onset=s.segments.onset) for s in samples]
+    t0 = time.perf_counter()
+    for _ in range(reps_cpu):
+        want = collate_mixlm(scores, perfs, segs, [False] * b, **KW)
+    cpu_ms = (time.perf_counter() - t0) / reps_cpu * 1e3
+    t0 = time.perf_counter()
+    for _ in range(reps_cpu):
+        moved = {k: torch.from_numpy(v).to(dev, non_blocking=True) for k, v in want.items()}
+        torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0) / reps_cpu * 1e3
+    ok = all(np.array_equal(getattr_path(data, k).cpu().numpy(), v) for k, v in want.items())
+
+    res = {"workload": f"MixedLM collate b={b} n<={L} (ragged 0.75-1.0), Ks=10 Kp=12", "notes": sum_n, "parity_vs_oracle": bool(ok),
+           "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes, "achieved_GBps": alg_bytes / kern_ms / 1e6, "peak_GBps": 8000.0,
+           "frac": alg_bytes / kern_ms / 1e6 / 8000.0, "device_call_ms": call_ms, "notes_per_s_device_call": sum_n / call_ms * 1e3,
+           "cpu_collate_ms": cpu_ms, "cpu_h2d_ms": h2d_ms, "notes_per_s_cpu_flow": sum_n / (cpu_ms + h2d_ms) * 1e3, "cpu_cores": 1}
+    print(json.dumps(res))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+def getattr_path(d, key):
+    return {"score": d.scores.tokens, "score_mask": d.scores.mask, "score_len": d.scores.lengths, "perf": d.performances.tokens,
+            "perf_mask": d.performances.mask, "perf_len": d.performances.lengths, "masked_perf": d.masked_performances.tokens,
+            "labels": d.labels.tokens, "bar": d.segments.bar, "beat": d.segments.beat, "onset": d.segments.onset,
+            "deadpan_mask": d.deadpan_mask}[key]
+
+
+if __name__ == "__main__":
+    main()
