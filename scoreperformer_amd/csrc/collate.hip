@@ -28,42 +28,73 @@ struct CollateArgs {
     uint8_t* deadpan_mask;
 };
 
+typedef long long i64x2 __attribute__((ext_vector_type(2)));
+
 // Idx = unsigned when the batch has < 2^32 output tokens (always, in practice): 32-bit divisions instead of 64-bit ones.
-template <typename Idx>
+// W = token dims per thread: 2 when both token widths are even (OctupleM: 10 / 12) -> 8-byte loads, 16-byte stores per lane.
+template <typename Idx, int W>
 __global__ __launch_bounds__(256) void collate_mixlm_kernel(CollateArgs a) {
-    const Idx n_perf = (Idx)a.b * a.Lp * a.Kp, n_score = (Idx)a.b * a.Ls * a.Ks, n_seg = a.seg_flat ? (Idx)a.b * a.Ls : 0;
+    const int KpW = a.Kp / W, KsW = a.Ks / W;
+    const Idx n_perf = (Idx)a.b * a.Lp * KpW, n_score = (Idx)a.b * a.Ls * KsW, n_seg = a.seg_flat ? (Idx)a.b * a.Ls : 0;
     const Idx total = n_perf + n_score + n_seg;
     for (Idx idx = (Idx)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (Idx)gridDim.x * 256) {
-        if (idx < n_perf) {                                   // performance token (i, pos, k)
-            const int k = (int)(idx % a.Kp);
-            const Idx row = idx / a.Kp;
-            const int pos = (int)(row % a.Lp), i = (int)(row / a.Lp);
+        if (idx < n_perf) {                                   // performance tokens (i, pos, k .. k+W-1)
+            const Idx row = idx / KpW;
+            const int k = (int)(idx - row * KpW) * W;
+            const int i = (int)(row / a.Lp), pos = (int)(row - (Idx)i * a.Lp);
             const int o0 = a.perf_off[i], n = a.perf_off[i + 1] - o0;
-            const int tok = pos < n ? a.perf_flat[(long)(o0 + pos) * a.Kp + k] : a.pad_id;
-            bool ignored = tok == a.pad_id;
-            for (int q = 0; q < a.n_ignore; ++q) ignored = ignored || tok == a.ignore_ids[q];
-            const bool dim_ignored = (a.ignore_dims >> k) & 1u;
-            a.perf[idx] = tok;
-            a.masked_perf[idx] = (!ignored && !dim_ignored) ? a.mask_id : tok;
-            a.labels[idx] = (!ignored && !(a.label_pad_ignored_dims && dim_ignored)) ? tok : a.label_pad_id;
+            int tok[W];
+            if (pos < n) {
+                const int32_t* src = a.perf_flat + (long)(o0 + pos) * a.Kp + k;
+                if (W == 2) { const int2 t = *reinterpret_cast<const int2*>(src); tok[0] = t.x; tok[W - 1] = t.y; }
+                else tok[0] = *src;
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; ++w) tok[w] = a.pad_id;
+            }
+            long long m[W], l[W], t64[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                bool ignored = tok[w] == a.pad_id;
+                for (int q = 0; q < a.n_ignore; ++q) ignored = ignored || tok[w] == a.ignore_ids[q];
+                const bool dim_ignored = (a.ignore_dims >> (k + w)) & 1u;
+                t64[w] = tok[w];
+                m[w] = (!ignored && !dim_ignored) ? a.mask_id : tok[w];
+                l[w] = (!ignored && !(a.label_pad_ignored_dims && dim_ignored)) ? tok[w] : a.label_pad_id;
+            }
+            const long e = (long)row * a.Kp + k;
+            if (W == 2) {
+                *reinterpret_cast<i64x2*>(a.perf + e) = i64x2{t64[0], t64[W - 1]};
+                *reinterpret_cast<i64x2*>(a.masked_perf + e) = i64x2{m[0], m[W - 1]};
+                *reinterpret_cast<i64x2*>(a.labels + e) = i64x2{l[0], l[W - 1]};
+            } else {
+                a.perf[e] = t64[0]; a.masked_perf[e] = m[0]; a.labels[e] = l[0];
+            }
             if (k == 0) {
                 a.perf_mask[row] = pos < n;
                 if (pos == 0) { a.perf_len[i] = n; a.deadpan_mask[i] = a.deadpan ? (a.deadpan[i] != 0) : 0; }
             }
-        } else if (idx < n_perf + n_score) {                  // score token
+        } else if (idx < n_perf + n_score) {                  // score tokens
             const Idx j = idx - n_perf;
-            const int k = (int)(j % a.Ks);
-            const Idx row = j / a.Ks;
-            const int pos = (int)(row % a.Ls), i = (int)(row / a.Ls);
+            const Idx row = j / KsW;
+            const int k = (int)(j - row * KsW) * W;
+            const int i = (int)(row / a.Ls), pos = (int)(row - (Idx)i * a.Ls);
             const int o0 = a.score_off[i], n = a.score_off[i + 1] - o0;
-            a.score[j] = pos < n ? a.score_flat[(long)(o0 + pos) * a.Ks + k] : a.pad_id;
+            const long e = (long)row * a.Ks + k;
+            if (W == 2) {
+                int2 t = {a.pad_id, a.pad_id};
+                if (pos < n) t = *reinterpret_cast<const int2*>(a.score_flat + (long)(o0 + pos) * a.Ks + k);
+                *reinterpret_cast<i64x2*>(a.score + e) = i64x2{t.x, t.y};
+            } else {
+                a.score[e] = pos < n ? a.score_flat[(long)(o0 + pos) * a.Ks + k] : a.pad_id;
+            }
             if (k == 0) {
                 a.score_mask[row] = pos < n;
                 if (pos == 0) a.score_len[i] = n;
             }
         } else {                                              // segment ids of score position (i, pos)
             const Idx row = idx - n_perf - n_score;
-            const int pos = (int)(row % a.Ls), i = (int)(row / a.Ls);
+            const int i = (int)(row / a.Ls), pos = (int)(row - (Idx)i * a.Ls);
             const int o0 = a.score_off[i], n = a.score_off[i + 1] - o0;
             const bool in = pos < n;
             a.bar[row] = in ? a.seg_flat[o0 + pos] : 0;
@@ -95,13 +126,17 @@ extern "C" int spn_collate_mixlm(const int32_t* score_flat, const int32_t* perf_
     a.ignore_dims = ignore_dims;
     a.score = score; a.score_mask = score_mask; a.score_len = score_len; a.perf = perf; a.perf_mask = perf_mask; a.perf_len = perf_len;
     a.masked_perf = masked_perf; a.labels = labels; a.bar = bar; a.beat = beat; a.onset = onset; a.deadpan_mask = deadpan_mask;
-    const long total = (long)b * Lp * Kp + (long)b * Ls * Ks + (seg_flat ? (long)b * Ls : 0);
+    const bool pair = Ks % 2 == 0 && Kp % 2 == 0 && ((uintptr_t)score_flat | (uintptr_t)perf_flat) % 8 == 0 &&
+                      ((uintptr_t)score | (uintptr_t)perf | (uintptr_t)masked_perf | (uintptr_t)labels) % 16 == 0;
+    const int W = pair ? 2 : 1;
+    const long total = (long)b * Lp * (Kp / W) + (long)b * Ls * (Ks / W) + (seg_flat ? (long)b * Ls : 0);
     long g = (total + 255) / 256;
-    if (g > 8192) g = 8192;
-    if (total < (1l << 32) - (1l << 22))
-        hipLaunchKernelGGL(collate_mixlm_kernel<unsigned>, dim3((unsigned)g), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL(collate_mixlm_kernel<long>, dim3((unsigned)g), dim3(256), 0, stream, a);
+    if (g > 16384) g = 16384;
+    const bool small = total < (1l << 32) - (1l << 23);
+    if (small && pair) hipLaunchKernelGGL((collate_mixlm_kernel<unsigned, 2>), dim3((unsigned)g), dim3(256), 0, stream, a);
+    else if (small) hipLaunchKernelGGL((collate_mixlm_kernel<unsigned, 1>), dim3((unsigned)g), dim3(256), 0, stream, a);
+    else if (pair) hipLaunchKernelGGL((collate_mixlm_kernel<long, 2>), dim3((unsigned)g), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((collate_mixlm_kernel<long, 1>), dim3((unsigned)g), dim3(256), 0, stream, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -129,6 +129,9 @@ def test_device_batch_drives_the_model():
                 masked_perf=want["masked_perf"], bars=want["bar"], beats=want["beat"], onsets=want["onset"], deadpan_mask=want["deadpan_mask"])
     host = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
     with torch.no_grad():
+        torch.manual_seed(3)                                  # the MMD prior sample
         a = model(**model.allocate_inputs(model.prepare_inputs(data), torch.device("cuda")))
+        torch.manual_seed(3)
         b = model(**host)
-    assert torch.equal(a.loss, b.loss)
+    # identical inputs (bit-exact above); the segment sums use float atomics, so allow summation-order noise
+    assert abs(a.loss.item() - b.loss.item()) < 1e-5 * abs(b.loss.item())
