@@ -102,6 +102,12 @@ int spn_embed_bwd(int nkeys, const float* const* tables, float* const* dtables, 
 /* ---- losses (models/scoreperformer/wrappers.py:49-59 CE; mmd_transformer.py:325-368 segments, 505-534 MMD) */
 int spn_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len,
                int ignore_index, float* lse, float* sums /* [2] ACCUMULATED */, int* argmax, long T, int V, spn_stream_t s);
+/* spn_ce_fwd + the evaluator's per-key sums in the same pass (models/scoreperformer/evaluator.py:38-45,73-104): over rows with a valid
+ * label, metrics[0] += #(argmax == label); metrics[1] += |tv[argmax] - tv[label]| (weighted = 0) or sum_c softmax_c |tv[label] - tv[c]|
+ * (weighted = 1); token_values = fp32 [V] or null (no distance).  metrics is ACCUMULATED; the valid count is sums[1]. */
+int spn_ce_fwd_eval(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index,
+                    float* lse, float* sums /* [2] ACCUMULATED */, int* argmax, const float* token_values, int weighted,
+                    float* metrics /* [2] ACCUMULATED */, long T, int V, spn_stream_t s);
 int spn_ce_bwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len,
                int ignore_index, const float* lse, const float* coef, void* dlogits, long ldd, long T, int V, int Vpad,
                spn_stream_t s);

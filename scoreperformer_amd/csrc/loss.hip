@@ -20,14 +20,18 @@ __device__ __forceinline__ float ld_logit(const TL* p) {
 }
 
 // per row: lse[row]; loss_sum += (lse - logit[label]) and count += 1 for non-ignored rows; argmax[row] (optional)
-template <typename TL>
+// EVAL (scoreperformer/models/scoreperformer/evaluator.py:48-106): the evaluator's per-key sums come out of the
+// same pass -- metrics[0] += #(argmax == label), metrics[1] += distance in token-value space: |tv[argmax] - tv[label]| (evaluator.py:41-42)
+// or, weighted, sum_c softmax_c * |tv[label] - tv[c]| (evaluator.py:44-45) -- over rows with a valid label; the valid count is sums[1].
+template <typename TL, bool EVAL>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logits, long ld, const long* __restrict__ labels,
                                                      long lab_bs, long lab_ts, int t_len, int ignore_index, float* __restrict__ lse,
                                                      float* __restrict__ sums /* [2]: loss sum, count */, int* __restrict__ argmax,
+                                                     const float* __restrict__ tv, int weighted, float* __restrict__ metrics,
                                                      long T, int V) {
-    __shared__ float blk[2][4];
+    __shared__ float blk[4][4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float loss = 0.f, cnt = 0.f;
+    float loss = 0.f, cnt = 0.f, hit = 0.f, dist = 0.f;
     // a wave walks rows with a grid stride: one pair of (same-address) atomics per BLOCK at the end, not per 4 rows
     for (long row = (long)blockIdx.x * 4 + w; row < T; row += (long)gridDim.x * 4) {
         const TL* lr = logits + row * ld;
@@ -48,18 +52,37 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logi
         for (int c = lane; c < V; c += 64) s += __expf(ld_logit(lr + c) - m);
         s = wave_sum(s);
         const float l = m + __logf(s);
+        const long lab = labels[(row / t_len) * lab_bs + (row % t_len) * lab_ts];   // same address in every lane: one broadcast load
+        if (EVAL && lab != ignore_index && tv && weighted) {
+            const float target = tv[lab];
+            float d = 0.f;
+            for (int c = lane; c < V; c += 64) d += __expf(ld_logit(lr + c) - l) * fabsf(target - tv[c]);
+            dist += d;                                                               // per-lane partial, reduced once per block
+        }
         if (lane == 0) {
             lse[row] = l;
             if (argmax) argmax[row] = am;
-            const long lab = labels[(row / t_len) * lab_bs + (row % t_len) * lab_ts];
-            if (lab != ignore_index) { loss += l - ld_logit(lr + lab); cnt += 1.f; }
+            if (lab != ignore_index) {
+                loss += l - ld_logit(lr + lab); cnt += 1.f;
+                if (EVAL) {
+                    hit += am == lab ? 1.f : 0.f;
+                    if (tv && !weighted) dist += fabsf(tv[am] - tv[lab]);
+                }
+            }
         }
     }
-    if (lane == 0) { blk[0][w] = loss; blk[1][w] = cnt; }
+    if (EVAL) dist = wave_sum(dist);
+    if (lane == 0) { blk[0][w] = loss; blk[1][w] = cnt; blk[2][w] = hit; blk[3][w] = dist; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const float ls = blk[0][0] + blk[0][1] + blk[0][2] + blk[0][3], cs = blk[1][0] + blk[1][1] + blk[1][2] + blk[1][3];
-        if (cs > 0.f) { atomicAdd(sums, ls); atomicAdd(sums + 1, cs); }
+        if (cs > 0.f) {
+            atomicAdd(sums, ls); atomicAdd(sums + 1, cs);
+            if (EVAL) {
+                atomicAdd(metrics, blk[2][0] + blk[2][1] + blk[2][2] + blk[2][3]);
+                if (tv) atomicAdd(metrics + 1, blk[3][0] + blk[3][1] + blk[3][2] + blk[3][3]);
+            }
+        }
     }
 }
 
@@ -256,12 +279,33 @@ inline int grid_for(long total, int block = 256) { long g = (total + block - 1) 
 
 // logits: [T, V] (fp32 dtype 0 / bf16 dtype 1, row stride ld); labels int64 [B, t_len] view, element strides (lab_bs, lab_ts), T = B*t_len.
 // sums[2] (loss sum, valid count) are ACCUMULATED (zero first).  argmax may be null.
+namespace {
+template <bool EVAL>
+void launch_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index, float* lse,
+                   float* sums, int* argmax, const float* tv, int weighted, float* metrics, long T, int V, hipStream_t s) {
+    dim3 grid(cdiv(T, 4) < 2048 ? cdiv(T, 4) : 2048);
+    if (dtype == 0)
+        hipLaunchKernelGGL((ce_fwd_kernel<float, EVAL>), grid, dim3(256), 0, s, (const float*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse,
+                           sums, argmax, tv, weighted, metrics, T, V);
+    else
+        hipLaunchKernelGGL((ce_fwd_kernel<bf16_t, EVAL>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index,
+                           lse, sums, argmax, tv, weighted, metrics, T, V);
+}
+}  // namespace
+
 extern "C" int spn_ce_fwd(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index, float* lse,
                           float* sums, int* argmax, long T, int V, hipStream_t s) {
     SPN_REQUIRE(logits && labels && lse && sums && T > 0 && V > 0, "spn_ce_fwd: bad arguments");
-    dim3 grid(cdiv(T, 4) < 2048 ? cdiv(T, 4) : 2048);
-    if (dtype == 0) hipLaunchKernelGGL((ce_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
-    else hipLaunchKernelGGL((ce_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)logits, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, T, V);
+    launch_ce_fwd<false>(logits, dtype, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, nullptr, 0, nullptr, T, V, s);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_ce_fwd_eval(const void* logits, int dtype, long ld, const long* labels, long lab_bs, long lab_ts, int t_len, int ignore_index,
+                               float* lse, float* sums, int* argmax, const float* token_values, int weighted, float* metrics, long T, int V,
+                               hipStream_t s) {
+    SPN_REQUIRE(logits && labels && lse && sums && metrics && T > 0 && V > 0, "spn_ce_fwd_eval: bad arguments");
+    launch_ce_fwd<true>(logits, dtype, ld, labels, lab_bs, lab_ts, t_len, ignore_index, lse, sums, argmax, token_values, weighted, metrics, T, V, s);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -627,7 +627,14 @@ class HeadCEFn(Function):
         ops.gemm(e2, tb, out=logits, bias=bias.detach() if bias is not None else None)
         lse = sums = am = None
         if labels is not None:
-            lse, sums, am = ops.ce_fwd(logits, V, labels, ignore_index=ignore_index, want_argmax=want_argmax)
+            spec = state.get("eval") if state is not None else None
+            if spec is not None:   # the evaluator's sums from the same pass over the logits
+                tv = spec["values"].get(key) if spec.get("values") else None
+                lse, sums, am, met = ops.ce_fwd(logits, V, labels, ignore_index=ignore_index, want_argmax=want_argmax,
+                                                eval_spec=(tv, spec.get("weighted", False)))
+                state.setdefault("metrics", {})[key] = met
+            else:
+                lse, sums, am = ops.ce_fwd(logits, V, labels, ignore_index=ignore_index, want_argmax=want_argmax)
         ctx.save_for_backward(e2, table, logits, lse, labels, sums, tpad)
         ctx.cfg = (ignore_index, e.shape, bias)
         ctx.mark_non_differentiable(logits)

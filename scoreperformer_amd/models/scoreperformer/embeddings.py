@@ -274,7 +274,7 @@ class _HeadBase(nn.Module):
 
     def _per_key(self, items, labels, ignore_index, want_argmax, label_counts=None):
         logits, sums, argmax = LazyLogits(), {}, {}
-        self.ce_state = {"active": None}
+        self.ce_state = {"active": None, "eval": getattr(self, "eval_spec", None)}   # eval_spec: set by ScorePerformerEvaluator.attach()
         counts = None
         if label_counts is not None and labels is not None:
             buf, ev = label_counts

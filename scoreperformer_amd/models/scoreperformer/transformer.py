@@ -43,6 +43,7 @@ class TupleTransformerOutput:
     # extensions (not in the reference): fused cross-entropy sums / argmax per key when `labels` is passed down
     ce_sums: Optional[Dict[str, Tensor]] = None
     argmax: Optional[Dict[str, Tensor]] = None
+    eval_sums: Optional[Dict[str, Tensor]] = None   # key -> (#correct, distance sum) when an evaluator is attached (section 8(f) N3)
 
 
 @dataclass
@@ -143,11 +144,12 @@ class TupleTransformer(nn.Module, Constructor):
             style_embeddings=style_embeddings, intermediates_cache=caches.transformer if caches is not None else None,
             return_hiddens=True)
 
-        logits = ce_sums = argmax = None
+        logits = ce_sums = argmax = eval_sums = None
         if not return_embeddings and self.lm_head is not None:
             res = self.lm_head(out, keys=logits_keys, labels=labels, want_argmax=want_argmax, label_counts=label_counts)
             if isinstance(res, tuple):
                 logits, ce_sums, argmax = res
+                eval_sums = getattr(self.lm_head, "ce_state", {}).get("metrics")
             else:
                 logits = res
         reg_values = None
@@ -157,4 +159,4 @@ class TupleTransformer(nn.Module, Constructor):
             raise AttributeError("'AttentionIntermediates' object has no attribute 'post_softmax_attn'")
         out_caches = TupleTransformerCaches(token_emb=token_emb, transformer=intermediates) if return_caches else None
         return TupleTransformerOutput(hidden_state=out, logits=logits, attentions=None, caches=out_caches,
-                                      reg_values=reg_values, ce_sums=ce_sums, argmax=argmax)
+                                      reg_values=reg_values, ce_sums=ce_sums, argmax=argmax, eval_sums=eval_sums)

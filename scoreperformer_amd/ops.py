@@ -429,8 +429,10 @@ def _label_view(labels: torch.Tensor):
     return labels, labels.shape[0], labels.shape[1], labels.stride(0), labels.stride(1)
 
 
-def ce_fwd(logits: torch.Tensor, V: int, labels: torch.Tensor, *, ignore_index: int = -100, want_argmax: bool = False):
-    """logits [T, >=V] (row stride free) -> (lse [T], sums [2] = (loss sum, valid count), argmax int32 [T] | None)."""
+def ce_fwd(logits: torch.Tensor, V: int, labels: torch.Tensor, *, ignore_index: int = -100, want_argmax: bool = False,
+           eval_spec=None):
+    """logits [T, >=V] (row stride free) -> (lse [T], sums [2] = (loss sum, valid count), argmax int32 [T] | None).
+    eval_spec = (token_values fp32 [V] | None, weighted): also returns metrics [2] = (#correct, distance sum) from the same pass."""
     lg = _rows2d(logits)
     labels, B, t_len, lbs, lts = _label_view(labels)
     T = B * t_len
@@ -439,6 +441,15 @@ def ce_fwd(logits: torch.Tensor, V: int, labels: torch.Tensor, *, ignore_index: 
     lse = torch.empty(T, device=lg.device, dtype=F32)
     sums = torch.zeros(2, device=lg.device, dtype=F32)
     am = torch.empty(T, device=lg.device, dtype=torch.int32) if want_argmax else None
+    if eval_spec is not None:
+        tv, weighted = eval_spec
+        if tv is not None and (tv.dtype != F32 or tv.numel() < V or not tv.is_contiguous() or tv.device != lg.device):
+            raise SpnError("ce_fwd: token values must be a contiguous fp32 [V] tensor on the logits' device")
+        metrics = torch.zeros(2, device=lg.device, dtype=F32)
+        call("spn_ce_fwd_eval", ptr(lg), c_int(_dt(lg)), c_long(lg.stride(0)), ptr(labels), c_long(lbs), c_long(lts), c_int(t_len),
+             c_int(ignore_index), ptr(lse), ptr(sums), ptr(am), ptr(tv), c_int(int(bool(weighted))), ptr(metrics), c_long(T), c_int(V),
+             stream_ptr())
+        return lse, sums, am, metrics
     call("spn_ce_fwd", ptr(lg), c_int(_dt(lg)), c_long(lg.stride(0)), ptr(labels), c_long(lbs), c_long(lts), c_int(t_len),
          c_int(ignore_index), ptr(lse), ptr(sums), ptr(am), c_long(T), c_int(V), stream_ptr())
     return lse, sums, am
