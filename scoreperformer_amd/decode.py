@@ -307,3 +307,72 @@ class GreedyDecoder:
                for k, v in zip(self.kc, self.vc)]
         return TupleTransformerCaches(token_emb=self.tok_emb[None, :n],
                                       transformer=TransformerIntermediates(hiddens=[h[None, :n] for h in self.hid], attention=att))
+
+
+class RenderSession(GreedyDecoder):
+    """The decode engine kept alive across the calls of the render loop.
+
+    The reference's loop (`inference/generators.py:160-262`) calls `unmask_tokens` once per chord group with `torch.cat`-grown caches,
+    re-slices them after every time window (`cut_caches`, 432-443) and rebuilds them from scratch whenever the context is cropped.
+    Here the caches are static `[max_len, .]` buffers and the valid prefix is one integer: extending = writing the new rows and
+    replaying the captured step, cutting = lowering `length`, cropping = `reset()` + recomputing the window with the same graph.
+    """
+
+    def __init__(self, decoder, max_len: int, dims: List[int], mask_token_id: int = 1, **kw):
+        super().__init__(decoder, max_len, **kw)
+        m, dev = self.m, self.dev
+        self._alloc(max_len)
+        K = len(m.token_emb.embs)
+        self.seq2d = torch.zeros(max_len, K, device=dev, dtype=torch.int64)
+        self.masked2d = torch.zeros(max_len, K, device=dev, dtype=torch.int64)
+        self.ctx2d = torch.zeros(max_len, m.context_emb_dim, device=dev, dtype=F32) if getattr(m, "context_emb_dim", 0) else None
+        self.style2d = torch.zeros(max_len, m.style_emb_dim, device=dev, dtype=F32) if getattr(m, "style_emb_dim", 0) else None
+        with torch.no_grad():
+            self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
+        self.dims, self.mask_token_id = [int(d) for d in dims], mask_token_id
+        self.length = 0            # positions 0 .. length-1 hold valid cache rows (token_emb, hiddens, keys, values)
+        self.tag = None            # whatever identifies the window the cache belongs to (set by the caller)
+        self._step_fn = self._step_fused if self.fused else self._step
+        self.steps_run = 0
+
+    def reset(self):
+        self.length, self.tag = 0, None
+        for k in self.kmax2:
+            k.zero_()
+
+    def truncate(self, length: int):
+        self.length = max(0, min(self.length, int(length)))
+
+    @torch.no_grad()
+    def decode(self, tokens: torch.Tensor, masked: torch.Tensor, context: Optional[torch.Tensor], style: Optional[torch.Tensor],
+               n_new: int) -> torch.Tensor:
+        """tokens / masked: int64 [Lin, K] (host or device), the last n_new rows carry MASK in the predicted dims; context / style:
+        device rows aligned with them.  Positions < self.length are taken from the caches.  Returns the n_new filled rows (device)."""
+        Lin, c = tokens.shape[0], self.length
+        if Lin > self.max_len:
+            raise ValueError(f"window of {Lin} notes exceeds the session's max_len {self.max_len}")
+        if c > Lin - 1:
+            raise ValueError("cache longer than the input window: truncate() or reset() first")
+        self.seq2d[c:Lin].copy_(tokens[c:Lin], non_blocking=True)
+        self.masked2d[c:Lin].copy_(masked[c:Lin], non_blocking=True)
+        if self.ctx2d is not None:
+            self.ctx2d[c:Lin].copy_(context[c:Lin])
+        if self.style2d is not None:
+            self.style2d[c:Lin].copy_(style[c:Lin])
+        self.pos.fill_(c)
+        steps = Lin - 1 - c
+        done = 0
+        if self.use_graph and self.graph is None and steps > 0:
+            self._step_fn(self.dims)                 # first step eager (warms every lazily built operand), then record once
+            done = 1
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_fn(self.dims)
+            self.graph = g
+        for _ in range(steps - done):
+            self.graph.replay() if self.use_graph else self._step_fn(self.dims)
+        self.steps_run += steps
+        self.length = Lin - 1
+        self.n_steps = self.length
+        return self.seq2d[Lin - n_new:Lin]

@@ -1,0 +1,92 @@
+"""GPU: the product render loop (scoreperformer_amd.inference.ScorePerformerGenerator over decode.RenderSession) replays the
+reference generator's golden calls: tokens bit-exact, same messages, same accepted-note bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from render_common import COLLATOR, load
+
+pytestmark = pytest.mark.gpu
+VOCAB, SEED, SCEN = load()
+
+
+def make(use_engine, dev):
+    from types import SimpleNamespace
+    from oracle.render_fakes import FakeMessenger, make_dataset
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.inference import ScorePerformerGenerator
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    model = ScorePerformer.init(model_config(preset="tiny", num_tokens=VOCAB))
+    model.load_state_dict(filled_state_dict(model, seed=SEED))
+    arena = ParamArena(model, dev)
+    model.eval()
+    collator = SimpleNamespace(mask_token_id=COLLATOR["mask_token_id"], mask_ignore_token_dims=COLLATOR["mask_ignore_token_dims"])
+
+    def gen_for(piece):
+        return ScorePerformerGenerator(model, make_dataset(VOCAB, [piece]), collator, FakeMessenger(VOCAB), device=dev, use_engine=use_engine)
+    return gen_for, arena
+
+
+def replay(gen, s, dev):
+    from scoreperformer_amd.modules.sampling import top_k
+    c = s["cfg"]
+    gen.prepare_performance_notes(0, score_embeddings=torch.from_numpy(s["score_emb"]).clone(), perf_embeddings=torch.from_numpy(s["perf_emb"]).clone())
+    assert np.array_equal(gen.perf_data.notes.cpu().numpy(), s["notes"])
+    t = 0.0
+    for i, call in enumerate(s["calls"]):
+        delta = torch.from_numpy(s["delta"]).clone() if c["delta_every"] and i % c["delta_every"] == 0 else None
+        seq, messages = gen.generate_performance_notes(
+            start_time=t, time_window=c["time_window"], time_window_overflow=c["time_window_overflow"], delta_embedding=delta,
+            max_context_len=c["max_context_len"], group_chord_notes=c["group_chord_notes"], filter_logits_fn=top_k, filter_kwargs={"k": 1})
+        want = call["tokens"]
+        if len(want) == 0:
+            assert seq is None and messages == [], i
+        else:
+            assert seq is not None and np.array_equal(seq.cpu().numpy(), want), i          # bit-exact greedy tokens
+            assert np.allclose(np.array(messages, np.float64).reshape(-1, 4), call["messages"], atol=1e-9), i
+        assert int(gen.predict_number_of_notes(start_time=t + c["time_window"], time_window=c["time_window"])) == call["predicted_notes"], i
+        t += c["time_window"]
+        yield i, call
+    assert gen.perf_data.reached_eos
+    assert np.array_equal(gen.perf_data.gen_seq.cpu().numpy(), s["gen_seq"])
+    assert np.allclose(gen.perf_data.embeddings.cpu().numpy(), s["final_embeddings"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", sorted(SCEN))
+def test_engine_render_loop_matches_the_reference_generator(name):
+    dev = torch.device("cuda")
+    gen_for, _ = make(True, dev)
+    s = SCEN[name]
+    gen = gen_for(s["piece"])
+    for i, call in replay(gen, s, dev):
+        # the static cache holds exactly the rows the reference's concatenated caches hold after the call
+        have = -1 if gen.perf_data.caches is None else gen.perf_data.caches.length
+        assert have == call["cache_len"], (i, have, call["cache_len"])
+    assert gen._session is not None and gen._session.steps_run > 0, "the HIP decode engine must have produced the tokens"
+
+
+def test_module_path_render_loop_matches_the_reference_generator():
+    """use_engine=False: `perf_decoder.unmask_tokens` with TupleTransformerCaches + cut_caches, as the reference calls it."""
+    dev = torch.device("cuda")
+    gen_for, _ = make(False, dev)
+    s = SCEN["single_notes"]
+    gen = gen_for(s["piece"])
+    gen.model.perf_decoder.use_decode_engine = False
+    for i, call in replay(gen, s, dev):
+        have = -1 if gen.perf_data.caches is None else gen.perf_data.caches.token_emb.shape[1]
+        assert have == call["cache_len"], (i, have, call["cache_len"])
+    assert gen._session is None
+
+
+def test_engine_window_must_fit():
+    dev = torch.device("cuda")
+    gen_for, _ = make(True, dev)
+    s = SCEN["single_notes"]
+    gen = gen_for(s["piece"])
+    gen.engine_max_len = 64
+    gen.prepare_performance_notes(0, score_embeddings=torch.from_numpy(s["score_emb"]), perf_embeddings=torch.from_numpy(s["perf_emb"]))
+    from scoreperformer_amd.modules.sampling import top_k
+    with pytest.raises(ValueError):
+        gen.generate_performance_notes(max_context_len=512, filter_logits_fn=top_k, filter_kwargs={"k": 1})
