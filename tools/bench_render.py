@@ -1,0 +1,79 @@
+"""Measure the render loop (N1) on the C5 model: notes/s of `ScorePerformerGenerator.generate_performance_notes` driven over a whole
+piece in successive time windows, with the persistent decode session (HIP engine) and with the module path (`unmask_tokens` +
+concatenated caches, the reference's call pattern on the same GPU).
+
+    python tools/bench_render.py [--notes 1200] [--context 512] [--window 0.5] [--out gpurun_out/render.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.render_fakes import FakeMessenger, make_dataset, make_piece      # noqa: E402  (stand-ins for dataset / messenger)
+from scoreperformer_amd.arena import ParamArena                              # noqa: E402
+from scoreperformer_amd.inference import ScorePerformerGenerator             # noqa: E402
+from scoreperformer_amd.models import ScorePerformer                         # noqa: E402
+from scoreperformer_amd.modules.sampling import top_k                        # noqa: E402
+from scoreperformer_amd.synthetic import model_config, PERFORMANCE_VOCAB     # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--notes", type=int, default=1200)
+    ap.add_argument("--context", type=int, default=512)
+    ap.add_argument("--window", type=float, default=0.5)
+    ap.add_argument("--module-notes", type=int, default=300)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = ScorePerformer.init(model_config("c5", dropout=0.0))
+    arena = ParamArena(model, dev)   # noqa: F841
+    model.eval()
+    dec = model.perf_decoder.model
+    collator = SimpleNamespace(mask_token_id=1, mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
+    res = {"workload": f"C5 render loop: {a.notes}-note piece, max_context_len {a.context}, time window {a.window} s, greedy, chord groups"}
+    for name, use_engine, notes in (("engine", True, a.notes), ("modules", False, a.module_notes)):
+        piece = make_piece(7, notes, PERFORMANCE_VOCAB)
+        g = torch.Generator().manual_seed(1)
+        ctx = torch.randn(notes + 2, dec.context_emb_dim, generator=g) * 0.5
+        sty = torch.randn(notes + 2, dec.style_emb_dim, generator=g) * 0.5
+        gen = ScorePerformerGenerator(model, make_dataset(PERFORMANCE_VOCAB, [piece]), collator, FakeMessenger(PERFORMANCE_VOCAB), device=dev,
+                                      use_engine=use_engine)
+        model.perf_decoder.use_decode_engine = use_engine
+        gen.prepare_performance_notes(0, score_embeddings=ctx, perf_embeddings=sty)
+        if use_engine:      # build the session + graph outside the timed region (one-off per generator)
+            gen.generate_performance_notes(start_time=0.0, time_window=1e-6, max_context_len=a.context, filter_logits_fn=top_k, filter_kwargs={"k": 1})
+            gen.reset()
+            gen.prepare_performance_notes(0, score_embeddings=ctx, perf_embeddings=sty)
+        torch.cuda.synchronize()
+        t, calls, messages = 0.0, 0, 0
+        t0 = time.perf_counter()
+        while not gen.perf_data.reached_eos and calls < 100000:
+            _, msg = gen.generate_performance_notes(start_time=t, time_window=a.window, time_window_overflow=0.1, max_context_len=a.context,
+                                                    filter_logits_fn=top_k, filter_kwargs={"k": 1})
+            messages += len(msg)
+            t += a.window
+            calls += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        done = gen.perf_data.gen_seq.shape[0] - 1
+        res[name] = {"notes": int(done), "calls": calls, "seconds": dt, "notes_per_s": done / dt, "messages": messages,
+                     "decoder_steps": int(gen._session.steps_run) if gen._session is not None else None,
+                     "music_seconds": t, "realtime_factor": t / dt}
+    res["speedup_engine_vs_modules"] = res["engine"]["notes_per_s"] / res["modules"]["notes_per_s"]
+    print(json.dumps(res))
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
