@@ -344,6 +344,24 @@ class RenderSession(GreedyDecoder):
         self.length = max(0, min(self.length, int(length)))
 
     @torch.no_grad()
+    def load_caches(self, caches):
+        """Adopt caches computed elsewhere (one batched module forward over a window: `TupleTransformerCaches`) as rows 0 .. n-1."""
+        n = caches.token_emb.shape[1]
+        if n > self.max_len:
+            raise ValueError("caches longer than the session")
+        self.reset()
+        self.tok_emb[:n].copy_(caches.token_emb[0])
+        for dst, h in zip(self.hid, caches.transformer.hiddens):
+            dst[:n].copy_(h[0])
+        for i, a in enumerate(caches.transformer.attention):
+            k, v = (a.keys[0], a.values[0]) if self.kvh == 1 else \
+                (a.keys[0].permute(1, 0, 2).reshape(n, -1), a.values[0].permute(1, 0, 2).reshape(n, -1))
+            self.kc[i][:n].copy_(k)
+            self.vc[i][:n].copy_(v)
+            self.kmax2[i].copy_(self.kc[i][:n].view(n, self.kvh, 64).pow(2).sum(-1).amax(0))   # the reach bound of dec_attn2
+        self.length = n
+
+    @torch.no_grad()
     def decode(self, tokens: torch.Tensor, masked: torch.Tensor, context: Optional[torch.Tensor], style: Optional[torch.Tensor],
                n_new: int) -> torch.Tensor:
         """tokens / masked: int64 [Lin, K] (host or device), the last n_new rows carry MASK in the predicted dims; context / style:

@@ -64,7 +64,12 @@ class _EngineCache:
 
 class ScorePerformerGenerator:
     def __init__(self, model, dataset, collator, messenger, device: Optional[Union[str, torch.device]] = None,
-                 use_engine: bool = True, engine_max_len: int = 1024):
+                 use_engine: bool = True, engine_max_len: int = 1024, prefill: str = "engine", prefill_min: int = 32):
+        """use_engine: greedy decoding through `decode.RenderSession`.  prefill: how the caches of a window are rebuilt after the
+        context was cropped (or on a cold start with a long known prefix): "engine" = note by note with the fp32 engine (bit-exact
+        with the reference's fp32 tokens), "modules" = ONE batched module forward over the window (bf16 GEMMs, like the reference's
+        own batched recompute but not bit-exact in near-tied arg-maxes), adopted by the session when the prefix has at least
+        `prefill_min` rows."""
         self.model = model
         assert model.perf_decoder is not None
         self.dataset = dataset
@@ -74,7 +79,9 @@ class ScorePerformerGenerator:
         self.eos_token_id = self.tokenizer[0, EOS_TOKEN]
         self.messenger = messenger
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
-        self.use_engine, self.engine_max_len = use_engine, engine_max_len
+        if prefill not in ("engine", "modules"):
+            raise ValueError("prefill must be 'engine' or 'modules'")
+        self.use_engine, self.engine_max_len, self.prefill, self.prefill_min = use_engine, engine_max_len, prefill, prefill_min
         self._session = None
         self._init_variables()
         self.perf_data = PerformanceData()
@@ -222,6 +229,9 @@ class ScorePerformerGenerator:
                     caches = None
                 if caches is None:
                     session.reset()
+                    have = last - 1 - n_new                                      # rows every new note can take from the caches
+                    if self.prefill == "modules" and have >= self.prefill_min:
+                        session.load_caches(self._prefill_modules(model_in[:have + 1], doubled[:have + 1], score_embs, perf_embs))
                 else:
                     session.truncate(caches.length)
                 rows = session.decode(torch.from_numpy(model_in), torch.from_numpy(doubled), score_embs, perf_embs, n_new)
@@ -265,6 +275,23 @@ class ScorePerformerGenerator:
                 caches = self.cut_caches(caches, right_idx=caches.token_emb.shape[1] - dropped)
         pd.caches = caches
         return gen_seq, messages
+
+    def _prefill_modules(self, model_in, doubled, score_embs, perf_embs):
+        """Caches of rows 0 .. len-2 of a window from one batched forward of the decoder modules (what `unmask_tokens` runs for its
+        first masked position with `caches=None`, wrappers.py:391-393)."""
+        from ..models.scoreperformer.embeddings import shared_tables
+        n = model_in.shape[0]
+        seq = torch.from_numpy(model_in).to(self.device)[None]
+        dec = self.model.perf_decoder
+        was_training = dec.model.training
+        dec.model.eval()
+        with torch.inference_mode(), shared_tables():
+            out = dec(seq, seq_masked=torch.from_numpy(doubled).to(self.device)[None],
+                      mask=torch.ones(1, n, dtype=torch.bool, device=self.device), return_embeddings=True, return_caches=True, caches=None,
+                      context=score_embs[:n].unsqueeze(0) if score_embs is not None else None,
+                      style_embeddings=perf_embs[:n].unsqueeze(0) if perf_embs is not None else None)
+        dec.model.train(was_training)
+        return out.caches
 
     def _unmask_modules(self, model_in, doubled, score_embs, perf_embs, caches, n_new, disable_caches, filter_logits_fn, filter_kwargs,
                         disable_tqdm):

@@ -113,3 +113,30 @@ def test_engine_window_must_fit():
     from scoreperformer_amd.modules.sampling import top_k
     with pytest.raises(ValueError):
         gen.generate_performance_notes(max_context_len=512, filter_logits_fn=top_k, filter_kwargs={"k": 1})
+
+
+def test_batched_prefill_adopts_module_caches():
+    """prefill="modules": after a crop the window's caches come from one batched module forward (bf16) and the session continues
+    from them.  Same loop, same bookkeeping; tokens may differ from the fp32 reference only through bf16 near-ties."""
+    from scoreperformer_amd.modules.sampling import top_k
+    dev = torch.device("cuda")
+    gen_for, _ = make(True, dev)
+    s = SCEN["crop"]
+    c = s["cfg"]
+    gen = gen_for(s["piece"])
+    gen.prefill, gen.prefill_min = "modules", 8
+    gen.prepare_performance_notes(0, score_embeddings=torch.from_numpy(s["score_emb"]).clone(), perf_embeddings=torch.from_numpy(s["perf_emb"]).clone())
+    t, calls = 0.0, 0
+    while not gen.perf_data.reached_eos and calls < 200:
+        gen.generate_performance_notes(start_time=t, time_window=c["time_window"], time_window_overflow=c["time_window_overflow"],
+                                       max_context_len=c["max_context_len"], filter_logits_fn=top_k, filter_kwargs={"k": 1})
+        t += c["time_window"]
+        calls += 1
+    got, want = gen.perf_data.gen_seq.cpu().numpy(), s["gen_seq"]
+    given = [d for d in range(12) if d not in (3, 5, 10, 11)]
+    assert gen.perf_data.reached_eos and got.shape == want.shape and np.array_equal(got[:, given], want[:, given])
+    # far fewer sequential steps than notes x window: the crops were served by batched forwards
+    exact = gen_for(s["piece"])
+    list(replay(exact, s, dev))
+    assert gen._session.steps_run < 0.5 * exact._session.steps_run
+    assert (got == want).mean() > 0.85

@@ -39,13 +39,14 @@ def main():
     dec = model.perf_decoder.model
     collator = SimpleNamespace(mask_token_id=1, mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
     res = {"workload": f"C5 render loop: {a.notes}-note piece, max_context_len {a.context}, time window {a.window} s, greedy, chord groups"}
-    for name, use_engine, notes in (("engine", True, a.notes), ("modules", False, a.module_notes)):
+    for name, use_engine, notes, prefill in (("engine", True, a.notes, "engine"), ("engine_batched_prefill", True, a.notes, "modules"),
+                                           ("modules", False, a.module_notes, "engine")):
         piece = make_piece(7, notes, PERFORMANCE_VOCAB)
         g = torch.Generator().manual_seed(1)
         ctx = torch.randn(notes + 2, dec.context_emb_dim, generator=g) * 0.5
         sty = torch.randn(notes + 2, dec.style_emb_dim, generator=g) * 0.5
         gen = ScorePerformerGenerator(model, make_dataset(PERFORMANCE_VOCAB, [piece]), collator, FakeMessenger(PERFORMANCE_VOCAB), device=dev,
-                                      use_engine=use_engine)
+                                      use_engine=use_engine, prefill=prefill)
         model.perf_decoder.use_decode_engine = use_engine
         gen.prepare_performance_notes(0, score_embeddings=ctx, perf_embeddings=sty)
         if use_engine:      # build the session + graph outside the timed region (one-off per generator)
@@ -68,6 +69,7 @@ def main():
                      "decoder_steps": int(gen._session.steps_run) if gen._session is not None else None,
                      "music_seconds": t, "realtime_factor": t / dt}
     res["speedup_engine_vs_modules"] = res["engine"]["notes_per_s"] / res["modules"]["notes_per_s"]
+    res["speedup_engine_batched_prefill_vs_modules"] = res["engine_batched_prefill"]["notes_per_s"] / res["modules"]["notes_per_s"]
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
