@@ -156,6 +156,12 @@ int spn_dec_head(int n, const float* const* tables, const int* V, const int* wid
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);
 
+/* batched (prefill) forms of the decode kernels: rows t0 .. t0+n-1 of a window whose tokens are known (the reference recomputes a
+ * cropped window in one batched forward, inference/generators.py:184-241 -> wrappers.py:391-393); K/V rows already in the caches. */
+int spn_dec_attn_rows(const float* q, long q_ld, const float* kcache, const float* vcache, const float* slopes, int t0, int n, float* o,
+                      long o_ld, int h, int kvh, float scale, spn_stream_t s);
+int spn_dec_glu_rows(const float* u, long u_ld, float* out, long out_ld, int n, int I, int act, int glu, spn_stream_t s);
+
 /* ---- device-side batch builder (scoreperformer/data/collators/score_performance.py:35-115,186-234; performance.py:18-92,100-115,
  *      213-247): raw ragged int32 tokens (samples concatenated, row offsets [b+1]) -> every tensor the MixedLM collator returns:
  *      padded int64 tokens, bool masks, lengths, bar/beat/onset ids (seg_flat = [3, sum_s] or null), deadpan flags, masked_perf, labels.

@@ -159,6 +159,57 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     }
 }
 
+// ---- batched (prefill) variants: rows t0 .. t0+n-1 of a window whose tokens are all known, one launch per operator instead of one
+//      per position.  Same arithmetic as the single-position kernels above; K/V rows are already in the caches.
+// grid = (h, n): block (hi, r) is query t = t0 + r over keys j <= t.
+__global__ __launch_bounds__(256) void dec_attn_rows_kernel(const float* __restrict__ q, long q_ld, const float* __restrict__ kcache,
+                                                            const float* __restrict__ vcache, const float* __restrict__ slopes, int t0,
+                                                            float* __restrict__ o, long o_ld, int h, int kvh, float scale) {
+    __shared__ float m_s[4], l_s[4], o_s[4][64];
+    const int hi = blockIdx.x, r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int kh = kvh == 1 ? 0 : hi;
+    const int t = t0 + r;
+    const long cw = (long)kvh * 64;
+    const float qd = q[(long)r * q_ld + hi * 64 + lane] * scale;
+    const float slope = slopes ? slopes[hi] : 0.f;
+    float m = -INFINITY, l = 0.f, acc = 0.f;
+    for (int j = w; j <= t; j += 4) {
+        const float kd = kcache[j * cw + kh * 64 + lane];
+        const float vd = vcache[j * cw + kh * 64 + lane];
+        const float s = wave_sum(qd * kd) - slope * (float)(t - j);
+        const float m_new = fmaxf(m, s);
+        const float alpha = __expf(m - m_new), p = __expf(s - m_new);
+        l = l * alpha + p;
+        acc = acc * alpha + p * vd;
+        m = m_new;
+    }
+    if (lane == 0) { m_s[w] = m; l_s[w] = l; }
+    o_s[w][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        const float mm = fmaxf(fmaxf(m_s[0], m_s[1]), fmaxf(m_s[2], m_s[3]));
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const float f = (m_s[qq] == -INFINITY) ? 0.f : __expf(m_s[qq] - mm);
+            num += o_s[qq][lane] * f;
+            den += l_s[qq] * f;
+        }
+        o[(long)r * o_ld + hi * 64 + lane] = num / den;
+    }
+}
+
+// out[r, i] = u[r, i] * act(u[r, I + i])  (glu) or act(u[r, i]);  grid.y = rows
+__global__ void dec_glu_rows_kernel(const float* __restrict__ u, long u_ld, float* __restrict__ out, long out_ld, int I, int act, int glu) {
+    const float* ur = u + (long)blockIdx.y * u_ld;
+    float* orow = out + (long)blockIdx.y * out_ld;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < I; i += gridDim.x * blockDim.x) {
+        const float g = glu ? ur[I + i] : ur[i];
+        const float a = act == 0 ? g / (1.f + __expf(-g)) : 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+        orow[i] = glu ? ur[i] * a : a;
+    }
+}
+
 // arg-max over logits[0..V) with banned ids -> if tokens[(*pos + 1), dim] == mask_id: write it there.  One block.
 __global__ __launch_bounds__(256) void dec_argmax_write_kernel(const float* __restrict__ logits, int V, unsigned ban_mask,
                                                                long* __restrict__ tokens, long tok_ld, int dim, int mask_id,
@@ -562,6 +613,21 @@ extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, con
     d.n = n; d.D = D;
     hipLaunchKernelGGL(dec_head_kernel, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
                        counter);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_dec_attn_rows(const float* q, long q_ld, const float* kcache, const float* vcache, const float* slopes, int t0, int n,
+                                 float* o, long o_ld, int h, int kvh, float scale, hipStream_t s) {
+    SPN_REQUIRE(q && kcache && vcache && o && n > 0 && t0 >= 0 && h > 0 && (kvh == 1 || kvh == h), "spn_dec_attn_rows: bad arguments");
+    hipLaunchKernelGGL(dec_attn_rows_kernel, dim3(h, n), dim3(256), 0, s, q, q_ld, kcache, vcache, slopes, t0, o, o_ld, h, kvh, scale);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_dec_glu_rows(const float* u, long u_ld, float* out, long out_ld, int n, int I, int act, int glu, hipStream_t s) {
+    SPN_REQUIRE(u && out && n > 0 && I > 0, "spn_dec_glu_rows: bad arguments");
+    hipLaunchKernelGGL(dec_glu_rows_kernel, dim3((I + 255) / 256, n), dim3(256), 0, s, u, u_ld, out, out_ld, I, act, glu);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

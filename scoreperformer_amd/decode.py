@@ -334,6 +334,8 @@ class RenderSession(GreedyDecoder):
         self.tag = None            # whatever identifies the window the cache belongs to (set by the caller)
         self._step_fn = self._step_fused if self.fused else self._step
         self.steps_run = 0
+        self.prefilled_rows = 0
+        self.prefill_min = 16      # shorter prefixes: the captured step is as fast
 
     def reset(self):
         self.length, self.tag = 0, None
@@ -362,10 +364,75 @@ class RenderSession(GreedyDecoder):
         self.length = n
 
     @torch.no_grad()
+    def prefill(self, n: int):
+        """Cache rows 0 .. n-1 from the tokens / embeddings already written to rows 0 .. n (by `decode`'s upload): the same fp32
+        arithmetic as `_step`, but every operator runs ONCE over all n positions (exact-fp32 GEMMs instead of n GEMVs, causal
+        attention with the position in the grid) -- what the reference does when it recomputes a cropped window in one forward."""
+        m, d = self.m, self.dim
+        te, tr = m.token_emb, m.transformer
+        cond = self.style2d[1:n + 1] if self.style2d is not None else None
+
+        def ln(x, norm):
+            if self.ada and isinstance(norm, AdaptiveLayerNorm):
+                gb = ops.gemm_f32(cond, norm.linear.weight.data, bias=norm.linear.bias.data)
+                return ops.layernorm_fwd(x, None, None, gb, out_dtype=F32, eps=norm.eps)[0]
+            if isinstance(norm, AdaptiveLayerNorm):
+                return ops.layernorm_fwd(x, None, None, None, out_dtype=F32, eps=norm.eps)[0]
+            return ops.layernorm_fwd(x, norm.weight.data, norm.bias.data, None, out_dtype=F32, eps=norm.eps)[0]
+
+        parts = []
+        for toks in (self.seq2d[0:n], self.masked2d[1:n + 1]):
+            e = torch.cat([t[toks[:, k]] for k, t in enumerate(self.tables)], dim=-1)          # gather + concat (data movement)
+            if isinstance(te.norm, nn.LayerNorm):
+                e = ops.layernorm_fwd(e, te.norm.weight.data, te.norm.bias.data, None, out_dtype=F32, eps=te.norm.eps)[0]
+            parts.append(ops.gemm_f32(e, te.project_emb.weight.data, bias=te.project_emb.bias.data))
+        x = ops.gemm_f32(torch.cat(parts, dim=-1), te.project_multiemb.weight.data, bias=te.project_multiemb.bias.data)
+        self.tok_emb[:n].copy_(x)
+        cols = [ln(x, m.emb_norm) if isinstance(m.emb_norm, nn.LayerNorm) else x]
+        if m.context_emb_mode == "cat" and self.ctx2d is not None:
+            cols.append(self.ctx2d[1:n + 1])
+        if m.style_emb_mode == "cat" and self.style2d is not None:
+            cols.append(self.style2d[1:n + 1])
+        xcat = torch.cat(cols, dim=-1) if len(cols) > 1 else cols[0]
+        if isinstance(m.project_emb, nn.Linear):
+            x = ops.gemm_f32(xcat, m.project_emb.weight.data, bias=m.project_emb.bias.data)
+        else:
+            x = xcat[:, :d].contiguous()
+        H, KV = self.heads * 64, self.kvh * 64
+        ai = 0
+        for lt, (norms, block, _res) in zip(tr.layer_types, tr.layers):
+            if lt == 'a':
+                self.hid[ai][:n].copy_(x)
+                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
+                qkv = ops.gemm_f32(ln(x, norms[0]), wqkv)
+                self.kc[ai][:n].copy_(qkv[:, H:H + KV])
+                self.vc[ai][:n].copy_(qkv[:, H + KV:H + 2 * KV])
+                self.kmax2[ai].copy_(torch.maximum(self.kmax2[ai], self.kc[ai][:n].view(n, self.kvh, 64).pow(2).sum(-1).amax(0)))
+                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+                o = torch.empty(n, H, device=self.dev, dtype=F32)
+                ops.dec_attn_rows(qkv, self.kc[ai], self.vc[ai], slopes, 0, o, h=self.heads, kvh=self.kvh, scale=block.scale)
+                ops.gemm_f32(o, block.to_out.weight.data, out=x, accumulate=True)
+                ai += 1
+            else:
+                lin = block.ff[0].proj if block.glu else block.ff[0][0]
+                u = ops.gemm_f32(ln(x, norms[0]), lin.weight.data, bias=lin.bias.data if lin.bias is not None else None)
+                inner = u.shape[1] // 2 if block.glu else u.shape[1]
+                g = ops.dec_glu_rows(u, torch.empty(n, inner, device=self.dev, dtype=F32), inner, act=block.act_code, glu=block.glu)
+                if isinstance(block.ff[1], nn.LayerNorm):
+                    g = ops.layernorm_fwd(g, block.ff[1].weight.data, block.ff[1].bias.data, None, out_dtype=F32, eps=block.ff[1].eps)[0]
+                out = block.ff[3]
+                ops.gemm_f32(g, out.weight.data, bias=out.bias.data if out.bias is not None else None, out=x, accumulate=True)
+        fn = tr.final_norm
+        self.hid[-1][:n].copy_(ln(x, fn) if not isinstance(fn, nn.Identity) else x)
+        self.length = n
+        self.prefilled_rows += n
+
+    @torch.no_grad()
     def decode(self, tokens: torch.Tensor, masked: torch.Tensor, context: Optional[torch.Tensor], style: Optional[torch.Tensor],
-               n_new: int) -> torch.Tensor:
+               n_new: int, batched_prefill: bool = True) -> torch.Tensor:
         """tokens / masked: int64 [Lin, K] (host or device), the last n_new rows carry MASK in the predicted dims; context / style:
-        device rows aligned with them.  Positions < self.length are taken from the caches.  Returns the n_new filled rows (device)."""
+        device rows aligned with them.  Positions < self.length are taken from the caches; a long uncached known prefix goes
+        through `prefill` (batched) unless batched_prefill=False (note by note).  Returns the n_new filled rows (device)."""
         Lin, c = tokens.shape[0], self.length
         if Lin > self.max_len:
             raise ValueError(f"window of {Lin} notes exceeds the session's max_len {self.max_len}")
@@ -377,6 +444,9 @@ class RenderSession(GreedyDecoder):
             self.ctx2d[c:Lin].copy_(context[c:Lin])
         if self.style2d is not None:
             self.style2d[c:Lin].copy_(style[c:Lin])
+        if batched_prefill and c == 0 and Lin - 1 - n_new >= self.prefill_min:
+            self.prefill(Lin - 1 - n_new)
+            c = self.length
         self.pos.fill_(c)
         steps = Lin - 1 - c
         done = 0

@@ -66,10 +66,10 @@ class ScorePerformerGenerator:
     def __init__(self, model, dataset, collator, messenger, device: Optional[Union[str, torch.device]] = None,
                  use_engine: bool = True, engine_max_len: int = 1024, prefill: str = "engine", prefill_min: int = 32):
         """use_engine: greedy decoding through `decode.RenderSession`.  prefill: how the caches of a window are rebuilt after the
-        context was cropped (or on a cold start with a long known prefix): "engine" = note by note with the fp32 engine (bit-exact
-        with the reference's fp32 tokens), "modules" = ONE batched module forward over the window (bf16 GEMMs, like the reference's
-        own batched recompute but not bit-exact in near-tied arg-maxes), adopted by the session when the prefix has at least
-        `prefill_min` rows."""
+        context was cropped (or on a cold start with a long known prefix): "engine" = one batched pass of the fp32 engine
+        (`RenderSession.prefill`: exact-fp32 GEMMs + position-parallel attention; reproduces the reference's fp32 tokens),
+        "sequential" = the fp32 engine note by note, "modules" = one batched module forward over the window (bf16 GEMMs; not
+        bit-exact in near-tied arg-maxes), adopted by the session when the prefix has at least `prefill_min` rows."""
         self.model = model
         assert model.perf_decoder is not None
         self.dataset = dataset
@@ -79,8 +79,8 @@ class ScorePerformerGenerator:
         self.eos_token_id = self.tokenizer[0, EOS_TOKEN]
         self.messenger = messenger
         self.device = torch.device(device) if device is not None else next(model.parameters()).device
-        if prefill not in ("engine", "modules"):
-            raise ValueError("prefill must be 'engine' or 'modules'")
+        if prefill not in ("engine", "sequential", "modules"):
+            raise ValueError("prefill must be 'engine', 'sequential' or 'modules'")
         self.use_engine, self.engine_max_len, self.prefill, self.prefill_min = use_engine, engine_max_len, prefill, prefill_min
         self._session = None
         self._init_variables()
@@ -234,7 +234,8 @@ class ScorePerformerGenerator:
                         session.load_caches(self._prefill_modules(model_in[:have + 1], doubled[:have + 1], score_embs, perf_embs))
                 else:
                     session.truncate(caches.length)
-                rows = session.decode(torch.from_numpy(model_in), torch.from_numpy(doubled), score_embs, perf_embs, n_new)
+                rows = session.decode(torch.from_numpy(model_in), torch.from_numpy(doubled), score_embs, perf_embs, n_new,
+                                      batched_prefill=self.prefill == "engine")
                 gen_tokens = rows.cpu().numpy()                                # the loop's one D2H copy per chord group
                 caches = _EngineCache(start_idx, session.length)
                 session.tag = caches

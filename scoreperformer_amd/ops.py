@@ -680,6 +680,19 @@ def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, co
          ptr(pos), ptr(part), ptr(counter), c_int(slabs), stream_ptr())
 
 
+def dec_attn_rows(q, kcache, vcache, slopes, t0, o, *, h, kvh, scale):
+    """Causal single-query attention for rows t0 .. t0+n-1 at once (q: [n, >= h*64] fp32 view, o: [n, h*64])."""
+    call("spn_dec_attn_rows", ptr(q), c_long(q.stride(0)), ptr(kcache), ptr(vcache), ptr(slopes), c_int(t0), c_int(q.shape[0]), ptr(o),
+         c_long(o.stride(0)), c_int(h), c_int(kvh), c_float(scale), stream_ptr())
+    return o
+
+
+def dec_glu_rows(u, out, I, *, act=0, glu=True):
+    call("spn_dec_glu_rows", ptr(u), c_long(u.stride(0)), ptr(out), c_long(out.stride(0)), c_int(u.shape[0]), c_int(I), c_int(act),
+         c_int(int(glu)), stream_ptr())
+    return out
+
+
 def dec_add_pos(pos, delta=1):
     call("spn_dec_add_pos", ptr(pos), c_int(delta), stream_ptr())
 

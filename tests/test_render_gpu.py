@@ -65,6 +65,19 @@ def test_engine_render_loop_matches_the_reference_generator(name):
         have = -1 if gen.perf_data.caches is None else gen.perf_data.caches.length
         assert have == call["cache_len"], (i, have, call["cache_len"])
     assert gen._session is not None and gen._session.steps_run > 0, "the HIP decode engine must have produced the tokens"
+    if name == "crop":
+        assert gen._session.prefilled_rows > 0          # cropped windows were re-primed by the batched fp32 pass
+
+
+def test_sequential_prefill_gives_the_same_tokens():
+    """prefill="sequential" (note-by-note recompute after a crop) and the batched fp32 prefill agree with the reference and each other."""
+    dev = torch.device("cuda")
+    gen_for, _ = make(True, dev)
+    s = SCEN["crop"]
+    gen = gen_for(s["piece"])
+    gen.prefill = "sequential"
+    list(replay(gen, s, dev))
+    assert gen._session.prefilled_rows == 0 and gen._session.steps_run > 0
 
 
 def test_module_path_render_loop_runs_the_same_loop():
@@ -137,6 +150,7 @@ def test_batched_prefill_adopts_module_caches():
     assert gen.perf_data.reached_eos and got.shape == want.shape and np.array_equal(got[:, given], want[:, given])
     # far fewer sequential steps than notes x window: the crops were served by batched forwards
     exact = gen_for(s["piece"])
+    exact.prefill = "sequential"
     list(replay(exact, s, dev))
     assert gen._session.steps_run < 0.5 * exact._session.steps_run
     assert (got == want).mean() > 0.85

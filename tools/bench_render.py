@@ -39,7 +39,8 @@ def main():
     dec = model.perf_decoder.model
     collator = SimpleNamespace(mask_token_id=1, mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
     res = {"workload": f"C5 render loop: {a.notes}-note piece, max_context_len {a.context}, time window {a.window} s, greedy, chord groups"}
-    for name, use_engine, notes, prefill in (("engine", True, a.notes, "engine"), ("engine_batched_prefill", True, a.notes, "modules"),
+    for name, use_engine, notes, prefill in (("engine", True, a.notes, "engine"), ("engine_sequential_prefill", True, a.module_notes * 2, "sequential"),
+                                           ("engine_batched_prefill", True, a.notes, "modules"),
                                            ("modules", False, a.module_notes, "engine")):
         piece = make_piece(7, notes, PERFORMANCE_VOCAB)
         g = torch.Generator().manual_seed(1)
@@ -67,6 +68,7 @@ def main():
         done = gen.perf_data.gen_seq.shape[0] - 1
         res[name] = {"notes": int(done), "calls": calls, "seconds": dt, "notes_per_s": done / dt, "messages": messages,
                      "decoder_steps": int(gen._session.steps_run) if gen._session is not None else None,
+                     "prefilled_rows": int(gen._session.prefilled_rows) if gen._session is not None else None,
                      "music_seconds": t, "realtime_factor": t / dt}
     res["speedup_engine_vs_modules"] = res["engine"]["notes_per_s"] / res["modules"]["notes_per_s"]
     res["speedup_engine_batched_prefill_vs_modules"] = res["engine_batched_prefill"]["notes_per_s"] / res["modules"]["notes_per_s"]
