@@ -82,3 +82,55 @@ def make_piece(seed, n_notes, vocab, notes_per_bar=6.0):
 def make_dataset(vocab, pieces):
     return SimpleNamespace(tokenizer=FakeTokenizer(vocab), performances=list(pieces), processor=FakeProcessor(),
                            performance_names=[f"piece{i}" for i in range(len(pieces))])
+
+
+class _Scores(list):
+    def __init__(self, seqs, name_to_idx):
+        super().__init__(seqs)
+        self._name_to_idx = name_to_idx
+
+
+# ---- a windowed score/performance dataset for `encode_embeddings` (generators.py:320-424) ----------------------------------------
+class FakeScoreDataset:
+    """One aligned score/performance pair served in bar windows, with the attributes `encode_embeddings` reads from the reference's
+    `ScorePerformanceDataset`: performance_names, _performance_map, scores (+ _name_to_idx), _score_indices, indexer, get(meta),
+    max_seq_len, max_bar, _beat_maps, _onset_maps, tokenizer, performances, processor."""
+
+    def __init__(self, vocab, perf_seq, max_seq_len=48, max_bar=256):
+        self.tokenizer = FakeTokenizer(vocab)
+        self.processor = FakeProcessor()
+        self.performances = [perf_seq]
+        self.performance_names = ["perf0"]
+        self._performance_map = {"perf0": ("score0", None)}
+        score_seq = perf_seq[:, :10].copy()
+        self.scores = _Scores([score_seq], {"score0": 0})
+        self._score_indices = [None]
+        self.indexer = SimpleNamespace(compute_bar_indices=self._bar_indices)
+        self.max_seq_len, self.max_bar = max_seq_len, max_bar
+        n = len(perf_seq)
+        self._beat_maps = [np.cumsum(np.r_[0, np.diff(perf_seq[:, 1]) != 0]).astype(np.int64) // 2 + ZERO]
+        self._onset_maps = [np.cumsum(np.r_[0, (np.diff(perf_seq[:, 0]) != 0) | (np.diff(perf_seq[:, 1]) != 0)]).astype(np.int64) + ZERO]
+        assert len(self._beat_maps[0]) == n
+
+    @staticmethod
+    def _bar_indices(score_seq):
+        bars = score_seq[:, 0] - ZERO
+        first = [int(np.argmax(bars >= b)) for b in range(int(bars.max()) + 1)]
+        return np.array(first + [len(score_seq)], dtype=np.int64)       # first note of every bar, then the total
+
+    def get(self, meta):
+        perf, score = self.performances[0], self.scores[0]
+        idx = self._bar_indices(score)
+        total_bars = len(idx) - 2
+        lo, hi = idx[meta.start_bar], idx[min(meta.end_bar, total_bars) + 1]
+        s, p = score[lo:hi].copy(), perf[lo:hi].copy()
+        seg = SimpleNamespace(bar=(s[:, 0] - s[0, 0] + ZERO).astype(np.int64), beat=(self._beat_maps[0][lo:hi] - self._beat_maps[0][lo] + ZERO),
+                              onset=(self._onset_maps[0][lo:hi] - self._onset_maps[0][lo] + ZERO))
+        pad = lambda a, left, right: np.concatenate([[a[0]]] * left + [a] + [[a[-1]]] * right)
+        sos, eos = meta.start_bar == 0, meta.end_bar >= total_bars
+        if sos:
+            s, p = FakeProcessor.add_sos_token(s), FakeProcessor.add_sos_token(p)
+        if eos:
+            s, p = FakeProcessor.add_eos_token(s), FakeProcessor.add_eos_token(p)
+        seg = SimpleNamespace(**{k: pad(getattr(seg, k), int(sos), int(eos)) for k in ("bar", "beat", "onset")})
+        return SimpleNamespace(score=s, perf=p, noisy_perf=None, segments=seg, directions=None, is_deadpan=False, meta=meta)

@@ -56,6 +56,22 @@ def get_end_bar(score_indices, start_bar=0, max_seq_len=512, max_bar=256):   # d
 
 
 @dataclass
+class ScorePerformanceSampleMeta:                       # data/datasets/score_performance.py:37-50 (what `dataset.get(meta=...)` reads)
+    idx: Optional[int]
+    score_idx: int
+    perf_idx: int
+    start_bar: int
+    end_bar: Optional[int]
+    start_idx: Optional[int] = None
+    end_idx: Optional[int] = None
+    bar_offset: int = 0
+    note_shifts: tuple = (0, 0)
+    augmentations: Optional[object] = None
+    noisy_augmentations: Optional[object] = None
+    is_deadpan: bool = False
+
+
+@dataclass
 class _EngineCache:
     """What `perf_data.caches` holds on the engine path: which window the session's cache rows belong to and how many are valid."""
     start_idx: int
@@ -348,8 +364,8 @@ class ScorePerformerGenerator:
             ds._score_indices[score_idx] = score_indices
         start_bar = 0
         end_bar = get_end_bar(score_indices, start_bar, ds.max_seq_len, ds.max_bar)
-        meta = ds.sample_meta(idx=None, score_idx=score_idx, perf_idx=perf_idx, start_bar=start_bar, end_bar=end_bar,
-                              augmentations=augmentations)
+        meta = ScorePerformanceSampleMeta(idx=None, score_idx=score_idx, perf_idx=perf_idx, start_bar=start_bar, end_bar=end_bar,
+                                          augmentations=augmentations)
         sample = ds.get(meta=meta)
         bar_idx, bar0 = tok.vocab_types_idx["Bar"], tok.zero_token
         score_seq = ds.scores[score_idx]

@@ -154,3 +154,39 @@ def test_batched_prefill_adopts_module_caches():
     list(replay(exact, s, dev))
     assert gen._session.steps_run < 0.5 * exact._session.steps_run
     assert (got == want).mean() > 0.85
+
+
+@pytest.mark.parametrize("overlay", [0.0, 0.5])
+def test_encode_embeddings_windows_match_the_reference(overlay):
+    """`encode_embeddings` (generators.py:320-424): bar windows of `dataset.max_seq_len` notes through the HIP encoders (batches built
+    by the device-side collator), overlapping parts dropped, against the reference's concatenated embeddings and latents."""
+    import os
+    from oracle.render_fakes import FakeMessenger, FakeScoreDataset
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    from scoreperformer_amd.inference import ScorePerformerGenerator
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "encode_embeddings.npz"))
+    dev = torch.device("cuda")
+    model = ScorePerformer.init(model_config(preset="tiny", num_tokens=VOCAB))
+    model.load_state_dict(filled_state_dict(model, seed=SEED))
+    arena = ParamArena(model, dev)   # noqa: F841
+    model.eval()
+    ds = FakeScoreDataset(VOCAB, z["piece"], max_seq_len=int(z["max_seq_len"]))
+    gen = ScorePerformerGenerator(model, ds, MixedLMScorePerformanceCollator(**COLLATOR), FakeMessenger(VOCAB), device=dev)
+    se, pe, lat = gen.encode_embeddings(0, compute_latents=True, overlay_bars=overlay)
+    for got, key in ((se, "score_emb"), (pe, "perf_emb")):
+        want = z[f"overlay{overlay}/{key}"]
+        got = got.float().cpu().numpy()
+        assert got.shape == want.shape                                  # the window bookkeeping: every note exactly once
+        assert np.abs(got - want).max() <= 0.03 * np.abs(want).max(), key   # bf16 encoder GEMMs
+    lat = lat if isinstance(lat, (list, tuple)) else [lat]
+    for i, t in enumerate(lat):
+        want = z[f"overlay{overlay}/latent{i}"]
+        assert tuple(t.shape) == want.shape
+        assert np.abs(t.float().cpu().numpy() - want).max() <= 0.05 * max(np.abs(want).max(), 1e-3), i
+    # prepare_performance_notes computes them itself when they are not passed (generators.py:87-91)
+    gen.prepare_performance_notes(0, overlay_bars=overlay)
+    assert gen.perf_data.embeddings.shape[0] == len(z["piece"]) + 2 and gen.perf_data.context.shape[0] == len(z["piece"]) + 2
