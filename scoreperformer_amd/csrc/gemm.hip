@@ -50,6 +50,7 @@ struct GemmArgs {
     int kt_per_split;         // K tiles per slice
     int ngroup;               // n-tiles per column group of the tile order
     int pp_addr_ok;           // both operands span < 2^31 bytes (the ping-pong kernel addresses them with 32-bit offsets)
+    int tx, ty;               // ping-pong kernel: tile grid (n-tiles, m-tiles); a launch with fewer blocks walks it persistently
 #ifdef SPN_GEMM_TIMING
     long long* dbg;
 #endif
@@ -427,21 +428,28 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int wr = wave >> 2, wc = wave & 3;
 #ifdef SPN_GEMM_TIMING
     const long long t_start = __builtin_amdgcn_s_memtime();
+    long long t_loop_end = t_start;
 #endif
     // workgroup id -> tile: XCD-contiguous (id % 8 = XCD), then column groups of `ngroup` n-tiles, m-tiles down each group (see
     // gemm_kernel): the 32 tiles an XCD runs together share few B panels and few A panels
-    const int nwg = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+    // the tile grid is g.tx x g.ty; a launch of exactly that many blocks runs one tile per block, a smaller one (256 blocks, one per CU)
+    // walks the tile ids block, block + 256, ... : no workgroup launch between tiles, and the next tile's first DMA goes out while the
+    // stores of the previous one drain
+    const int nwg = g.tx * g.ty, first = blockIdx.y * gridDim.x + blockIdx.x, stride = gridDim.x * gridDim.y;
+    // tile id -> tile: XCD-contiguous (id % 8 = XCD), then column groups of `ngroup` n-tiles, m-tiles down each group (see
+    // gemm_kernel): the 32 tiles an XCD runs together share few B panels and few A panels
     auto tile_of = [&](int id, int& tm, int& tn) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-        const int G = g.ngroup, mt = gridDim.y, per = G * mt;
+        const int G = g.ngroup, mt = g.ty, per = G * mt;
         const int c = wg / per, within = wg - c * per;
-        const int gw = min(G, (int)gridDim.x - c * G);
+        const int gw = min(G, g.tx - c * G);
         tm = (within / gw) * PP_BM;
         tn = (c * G + within % gw) * PP_BN;
     };
+    for (int vid = first; vid < nwg; vid += stride) {
     int m0, n0;
-    tile_of(bid, m0, n0);
+    tile_of(vid, m0, n0);
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
     const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();   // balances the second group's extra barrier
 #ifdef SPN_GEMM_TIMING
-    const long long t_loop_end = __builtin_amdgcn_s_memtime();
+    t_loop_end = __builtin_amdgcn_s_memtime();
     if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4) && lane == 0)
         for (int k = 0; k < 8; ++k) g.dbg[(wave >> 2) * 8 + k] = seg[k];
 #endif
@@ -645,6 +653,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                 *reinterpret_cast<uint4*>(dst) = val;
             }
         }
+    }
+    __syncthreads();   // every wave has read its staging slab back: the ring may be refilled for the next tile
     }
 #ifdef SPN_GEMM_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -756,6 +766,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
     g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
+    g.tx = grid.x; g.ty = grid.y;
+    static const int persist_env = getenv("SPN_GEMM_PERSIST") ? atoi(getenv("SPN_GEMM_PERSIST")) : 0;   // tuning aid: 0 off, else min rounds
+    if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);
