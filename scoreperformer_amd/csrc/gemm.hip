@@ -447,37 +447,31 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         tm = (within / gw) * PP_BM;
         tn = (c * G + within % gw) * PP_BN;
     };
-    for (int vid = first; vid < nwg; vid += stride) {
-    int m0, n0;
-    tile_of(vid, m0, n0);
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
     const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
     const int nt_all = g.K / PP_BK;
     const int t_begin = split ? blockIdx.z * g.kt_per_split : 0;
     const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
-    if (nt <= 0) return;
+    if (nt <= 0 || first >= nwg) return;
     const int kbase = t_begin * PP_BK;
     const int total = 4 * nt;   // half-tiles in the stream
-
-    f32x16 acc[4][2];   // acc[2h + i][j]: rows 64h + 32i.., columns 32j..
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    int m0, n0;
+    tile_of(first, m0, n0);
+    int extra = 0;              // VMEM stores of the previous tile's epilogue that are younger than this tile's prologue DMA
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
     uint32_t vo[4][2];   // [kind][piece]
+    auto set_tile = [&](int tm, int tn) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        vo[0][i] = pp_voffset<TA, 64>(g.lda, m0, g.M, 0, wave, lane, i);
-        vo[1][i] = pp_voffset<TB, 32>(g.ldb, n0, g.N, 0, wave, lane, i);
-        vo[2][i] = pp_voffset<TB, 32>(g.ldb, n0, g.N, 1, wave, lane, i);
-        vo[3][i] = pp_voffset<TA, 64>(g.lda, m0, g.M, 1, wave, lane, i);
-    }
+        for (int i = 0; i < 2; ++i) {
+            vo[0][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 0, wave, lane, i);
+            vo[1][i] = pp_voffset<TB, 32>(g.ldb, tn, g.N, 0, wave, lane, i);
+            vo[2][i] = pp_voffset<TB, 32>(g.ldb, tn, g.N, 1, wave, lane, i);
+            vo[3][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 1, wave, lane, i);
+        }
+    };
+    set_tile(m0, n0);
     auto issue = [&](int c, int t) {   // c is a compile-time constant at every call site
         const int k0 = kbase + t * PP_BK;
         const bool isA = (c == 0 || c == 3);
@@ -488,14 +482,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(dst + i * 1024), 16, vo[c][i], soff, 0, 0);
     };
     // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
+    // Stores of the previous tile's epilogue sit between S[5] and S[6] of this tile in the (in-order) VM counter: while the awaited
+    // half-tile is one of S[0..5] (phases <= 3) they count among the younger operations.
+    constexpr int NS = sizeof(OutT) == 2 ? 16 : 32;   // store instructions per wave of one interior-tile epilogue
     auto wait_landed = [&](int p) {
-#ifdef PP_WAIT_ALTERNATE
-        // variant: wait only in even phases (and the prologue), one half-tile deeper, so that the following odd phase needs none
-        if (p >= 0 && (p & 1)) return;
-        const int younger = min(p + PP_LEAD + 1, total) - (p + 4);
-#else
         const int younger = min(p + PP_LEAD + 1, total) - (p + 3);
-#endif
+        if (extra && p <= 3) {   // younger == 4 here (total >= 16)
+            if (NS == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            return;
+        }
         if (younger >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -519,8 +515,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     TSTAMP(6)
 
     // prologue: S[0..5] = K tile 0 and AX, BX of K tile 1
-    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
-    if (nt > 1) { issue(0, 1); issue(1, 1); }
+    auto prologue = [&]() {
+        issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+        if (nt > 1) { issue(0, 1); issue(1, 1); }
+    };
+    prologue();
+    for (int vid = first; vid < nwg; vid += stride) {
+    f32x16 acc[4][2];   // acc[2h + i][j]: rows 64h + 32i.., columns 32j..
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
     wait_landed(-1);
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind the first
@@ -602,59 +610,72 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #undef PP_SYNC_MFMA_END
 #undef PP_SLOT
 
-    // ---- epilogue: through the wave's own 16 KiB LDS slab, so that C leaves as whole 128-byte row segments (see gemm_kernel) ----
+    // ---- epilogue: through the wave's own 4 KiB slab of the 32 KiB the ring leaves free, so that C leaves as whole 128-byte row
+    //      segments (see gemm_kernel) while the ring already receives the NEXT tile's first half-tiles ----
     OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
     const bool lead = !split || blockIdx.z == 0;
-    __syncthreads();   // every wave is done with the operand ring
-    constexpr int ES = sizeof(OutT), ROWB = 64 * ES, CPR = ROWB / 16;    // bytes per row of the wave's 128x64 block, chunks per row
-    constexpr int RPP = 16384 / ROWB, NPASS = 128 / RPP;                  // rows per pass: 128 (bf16) / 64 (fp32)
-    char* stg = smem + wave * 16384;
+    constexpr int ES = sizeof(OutT);
+    constexpr int JP = ES == 2 ? 2 : 1;                 // 32-column halves of the wave's 128x64 block staged per pass
+    constexpr int ROWB = 32 * JP * ES, CPR = ROWB / 16; // 128-byte rows, 8 chunks: a pass = 32 rows = 4 KiB
+    char* stg = smem + 8 * PP_HALF + wave * 4096;
     f32x4 bv[8];
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq)
         bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4))
                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // every wave is done with the operand ring
+    const int cm0 = m0, cn0 = n0;
+    const bool has_next = vid + stride < nwg;
+    if (has_next) {    // the next tile's prologue DMA goes out now: its latency hides behind this epilogue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads above; nothing else is outstanding)
+        tile_of(vid + stride, m0, n0);
+        set_tile(m0, n0);
+        prologue();
+    }
+    // interior tiles issue exactly NS store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
+    extra = (has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0;
 #pragma unroll
-    for (int pass = 0; pass < NPASS; ++pass) {
+    for (int i = 0; i < 4; ++i) {
+        const int row = lane & 31;
+        const int m = cm0 + wr * 128 + 32 * i + row;
+        const float rs = g.rowmask ? (g.rowmask[min(m, g.M - 1)] ? 1.f : 0.f) : 1.f;
 #pragma unroll
-        for (int ii = 0; ii < RPP / 32; ++ii) {
-            const int i = pass * (RPP / 32) + ii;
-            const int row = 32 * ii + (lane & 31);
-            const int m = m0 + wr * 128 + 32 * i + (lane & 31);
-            const float rs = g.rowmask ? (g.rowmask[min(m, g.M - 1)] ? 1.f : 0.f) : 1.f;
+        for (int jh = 0; jh < 2 / JP; ++jh) {
 #pragma unroll
-            for (int jq = 0; jq < 8; ++jq) {
-                const int j = jq >> 2, q = jq & 3;
-                const int n = n0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
-                f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[jq]) * rs;
-                if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
-                const int colb = (32 * j + 8 * q + (lane >> 5) * 4) * ES;
-                char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
+            for (int jj = 0; jj < JP; ++jj) {
+                const int j = jh * JP + jj;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = cn0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
+                    f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[j * 4 + q]) * rs;
+                    if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                    const int colb = (32 * jj + 8 * q + (lane >> 5) * 4) * ES;
+                    char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
+                    if constexpr (ES == 4) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    } else {
+                        uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                const uint4 val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ r) & (CPR - 1)) << 4));
+                const int mo = cm0 + wr * 128 + 32 * i + r, no = cn0 + wc * 64 + jh * JP * 32 + chunk * (16 / ES);
+                if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
+                OutT* dst = C + (long)mo * g.ldc + no;
                 if constexpr (ES == 4) {
+                    f32x4 v = __builtin_bit_cast(f32x4, val);
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
-                    uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = pk;
+                    *reinterpret_cast<uint4*>(dst) = val;
                 }
             }
         }
-#pragma unroll
-        for (int it = 0; it < RPP * CPR / 64; ++it) {
-            const int row = it * (64 / CPR) + lane / CPR, chunk = lane % CPR;
-            const uint4 val = *reinterpret_cast<const uint4*>(stg + row * ROWB + (((chunk ^ row) & (CPR - 1)) << 4));
-            const int mo = m0 + wr * 128 + pass * RPP + row, no = n0 + wc * 64 + chunk * (16 / ES);
-            if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
-            OutT* dst = C + (long)mo * g.ldc + no;
-            if constexpr (ES == 4) {
-                f32x4 v = __builtin_bit_cast(f32x4, val);
-                if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else {
-                *reinterpret_cast<uint4*>(dst) = val;
-            }
-        }
     }
-    __syncthreads();   // every wave has read its staging slab back: the ring may be refilled for the next tile
     }
 #ifdef SPN_GEMM_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -756,7 +777,7 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     } else {
         g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
-    constexpr int LDS_BYTES = 8 * PP_HALF;
+    constexpr int LDS_BYTES = 8 * PP_HALF + 8 * 4096;   // operand ring + epilogue staging
     static bool attr_done = false;
     if (!attr_done) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
