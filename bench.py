@@ -140,7 +140,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        # RCCL's version banner sits in the C stdio buffer until exit: push it out first so that the JSON line is the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def roofline_leg(ops, step, args):
