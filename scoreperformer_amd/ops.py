@@ -24,6 +24,19 @@ def _dt(t_or_dtype) -> int:
     raise SpnError(f"unsupported dtype {dt}")
 
 
+def _fit8(t: torch.Tensor, k_rows: bool, K8: int) -> torch.Tensor:
+    """GEMM operand with 8-element aligned rows, a 16-byte aligned base and K zero-padded to K8 (a copy only when needed).
+    k_rows: K is the row dimension (the operand is stored transposed)."""
+    rows, cols = t.shape
+    ok = t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 and (rows == K8 if k_rows else cols == K8)
+    if ok:
+        return t
+    R, C = (K8, (cols + 7) // 8 * 8) if k_rows else (rows, K8)
+    buf = torch.zeros((R, C), device=t.device, dtype=t.dtype)
+    buf[:rows, :cols].copy_(t)
+    return buf[:, :cols] if k_rows else buf
+
+
 def _rows2d(t: torch.Tensor) -> torch.Tensor:
     """View as 2-D [rows, cols] with unit inner stride (no copy when possible)."""
     if t.ndim != 2:
@@ -57,6 +70,27 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, ta: bool = False, tb: bool = False
         out = torch.empty((M, N), device=a.device, dtype=out_dtype)
     if out.shape != (M, N) or out.stride(1) != 1:
         raise SpnError("gemm: bad output tensor")
+    # the kernels load 16-byte (8-element) row pieces: operands of a model whose widths are not multiples of 8 are copied once into
+    # zero-padded buffers (zero K-columns add nothing); a padded M (A stored transposed) or N (B stored transposed) is computed into a
+    # padded C and the valid block copied out
+    K8 = (K + 7) // 8 * 8
+    M8, N8 = ((M + 7) // 8 * 8 if ta else M), ((N + 7) // 8 * 8 if tb else N)
+    a, b = _fit8(a, ta, K8), _fit8(b, tb, K8)
+    if (M8, N8) != (M, N):   # rare (widths off the 8-grid): padded product, then the epilogue terms on the valid block
+        a = torch.nn.functional.pad(a, (0, M8 - a.shape[1])) if ta and a.shape[1] != M8 else a
+        b = torch.nn.functional.pad(b, (0, N8 - b.shape[1])) if tb and b.shape[1] != N8 else b
+        pb = torch.nn.functional.pad(bias, (0, N8 - N)) if bias is not None and N8 != N else bias
+        res = gemm(a, b, ta=ta, tb=tb, out_dtype=F32, bias=pb, alpha=alpha)[:M, :N]
+        if rowmask is not None:
+            res = res * rowmask.reshape(-1, 1).to(F32)
+        if residual is not None:
+            res = res + _rows2d(residual)
+        if accumulate:
+            out.add_(res)
+        else:
+            out.copy_(res)
+        return out
+    K = K8
     flags = (1 if ta else 0) | (2 if tb else 0) | (4 if out.dtype == F32 else 0) | (8 if accumulate else 0)
     if residual is not None:
         residual = _rows2d(residual)

@@ -100,3 +100,31 @@ def test_mlm_single_run_unmask(dev):
         out = mlm.unmask_tokens(tokens, single_run=True, x_extra=batch["masked_perf"], context=enc.score_embeddings,
                                 style_embeddings=enc.perf_embeddings)
     assert int((out == 1).sum()) == 0 and (out[tokens != 1] == tokens[tokens != 1]).all()
+
+
+def test_model_widths_off_the_8_element_grid(dev):
+    """A model whose latent widths are not multiples of 8 (sum 12): the GEMM wrapper pads the operands; forward matches the oracle,
+    backward runs and every gradient is finite."""
+    from oracle import ref_cpu
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    vocab = {"Bar": 40, "Position": 36, "Pitch": 28, "Velocity": 36, "Duration": 37, "Tempo": 29, "TimeSig": 10, "PositionShift": 21,
+             "NotesInOnset": 16, "PositionInOnset": 16, "RelOnsetDev": 45, "RelPerfDuration": 25}
+    kw = dict(preset="tiny", num_tokens=vocab, dim=32, heads=2, depths=(1, 1, 1), emb_dims=8, latent_dim=[4, 4, 2, 2], max_seq_len=64)
+    cfg = model_config(**kw)
+    model = ScorePerformer.init(model_config(**kw))
+    sd = filled_state_dict(model, seed=1)
+    model.load_state_dict(sd)
+    arena = ParamArena(model, dev)
+    model.train()
+    batch = synthetic_batch(2, 24, seed=5, ragged=True, num_tokens=vocab)
+    z = [torch.randn(256, d, generator=torch.Generator().manual_seed(i)) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
+    model.perf_encoder._z_override = [t.to(dev) for t in z]
+    out = model(**{k: v.to(dev) for k, v in batch.items()})
+    arena.zero_grad()
+    out.loss.backward()
+    ref = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
+    assert abs(float(out.loss.detach()) - float(ref["loss"])) <= 1e-2 * float(ref["loss"])
+    assert bool(torch.isfinite(arena.grads).all()) and float(arena.grads.abs().sum()) > 0

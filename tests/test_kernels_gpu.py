@@ -346,3 +346,22 @@ def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
     assert rel_err(dq, qr.grad) < 4e-2
     assert rel_err(dk, kr.grad) < 4e-2
     assert rel_err(dv, vr.grad) < 4e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,ta,tb", [(37, 50, 27, False, False), (37, 50, 27, True, False), (37, 50, 27, False, True),
+                                        (37, 50, 27, True, True), (300, 44, 260, False, False), (129, 12, 100, True, True)])
+def test_gemm_accepts_widths_that_are_not_multiples_of_8(M, N, K, ta, tb):
+    """Model widths off the 8-element grid (a `dim` of 100, a latent of 12): the wrapper pads the operands, results are unchanged."""
+    from scoreperformer_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).bfloat16().to(dev)
+    b = torch.randn((K, N) if tb else (N, K), generator=g).bfloat16().to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = ops.gemm(a, b, ta=ta, tb=tb, out_dtype=torch.float32, bias=bias)
+    ref = (a.float().t() if ta else a.float()) @ (b.float() if tb else b.float().t()) + bias
+    assert out.shape == (M, N)
+    assert torch.allclose(out, ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    out16 = ops.gemm(a, b, ta=ta, tb=tb)
+    assert torch.allclose(out16.float(), ref - bias, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
