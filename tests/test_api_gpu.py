@@ -128,3 +128,29 @@ def test_model_widths_off_the_8_element_grid(dev):
     ref = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
     assert abs(float(out.loss.detach()) - float(ref["loss"])) <= 1e-2 * float(ref["loss"])
     assert bool(torch.isfinite(arena.grads).all()) and float(arena.grads.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["no_cont_tokens", "no_masked_seq", "no_score_enc", "no_saln", "no_io_tie", "custom_hierarchy"])
+def test_ablation_recipe_variants_match_the_reference_loss(dev, name):
+    """The model variants of recipes/scoreperformer/ablation/*.yaml and custom_hierarchy.yaml: HIP forward against the reference's own
+    loss (tests/golden/ablations.npz); backward runs."""
+    from test_ablations_cpu import golden
+    from oracle.variants import SMALL_VOCAB, ablation_config
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import synthetic_batch
+    model = ScorePerformer.init(ablation_config(name))
+    model.load_state_dict(filled_state_dict(model, seed=1))
+    arena = ParamArena(model, dev)
+    model.train()
+    draws, loss, losses = golden(name)
+    model.perf_encoder._z_override = [z.to(dev) for z in draws]
+    batch = synthetic_batch(2, 40, seed=5, ragged=True, num_tokens=SMALL_VOCAB, device=dev)
+    out = model(**batch)
+    arena.zero_grad()
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - loss) < 1e-2 * abs(loss), (float(out.loss.detach()), loss)   # tiny model, bf16 GEMMs
+    for k, v in losses.items():
+        assert abs(float(out.losses[k]) - v) < 3e-2 * max(1.0, abs(v)), k
+    assert bool(torch.isfinite(arena.grads).all())
