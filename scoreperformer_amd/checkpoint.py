@@ -61,13 +61,24 @@ def _adamw_state_on_host(optimizer):
     return sd
 
 
+def _plain(obj):
+    """Config containers -> builtin dicts / lists (a checkpoint must unpickle without this package)."""
+    if obj is None or isinstance(obj, (str, int, float, bool)):
+        return obj
+    if isinstance(obj, dict):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    if hasattr(obj, "items"):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    return OmegaConf.to_container(obj, resolve=True) if hasattr(OmegaConf, "to_container") else obj
+
+
 def save_checkpoint(path: str, model, optimizer=None, *, model_config=None, experiment: Optional[dict] = None, lr_scheduler=None,
                     minimal: bool = False) -> dict:
     """`Trainer._save_checkpoint` (trainer.py:296-314).  `model_config`: dict / attr-dict of the model section; `experiment`:
     {"config", "trainer", "state"} JSON strings (kept verbatim)."""
-    cfg = model_config
-    if cfg is not None and not isinstance(cfg, dict):
-        cfg = OmegaConf.to_container(cfg, resolve=True)
+    cfg = _plain(model_config)   # plain dict / list / scalars, like OmegaConf.to_container(..., resolve=True) in the reference
     checkpoint = {
         "experiment": dict({"config": None, "trainer": None, "state": None}, **(experiment or {})),
         "model": {"config": cfg, "state_dict": model_state_dict(model, getattr(optimizer, "arena", None))},

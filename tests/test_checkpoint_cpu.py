@@ -63,3 +63,25 @@ def test_warm_start_ignores_layers_and_mismatched_keys():
             assert torch.equal(after[k], before[k]), k
         else:
             assert torch.equal(after[k], ref["model"]["state_dict"][k]), k
+
+
+def test_saved_config_is_plain_builtins(tmp_path):
+    """The model config goes into the file as builtin dicts / lists (trainer.py:305: OmegaConf.to_container), whatever container
+    the caller holds: the file must unpickle without this package's config classes."""
+    import pickle
+    from scoreperformer_amd.checkpoint import save_checkpoint
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    from oracle.variants import SMALL_VOCAB
+    cfg = model_config(preset="tiny", num_tokens=SMALL_VOCAB, dim=32, heads=2, depths=(1, 1, 1), emb_dims=8, latent_dim=[8, 4, 2, 2], max_seq_len=64)
+    model = ScorePerformer.init(cfg)                      # `init` wraps the dict in the package's attr-dict container
+    out = str(tmp_path / "c.pt")
+    save_checkpoint(out, model, None, model_config=model.config if hasattr(model, "config") else cfg, minimal=True)
+    again = torch.load(out, map_location="cpu", weights_only=True)     # weights_only: builtin containers and tensors only
+
+    def check(o):
+        assert type(o) in (dict, list, str, int, float, bool, type(None)), type(o)
+        for v in (o.values() if isinstance(o, dict) else o if isinstance(o, list) else ()):
+            check(v)
+    check(again["model"]["config"])
+    assert ScorePerformer.from_pretrained(out) is not None
