@@ -135,3 +135,21 @@ def test_device_batch_drives_the_model():
         b = model(**host)
     # identical inputs (bit-exact above); the segment sums use float atomics, so allow summation-order noise
     assert abs(a.loss.item() - b.loss.item()) < 1e-5 * abs(b.loss.item())
+
+
+def test_device_collator_as_dataloader_collate_fn():
+    """`DataLoader(dataset, collate_fn=collator)` in the training process (num_workers=0), as experiments/trainer.py builds it."""
+    from oracle.collate_cpu import collate_mixlm
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator
+    ins = ragged(np.random.default_rng(77), 10, 5, 40, 10, 12)
+    samples = samples_of(ins)
+    kw = dict(pad_to_multiple_of=8, mask_ignore_token_ids=[0, 1, 2, 3], mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
+    loader = torch.utils.data.DataLoader(samples, batch_size=4, shuffle=False, collate_fn=MixedLMScorePerformanceCollator(**kw), pin_memory=True)
+    seen = 0
+    for data in loader:
+        n = data.performances.tokens.shape[0]
+        sl = slice(seen, seen + n)
+        want = collate_mixlm(ins["scores"][sl], ins["perfs"][sl], ins["segments"][sl], ins["deadpan"][sl], **kw)
+        check(data, want, keys=list(want))
+        seen += n
+    assert seen == 10
