@@ -12,7 +12,9 @@ import csv, sys, collections, os
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     if os.environ["FILT"] not in r['Kernel_Name']: continue
-    k = r['Kernel_Name'].split('(')[0][-48:]
+    import re
+    m = re.search(r'(\w+_kernel(<[\w, ]+>)?)', r['Kernel_Name'])
+    k = m.group(1) if m else r['Kernel_Name'][:60]
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
 for k, d in agg.items():
     print(k)
