@@ -650,19 +650,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
                     f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[j * 4 + q]) * rs;
                     if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
                     const int colb = (32 * jj + 8 * q + (lane >> 5) * 4) * ES;
-                    char* dst = stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4) + (colb & 15);
                     if constexpr (ES == 4) {
-                        *reinterpret_cast<f32x4*>(dst) = v;
+                        *reinterpret_cast<f32x4*>(stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4)) = v;
                     } else {
+                        // 8-byte pieces: the 32 rows of a half-wave share one column, so the XOR key works on 8-byte slots with 4 row
+                        // bits (rows r and r + 16 collide, which 256 bytes per half-wave cannot avoid); keyed on 16-byte chunks
+                        // with 3 row bits the write was a 4-way bank conflict (SQ_LDS_BANK_CONFLICT: 5 k cycles per tile)
                         uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(dst) = pk;
+                        *reinterpret_cast<uint2*>(stg + row * ROWB + ((((colb >> 3) ^ row) & 15) << 3)) = pk;
                     }
                 }
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int r = it * 8 + (lane >> 3), chunk = lane & 7;
-                const uint4 val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ r) & (CPR - 1)) << 4));
+                uint4 val;
+                if constexpr (ES == 4) {
+                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ r) & (CPR - 1)) << 4));
+                } else {   // slots 2c, 2c+1 of row r live in chunk c ^ (r >> 1), swapped when r is odd
+                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ (r >> 1)) & (CPR - 1)) << 4));
+                    if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                }
                 const int mo = cm0 + wr * 128 + 32 * i + r, no = cn0 + wc * 64 + jh * JP * 32 + chunk * (16 / ES);
                 if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
                 OutT* dst = C + (long)mo * g.ldc + no;
