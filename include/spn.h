@@ -173,6 +173,10 @@ int spn_collate_mixlm(const int32_t* score_flat, const int32_t* perf_flat, const
                       long long* masked_perf, long long* labels, long long* bar, long long* beat, long long* onset, uint8_t* deadpan_mask,
                       spn_stream_t stream);
 
+/* one more ragged token array of the batch, padded: the noisy performance (score_performance.py:48-51,66-69,94-95) */
+int spn_collate_pad_tokens(const int32_t* flat, const int32_t* off, int b, int K, int L, int pad_id, long long* out, uint8_t* mask,
+                           long long* len, spn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,7 +104,37 @@ __global__ __launch_bounds__(256) void collate_mixlm_kernel(CollateArgs a) {
     }
 }
 
+// out[i, pos, :] = pos < n_i ? flat[off_i + pos, :] : pad;  mask, lengths alike: one more ragged token array of the batch (the
+// "noisy performance" of score_performance.py:48-51,66-69,94-95), same element-per-thread scheme
+__global__ __launch_bounds__(256) void collate_pad_kernel(const int32_t* __restrict__ flat, const int32_t* __restrict__ off, int b, int K, int L,
+                                                          int pad_id, long long* __restrict__ out, uint8_t* __restrict__ mask,
+                                                          long long* __restrict__ len) {
+    const long total = (long)b * L * K;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        const long row = idx / K;
+        const int pos = (int)(row % L), i = (int)(row / L);
+        const int o0 = off[i], n = off[i + 1] - o0;
+        out[idx] = pos < n ? flat[(long)(o0 + pos) * K + k] : pad_id;
+        if (k == 0) {
+            mask[row] = pos < n;
+            if (pos == 0) len[i] = n;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int spn_collate_pad_tokens(const int32_t* flat, const int32_t* off, int b, int K, int L, int pad_id, long long* out, uint8_t* mask,
+                                      long long* len, hipStream_t stream) {
+    SPN_REQUIRE(flat && off && out && mask && len && b > 0 && K > 0 && L > 0, "spn_collate_pad_tokens: bad arguments");
+    const long total = (long)b * L * K;
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(collate_pad_kernel, dim3((unsigned)g), dim3(256), 0, stream, flat, off, b, K, L, pad_id, out, mask, len);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
 
 extern "C" int spn_collate_mixlm(const int32_t* score_flat, const int32_t* perf_flat, const int32_t* seg_flat, const int32_t* score_off,
                                  const int32_t* perf_off, const uint8_t* deadpan, int b, int Ks, int Kp, int Ls, int Lp, long sum_s,

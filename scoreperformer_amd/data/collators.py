@@ -91,8 +91,9 @@ class MixedLMScorePerformanceCollator:
     def __call__(self, batch, inference: bool = False, return_tensors: bool = True) -> MixedLMScorePerformanceInputs:
         if not torch.cuda.is_available():
             raise SpnError("MixedLMScorePerformanceCollator builds the batch on the GPU; no HIP device is visible (no CPU fallback)")
-        if any(getattr(s, "noisy_perf", None) is not None for s in batch) or any(getattr(s, "directions", None) is not None for s in batch):
-            raise NotImplementedError("noisy performances / score directions are outside the accelerated path (SURVEY.md section 8)")
+        if any(getattr(s, "directions", None) is not None for s in batch):
+            raise NotImplementedError("score directions (classifier labels) are outside the accelerated path (SURVEY.md section 8)")
+        has_noisy = all(getattr(s, "noisy_perf", None) is not None for s in batch)      # score_performance.py:48
         b = len(batch)
         Ks, Kp = batch[0].score.shape[-1], batch[0].perf.shape[-1]
         if batch[0].score.ndim != 2 or batch[0].perf.ndim != 2:
@@ -109,7 +110,11 @@ class MixedLMScorePerformanceCollator:
         o_soff = o_seg + (3 * sum_s if has_seg else 0)
         o_poff = o_soff + b + 1
         o_dead = o_poff + b + 1
-        words = o_dead + (b + 3) // 4
+        o_noisy = o_dead + (b + 3) // 4
+        n_n = np.fromiter((len(s.noisy_perf) for s in batch), np.int64, b) if has_noisy else None
+        sum_n = int(n_n.sum()) if has_noisy else 0
+        o_noff = o_noisy + sum_n * Kp
+        words = o_noff + (b + 1 if has_noisy else 0)
         host = self._stage(words)
         h = host.numpy()
         np.concatenate([s.score for s in batch], out=h[:o_perf].reshape(sum_s, Ks), casting="unsafe")
@@ -121,8 +126,12 @@ class MixedLMScorePerformanceCollator:
         np.cumsum(n_s, out=h[o_soff + 1:o_poff], dtype=np.int32)
         h[o_poff] = 0
         np.cumsum(n_p, out=h[o_poff + 1:o_dead], dtype=np.int32)
-        dead = h[o_dead:words].view(np.uint8)
+        dead = h[o_dead:o_noisy].view(np.uint8)
         dead[:b] = [bool(s.is_deadpan) for s in batch]
+        if has_noisy:
+            np.concatenate([s.noisy_perf for s in batch], out=h[o_noisy:o_noff].reshape(sum_n, Kp), casting="unsafe")
+            h[o_noff] = 0
+            np.cumsum(n_n, out=h[o_noff + 1:words], dtype=np.int32)
 
         dev = host.to(self.device, non_blocking=True)
         self._staged = torch.cuda.Event()
@@ -132,14 +141,19 @@ class MixedLMScorePerformanceCollator:
             dims |= 1 << (d % Kp)
         t = ops.collate_mixlm(
             dev[:o_perf], dev[o_perf:o_seg], dev[o_seg:o_soff] if has_seg else None, dev[o_soff:o_poff], dev[o_poff:o_dead],
-            dev[o_dead:words].view(torch.uint8), b=b, Ks=Ks, Kp=Kp, Ls=lens["score"], Lp=lens["performance"], pad_id=self.pad_token_id,
+            dev[o_dead:o_noisy].view(torch.uint8), b=b, Ks=Ks, Kp=Kp, Ls=lens["score"], Lp=lens["performance"], pad_id=self.pad_token_id,
             mask_id=self.mask_token_id, label_pad_id=self.label_pad_token_id,
             ignore_ids=sorted(self.mask_ignore_token_ids - {self.pad_token_id}), ignore_dims=dims,
             label_pad_ignored_dims=self.label_pad_ignored_dims)
         perf = SeqInputs(t["perf"], t["perf_mask"], t["perf_len"])
+        noisy = None
+        if has_noisy:   # padded like the score (always to the multiple, score_performance.py:50)
+            noisy = SeqInputs(*ops.collate_pad_tokens(dev[o_noisy:o_noff], dev[o_noff:words], b=b, K=Kp, L=self.pad_len(int(n_n.max())),
+                                                      pad_id=self.pad_token_id))
         return MixedLMScorePerformanceInputs(
             scores=SeqInputs(t["score"], t["score_mask"], t["score_len"]),
             performances=perf,
+            noisy_performances=noisy,
             segments=SeqSegments(t["bar"], t["beat"], t["onset"]) if has_seg else None,
             deadpan_mask=t["deadpan_mask"],
             masked_performances=SeqInputs(t["masked_perf"], t["perf_mask"].clone(), t["perf_len"]),   # score_performance.py:212

@@ -765,3 +765,14 @@ def collate_mixlm(score_flat, perf_flat, seg_flat, score_off, perf_off, deadpan,
          ptr(out["perf"]), ptr(out["perf_mask"]), ptr(out["perf_len"]), ptr(out["masked_perf"]), ptr(out["labels"]), ptr(out.get("bar")),
          ptr(out.get("beat")), ptr(out.get("onset")), ptr(out["deadpan_mask"]), stream_ptr())
     return out
+
+
+def collate_pad_tokens(flat, off, *, b, K, L, pad_id=0):
+    """Ragged int32 tokens [sum_n, K] + row offsets [b+1] -> (tokens int64 [b, L, K], mask bool [b, L], lengths int64 [b])."""
+    require_gpu(flat, off)
+    dev = flat.device
+    out = torch.empty((b, L, K), device=dev, dtype=torch.int64)
+    mask = torch.empty((b, L), device=dev, dtype=torch.bool)
+    lens = torch.empty(b, device=dev, dtype=torch.int64)
+    call("spn_collate_pad_tokens", ptr(flat), ptr(off), c_int(b), c_int(K), c_int(L), c_int(pad_id), ptr(out), ptr(mask), ptr(lens), stream_ptr())
+    return out, mask, lens

@@ -17,7 +17,8 @@ def load_cases():
         n = len([k for k in z.files if k.startswith(f"{name}/in/score")])
         ins = dict(scores=[z[f"{name}/in/score{i}"] for i in range(n)], perfs=[z[f"{name}/in/perf{i}"] for i in range(n)],
                    segments=[{s: z[f"{name}/in/{s}{i}"] for s in ("bar", "beat", "onset")} for i in range(n)],
-                   deadpan=z[f"{name}/in/deadpan"].tolist())
+                   deadpan=z[f"{name}/in/deadpan"].tolist(),
+                   noisy=[z[f"{name}/in/noisy{i}"] for i in range(n)] if f"{name}/in/noisy0" in z.files else None)
         outs = {k.split("/out/")[1]: z[k] for k in z.files if k.startswith(f"{name}/out/")}
         cases[name] = (kw, ins, outs)
     return cases
@@ -30,7 +31,7 @@ CASES = load_cases()
 def test_oracle_collator_is_bit_exact_against_the_reference(name):
     from oracle.collate_cpu import collate_mixlm
     kw, ins, ref = CASES[name]
-    got = collate_mixlm(ins["scores"], ins["perfs"], ins["segments"], ins["deadpan"], **kw)
+    got = collate_mixlm(ins["scores"], ins["perfs"], ins["segments"], ins["deadpan"], noisy=ins["noisy"], **kw)
     for key, want in ref.items():
         have = got["perf_mask"] if key == "labels_mask" else got[key]
         assert have.shape == want.shape and have.dtype == want.dtype, (key, have.shape, want.shape, have.dtype, want.dtype)

@@ -16,6 +16,8 @@ FIELDS = {
     "masked_perf": lambda d: d.masked_performances.tokens, "labels": lambda d: d.labels.tokens, "labels_mask": lambda d: d.labels.mask,
     "bar": lambda d: d.segments.bar, "beat": lambda d: d.segments.beat, "onset": lambda d: d.segments.onset,
     "deadpan_mask": lambda d: d.deadpan_mask,
+    "noisy": lambda d: d.noisy_performances.tokens, "noisy_mask": lambda d: d.noisy_performances.mask,
+    "noisy_len": lambda d: d.noisy_performances.lengths,
 }
 
 
@@ -23,7 +25,8 @@ def samples_of(ins, with_segments=True):
     out = []
     for i in range(len(ins["perfs"])):
         seg = SimpleNamespace(**ins["segments"][i]) if with_segments and ins["segments"] is not None else None
-        out.append(SimpleNamespace(score=ins["scores"][i], perf=ins["perfs"][i], noisy_perf=None, directions=None, segments=seg,
+        noisy = ins["noisy"][i] if ins.get("noisy") is not None else None
+        out.append(SimpleNamespace(score=ins["scores"][i], perf=ins["perfs"][i], noisy_perf=noisy, directions=None, segments=seg,
                                    is_deadpan=bool(ins["deadpan"][i])))
     return out
 
@@ -95,9 +98,12 @@ def test_device_collator_refuses_unsupported_fields():
     from scoreperformer_amd.data import MixedLMScorePerformanceCollator
     ins = ragged(np.random.default_rng(1), 2, 4, 8, 10, 12)
     smp = samples_of(ins)
-    smp[1].noisy_perf = smp[1].perf
+    smp[1].directions = {"dynamics": {}}
     with pytest.raises(NotImplementedError):
         MixedLMScorePerformanceCollator()(smp)
+    smp[1].directions = None
+    smp[1].noisy_perf = smp[1].perf                      # only some samples carry one: none is collated (score_performance.py:48)
+    assert MixedLMScorePerformanceCollator()(smp).noisy_performances is None
 
 
 def test_device_batch_drives_the_model():
