@@ -474,9 +474,11 @@ def score_performer_forward(
         score_emb, _ = tuple_transformer(sd, "score_encoder.", cfg["score_encoder"], [batch["score"]], causal=False,
                                          mask=batch["score_mask"])
     pe_cfg = cfg["perf_encoder"]
-    hidden, _ = tuple_transformer(sd, "perf_encoder.", pe_cfg, [perf], causal=False, mask=pmask)
+    # the style encoder reads the noisy performance when the batch carries one (model.py:296-298)
+    enc_in, enc_mask = batch.get("noisy_perf", perf), batch.get("noisy_perf_mask", pmask)
+    hidden, _ = tuple_transformer(sd, "perf_encoder.", pe_cfg, [enc_in], causal=False, mask=enc_mask)
     segs = {"bar_mean": batch["bars"], "beat_mean": batch["beats"], "onset_mean": batch["onsets"]}
-    enc = mmd_heads(sd, "perf_encoder.", pe_cfg, hidden, pmask, segs, batch["deadpan_mask"], z_samples,
+    enc = mmd_heads(sd, "perf_encoder.", pe_cfg, hidden, enc_mask, segs, batch["deadpan_mask"], z_samples,
                     training=training, drop_masks=drop_masks)
     dcfg = cfg["perf_decoder"]
     # MixedLM shift (wrappers.py:409-431)

@@ -22,7 +22,7 @@ warnings.filterwarnings("ignore")
 from scoreperformer.models import ScorePerformer  # noqa: E402  (the reference)
 
 from oracle.refimport.make_golden import RandnRecorder  # noqa: E402
-from oracle.variants import NAMES, SMALL_VOCAB, ablation_config  # noqa: E402
+from oracle.variants import NAMES, SMALL_VOCAB, ablation_config, variant_batch  # noqa: E402
 from oracle.weights import filled_state_dict  # noqa: E402
 from scoreperformer_amd.synthetic import synthetic_batch  # noqa: E402
 
@@ -38,7 +38,7 @@ def main():
         model.train()
         with RandnRecorder() as rec:
             torch.manual_seed(3)
-            res = model(**batch)
+            res = model(**variant_batch(name, batch))
         out[f"{name}/loss"] = np.float64(float(res.loss))
         for k, v in res.losses.items():
             out[f"{name}/losses/{k}"] = np.float64(float(v))

@@ -4,7 +4,7 @@ from scoreperformer_amd.synthetic import model_config
 
 SMALL_VOCAB = {"Bar": 40, "Position": 36, "Pitch": 28, "Velocity": 36, "Duration": 37, "Tempo": 29, "TimeSig": 10, "PositionShift": 21,
                "NotesInOnset": 16, "PositionInOnset": 16, "RelOnsetDev": 45, "RelPerfDuration": 25}
-NAMES = ["no_cont_tokens", "no_masked_seq", "no_score_enc", "no_saln", "no_io_tie", "custom_hierarchy"]
+NAMES = ["no_cont_tokens", "no_masked_seq", "no_score_enc", "no_saln", "no_io_tie", "custom_hierarchy", "noisy_perf"]
 
 
 def ablation_config(name: str):
@@ -33,4 +33,19 @@ def ablation_config(name: str):
         c["perf_encoder"]["aggregate_mode"] = ["mean", "bar_mean"]
         c["perf_encoder"]["latent_dim"] = [16, 16]
         return c
+    if name == "noisy_perf":            # base model; the batch carries a noisy performance for the style encoder (base.yaml:50)
+        return base()
     raise KeyError(name)
+
+
+def variant_batch(name: str, batch):
+    """Inputs of a variant: `noisy_perf` adds a perturbed copy of the performance (velocity / timing dims re-drawn)."""
+    if name != "noisy_perf":
+        return batch
+    import torch
+    g = torch.Generator().manual_seed(99)
+    noisy = batch["perf"].clone()
+    for dim, key in ((3, "Velocity"), (10, "RelOnsetDev"), (11, "RelPerfDuration")):
+        draw = torch.randint(4, SMALL_VOCAB[key], noisy[..., dim].shape, generator=g)
+        noisy[..., dim] = torch.where(batch["perf_mask"] & (noisy[..., dim] > 3), draw, noisy[..., dim])
+    return dict(batch, noisy_perf=noisy, noisy_perf_mask=batch["perf_mask"].clone())

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.variants import NAMES, SMALL_VOCAB, ablation_config
+from oracle.variants import NAMES, SMALL_VOCAB, ablation_config, variant_batch
 
 Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ablations.npz"))
 
@@ -25,7 +25,7 @@ def test_oracle_matches_the_reference_on_ablation_variants(name):
     from scoreperformer_amd.synthetic import synthetic_batch
     cfg = ablation_config(name)
     sd = filled_state_dict(ScorePerformer.init(ablation_config(name)), seed=1)
-    batch = synthetic_batch(2, 40, seed=5, ragged=True, num_tokens=SMALL_VOCAB)
+    batch = variant_batch(name, synthetic_batch(2, 40, seed=5, ragged=True, num_tokens=SMALL_VOCAB))
     draws, loss, losses = golden(name)
     with torch.no_grad():
         got = ref_cpu.score_performer_forward(sd, cfg, batch, draws, training=True)

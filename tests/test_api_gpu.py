@@ -130,12 +130,12 @@ def test_model_widths_off_the_8_element_grid(dev):
     assert bool(torch.isfinite(arena.grads).all()) and float(arena.grads.abs().sum()) > 0
 
 
-@pytest.mark.parametrize("name", ["no_cont_tokens", "no_masked_seq", "no_score_enc", "no_saln", "no_io_tie", "custom_hierarchy"])
+@pytest.mark.parametrize("name", ["no_cont_tokens", "no_masked_seq", "no_score_enc", "no_saln", "no_io_tie", "custom_hierarchy", "noisy_perf"])
 def test_ablation_recipe_variants_match_the_reference_loss(dev, name):
     """The model variants of recipes/scoreperformer/ablation/*.yaml and custom_hierarchy.yaml: HIP forward against the reference's own
     loss (tests/golden/ablations.npz); backward runs."""
     from test_ablations_cpu import golden
-    from oracle.variants import SMALL_VOCAB, ablation_config
+    from oracle.variants import SMALL_VOCAB, ablation_config, variant_batch
     from oracle.weights import filled_state_dict
     from scoreperformer_amd.arena import ParamArena
     from scoreperformer_amd.models import ScorePerformer
@@ -146,7 +146,7 @@ def test_ablation_recipe_variants_match_the_reference_loss(dev, name):
     model.train()
     draws, loss, losses = golden(name)
     model.perf_encoder._z_override = [z.to(dev) for z in draws]
-    batch = synthetic_batch(2, 40, seed=5, ragged=True, num_tokens=SMALL_VOCAB, device=dev)
+    batch = {k: v.to(dev) for k, v in variant_batch(name, synthetic_batch(2, 40, seed=5, ragged=True, num_tokens=SMALL_VOCAB)).items()}
     out = model(**batch)
     arena.zero_grad()
     out.loss.backward()
