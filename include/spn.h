@@ -156,6 +156,13 @@ int spn_dec_head(int n, const float* const* tables, const int* V, const int* wid
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);
 
+/* spn_dec_head with sampling instead of the arg-max (modules/sampling.py:28-59: top_k filter, temperature, one multinomial draw):
+ * logits = scratch [n, ldl]; topk[n] = ids kept per key (device); seed = device scalar mixed with the position and the key. */
+int spn_dec_head_sample(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
+                        const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld,
+                        int mask_id, const int* pos, float* part, int* counter, int slabs, float* logits, int ldl, const int* topk,
+                        float temperature, const unsigned* seed, spn_stream_t s);
+
 /* batched (prefill) forms of the decode kernels: rows t0 .. t0+n-1 of a window whose tokens are known (the reference recomputes a
  * cropped window in one batched forward, inference/generators.py:184-241 -> wrappers.py:391-393); K/V rows already in the caches. */
 int spn_dec_attn_rows(const float* q, long q_ld, const float* kcache, const float* vcache, const float* slopes, int t0, int n, float* o,

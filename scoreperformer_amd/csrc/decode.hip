@@ -446,10 +446,17 @@ struct DecHeadDesc {
     int V[16], width[16], col0[16], dim[16];
     int n, D;
 };
+// SAMPLE: instead of the arg-max, top-k filtering + temperature + one multinomial draw (modules/sampling.py:28-59 top_k +
+// filter_logits_and_sample), on the device: every slab also stores its logits, the last slab block ranks them (keep the topk[q]
+// largest, ties to the lower id), normalises exp((l - max) / T) over the kept ones and inverts the CDF at a counter-based uniform
+// u = hash(*seed, *pos, q).  The draw cannot reproduce torch.multinomial's stream; its distribution is the reference's.
+struct DecSampleArgs { float* logits; int ldl; const int* topk; float inv_temperature; const unsigned* seed; };
+__device__ __forceinline__ unsigned dec_mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <bool SAMPLE>
 __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const float* __restrict__ e, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, unsigned ban_mask,
                                                        long* __restrict__ tokens, long tok_ld, int mask_id, const int* __restrict__ pos,
-                                                       float* __restrict__ part, int* __restrict__ counter) {
+                                                       float* __restrict__ part, int* __restrict__ counter, DecSampleArgs sa) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float bv[4];
@@ -480,10 +487,61 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
         for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
         acc = wave_sum(acc);
         if (v < 32 && ((ban_mask >> v) & 1u)) acc = -INFINITY;
+        if (SAMPLE && lane == 0) sa.logits[(long)q * sa.ldl + v] = acc;
         if (acc > best || (acc == best && v < idx)) { best = acc; idx = v; }
     }
     if (lane == 0) { bv[w] = best; bi[w] = idx; }
     __syncthreads();
+    if (SAMPLE) {
+        __shared__ int last_flag;
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last_flag = atomicAdd(counter + q, 1) == nsl - 1;
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __threadfence();
+        // all V logits of this key are in global memory now: rank, filter, normalise, draw (V <= 2048: reuse xs)
+        for (int v = threadIdx.x; v < V; v += 256) xs[v] = sa.logits[(long)q * sa.ldl + v];
+        __syncthreads();
+        const int keep_n = sa.topk[q];
+        float mx = -INFINITY;
+        for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, xs[v]);
+        mx = wave_max(mx);
+        if (lane == 0) red[w] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float mine_sum = 0.f;
+        // weights in place of the logits (two passes: ranks read every logit, so the weights go to the upper half of xs... V <= 1024)
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float lv = xs[v];
+            int rank = 0;
+            for (int u = 0; u < V; ++u) { const float lu = xs[u]; rank += (lu > lv) || (lu == lv && u < v); }
+            const float wgt = (rank < keep_n && lv > -INFINITY) ? __expf((lv - mx) * sa.inv_temperature) : 0.f;
+            xs[1024 + v] = wgt;
+            mine_sum += wgt;
+        }
+        mine_sum = wave_sum(mine_sum);
+        if (lane == 0) red[4 + w] = mine_sum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float total = red[4] + red[5] + red[6] + red[7];
+            const unsigned r = dec_mix(dec_mix(*sa.seed ^ 0x9e3779b9u * (unsigned)(*pos + 1)) + 0x85ebca6bu * (unsigned)(q + 1));
+            const float target = (float)(r >> 8) * (1.f / 16777216.f) * total;
+            float cum = 0.f;
+            int pick = -1, lastpos = 0;
+            for (int v = 0; v < V; ++v) {
+                const float wgt = xs[1024 + v];
+                if (wgt > 0.f) { lastpos = v; cum += wgt; if (pick < 0 && cum > target) pick = v; }
+            }
+            if (pick < 0) pick = lastpos;
+            long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
+            if (*cell == mask_id) *cell = pick;
+            counter[q] = 0;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         for (int r = 1; r < 4; ++r) if (bv[r] > best || (bv[r] == best && bi[r] < idx)) { best = bv[r]; idx = bi[r]; }
         float* mine = part + ((long)q * nsl + sl) * 2;
@@ -611,8 +669,27 @@ extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, con
     memset(&d, 0, sizeof(d));
     for (int i = 0; i < n; ++i) { d.table[i] = tables[i]; d.V[i] = V[i]; d.width[i] = width[i]; d.col0[i] = col0[i]; d.dim[i] = dim[i]; }
     d.n = n; d.D = D;
-    hipLaunchKernelGGL(dec_head_kernel, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
-                       counter);
+    hipLaunchKernelGGL(dec_head_kernel<false>, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
+                       counter, DecSampleArgs{});
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_dec_head_sample(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
+                                   const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens,
+                                   long tok_ld, int mask_id, const int* pos, float* part, int* counter, int slabs, float* logits, int ldl,
+                                   const int* topk, float temperature, const unsigned* seed, hipStream_t s) {
+    SPN_REQUIRE(n > 0 && n <= 16 && tables && e && gamma && beta && tokens && pos && D > 0 && D <= 2048, "spn_dec_head_sample: bad arguments");
+    SPN_REQUIRE(part && counter && slabs > 0 && slabs <= 64 && logits && topk && seed && temperature > 0.f, "spn_dec_head_sample: bad arguments");
+    DecHeadDesc d;
+    memset(&d, 0, sizeof(d));
+    for (int i = 0; i < n; ++i) {
+        SPN_REQUIRE(V[i] <= 1024 && V[i] <= ldl, "spn_dec_head_sample: vocabularies up to 1024 ids");
+        d.table[i] = tables[i]; d.V[i] = V[i]; d.width[i] = width[i]; d.col0[i] = col0[i]; d.dim[i] = dim[i];
+    }
+    d.n = n; d.D = D;
+    hipLaunchKernelGGL(dec_head_kernel<true>, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
+                       counter, DecSampleArgs{logits, ldl, topk, 1.f / temperature, seed});
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

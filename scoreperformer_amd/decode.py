@@ -41,6 +41,7 @@ class GreedyDecoder:
         self.dim = m.dim
         self.ada = tr.ada_norm
         self.graph = None
+        self.sampling = None       # None = arg-max; dict(topk=int32 device tensor [n dims], temperature=float) = top-k sampling
 
     # -- buffers -------------------------------------------------------------------------------------------
     def _alloc(self, L):
@@ -76,6 +77,8 @@ class GreedyDecoder:
         self.att_counter = torch.zeros(self.heads, device=dev, dtype=torch.int32)
         self.head_part = z(16 * 8 * 2)
         self.head_counter = torch.zeros(16, device=dev, dtype=torch.int32)
+        self.head_logits = z(16, 1024)
+        self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.kmax2 = [z(self.kvh) for _ in range(n_attn)]
         tr = m.transformer
         self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
@@ -248,10 +251,19 @@ class GreedyDecoder:
             offs = [0]
             for w in head.split_dims:
                 offs.append(offs[-1] + w)
-            ops.dec_head([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
-                         head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part, self.head_counter, slabs=self.head_slabs)
+            if self.sampling is not None:
+                ops.dec_head_sample([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
+                                    head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part,
+                                    self.head_counter, self.head_logits, self.sampling["topk"], self.seed_dev,
+                                    temperature=self.sampling["temperature"], slabs=self.head_slabs)
+            else:
+                ops.dec_head([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
+                             head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part, self.head_counter,
+                             slabs=self.head_slabs)
             ops.dec_add_pos(pos, 1)
             return
+        if self.sampling is not None:
+            raise NotImplementedError("decode engine: sampling needs the fused tied LM head")
         # other head / norm combinations: the unfused tail
         if not isinstance(fn, nn.Identity):
             self._ln(self.x, fn, self.h, True)
@@ -336,6 +348,30 @@ class RenderSession(GreedyDecoder):
         self.steps_run = 0
         self.prefilled_rows = 0
         self.prefill_min = 16      # shorter prefixes: the captured step is as fast
+
+    def configure(self, sampling: Optional[dict]):
+        """sampling=None: arg-max (greedy).  sampling=dict(k=int|None, thres=0.9, temperature=1.0, seed=int): `top_k` filtering
+        (modules/sampling.py:28-33: k, or ceil((1 - thres) * V) per key) + one multinomial draw per token.  Switching between the
+        two, or changing the temperature, re-records the step graph."""
+        if sampling is None:
+            if self.sampling is not None:
+                self.sampling, self.graph = None, None
+            return
+        head = self.m.lm_head
+        if not (isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and self.fused):
+            raise NotImplementedError("decode engine: sampling needs the fused tied LM head")
+        import math
+        V = [self.tables[d].shape[0] for d in self.dims]
+        ks = [int(sampling["k"]) if sampling.get("k") is not None else math.ceil((1 - sampling.get("thres", 0.9)) * v) for v in V]
+        ks = [max(1, min(k, v)) for k, v in zip(ks, V)]
+        temperature = float(sampling.get("temperature", 1.0))
+        if self.sampling is None or self.sampling["temperature"] != temperature:
+            self.graph = None
+            self.sampling = {"topk": torch.tensor(ks, device=self.dev, dtype=torch.int32), "temperature": temperature, "ks": ks,
+                             "calls": int(sampling.get("seed", 0))}
+        elif self.sampling["ks"] != ks:
+            self.sampling["topk"].copy_(torch.tensor(ks, dtype=torch.int32))
+            self.sampling["ks"] = ks
 
     def reset(self):
         self.length, self.tag = 0, None
@@ -448,6 +484,9 @@ class RenderSession(GreedyDecoder):
             self.prefill(Lin - 1 - n_new)
             c = self.length
         self.pos.fill_(c)
+        if self.sampling is not None:   # a fresh stream per call: positions repeat after a cut, (seed, position, key) must not
+            self.sampling["calls"] += 1
+            self.seed_dev.fill_((self.sampling["calls"] * 0x9E3779B1) & 0x7FFFFFFF)
         steps = Lin - 1 - c
         done = 0
         if self.use_graph and self.graph is None and steps > 0:

@@ -99,6 +99,7 @@ class ScorePerformerGenerator:
             raise ValueError("prefill must be 'engine', 'sequential' or 'modules'")
         self.use_engine, self.engine_max_len, self.prefill, self.prefill_min = use_engine, engine_max_len, prefill, prefill_min
         self._session = None
+        self.sampling_seed = 0
         self._init_variables()
         self.perf_data = PerformanceData()
 
@@ -164,7 +165,9 @@ class ScorePerformerGenerator:
         return end
 
     def _session_for(self, filter_logits_fn, filter_kwargs, disable_caches):
-        if not self.use_engine or disable_caches or self.device.type != "cuda" or not is_greedy(filter_logits_fn, filter_kwargs):
+        """The decode session when the engine covers this call: greedy (`top_k` with k = 1) or `top_k` sampling at temperature 1
+        (what `unmask_tokens` is called with, generators.py:223-233); other filters take the module path."""
+        if not self.use_engine or disable_caches or self.device.type != "cuda" or filter_logits_fn is not top_k:
             return None
         if self._session is None:
             from ..decode import RenderSession
@@ -174,6 +177,14 @@ class ScorePerformerGenerator:
             except NotImplementedError:
                 self.use_engine = False
                 return None
+        try:
+            if is_greedy(filter_logits_fn, filter_kwargs):
+                self._session.configure(None)
+            else:
+                kw = dict(filter_kwargs or {})
+                self._session.configure(dict(k=kw.get("k"), thres=kw.get("thres", 0.9), temperature=1.0, seed=self.sampling_seed))
+        except NotImplementedError:
+            return None
         return self._session
 
     def generate_performance_notes(self, start_time: float = 0., time_window: float = 0.2, time_window_overflow: float = 0.1,

@@ -727,6 +727,18 @@ def dec_glu_rows(u, out, I, *, act=0, glu=True):
     return out
 
 
+def dec_head_sample(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, logits, topk, seed, *, temperature=1.0,
+                    slabs=8, ban_mask=0b11, mask_id=1):
+    """dec_head with top-k filtering + temperature + one multinomial draw per key instead of the arg-max (logits: fp32 scratch
+    [n, ld]; topk: int32 [n] on the device; seed: int32/uint32 device scalar)."""
+    V = [t.shape[0] for t in tables]
+    W = [t.shape[1] for t in tables]
+    call("spn_dec_head_sample", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(W), _int_array(col0), _int_array(dims),
+         c_int(D), ptr(e), ptr(gamma), ptr(beta), c_float(eps), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)),
+         c_int(mask_id), ptr(pos), ptr(part), ptr(counter), c_int(slabs), ptr(logits), c_int(logits.stride(0)), ptr(topk),
+         c_float(temperature), ptr(seed), stream_ptr())
+
+
 def dec_add_pos(pos, delta=1):
     call("spn_dec_add_pos", ptr(pos), c_int(delta), stream_ptr())
 

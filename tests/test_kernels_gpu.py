@@ -365,3 +365,48 @@ def test_gemm_accepts_widths_that_are_not_multiples_of_8(M, N, K, ta, tb):
     assert torch.allclose(out, ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
     out16 = ops.gemm(a, b, ta=ta, tb=tb)
     assert torch.allclose(out16.float(), ref - bias, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+
+
+def test_dec_head_sample_draws_from_the_top_k_softmax():
+    """spn_dec_head_sample: banned ids never drawn, only the k largest logits drawn, frequencies = softmax(top-k logits / T)."""
+    from scoreperformer_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    D, widths, V = 96, [32, 64], [40, 150]
+    tables = [torch.randn(v, w, generator=g).to(dev) * 0.35 for v, w in zip(V, widths)]
+    e = torch.randn(D, generator=g).to(dev)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).to(dev), (torch.randn(D, generator=g) * 0.1).to(dev)
+    xn = torch.nn.functional.layer_norm(e, (D,), gamma, beta, 1e-5)
+    col0, ks, T = [0, 32], [5, 12], 0.8
+    want = []
+    for t, c, w, k in zip(tables, col0, widths, ks):
+        lg = t @ xn[c:c + w]
+        lg[:2] = -float("inf")                                   # PAD / MASK banned (wrappers.py:368-369)
+        top = torch.topk(lg, k)
+        p = torch.zeros_like(lg)
+        p[top.indices] = torch.softmax(top.values / T, -1)
+        want.append(p.cpu())
+    tokens = torch.zeros(2, 12, dtype=torch.int64, device=dev)
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    part = torch.zeros(16 * 8 * 2, device=dev)
+    counter = torch.zeros(16, dtype=torch.int32, device=dev)
+    logits = torch.zeros(16, 1024, device=dev)
+    topk = torch.tensor(ks, dtype=torch.int32, device=dev)
+    seed = torch.zeros(1, dtype=torch.int32, device=dev)
+    N = 6000
+    draws = torch.zeros(N, 2, dtype=torch.int64, device=dev)
+    for i in range(N):
+        tokens[1, 3] = 1
+        tokens[1, 5] = 1
+        seed.fill_(i * 7919 + 13)
+        ops.dec_head_sample(tables, col0, [3, 5], D, e, gamma, beta, 1e-5, tokens, pos, part, counter, logits, topk, seed, temperature=T, slabs=8)
+        draws[i, 0], draws[i, 1] = tokens[1, 3], tokens[1, 5]
+    draws = draws.cpu()
+    for j in range(2):
+        freq = torch.bincount(draws[:, j], minlength=V[j]).float() / N
+        assert float(freq[want[j] == 0].sum()) == 0.0            # nothing outside the top-k, nothing banned
+        assert float((freq - want[j]).abs().max()) < 0.03, (freq, want[j])
+    # a known token (no MASK in the cell) is left alone
+    tokens[1, 3] = 17
+    ops.dec_head_sample(tables, col0, [3, 5], D, e, gamma, beta, 1e-5, tokens, pos, part, counter, logits, topk, seed, temperature=T, slabs=8)
+    assert int(tokens[1, 3]) == 17

@@ -190,3 +190,38 @@ def test_encode_embeddings_windows_match_the_reference(overlay):
     # prepare_performance_notes computes them itself when they are not passed (generators.py:87-91)
     gen.prepare_performance_notes(0, overlay_bars=overlay)
     assert gen.perf_data.embeddings.shape[0] == len(z["piece"]) + 2 and gen.perf_data.context.shape[0] == len(z["piece"]) + 2
+
+
+def test_engine_render_loop_with_top_k_sampling():
+    """`filter_logits_fn=top_k` with k > 1 (the reference's default is sampling): the session samples on the device.  Draws cannot
+    match torch.multinomial's stream, so: runs to EOS, score-given dims exact, predicted tokens valid ids, same seed -> same piece,
+    other seed -> another piece, and it is not the greedy piece."""
+    from scoreperformer_amd.modules.sampling import top_k
+    dev = torch.device("cuda")
+    gen_for, _ = make(True, dev)
+    s = SCEN["long_context"]
+    c = s["cfg"]
+    given = [d for d in range(12) if d not in (3, 5, 10, 11)]
+    sizes = list(VOCAB.values())
+
+    def render(seed, kw):
+        gen = gen_for(s["piece"])
+        gen.sampling_seed = seed
+        gen.prepare_performance_notes(0, score_embeddings=torch.from_numpy(s["score_emb"]).clone(), perf_embeddings=torch.from_numpy(s["perf_emb"]).clone())
+        t, calls = 0.0, 0
+        while not gen.perf_data.reached_eos and calls < 300:
+            gen.generate_performance_notes(start_time=t, time_window=c["time_window"], time_window_overflow=c["time_window_overflow"],
+                                           max_context_len=c["max_context_len"], filter_logits_fn=top_k, filter_kwargs=kw)
+            t += c["time_window"]
+            calls += 1
+        assert gen.perf_data.reached_eos and gen._session is not None and gen._session.steps_run > 0
+        return gen.perf_data.gen_seq.cpu().numpy()
+
+    a, b, other, greedy = render(1, {"k": 4}), render(1, {"k": 4}), render(2, {"k": 4}), render(1, {"k": 1})
+    assert np.array_equal(greedy, s["gen_seq"])
+    assert a.shape == s["gen_seq"].shape and np.array_equal(a[:, given], s["gen_seq"][:, given])
+    for d in (3, 5, 10, 11):
+        assert a[1:, d].min() >= 2 and a[:, d].max() < sizes[d]
+    assert np.array_equal(a, b) and not np.array_equal(a, other) and not np.array_equal(a, greedy)
+    default = render(3, None)                                    # thres 0.9: k = ceil(0.1 * V) per key
+    assert default.shape == a.shape

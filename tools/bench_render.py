@@ -39,9 +39,13 @@ def main():
     dec = model.perf_decoder.model
     collator = SimpleNamespace(mask_token_id=1, mask_ignore_token_dims=[0, 1, 2, 4, 6, 7, 8, 9])
     res = {"workload": f"C5 render loop: {a.notes}-note piece, max_context_len {a.context}, time window {a.window} s, greedy, chord groups"}
-    for name, use_engine, notes, prefill in (("engine", True, a.notes, "engine"), ("engine_sequential_prefill", True, a.module_notes * 2, "sequential"),
-                                           ("engine_batched_prefill", True, a.notes, "modules"),
-                                           ("modules", False, a.module_notes, "engine")):
+    GREEDY, SAMPLE = {"k": 1}, None      # None: the reference's default, top-k sampling with k = ceil(0.1 * V) per key
+    for name, use_engine, notes, prefill, fkw in (("engine", True, a.notes, "engine", GREEDY),
+                                                  ("engine_sequential_prefill", True, a.module_notes * 2, "sequential", GREEDY),
+                                                  ("engine_batched_prefill", True, a.notes, "modules", GREEDY),
+                                                  ("modules", False, a.module_notes, "engine", GREEDY),
+                                                  ("engine_sampling", True, a.notes, "engine", SAMPLE),
+                                                  ("modules_sampling", False, a.module_notes, "engine", SAMPLE)):
         piece = make_piece(7, notes, PERFORMANCE_VOCAB)
         g = torch.Generator().manual_seed(1)
         ctx = torch.randn(notes + 2, dec.context_emb_dim, generator=g) * 0.5
@@ -51,7 +55,7 @@ def main():
         model.perf_decoder.use_decode_engine = use_engine
         gen.prepare_performance_notes(0, score_embeddings=ctx, perf_embeddings=sty)
         if use_engine:      # build the session + graph outside the timed region (one-off per generator)
-            gen.generate_performance_notes(start_time=0.0, time_window=1e-6, max_context_len=a.context, filter_logits_fn=top_k, filter_kwargs={"k": 1})
+            gen.generate_performance_notes(start_time=0.0, time_window=1e-6, max_context_len=a.context, filter_logits_fn=top_k, filter_kwargs=fkw)
             gen.reset()
             gen.prepare_performance_notes(0, score_embeddings=ctx, perf_embeddings=sty)
         torch.cuda.synchronize()
@@ -59,7 +63,7 @@ def main():
         t0 = time.perf_counter()
         while not gen.perf_data.reached_eos and calls < 100000:
             _, msg = gen.generate_performance_notes(start_time=t, time_window=a.window, time_window_overflow=0.1, max_context_len=a.context,
-                                                    filter_logits_fn=top_k, filter_kwargs={"k": 1})
+                                                    filter_logits_fn=top_k, filter_kwargs=fkw)
             messages += len(msg)
             t += a.window
             calls += 1
@@ -72,6 +76,7 @@ def main():
                      "music_seconds": t, "realtime_factor": t / dt}
     res["speedup_engine_vs_modules"] = res["engine"]["notes_per_s"] / res["modules"]["notes_per_s"]
     res["speedup_engine_batched_prefill_vs_modules"] = res["engine_batched_prefill"]["notes_per_s"] / res["modules"]["notes_per_s"]
+    res["speedup_sampling_engine_vs_modules"] = res["engine_sampling"]["notes_per_s"] / res["modules_sampling"]["notes_per_s"]
     print(json.dumps(res))
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
