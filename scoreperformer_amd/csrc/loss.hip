@@ -111,16 +111,32 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const TL* __restrict__ logi
 // ---------------------------------------------------------------------------------------------------------
 // segments
 // ---------------------------------------------------------------------------------------------------------
+// counts[b, seg[b, i]] += 1.  Ids come in runs (the collator's contract: sorted per sample), and the whole-sequence mode has ONE id per
+// sample: a thread walks 32 consecutive positions and flushes one atomic per run instead of one per position (128 k same-address
+// atomics on 2 counters per sample cost 0.5 ms).
 __global__ void seg_count_kernel(const long* __restrict__ seg, float* __restrict__ counts, long BT, int t, int S) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < BT; i += (long)gridDim.x * blockDim.x) {
-        const long b = i / t;
-        atomicAdd(counts + b * S + seg[i], 1.f);
+    constexpr int CH = 32;
+    const long nchunk = (BT + CH - 1) / CH;
+    for (long ch = (long)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (long)gridDim.x * blockDim.x) {
+        const long i0 = ch * CH, i1 = i0 + CH < BT ? i0 + CH : BT;
+        long cur = -1, cb = 0;
+        float n = 0.f;
+        for (long i = i0; i < i1; ++i) {
+            const long b = i / t, sgm = seg[i];
+            if (sgm != cur || b != cb) {
+                if (n > 0.f) atomicAdd(counts + cb * S + cur, n);
+                cur = sgm; cb = b; n = 0.f;
+            }
+            n += 1.f;
+        }
+        if (n > 0.f) atomicAdd(counts + cb * S + cur, n);
     }
 }
 
 // out[b, s, c] += sum over maximal runs of equal ids of x[b, t, c] * scale(b, s);  one thread per (b, c), grid.y = b.
 // scale = 1 / max(counts, 1) when counts != null (mean) else 1 (sum).  Runs are flushed with one atomicAdd, so ids need
 // not be sorted (sorted ids -- the collator's contract -- give exactly one atomic per segment and column).
+// Rows are taken 8 at a time: the 8 ids and 8 values are loaded first (independent loads in flight), then folded in order.
 template <typename TX>
 __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, const long* __restrict__ seg,
                                const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out,
@@ -134,36 +150,56 @@ __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, c
     if (i_begin >= i_end) return;                                                  // a run cut by a chunk border is
     float acc = 0.f;                                                               // completed by the atomics
     long cur = sb[i_begin];
-    for (int i = i_begin; i < i_end; ++i) {
-        const long s = sb[i];
-        if (s != cur) {
-            const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f;
-            if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * sc);
-            acc = 0.f; cur = s;
+    auto flush = [&](long sgm) {
+        const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + sgm], 1.f) : 1.f;
+        if (acc != 0.f) atomicAdd(out + ((long)b * S + sgm) * d + c, acc * sc);
+    };
+    for (int i = i_begin; i < i_end; i += 8) {
+        long sg[8];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = min(i + u, i_end - 1);
+            sg[u] = sb[r];
+            if constexpr (sizeof(TX) == 4) v[u] = xb[(long)r * x_ts + c]; else v[u] = bf2f(xb[(long)r * x_ts + c]);
+            if (i + u >= i_end || (rowmask && !rowmask[(long)b * t + r])) v[u] = 0.f;
         }
-        float v;
-        if constexpr (sizeof(TX) == 4) v = xb[(long)i * x_ts + c]; else v = bf2f(xb[(long)i * x_ts + c]);
-        if (rowmask && !rowmask[(long)b * t + i]) v = 0.f;
-        acc += v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (sg[u] != cur) { flush(cur); acc = 0.f; cur = sg[u]; }
+            acc += v[u];
+        }
     }
-    const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f;
-    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * sc);
+    flush(cur);
 }
 
 // y[b, t, c] = src[b, seg[b,t], c] * scale * (rowmask ? rowmask[b,t] : 1);  scale = 1/max(counts[b,seg],1) if counts
+// VEC = 4: d, y_ld multiples of 4 and 16-byte aligned bases -> one float4 per thread; 32-bit index arithmetic (b*t*d < 2^31).
+template <int VEC>
 __global__ void seg_gather_kernel(const float* __restrict__ src, const long* __restrict__ seg, const float* __restrict__ counts,
-                                  const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, long BT, int t, int S, int d,
+                                  const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, unsigned BT, int t, int S, int d,
                                   int accumulate) {
-    const long total = BT * d;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long r = idx / d;
-        const int c = idx % d;
-        const long b = r / t;
-        const long s = seg[r];
-        float v = src[(b * S + s) * d + c];
-        if (counts) v /= fmaxf(counts[b * S + s], 1.f);
-        if (rowmask && !rowmask[r]) v = 0.f;
-        if (accumulate) y[r * y_ld + c] += v; else y[r * y_ld + c] = v;
+    const unsigned dv = (unsigned)d / VEC, total = BT * dv;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned r = idx / dv, c = (idx - r * dv) * VEC;
+        const unsigned b = r / (unsigned)t;
+        const long sgm = seg[r];
+        const bool live = !(rowmask && !rowmask[r]);
+        const float den = counts ? fmaxf(counts[(long)b * S + sgm], 1.f) : 1.f;
+        const float* sp = src + ((long)b * S + sgm) * d + c;
+        float* yp = y + (long)r * y_ld + c;
+        if (VEC == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+            if (counts) v = v / den;
+            if (!live) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(yp);
+            *reinterpret_cast<f32x4*>(yp) = v;
+        } else {
+            float v = *sp;
+            if (counts) v /= den;
+            if (!live) v = 0.f;
+            *yp = accumulate ? *yp + v : v;
+        }
     }
 }
 
@@ -323,7 +359,7 @@ extern "C" int spn_ce_bwd(const void* logits, int dtype, long ld, const long* la
 // counts[b, S] fp32 (zeroed by caller) += number of rows per segment id
 extern "C" int spn_segment_count(const long* seg, float* counts, int b, int t, int S, hipStream_t s) {
     SPN_REQUIRE(seg && counts && b > 0 && t > 0 && S > 0, "spn_segment_count: bad arguments");
-    hipLaunchKernelGGL(seg_count_kernel, dim3(grid_for((long)b * t)), dim3(256), 0, s, seg, counts, (long)b * t, t, S);
+    hipLaunchKernelGGL(seg_count_kernel, dim3(grid_for(((long)b * t + 31) / 32)), dim3(256), 0, s, seg, counts, (long)b * t, t, S);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -344,8 +380,12 @@ extern "C" int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, c
 extern "C" int spn_segment_gather(const float* src, const long* seg, const float* counts, const uint8_t* rowmask, float* y, long y_ld,
                                   int b, int t, int S, int d, int accumulate, hipStream_t s) {
     SPN_REQUIRE(src && seg && y && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_gather: bad arguments");
-    hipLaunchKernelGGL(seg_gather_kernel, dim3(grid_for((long)b * t * d)), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
-                       (long)b * t, t, S, d, accumulate);
+    SPN_REQUIRE((long)b * t * d < (1l << 31), "spn_segment_gather: b*t*d must be below 2^31");
+    const bool vec = d % 4 == 0 && y_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)y) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(seg_gather_kernel<4>, dim3(grid_for((long)b * t * (d / 4))), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
+                                (unsigned)(b * t), t, S, d, accumulate);
+    else hipLaunchKernelGGL(seg_gather_kernel<1>, dim3(grid_for((long)b * t * d)), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
+                            (unsigned)(b * t), t, S, d, accumulate);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
