@@ -125,58 +125,72 @@ struct GatherDesc {
     int nkeys, D;
 };
 
+// One wave per ROW PAIR: the gathers of both rows (2 x NV table-row pieces per lane, from L2) are issued before either row is
+// reduced -- the kernel is bound by the latency of those dependent gathers, not by bandwidth.
 template <int NV>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         bf16_t* __restrict__ y, long ldy, float* __restrict__ mean,
                                                         float* __restrict__ rstd, int T, float eps) {
+    constexpr int RPW = 2;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= T) return;
-    f32x4 v[NV];
-    float sum = 0.f;
-    // the row's token tuple: one load by the first nkeys lanes, broadcast (instead of a token load in front of every table load)
-    const int tok_l = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= T) return;
+    f32x4 v[RPW][NV];
+    int tok_l[RPW];
+    // a row's token tuple: one load by the first nkeys lanes, broadcast (instead of a token load in front of every table load)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, T - 1);
+        tok_l[r] = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (lane + 64 * i) * 4;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         int kk = 0;
         for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
-        const long tok = __shfl(tok_l, kk, 64);
-        if (col < d.D) {
-            v[i] = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const long tok = __shfl(tok_l[r], kk, 64);
+            v[r][i] = col < d.D ? *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk])) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    float mu = 0.f, rs = 1.f;
-    if (gamma) {
-        mu = wave_sum(sum) / (float)d.D;
-        float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= T) break;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += v[r][i][0] + v[r][i][1] + v[r][i][2] + v[r][i][3];
+        float mu = 0.f, rs = 1.f;
+        if (gamma) {
+            mu = wave_sum(sum) / (float)d.D;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = (lane + 64 * i) * 4;
+                if (col < d.D) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float t = v[r][i][e] - mu; sq += t * t; }
+                }
+            }
+            rs = rsqrtf(wave_sum(sq) / (float)d.D + eps);
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (lane + 64 * i) * 4;
-            if (col < d.D) {
+            if (col >= d.D) continue;
+            f32x4 o = v[r][i];
+            if (gamma) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; sq += t * t; }
+                for (int e = 0; e < 4; ++e) o[e] = (v[r][i][e] - mu) * rs * ga[e] + be[e];
             }
+            uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(y + (long)row * ldy + col) = pk;
         }
-        rs = rsqrtf(wave_sum(sq) / (float)d.D + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int col = (lane + 64 * i) * 4;
-        if (col >= d.D) continue;
-        f32x4 o = v[i];
-        if (gamma) {
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * ga[e] + be[e];
-        }
-        uint2 pk; pk.x = pack_bf2(o[0], o[1]); pk.y = pack_bf2(o[2], o[3]);
-        *reinterpret_cast<uint2*>(y + (long)row * ldy + col) = pk;
     }
 }
 
@@ -383,7 +397,7 @@ extern "C" int spn_embed_fwd(int nkeys, const float* const* tables, const int* V
     SPN_REQUIRE(D > 0 && D <= 2048 && ldy % 4 == 0, "spn_embed_fwd: widths must be multiples of 4, total <= 2048");
     SPN_REQUIRE(!gamma || (mean && rstd && beta), "spn_embed_fwd: mean/rstd/beta required with gamma");
     const int nv = round_nv((D + 255) / 256);
-    dim3 grid(cdiv(T, 4));
+    dim3 grid(cdiv(T, 8));   // 4 waves x 2 rows
 #define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_fwd_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, gamma, beta, (bf16_t*)y, ldy, mean, rstd, T, eps); break;
     switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
 #undef CASE
