@@ -199,13 +199,27 @@ __global__ __launch_bounds__(256) void colsum_bf16x8_kernel(const bf16_t* __rest
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = min(T, r0 + rows_per_block);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (col < N)
-        for (long t = r0 + rg; t < r1; t += 8) {
+    if (col < N) {
+        long t = r0 + rg;
+        for (; t + 56 < r1; t += 64) {   // 8 row loads in flight per lane: a block holds few waves, one load each left HBM idle
+            uint4 u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = *reinterpret_cast<const uint4*>(x + (t + 8 * q) * ldx + col);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float f[8];
+                unpack8(u[q], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+        }
+        for (; t < r1; t += 8) {
             float f[8];
             unpack8(*reinterpret_cast<const uint4*>(x + t * ldx + col), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += f[e];
         }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rg][cg][e] = acc[e];
     __syncthreads();
