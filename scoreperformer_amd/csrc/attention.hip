@@ -266,27 +266,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // ==========================================================================================================
 // delta[b,h,i] = sum_d o * dO      grid: ceil(b*nq*h / 256) threads, one (b,i,h) per thread
 // ==========================================================================================================
+// delta[b, h, i] = sum_d O[b, i, h, d] * dO[b, i, h, d]: 8 lanes per (row, head), 16 bytes each -> a wave reads whole 128-byte lines
 __global__ void attn_delta_kernel(AttnArgs a, float* delta) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)a.b * a.nq * a.h;
-    if (idx >= total) return;
-    const int hi = idx % a.h;
-    const long bi_i = idx / a.h;
-    const int i = bi_i % a.nq, bi = bi_i / a.nq;
-    const bf16_t* op = a.o + bi * a.o_bs + (long)i * a.o_ns + hi * a.o_hs;
-    const bf16_t* dp = a.d_o + bi * a.o_bs + (long)i * a.o_ns + hi * a.o_hs;
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned grp = t >> 3, ch = t & 7;
+    const unsigned total = (unsigned)a.b * a.nq * a.h;
+    const bool live = grp < total;
+    const unsigned gi = live ? grp : total - 1;
+    const unsigned hi = gi % (unsigned)a.h, bi_i = gi / (unsigned)a.h;
+    const unsigned i = bi_i % (unsigned)a.nq, bi = bi_i / (unsigned)a.nq;
+    const long off = (long)bi * a.o_bs + (long)i * a.o_ns + (long)hi * a.o_hs + ch * 8;
+    const uint4 x = *reinterpret_cast<const uint4*>(a.o + off), y = *reinterpret_cast<const uint4*>(a.d_o + off);
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
     float acc = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        uint4 x = *reinterpret_cast<const uint4*>(op + ch * 8), y = *reinterpret_cast<const uint4*>(dp + ch * 8);
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc += bf2f(xs[e] & 0xffff) * bf2f(ys[e] & 0xffff);
-            acc += bf2f(xs[e] >> 16) * bf2f(ys[e] >> 16);
-        }
+    for (int e = 0; e < 4; ++e) {
+        acc += bf2f(xs[e] & 0xffff) * bf2f(ys[e] & 0xffff);
+        acc += bf2f(xs[e] >> 16) * bf2f(ys[e] >> 16);
     }
-    delta[((long)bi * a.h + hi) * a.nq + i] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (live && ch == 0) delta[((long)bi * a.h + hi) * a.nq + i] = acc;
 }
 
 // ==========================================================================================================
@@ -672,7 +673,7 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     rc = prepare_band(a, stream);
     if (rc) return rc;
     const long total = (long)b * nq * h;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, delta);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total * 8, 256)), dim3(256), 0, stream, a, delta);
     launch_attn_dkv(a, stream);
     if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
