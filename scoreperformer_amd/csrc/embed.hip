@@ -417,7 +417,8 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
     if (gamma) {
         SPN_REQUIRE(mean && rstd && dgamma && dbeta && ws, "spn_embed_bwd: LayerNorm buffers required with gamma");
         const int nv = round_nv((D + 255) / 256);
-        int rpb = cdiv(T, 1024); rpb = ((rpb + 3) / 4) * 4;
+        static const int stats_blocks = getenv("SPN_EMBED_STATS_BLOCKS") ? atoi(getenv("SPN_EMBED_STATS_BLOCKS")) : 2048;   // tuning aid (2048: -5 % over 1024; 256 or 16384: slower)
+        int rpb = cdiv(T, stats_blocks); rpb = ((rpb + 3) / 4) * 4;
         dim3 grid(cdiv(T, rpb));
 #define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_bwd_stats_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, dgamma, dbeta, T, rpb); break;
         switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
