@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ 
         const float* O = pass == 0 ? y : z;
         const int NO = pass == 0 ? N : Z;
         const float cc = pass == 0 ? c_yy : c_zy;
-        for (int o0 = 0; o0 < NO; o0 += 64) {
+        for (int o0 = blockIdx.y * 64; o0 < NO; o0 += 64 * gridDim.y) {   // the "others" are split over gridDim.y blocks per j tile
             __syncthreads();
             for (int e = threadIdx.x; e < 64 * DP; e += 256) {
                 const int r = e / DP, c = e % DP;
@@ -305,7 +305,10 @@ __global__ __launch_bounds__(256) void mmd_bwd_kernel(const float* __restrict__ 
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * D; e += 256) {
         const int r = e / D, c = e % D;
-        if (j0 + r < N) dy[(long)(j0 + r) * D + c] = res[r][c];
+        if (j0 + r < N) {
+            if (gridDim.y == 1) dy[(long)(j0 + r) * D + c] = res[r][c];
+            else if (res[r][c] != 0.f) atomicAdd(dy + (long)(j0 + r) * D + c, res[r][c]);   // dy zeroed by the launcher
+        }
     }
 }
 
@@ -402,7 +405,10 @@ extern "C" int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w
 extern "C" int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, int D, const float* coef, float* dy,
                            hipStream_t s) {
     SPN_REQUIRE(z && y && w && coef && dy && Z > 0 && N > 0 && D > 0 && D <= MMD_MAXD, "spn_mmd_bwd: bad arguments (D <= 64)");
-    dim3 grid(cdiv(N, 64));
+    // 64 j rows per block leaves most CUs idle at N = 4096 (64 blocks): split the loop over the other rows 8 ways
+    const int split = N >= 1024 ? 8 : 1;
+    if (split > 1) hipMemsetAsync(dy, 0, (size_t)N * D * sizeof(float), s);
+    dim3 grid(cdiv(N, 64), split);
     if (D <= 4) hipLaunchKernelGGL((mmd_bwd_kernel<4>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
     else if (D <= 8) hipLaunchKernelGGL((mmd_bwd_kernel<8>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
     else if (D <= 16) hipLaunchKernelGGL((mmd_bwd_kernel<16>), grid, dim3(256), 0, s, z, Z, y, w, N, D, coef, dy);
