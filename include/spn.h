@@ -79,6 +79,9 @@ int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dt
 int spn_colsum(const void* x, int x_dtype, long ldx, float* out /* ACCUMULATED */, long T, int N, spn_stream_t s);
 int spn_mish_fwd(const float* x, float* y, long n, spn_stream_t s);
 int spn_mish_bwd(const float* x, const float* dy, float* dx, long n, spn_stream_t s);
+/* x[r,:] = 0 where m[r] == 0, in place, bf16 [R, D]: the row mask of a Linear's backward applied to the bf16 gradient copy that the
+ * LayerNorm backward already wrote (instead of a masked cast pass over the fp32 gradient) */
+int spn_zero_masked_rows(void* x, long ldx, const uint8_t* m, long R, int D, spn_stream_t s);
 int spn_rows_all_nonzero(const float* x, long ldx, uint8_t* mask, long R, int D, spn_stream_t s);
 int spn_mask_rows(const float* x, long ldx, const uint8_t* m, float* y, long ldy, long R, int D, int invert, spn_stream_t s);
 

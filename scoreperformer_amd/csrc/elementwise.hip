@@ -276,6 +276,16 @@ __global__ void mask_rows_kernel(const float* __restrict__ x, long ldx, const ui
 
 inline int grid_for(long total, int block = 256) { long g = (total + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
+// x[r, :] = 0 for the rows with m[r] == 0, in place (bf16 [R, D], D % 8 == 0): only the masked rows are touched, so a batch
+// without padding costs one pass over the mask bytes
+__global__ void zero_masked_rows_kernel(bf16_t* __restrict__ x, long ldx, const uint8_t* __restrict__ m, long R, int D) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+        if (m[r]) continue;
+        for (int c = lane * 8; c < D; c += 512) *reinterpret_cast<uint4*>(x + r * ldx + c) = uint4{0u, 0u, 0u, 0u};
+    }
+}
+
 }  // namespace
 
 // act: 0 = SiLU, 1 = GELU(erf).  glu != 0: u is [T, 2I] (value | gate), out [T, I];  glu == 0: u [T, I].
@@ -373,6 +383,15 @@ extern "C" int spn_mish_fwd(const float* x, float* y, long n, hipStream_t s) {
 extern "C" int spn_mish_bwd(const float* x, const float* dy, float* dx, long n, hipStream_t s) {
     SPN_REQUIRE(x && dy && dx && n > 0, "spn_mish_bwd: bad arguments");
     hipLaunchKernelGGL(mish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, dy, dx, n);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+extern "C" int spn_zero_masked_rows(void* x, long ldx, const uint8_t* m, long R, int D, hipStream_t s) {
+    SPN_REQUIRE(x && m && R > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0, "spn_zero_masked_rows: bf16 rows of 8-element pieces");
+    long g = (R + 3) / 4;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, (bf16_t*)x, ldx, m, R, D);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

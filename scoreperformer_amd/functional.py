@@ -71,10 +71,19 @@ def to_bf16(x: torch.Tensor, rowmask: Optional[torch.Tensor] = None) -> torch.Te
 
 def _bf16_grad(dy: torch.Tensor, n: int, rowmask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[T, n] bf16 operand of a backward GEMM.  A LayerNorm backward that produced `dy` in fp32 also wrote its bf16 copy
-    (`dy._spn_bf16`, set on the very tensor object autograd hands on): use it instead of a cast pass."""
-    shadow = getattr(dy, "_spn_bf16", None) if rowmask is None else None
-    if shadow is not None and shadow.numel() == dy.numel():
-        return shadow.reshape(-1, n)
+    (`dy._spn_bf16`, set on the very tensor object autograd hands on): use it instead of a cast pass.  With a row mask the copy is
+    masked IN PLACE (only the padded rows are written; the fp32 `dy`, which continues down the residual path, is untouched) and
+    remembers the mask, so that a consumer with another mask (or none) falls back to the cast."""
+    shadow = getattr(dy, "_spn_bf16", None)
+    if shadow is not None and shadow.numel() == dy.numel() and n % 8 == 0:
+        applied = getattr(dy, "_spn_bf16_mask", None)
+        if rowmask is None and applied is None:
+            return shadow.reshape(-1, n)
+        if rowmask is not None and (applied is None or applied is rowmask):
+            if applied is None:
+                ops.zero_masked_rows(shadow.reshape(-1, n), rowmask)
+                dy._spn_bf16_mask = rowmask
+            return shadow.reshape(-1, n)
     return to_bf16(dy.reshape(-1, n), rowmask=rowmask)
 
 
@@ -83,6 +92,9 @@ def _with_shadow(dx: torch.Tensor, shape) -> torch.Tensor:
     shadow = getattr(dx, "_spn_bf16", None)
     if shadow is not None:
         out._spn_bf16 = shadow
+        mask = getattr(dx, "_spn_bf16_mask", None)
+        if mask is not None:
+            out._spn_bf16_mask = mask
     return out
 
 

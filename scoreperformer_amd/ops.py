@@ -331,6 +331,16 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, ta=False, tb=False, bias=None,
     return out
 
 
+def zero_masked_rows(x: torch.Tensor, m: torch.Tensor) -> torch.Tensor:
+    """In place: bf16 rows of x [R, D] with m[r] == 0 become zero (only those rows are written)."""
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != BF16 or x2.stride(1) != 1:
+        raise SpnError("zero_masked_rows: bf16 rows with unit inner stride")
+    call("spn_zero_masked_rows", ptr(x2), c_long(x2.stride(0)), ptr(_mask_u8(m.reshape(-1))), c_long(x2.shape[0]), c_int(x2.shape[1]),
+         stream_ptr())
+    return x
+
+
 def rows_all_nonzero(x: torch.Tensor) -> torch.Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     m = torch.empty(x2.shape[0], device=x.device, dtype=torch.uint8)
