@@ -57,6 +57,8 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
                 kbias[kb][hh] = (jc * slope2 + sj0) * sg;
             }
     }
+    // one counter per (row c of the block, key tile, lane group g): rowc[0] is the row's constant, the tile index comes in here
+    const uint32_t keep32 = DROP ? drop_keep32(rowc[0] + __umul24((uint32_t)((j0 >> 4) + g), 0xEBCA77u), thr8) : 0xffffffffu;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const float u = MODE == T_LEFT ? -slope2 * i_f[qb] : (MODE == T_RIGHT ? slope2 * i_f[qb] : 0.f);
@@ -106,19 +108,14 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
             }
         l_run[qb] += psum2.x + psum2.y;   // the softmax normaliser is that of the un-dropped probabilities
         if (DROP) {
-            uint32_t kw = 0;   // keep bits of this lane's 16 scores, bit 4*kb + r
+            const uint32_t kw = (keep32 >> (16 * qb)) & 0xffffu;   // keep bits of this lane's 16 scores of row block qb, bit 4*kb + r
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const int jh = (j0 + 16 * kb + 4 * g) >> 1;
-                const uint32_t mine = drop_bits(rowc[qb], jh + i_odd), other = lane_swap1(mine);   // lane parity == i_odd
-                const uint32_t b0 = i_odd ? other : mine, b1 = i_odd ? mine : other;
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool keep = drop_keep(r < 2 ? b0 : b1, i_odd, r & 1, thr8);
-                    if (!keep) s[kb][qb][r] = 0.f;
-                    kw |= keep ? (1u << (4 * kb + r)) : 0u;
+                    const int m = __builtin_amdgcn_sbfe(keep32, 16 * qb + 4 * kb + r, 1);   // all-ones when kept
+                    s[kb][qb][r] = __int_as_float(__float_as_int(s[kb][qb][r]) & m);
                 }
-            }
             bitp[qb * bstride] = (uint16_t)kw;
         }
     }
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (DROP) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
-            rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, (a.nq + 1) >> 1, (q0 + 32 * w + 16 * qb + c) >> 1);
+            rowc[qb] = drop_row_const(a.seed, bi * a.h + hi, a.nq, q0 + 32 * w + 16 * qb + c);
     }
 
     const long bstride = (long)a.nkt64 * 64;   // keep-bit words between consecutive 16-query tiles

@@ -141,6 +141,21 @@ __device__ __forceinline__ uint32_t drop_hash(uint32_t x) {
     return x ^ (x >> 15);
 }
 __device__ __forceinline__ uint32_t drop_bits(uint32_t row_const, int j_half) { return drop_hash(row_const + __umul24((uint32_t)j_half, 0xEBCA77u)); }
+// Forward keep mask of a lane's 2 x 16 scores of one key tile (rows c and c + 16 of the wave's block, keys 16 kb + 4 g + r) as ONE
+// 32-bit word: bit 16 qb + 4 kb + r.  Eight random words (one strong mix of the (row, key group) counter, seven light ones chained
+// from it) are folded digit by digit along the binary expansion of thr8 / 256 -- AND for a 0 digit, OR for a 1 digit, least
+// significant first -- which leaves every bit set with probability exactly thr8 / 256 (the drop mask).  ~2 VALU ops per score
+// instead of a byte compare per score; the backward kernels read the bits the forward stored, so only this function defines the mask.
+__device__ __forceinline__ uint32_t drop_light(uint32_t x) { x ^= x >> 11; return __umul24(x, 0xD35A2Du) + (x >> 8); }
+__device__ __forceinline__ uint32_t drop_keep32(uint32_t counter, uint32_t thr8) {
+    uint32_t w = drop_hash(counter), acc = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        acc = ((thr8 >> k) & 1u) ? (acc | w) : (acc & w);   // thr8 is wave-uniform
+        if (k < 7) w = drop_light(w + 0x9E3779B1u);
+    }
+    return ~acc;
+}
 // Lanes l and l^1 hold neighbouring rows (or columns) of the same 2x2 blocks and need the same two hashes: each computes one
 // and they swap through DPP (quad_perm [1,0,3,2]), halving the hash count.
 __device__ __forceinline__ uint32_t lane_swap1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
