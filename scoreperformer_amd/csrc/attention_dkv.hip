@@ -54,8 +54,9 @@ __device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile
                     const float pv = fast_exp2(e);
                     if (DROP) {   // row r of this lane's key column: halfword r of bw[qb], bit boff[kb] (see attention_common.h)
                         const uint32_t keepm = (uint32_t)__builtin_amdgcn_sbfe((int)(r < 2 ? bw[qb].x : bw[qb].y), boff[kb] + 16 * (r & 1), 1);
-                        p[qq][kb][r] = __uint_as_float(__float_as_uint(pv) & keepm);                      // P_dropped feeds dV
-                        ds[qq][kb][r] = pv * (__uint_as_float(__float_as_uint(acc2[r]) & keepm) - d4[r]);
+                        const float pm = __uint_as_float(__float_as_uint(pv) & keepm);                     // P_dropped feeds dV
+                        p[qq][kb][r] = pm;
+                        ds[qq][kb][r] = fmaf(pm, acc2[r], -(pv * d4[r]));   // = pv * (keep ? dP : 0) - pv * delta: one AND less
                     } else {
                         p[qq][kb][r] = pv;
                         ds[qq][kb][r] = pv * (acc2[r] - d4[r]);
