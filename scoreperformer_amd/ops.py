@@ -399,9 +399,14 @@ def table_build_bwd(tv, w0, b0, w1, dout, h1, *, has_iw: bool, dense: bool, disc
     E = [w.numel() for w in w0]
     dev = tv[0].device
     dout = [d.contiguous() for d in dout]
-    dw0 = [torch.zeros(e, device=dev, dtype=F32) for e in E]
-    db0 = [torch.zeros(e, device=dev, dtype=F32) for e in E] if dense else [None] * n
-    db1 = [torch.zeros(e, device=dev, dtype=F32) for e in E] if dense else [None] * n
+    # one zero fill for all the accumulated vectors (3 per key), handed out as views
+    zbuf = torch.zeros((3 if dense else 1) * sum(E), device=dev, dtype=F32)
+    offs = [0]
+    for e in E:
+        offs.append(offs[-1] + e)
+    dw0 = [zbuf[offs[i]:offs[i + 1]] for i in range(n)]
+    db0 = [zbuf[offs[-1] + offs[i]:offs[-1] + offs[i + 1]] for i in range(n)] if dense else [None] * n
+    db1 = [zbuf[2 * offs[-1] + offs[i]:2 * offs[-1] + offs[i + 1]] for i in range(n)] if dense else [None] * n
     diw = [torch.empty(v, e, device=dev, dtype=F32) for v, e in zip(V, E)] if has_iw else [None] * n
     dval = [torch.empty(v, e, device=dev, dtype=F32) for v, e in zip(V, E)] if dense else [None] * n
     none = [None] * n
