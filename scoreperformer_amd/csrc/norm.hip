@@ -96,8 +96,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
     const int row_end = min(T, row_begin + rows_per_block);
     for (int row = row_begin + w; row < row_end; row += 4) {
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[NV], gq[NV];
+        f32x4 xh[NV], gq[NV], dr[NV];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {   // the residual gradient is requested with the other operands, not behind the two reductions
+            const int col = (lane + 64 * i) * 4;
+            dr[i] = (dres && col < D) ? *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (lane + 64 * i) * 4;
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs * (gq[i][e] - s1 - xh[i][e] * s2);
-            if (dres) o += *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col);
+            o += dr[i];
             IO<TDx>::store4(dx + (long)row * lddx + col, o);
             if (dx16) IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);   // bf16 copy = the next backward GEMM's operand
         }
@@ -217,7 +222,8 @@ extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const voi
     SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldgb % 4 == 0 && lddgb % 4 == 0 &&
                 lddres % 4 == 0 && lddx16 % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
     const int nv = round_nv((D + 255) / 256);
-    int rpb = cdiv(T, 2048);  // <= 2048 blocks
+    static const int bwd_blocks = getenv("SPN_LN_BWD_BLOCKS") ? atoi(getenv("SPN_LN_BWD_BLOCKS")) : 2048;   // tuning aid
+    int rpb = cdiv(T, bwd_blocks);
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));
     int rc;

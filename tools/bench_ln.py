@@ -18,3 +18,13 @@ t = timeit(lambda: ops.layernorm_fwd(x, g, b, out=y))
 print(f"ln_fwd affine  fp32->bf16: {t:7.1f} us  {T*D*6/t/1e6:5.2f} TB/s")
 t = timeit(lambda: ops.layernorm_fwd(x, None, None, gb, out=y))
 print(f"ln_fwd adaptive fp32->bf16: {t:7.1f} us  {T*D*(6+8)/t/1e6:5.2f} TB/s")
+# backward at the step's shapes: affine with fork (d_residual), fp32 dx + bf16 copy
+dy = torch.randn(T, D, device=dev).bfloat16(); dres = torch.randn(T, D, device=dev)
+_, mean, rstd = ops.layernorm_fwd(x, g, b)
+import inspect
+def bwd_affine():
+    return ops.layernorm_bwd(x, dy, g, None, mean, rstd, dres=dres, want_dx16=True, dgamma=torch.zeros(D, device=dev), dbeta=torch.zeros(D, device=dev))
+try:
+    t = timeit(bwd_affine); print(f"ln_bwd affine+fork: {t:7.1f} us  {T*D*(4+2+4+4+2)/t/1e6:5.2f} TB/s")
+except TypeError as e:
+    print("ln_bwd signature:", inspect.signature(ops.layernorm_bwd))
