@@ -286,7 +286,15 @@ class AdaLayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, cond, weight, bias, out_fp32: bool, eps: float, fork: bool = False):
         D = x.shape[-1]
-        cb = to_bf16(cond)
+        cached = getattr(cond, "_spn_bf16_cast", None)   # every adaptive norm of a stack gets the same condition tensor: cast once
+        if cached is not None and cached[0] == cond._version:
+            cb = cached[1]
+        else:
+            cb = to_bf16(cond)
+            try:
+                cond._spn_bf16_cast = (cond._version, cb)
+            except Exception:
+                pass
         c2 = cb.reshape(-1, cb.shape[-1])
         gb = ops.gemm(c2, bf16_weight(weight), out_dtype=F32, bias=bias.detach())
         y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
