@@ -410,3 +410,42 @@ def test_dec_head_sample_draws_from_the_top_k_softmax():
     tokens[1, 3] = 17
     ops.dec_head_sample(tables, col0, [3, 5], D, e, gamma, beta, 1e-5, tokens, pos, part, counter, logits, topk, seed, temperature=T, slabs=8)
     assert int(tokens[1, 3]) == 17
+
+
+@pytest.mark.parametrize("E,V,with_ln,pad_rows", [(128, [260, 132, 16, 92, 133, 40], True, True),     # one-hot MFMA scatter (recipe widths)
+                                                  (128, [260, 132, 16, 92], False, False),           # ... without the LayerNorm
+                                                  (32, [40, 36, 16, 28, 37], True, True)])           # LDS-atomic scatter (other widths)
+def test_embedding_forward_backward_match_torch(E, V, with_ln, pad_rows):
+    """spn_embed_fwd / spn_embed_bwd (gather + concat + LayerNorm and its backward into the per-key tables) against fp32 autograd.
+    The E = 128 case runs the one-hot MFMA scatter, whose gradient tile is rounded to bf16 before it is accumulated in fp32."""
+    from scoreperformer_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5 + E)
+    B, t = 3, 333                                     # not a multiple of the 64-row stage
+    K, D = len(V), len(V) * E
+    tables = [torch.randn(v, E, generator=g).to(dev) for v in V]
+    tokens = torch.stack([torch.randint(0, v, (B, t), generator=g) for v in V], -1)
+    if pad_rows:
+        tokens[1, 200:] = 0                           # padding rows: token 0 = padding_idx, no table gradient
+    tokens = tokens.to(dev)
+    gamma = (torch.rand(D, generator=g) + 0.5).to(dev) if with_ln else None
+    beta = (torch.randn(D, generator=g) * 0.1).to(dev) if with_ln else None
+    y, mean, rstd = ops.embed_fwd(tables, tokens, gamma, beta)
+    ref_tabs = [tb.clone().requires_grad_(True) for tb in tables]
+    x = torch.cat([torch.nn.functional.embedding(tokens[..., k], ref_tabs[k], padding_idx=0) for k in range(K)], -1)
+    # (nn.Embedding semantics: the padding row is looked up like any other; only its gradient is dropped)
+    rg = gamma.clone().requires_grad_(True) if with_ln else None
+    rb = beta.clone().requires_grad_(True) if with_ln else None
+    yr = torch.nn.functional.layer_norm(x, (D,), rg, rb, 1e-5) if with_ln else x
+    assert rel_err(y.view(B, t, D), yr) < 1e-2
+    dy = torch.randn(B * t, D, generator=g).to(dev).bfloat16()
+    yr.backward(dy.float().view(B, t, D))
+    dgamma = torch.zeros(D, device=dev) if with_ln else None
+    dbeta = torch.zeros(D, device=dev) if with_ln else None
+    dts = ops.embed_bwd(tables, tokens, dy, gamma, mean, rstd, dgamma=dgamma, dbeta=dbeta, padding_idx=0)
+    tol = 1.5e-2 if E == 128 else 2e-3
+    for k in range(K):
+        assert float(dts[k][0].abs().max()) == 0.0                       # padding row
+        assert rel_err(dts[k], ref_tabs[k].grad) < tol, (k, rel_err(dts[k], ref_tabs[k].grad))
+    if with_ln:
+        assert rel_err(dgamma, rg.grad) < 2e-3 and rel_err(dbeta, rb.grad) < 2e-3
