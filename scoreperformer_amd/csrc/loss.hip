@@ -150,10 +150,7 @@ __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, c
     if (i_begin >= i_end) return;                                                  // a run cut by a chunk border is
     float acc = 0.f;                                                               // completed by the atomics
     long cur = sb[i_begin];
-    auto flush = [&](long sgm) {
-        const float sc = counts ? 1.f / fmaxf(counts[(long)b * S + sgm], 1.f) : 1.f;
-        if (acc != 0.f) atomicAdd(out + ((long)b * S + sgm) * d + c, acc * sc);
-    };
+    const uint8_t* mb = rowmask ? rowmask + (long)b * t : nullptr;
     for (int i = i_begin; i < i_end; i += 8) {
         long sg[8];
         float v[8];
@@ -161,16 +158,22 @@ __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, c
         for (int u = 0; u < 8; ++u) {
             const int r = min(i + u, i_end - 1);
             sg[u] = sb[r];
-            if constexpr (sizeof(TX) == 4) v[u] = xb[(long)r * x_ts + c]; else v[u] = bf2f(xb[(long)r * x_ts + c]);
-            if (i + u >= i_end || (rowmask && !rowmask[(long)b * t + r])) v[u] = 0.f;
+            float xv;
+            if constexpr (sizeof(TX) == 4) xv = xb[(long)r * x_ts + c];
+            else xv = bf2f(xb[(long)r * x_ts + c]);
+            const bool live = (i + u < i_end) && (mb == nullptr || mb[r] != 0);
+            v[u] = live ? xv : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (sg[u] != cur) { flush(cur); acc = 0.f; cur = sg[u]; }
+            if (sg[u] != cur) {
+                if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
+                acc = 0.f; cur = sg[u];
+            }
             acc += v[u];
         }
     }
-    flush(cur);
+    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
 }
 
 // y[b, t, c] = src[b, seg[b,t], c] * scale * (rowmask ? rowmask[b,t] : 1);  scale = 1/max(counts[b,seg],1) if counts

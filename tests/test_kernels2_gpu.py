@@ -1,0 +1,136 @@
+"""GPU: the elementwise / reduction / loss-side kernels against plain PyTorch fp32 at sizes that reach their fast paths
+(unrolled column sums, activation backward with fused bias sums, run-length segment kernels, split MMD backward, masked casts)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def rel_err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+@pytest.mark.parametrize("glu,act,I", [(True, 0, 2048), (True, 0, 96), (False, 1, 512)])
+def test_activation_forward_backward_and_fused_bias_sums(glu, act, I):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(1 + I)
+    T = 2500
+    W = 2 * I if glu else I
+    u = torch.randn(T, W, generator=g).to(DEV).bfloat16()
+    d = torch.randn(T, I, generator=g).to(DEV).bfloat16()
+    fn = F.silu if act == 0 else F.gelu
+    ur = u.float().requires_grad_(True)
+    ref = ur[:, :I] * fn(ur[:, I:]) if glu else fn(ur)
+    out = ops.act_fwd(u, act=act, glu=glu)
+    assert rel_err(out, ref) < 1e-2
+    ref.backward(d.float())
+    bias_sum = torch.zeros(W, device=DEV) if ops.act_bwd_can_fuse_colsum(W, glu) else None
+    du = ops.act_bwd(u, d, act=act, glu=glu, colsum=bias_sum)
+    assert rel_err(du, ur.grad) < 1.5e-2
+    if bias_sum is not None:   # the fused column sums are those of the bf16 du the consumer GEMMs read
+        assert rel_err(bias_sum, du.float().sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("N,dtype", [(512, torch.bfloat16), (640, torch.bfloat16), (36, torch.bfloat16), (512, torch.float32)])
+def test_column_sums(N, dtype):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(5003, N, generator=g).to(DEV).to(dtype)       # odd row count: unrolled body + tail
+    out = torch.full((N,), 2.0, device=DEV)
+    ops.colsum(x, out=out)                                         # accumulates
+    assert rel_err(out - 2.0, x.float().sum(0)) < 2e-5 * (1 if dtype == torch.float32 else 50)
+
+
+def test_masked_cast_and_in_place_row_mask():
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 211, 512, generator=g).to(DEV)
+    m = (torch.rand(3, 211, generator=g) < 0.7).to(DEV)
+    y = ops.cast(x, torch.bfloat16, rowmask=m)
+    assert torch.equal(y, (x * m[..., None]).bfloat16())
+    z = x.bfloat16()
+    ops.zero_masked_rows(z.view(-1, 512), m)
+    assert torch.equal(z, y)
+    assert torch.equal(ops.cast(y, torch.float32), y.float())
+
+
+@pytest.mark.parametrize("d,S,mode", [(512, 90, "runs"), (32, 300, "runs"), (4, 2, "constant"), (20, 50, "unsorted")])
+def test_segment_count_sum_gather(d, S, mode):
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(d + S)
+    b, t = 5, 777
+    if mode == "constant":
+        seg = torch.ones(b, t, dtype=torch.long)
+    elif mode == "runs":
+        seg = torch.cumsum((torch.rand(b, t, generator=g) < (S - 2) / t).long(), 1).clamp_max(S - 1)
+    else:
+        seg = torch.randint(0, S, (b, t), generator=g)
+    seg = seg.to(DEV)
+    x = torch.randn(b, t, d, generator=g).to(DEV)
+    mask = (torch.rand(b, t, generator=g) < 0.8).to(DEV)
+    counts = ops.segment_count(seg, S)
+    onehot = F.one_hot(seg, S).float()                               # [b, t, S]
+    assert torch.equal(counts, onehot.sum(1))
+    sums = ops.segment_sum(x, seg, S)
+    want = torch.einsum("bts,btd->bsd", onehot, x)
+    assert rel_err(sums, want) < 1e-5
+    means = ops.segment_sum(x, seg, S, counts=counts, rowmask=mask)
+    want_m = torch.einsum("bts,btd->bsd", onehot, x * mask[..., None]) / counts.clamp_min(1)[..., None]
+    assert rel_err(means, want_m) < 1e-5
+    src = torch.randn(b, S, d, generator=g).to(DEV)
+    y = ops.segment_gather(src, seg, counts=counts, rowmask=mask)
+    want_y = torch.gather(src / counts.clamp_min(1)[..., None], 1, seg[..., None].expand(b, t, d)) * mask[..., None]
+    assert rel_err(y, want_y) < 1e-6
+    wide = torch.randn(b, t, d + 8, generator=g).to(DEV)             # accumulate into a column slice of a wider buffer
+    before = wide.clone()
+    ops.segment_gather(src, seg, out=wide[..., 4:4 + d], accumulate=True)
+    assert rel_err(wide[..., 4:4 + d], before[..., 4:4 + d] + torch.gather(src, 1, seg[..., None].expand(b, t, d))) < 1e-6
+    assert torch.equal(wide[..., :4], before[..., :4]) and torch.equal(wide[..., 4 + d:], before[..., 4 + d:])
+
+
+@pytest.mark.parametrize("N,D", [(1500, 32), (300, 8), (2100, 4)])
+def test_mmd_forward_backward(N, D):
+    """MMDFn = compute_mmd of the reference (mmd_transformer.py:521-534) with 0/1 row weights; N >= 1024 takes the split backward."""
+    from scoreperformer_amd import functional as F_
+    g = torch.Generator().manual_seed(N)
+    Z = 256
+    y = torch.randn(N, D, generator=g).to(DEV)
+    z = torch.randn(Z, D, generator=g).to(DEV)
+    w = (torch.rand(N, generator=g) < 0.6).float().to(DEV)
+
+    def kernel_mean(a, b_):
+        d2 = (a[:, None, :] - b_[None, :, :]).pow(2).mean(2) / D
+        return torch.exp(-d2)
+
+    yr = y.clone().requires_grad_(True)
+    ys = yr[w > 0]
+    ref = kernel_mean(z, z).mean() + kernel_mean(ys, ys).mean() - 2 * kernel_mean(z, ys).mean()
+    yt = y.clone().requires_grad_(True)
+    got = F_.MMDFn.apply(yt, w, z)
+    assert abs(float(got) - float(ref)) < 1e-5 + 1e-4 * abs(float(ref))
+    ref.backward()
+    got.backward()
+    assert rel_err(yt.grad, yr.grad) < 1e-3
+    assert float(yt.grad[w == 0].abs().max()) == 0.0
+
+
+def test_cross_entropy_forward_backward():
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, t, V = 3, 401, 165
+    logits = (torch.randn(B * t, 168, generator=g) * 3).to(DEV)[:, :V]        # padded row stride
+    labels = torch.randint(0, V, (B, t, 3), generator=g)
+    labels[torch.rand(B, t, generator=g) < 0.3] = -100
+    lab = labels.to(DEV)[..., 1]                                             # strided label column
+    lse, sums, am = ops.ce_fwd(logits, V, lab, want_argmax=True)
+    lr = logits.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, lab.reshape(-1), ignore_index=-100, reduction="sum")
+    assert abs(float(sums[0]) - float(ref)) < 1e-4 * float(ref) and float(sums[1]) == float((lab != -100).sum())
+    assert torch.equal(am.long(), logits.argmax(-1)) and rel_err(lse, torch.logsumexp(logits, -1)) < 1e-6
+    ref.backward()
+    coef = torch.ones(1, device=DEV)
+    dl = ops.ce_bwd(logits, V, lab, lse, coef)
+    assert rel_err(dl[:, :V], lr.grad) < 1e-2 and float(dl[:, V:].abs().max()) == 0.0
