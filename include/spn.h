@@ -66,6 +66,12 @@ int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long
                       long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,
                       long lddx, void* dx16 /* optional bf16 copy of dx */, long lddx16, float* dgamma, float* dbeta, void* dgb,
                       long lddgb, int T, int D, spn_stream_t stream);
+/* adaptive LayerNorm with the per-token (gamma | beta) rows in bf16 (modules/layers.py:41-47: gamma, beta = Linear(condition)) */
+int spn_layernorm_fwd_gb16(const void* x, int x_dtype, long ldx, const void* gb16, long ldgb, void* y, int y_dtype, long ldy,
+                           float* mean, float* rstd, int T, int D, float eps, spn_stream_t stream);
+int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
+                           const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx,
+                           void* dx16, long lddx16, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
 
 /* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
 /* p_drop > 0: nn.Dropout on the activation output (feedforward.py:57-60); the mask is a pure function of (seed, index) */

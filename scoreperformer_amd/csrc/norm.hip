@@ -28,9 +28,11 @@ template <> struct IO<bf16_t> {
 // ---------------------------------------------------------------------------------------------------------
 template <typename TIn, typename TOut, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, long ldx, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, const float* __restrict__ gb, long ldgb,
+                                                     const float* __restrict__ beta, const void* __restrict__ gb_, long ldgb, int gb16,
                                                      TOut* __restrict__ y, long ldy, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int T, int D, float eps) {
+    const float* gb = reinterpret_cast<const float*>(gb_);            // (gamma | beta) rows: fp32, or bf16 when gb16
+    const bf16_t* gbh = reinterpret_cast<const bf16_t*>(gb_);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs;
         if (gb) {
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + D + col);
+            const f32x4 ga = gb16 ? IO<bf16_t>::load4(gbh + (long)row * ldgb + col) : *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
+            const f32x4 be = gb16 ? IO<bf16_t>::load4(gbh + (long)row * ldgb + D + col) : *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + D + col);
             o = o * ga + be;
         } else if (gamma) {
             const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col);
@@ -81,13 +83,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TIn* __restrict__ x, 
 // dgb (adaptive): [T, 2D] bf16 rows (dy * xhat | dy), consumed as a GEMM operand by the AdaLN linear's backward.
 template <typename TIn, typename TDx, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
-                                                     const float* __restrict__ gamma, const float* __restrict__ gb, long ldgb,
+                                                     const float* __restrict__ gamma, const void* __restrict__ gb_, long ldgb, int gb16,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, long lddres, TDx* __restrict__ dx, long lddx,
                                                      bf16_t* __restrict__ dx16, long lddx16,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      bf16_t* __restrict__ dgb, long lddgb, int T, int D, int rows_per_block) {
     __shared__ float red[4][64 * NV * 4 + 4];
+    const float* gb = reinterpret_cast<const float*>(gb_);
+    const bf16_t* gbh = reinterpret_cast<const bf16_t*>(gb_);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     f32x4 pg[NV], pb[NV];
 #pragma unroll
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
             const f32x4 xv = IO<TIn>::load4(x + (long)row * ldx + col);
             const f32x4 d = IO<bf16_t>::load4(dy + (long)row * lddy + col);
             f32x4 ga = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (gb) ga = *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
+            if (gb) ga = gb16 ? IO<bf16_t>::load4(gbh + (long)row * ldgb + col) : *reinterpret_cast<const f32x4*>(gb + (long)row * ldgb + col);
             else if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + col);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -162,12 +166,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
 }
 
 template <typename TIn, typename TOut>
-int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const float* gamma, const float* beta, const float* gb,
-               long ldgb, void* y, long ldy, float* mean, float* rstd, int T, int D, float eps) {
+int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const float* gamma, const float* beta, const void* gb,
+               long ldgb, int gb16, void* y, long ldy, float* mean, float* rstd, int T, int D, float eps) {
 #define CASE(NV_)                                                                                                        \
     case NV_:                                                                                                            \
         hipLaunchKernelGGL((ln_fwd_kernel<TIn, TOut, NV_>), grid, dim3(256), 0, s, (const TIn*)x, ldx, gamma, beta, gb,  \
-                           ldgb, (TOut*)y, ldy, mean, rstd, T, D, eps);                                                  \
+                           ldgb, gb16, (TOut*)y, ldy, mean, rstd, T, D, eps);                                            \
         break;
     switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
 #undef CASE
@@ -176,12 +180,12 @@ int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const 
 
 template <typename TIn, typename TDx>
 int launch_bwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const void* dy, long lddy, const float* gamma,
-               const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres, long lddres, void* dx,
+               const void* gb, long ldgb, int gb16, const float* mean, const float* rstd, const float* dres, long lddres, void* dx,
                long lddx, bf16_t* dx16, long lddx16, float* dgamma, float* dbeta, bf16_t* dgb, long lddgb, int T, int D, int rpb) {
 #define CASE(NV_)                                                                                                        \
     case NV_:                                                                                                            \
         hipLaunchKernelGGL((ln_bwd_kernel<TIn, TDx, NV_>), grid, dim3(256), 0, s, (const TIn*)x, ldx, (const bf16_t*)dy, \
-                           lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, (TDx*)dx, lddx, dx16, lddx16, dgamma, dbeta, dgb, lddgb, T, D, \
+                           lddy, gamma, gb, ldgb, gb16, mean, rstd, dres, lddres, (TDx*)dx, lddx, dx16, lddx16, dgamma, dbeta, dgb, lddgb, T, D, \
                            rpb);                                                                                         \
         break;
     switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
@@ -193,31 +197,27 @@ static inline int round_nv(int nv) { return nv <= 2 ? nv : nv <= 4 ? 4 : nv <= 6
 
 }  // namespace
 
-// dtype codes: 0 = fp32, 1 = bf16.  gamma/beta: [D] fp32 or null;  gb: [T, 2D] fp32 (ldgb) or null.
-extern "C" int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, const float* gb,
-                                 long ldgb, void* y, int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps,
-                                 hipStream_t stream) {
+namespace {
+int ln_fwd_impl(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, const void* gb, long ldgb, int gb16, void* y,
+                int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps, hipStream_t stream) {
     SPN_REQUIRE(x && y && T > 0 && D > 0, "spn_layernorm_fwd: bad arguments");
     SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && ldy % 4 == 0 && ldgb % 4 == 0,
                 "spn_layernorm_fwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
     const int nv = round_nv((D + 255) / 256);
     dim3 grid(cdiv(T, 4));
     int rc;
-    if (x_dtype == 0 && y_dtype == 1) rc = launch_fwd<float, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
-    else if (x_dtype == 0 && y_dtype == 0) rc = launch_fwd<float, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
-    else if (x_dtype == 1 && y_dtype == 1) rc = launch_fwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
-    else rc = launch_fwd<bf16_t, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, y, ldy, mean, rstd, T, D, eps);
+    if (x_dtype == 0 && y_dtype == 1) rc = launch_fwd<float, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, gb16, y, ldy, mean, rstd, T, D, eps);
+    else if (x_dtype == 0 && y_dtype == 0) rc = launch_fwd<float, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, gb16, y, ldy, mean, rstd, T, D, eps);
+    else if (x_dtype == 1 && y_dtype == 1) rc = launch_fwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, gb16, y, ldy, mean, rstd, T, D, eps);
+    else rc = launch_fwd<bf16_t, float>(nv, grid, stream, x, ldx, gamma, beta, gb, ldgb, gb16, y, ldy, mean, rstd, T, D, eps);
     if (rc) { spn_set_error("spn_layernorm_fwd: unsupported width"); return rc; }
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
 
-// dx[T,D] (fp32 or bf16) = (dres or 0) + LN backward; dy is bf16.  Affine: dgamma/dbeta [D] fp32 are ACCUMULATED
-// (atomics; zero them first).  Adaptive: dgb [T,2D] bf16 rows are written.  dx16 (optional): bf16 copy of dx, row stride lddx16.
-extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma,
-                                 const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres,
-                                 long lddres, void* dx, int dx_dtype, long lddx, void* dx16, long lddx16, float* dgamma,
-                                 float* dbeta, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
+int ln_bwd_impl(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma, const void* gb, long ldgb, int gb16,
+                const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx, void* dx16,
+                long lddx16, float* dgamma, float* dbeta, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
     SPN_REQUIRE(x && dy && mean && rstd && dx && T > 0 && D > 0, "spn_layernorm_bwd: bad arguments");
     SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldgb % 4 == 0 && lddgb % 4 == 0 &&
                 lddres % 4 == 0 && lddx16 % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
@@ -227,11 +227,44 @@ extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const voi
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));
     int rc;
-    if (x_dtype == 0 && dx_dtype == 0) rc = launch_bwd<float, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else if (x_dtype == 0 && dx_dtype == 1) rc = launch_bwd<float, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else if (x_dtype == 1 && dx_dtype == 0) rc = launch_bwd<bf16_t, float>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
-    else rc = launch_bwd<bf16_t, bf16_t>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb);
+#define LNB(TI_, TD_) launch_bwd<TI_, TD_>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, gb16, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb)
+    if (x_dtype == 0 && dx_dtype == 0) rc = LNB(float, float);
+    else if (x_dtype == 0 && dx_dtype == 1) rc = LNB(float, bf16_t);
+    else if (x_dtype == 1 && dx_dtype == 0) rc = LNB(bf16_t, float);
+    else rc = LNB(bf16_t, bf16_t);
+#undef LNB
     if (rc) { spn_set_error("spn_layernorm_bwd: unsupported width"); return rc; }
     SPN_LAUNCH_CHECK();
     return SPN_OK;
+}
+}  // namespace
+
+// dtype codes: 0 = fp32, 1 = bf16.  gamma/beta: [D] fp32 or null;  gb: [T, 2D] fp32 (ldgb) or null.
+extern "C" int spn_layernorm_fwd(const void* x, int x_dtype, long ldx, const float* gamma, const float* beta, const float* gb,
+                                 long ldgb, void* y, int y_dtype, long ldy, float* mean, float* rstd, int T, int D, float eps,
+                                 hipStream_t stream) {
+    return ln_fwd_impl(x, x_dtype, ldx, gamma, beta, gb, ldgb, 0, y, y_dtype, ldy, mean, rstd, T, D, eps, stream);
+}
+// the adaptive form with the per-token (gamma | beta) rows in bf16 (half the bytes of the largest tensor of an adaptive norm)
+extern "C" int spn_layernorm_fwd_gb16(const void* x, int x_dtype, long ldx, const void* gb16, long ldgb, void* y, int y_dtype, long ldy,
+                                      float* mean, float* rstd, int T, int D, float eps, hipStream_t stream) {
+    SPN_REQUIRE(gb16, "spn_layernorm_fwd_gb16: gb required");
+    return ln_fwd_impl(x, x_dtype, ldx, nullptr, nullptr, gb16, ldgb, 1, y, y_dtype, ldy, mean, rstd, T, D, eps, stream);
+}
+
+// dx[T,D] (fp32 or bf16) = (dres or 0) + LN backward; dy is bf16.  Affine: dgamma/dbeta [D] fp32 are ACCUMULATED
+// (atomics; zero them first).  Adaptive: dgb [T,2D] bf16 rows are written.  dx16 (optional): bf16 copy of dx, row stride lddx16.
+extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const float* gamma,
+                                 const float* gb, long ldgb, const float* mean, const float* rstd, const float* dres,
+                                 long lddres, void* dx, int dx_dtype, long lddx, void* dx16, long lddx16, float* dgamma,
+                                 float* dbeta, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
+    return ln_bwd_impl(x, x_dtype, ldx, dy, lddy, gamma, gb, ldgb, 0, mean, rstd, dres, lddres, dx, dx_dtype, lddx, dx16, lddx16, dgamma,
+                       dbeta, dgb, lddgb, T, D, stream);
+}
+extern "C" int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
+                                      const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,
+                                      long lddx, void* dx16, long lddx16, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
+    SPN_REQUIRE(gb16, "spn_layernorm_bwd_gb16: gb required");
+    return ln_bwd_impl(x, x_dtype, ldx, dy, lddy, nullptr, gb16, ldgb, 1, mean, rstd, dres, lddres, dx, dx_dtype, lddx, dx16, lddx16,
+                       nullptr, nullptr, dgb, lddgb, T, D, stream);
 }

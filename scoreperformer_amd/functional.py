@@ -280,6 +280,11 @@ def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5, fork=False):
     return LayerNormFn.apply(x, gamma, beta, out_fp32, eps, fork)
 
 
+# dtype of the per-token (gamma | beta) rows of an adaptive norm: the largest tensor of the norm ([T, 2D]); SPN_ADALN_GB=bf16 halves it
+import os as _os
+ADALN_GB_DTYPE = BF16 if _os.environ.get("SPN_ADALN_GB", "fp32") == "bf16" else F32
+
+
 class AdaLayerNormFn(Function):
     """y = gamma_t * LN(x) + beta_t,  (gamma_t | beta_t) = cond @ W^T + b   (modules/layers.py:31-47)."""
 
@@ -296,7 +301,7 @@ class AdaLayerNormFn(Function):
             except Exception:
                 pass
         c2 = cb.reshape(-1, cb.shape[-1])
-        gb = ops.gemm(c2, bf16_weight(weight), out_dtype=F32, bias=bias.detach())
+        gb = ops.gemm(c2, bf16_weight(weight), out_dtype=ADALN_GB_DTYPE, bias=bias.detach())   # [T, 2D] (gamma | beta)
         y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
         ctx.save_for_backward(x, c2, gb, mean, rstd)
         ctx.weight_ref, ctx.bias_ref, ctx.cond_shape, ctx.cond_dtype = weight, bias, cond.shape, cond.dtype

@@ -125,8 +125,12 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
     rstd = torch.empty(T, device=x.device, dtype=F32)
     if gb is not None:
         gb = _rows2d(gb)
-        if gb.dtype != F32 or gb.shape != (T, 2 * D):
-            raise SpnError("layernorm: gb must be fp32 [T, 2D]")
+        if gb.dtype not in (F32, BF16) or gb.shape != (T, 2 * D):
+            raise SpnError("layernorm: gb must be fp32 or bf16 [T, 2D]")
+        if gb.dtype == BF16:
+            call("spn_layernorm_fwd_gb16", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(gb), c_long(gb.stride(0)), ptr(y), c_int(_dt(y)),
+                 c_long(y.stride(0)), ptr(mean), ptr(rstd), c_int(T), c_int(D), c_float(eps), stream_ptr())
+            return y, mean, rstd
     call("spn_layernorm_fwd", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(gamma), ptr(beta), ptr(gb),
          c_long(gb.stride(0) if gb is not None else 0), ptr(y), c_int(_dt(y)), c_long(y.stride(0)), ptr(mean), ptr(rstd),
          c_int(T), c_int(D), c_float(eps), stream_ptr())
@@ -150,6 +154,13 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tenso
         gb = _rows2d(gb)
     if dres is not None:
         dres = _rows2d(dres)
+    if gb is not None and gb.dtype == BF16:
+        call("spn_layernorm_bwd_gb16", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gb),
+             c_long(gb.stride(0)), ptr(mean), ptr(rstd), ptr(dres), c_long(dres.stride(0) if dres is not None else 0), ptr(dx),
+             c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D), ptr(dgb), c_long(2 * D), c_int(T), c_int(D), stream_ptr())
+        if dx16 is not None:
+            dx._spn_bf16 = dx16
+        return dx, dgb
     call("spn_layernorm_bwd", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gamma),
          ptr(gb), c_long(gb.stride(0) if gb is not None else 0), ptr(mean), ptr(rstd), ptr(dres),
          c_long(dres.stride(0) if dres is not None else 0), ptr(dx), c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D),
