@@ -373,14 +373,15 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_mfma_kernel(GatherDesc 
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nt][r] = 0.f;
-    const int pr = tid >> 3, pc = (tid & 7) * 2;    // producer role: row of the stage, first of its two 8-column chunks
+    const int pr = tid >> 3, pc = tid & 7;          // producer role: row of the stage; its two 8-column chunks are pc and pc + 8
+    // (8 consecutive lanes cover 128 contiguous bytes of a row: whole-line gradient loads, conflict-free 16-byte LDS writes)
     // the producer is software-pipelined: the raw loads of stage s+1 (gradient pieces, gathered table rows, row statistics) are issued
     // before the MFMAs of stage s and consumed after them; the token of stage s+2 (the gather address) is fetched one stage earlier
     f32x4 gam[2][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        gam[h][0] = gamma ? *reinterpret_cast<const f32x4*>(gamma + c0 + (pc + h) * 8) : f32x4{1.f, 1.f, 1.f, 1.f};
-        gam[h][1] = gamma ? *reinterpret_cast<const f32x4*>(gamma + c0 + (pc + h) * 8 + 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        gam[h][0] = gamma ? *reinterpret_cast<const f32x4*>(gamma + c0 + (pc + 8 * h) * 8) : f32x4{1.f, 1.f, 1.f, 1.f};
+        gam[h][1] = gamma ? *reinterpret_cast<const f32x4*>(gamma + c0 + (pc + 8 * h) * 8 + 4) : f32x4{1.f, 1.f, 1.f, 1.f};
     }
     auto load_tok = [&](int base) {
         const int gr = base + pr;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_mfma_kernel(GatherDesc 
         const int tk = tok < 0 ? 0 : tok;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = (pc + h) * 8;
+            const int c = (pc + 8 * h) * 8;
             r.dyv[h] = *reinterpret_cast<const uint4*>(dy + (long)gr * lddy + c0 + c);
             if (gamma) {
                 r.x[h][0] = *reinterpret_cast<const f32x4*>(tab + (long)tk * 128 + c);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512) void embed_bwd_scatter_mfma_kernel(GatherDesc 
                     }
                     out = pack8f(g);
                 }
-                *reinterpret_cast<uint4*>(stage[buf] + em_rc_off(pr, pc + h)) = out;
+                *reinterpret_cast<uint4*>(stage[buf] + em_rc_off(pr, pc + 8 * h)) = out;
             }
         }
         if (base + 64 < row_end) {   // next stage's loads go out now and land behind the MFMAs below
