@@ -36,37 +36,40 @@ class Model(nn.Module, Constructor):
 
     @classmethod
     def from_pretrained(cls, checkpoint_path: str):
-        checkpoint = torch.load(checkpoint_path, map_location='cpu')
-        model = cls.init(OmegaConf.create(checkpoint['model']['config']))
-        model.load_state_dict(checkpoint['model']['state_dict'], strict=True)
+        """Model of the checkpoint's own config with its weights, strictly loaded (models/base.py:43-53)."""
+        saved = torch.load(checkpoint_path, map_location="cpu")["model"]
+        model = cls.init(OmegaConf.create(saved["config"]))
+        model.load_state_dict(saved["state_dict"], strict=True)
         return model
 
     def load(self, state_dict: Dict[str, Tensor], ignore_layers: Optional[List] = None, ignore_mismatched_keys: bool = False):
-        ignore_layers = ignore_layers or []
-        model_state = self.state_dict()
-        extra_keys = [k for k in state_dict.keys() if k not in model_state]
-        if extra_keys:
-            logger.warning(f"The following checkpoint keys are not presented in the model and will be ignored: {extra_keys}")
-            state_dict = {k: v for k, v in state_dict.items() if k not in extra_keys}
-        ignored_keys = []
+        """Tolerant load (models/base.py:55-93): keys the model does not have are dropped with a warning; with
+        `ignore_mismatched_keys` so are keys whose shapes differ; `ignore_layers` drops every key containing one of the given
+        substrings; whatever remains overwrites the model's current state."""
+        own = self.state_dict()
+        unknown = [k for k in state_dict if k not in own]
+        if unknown:
+            logger.warning(f"The following checkpoint keys are not presented in the model and will be ignored: {unknown}")
+        skipped = []
         if ignore_mismatched_keys:
-            auto = [k for k, v in state_dict.items() if v.data.shape != model_state[k].data.shape]
-            logger.info(f"Automatically found the checkpoint keys incompatible with the model: {auto}")
-            ignored_keys.extend(auto)
-        if ignore_layers:
-            ignored_keys.extend(k for k in state_dict if any(layer in k for layer in ignore_layers))
-        if ignored_keys:
-            state_dict = {k: v for k, v in state_dict.items() if k not in ignored_keys}
-            logger.info(f"The following checkpoint keys were ignored: {ignored_keys}")
-        model_state.update(state_dict)
-        self.load_state_dict(model_state)
+            mismatched = [k for k, v in state_dict.items() if k in own and v.data.shape != own[k].data.shape]
+            logger.info(f"Automatically found the checkpoint keys incompatible with the model: {mismatched}")
+            skipped += mismatched
+        for fragment in (ignore_layers or []):
+            skipped += [k for k in state_dict if k in own and fragment in k and k not in skipped]
+        if skipped:
+            logger.info(f"The following checkpoint keys were ignored: {skipped}")
+        drop = set(unknown) | set(skipped)
+        own.update({k: v for k, v in state_dict.items() if k not in drop})
+        self.load_state_dict(own)
         return self
 
     def freeze(self, exception_list=None):
-        not_frozen = []
-        exception_list = exception_list or []
+        """requires_grad only for the parameters whose names start with one of `exception_list` (models/base.py:95-102)."""
+        keep = tuple(exception_list or ())
+        trainable = []
         for name, param in self.named_parameters():
-            param.requires_grad = any(name.startswith(layer) for layer in exception_list)
+            param.requires_grad = bool(keep) and name.startswith(keep)
             if param.requires_grad:
-                not_frozen.append(name)
-        logger.info(f"The model graph has been frozen, except for the following parameters: {not_frozen}")
+                trainable.append(name)
+        logger.info(f"The model graph has been frozen, except for the following parameters: {trainable}")

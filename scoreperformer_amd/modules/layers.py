@@ -17,11 +17,11 @@ class Residual(nn.Module):
     def forward(self, x, residual):
         # the transformer stack fuses the plain residual add into the producing GEMM's epilogue; this eager path only
         # serves stand-alone use and the (unused in shipped recipes) scaled variants
-        if self.residual_scale is not None:
-            residual = residual * self.residual_scale
-        if self.scale_residual_constant != 1:
-            residual = residual * self.scale_residual_constant
-        return x.to(residual.dtype) + residual
+        skip = residual
+        for factor in (self.residual_scale, None if self.scale_residual_constant == 1 else self.scale_residual_constant):
+            if factor is not None:
+                skip = skip * factor
+        return skip + x.to(skip.dtype)
 
     @property
     def is_plain(self):
@@ -39,12 +39,12 @@ class LayerNorm(nn.LayerNorm):
 class AdaptiveLayerNorm(nn.Module):
     def __init__(self, dim: int, condition_dim: int, eps: float = 1e-5):
         super().__init__()
-        self.dim = dim
-        self.eps = eps
+        self.dim, self.eps = dim, eps
+        # parameter-free norm + Linear(condition -> gamma | beta); the bias starts at (1 | 0), i.e. a plain normalisation
         self.norm = nn.LayerNorm(dim, eps=eps, elementwise_affine=False)
-        self.linear = nn.Linear(condition_dim, dim * 2)
-        self.linear.bias.data[:dim] = 1
-        self.linear.bias.data[dim:] = 0
+        self.linear = nn.Linear(condition_dim, 2 * dim)
+        with torch.no_grad():
+            self.linear.bias.copy_(torch.cat([torch.ones(dim), torch.zeros(dim)]))
 
     def forward(self, x: Tensor, condition: Optional[Tensor] = None, out_fp32: bool = False, fork: bool = False):
         if condition is None:  # gamma = 1, beta = 0

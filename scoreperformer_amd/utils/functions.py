@@ -1,43 +1,51 @@
-"""Small helpers with the same names as `scoreperformer/utils/functions.py:16-44,91-108`."""
-from enum import Enum
-from inspect import isfunction
+"""Small helpers under the names the reference uses (`scoreperformer/utils/functions.py:16-44,91-108`): None tests, defaults,
+mask reduction and the string enum whose lookup failure lists the valid values."""
+import enum
+import functools
+import inspect
+import operator
 
 
-def exists(val):
-    return val is not None
+def exists(val) -> bool:
+    """True for anything but None (0, empty containers and False do exist)."""
+    return not (val is None)
 
 
 def default(val, d):
-    if exists(val):
+    """`val` unless it is None; a plain function given as the default is called to produce it (lazily built defaults)."""
+    if val is not None:
         return val
-    return d() if isfunction(d) else d
+    return d() if inspect.isfunction(d) else d
 
 
 class equals:
+    """Predicate object: `equals(3)(x)` is `x == 3`; further call arguments are accepted and ignored (filter callbacks)."""
+    __slots__ = ("val",)
+
     def __init__(self, val):
         self.val = val
 
-    def __call__(self, x, *args, **kwargs):
-        return x == self.val
+    def __call__(self, x, *_, **__):
+        return self.val == x
 
 
 def or_reduce(masks):
-    head, *body = masks
-    for rest in body:
-        head = head | rest
-    return head
+    """Element-wise OR of one or more boolean masks."""
+    return functools.reduce(operator.or_, masks)
 
 
-class ExplicitEnum(str, Enum):
+class ExplicitEnum(str, enum.Enum):
+    """String-valued enum: members compare equal to their strings; an unknown value names the admissible ones."""
+
     @classmethod
-    def _missing_(cls, value):
-        raise ValueError(f"{value} is not a valid {cls.__name__}, please select one of "
-                         f"{list(cls._value2member_map_.keys())}")
+    def list(cls):
+        return [member.value for member in cls]
 
     @classmethod
     def has_value(cls, value):
         return value in cls._value2member_map_
 
     @classmethod
-    def list(cls):
-        return [c.value for c in cls]
+    def _missing_(cls, value):
+        valid = list(cls._value2member_map_.keys())
+        raise ValueError(f"{value} is not a valid {cls.__name__}, please select one of {valid}")
