@@ -45,7 +45,7 @@ int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, l
  *      kvh = 1 is multi-query.  strides: {q_bs,q_ns,q_hs, k_.., v_.., o_..} (+ {dq_.., dk_.., dv_..} for bwd). */
 int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const float* slopes,
                  int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, float p_drop,
-                 unsigned seed, void* dropbits, spn_stream_t stream);
+                 unsigned seed, void* dropbits, float* band, spn_stream_t stream);
 /* p_drop > 0: attention dropout (attend.py:122).  The mask is a pure function of (seed, b, h, i, j); the forward also writes
  * it as keep bits (1 bit per score) into `dropbits` (spn_attn_dropbits_elems() uint16 words), which the backward reads back.
  * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
@@ -53,10 +53,13 @@ long spn_attn_dropbits_elems(int b, int h, int nq, int nk);
 /* ALiBi band skipping: key tiles whose probabilities are provably below 2^-log2_threshold of the row maximum (Cauchy-Schwarz
  * bound on q.k plus the linear distance penalty) are not visited, forward and backward alike.  Default 40; 0 = visit all. */
 void spn_attn_set_band(float log2_threshold);
+/* `band` (optional, spn_attn_band_elems floats): caller-owned buffer of the band bounds; spn_attn_fwd fills it and spn_attn_bwd of
+ * the same q / k / mask reuses it instead of recomputing them (null: internal workspace, recomputed) */
+long spn_attn_band_elems(int b, int h, int kvh, int nq);
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
                  int nq, int nk, int causal, float scale, const long* strides, float p_drop, const void* dropbits,
-                 spn_stream_t stream);
+                 const float* band, spn_stream_t stream);
 
 /* ---- LayerNorm / AdaptiveLayerNorm (modules/transformer/transformer.py:106,123-125,192-193,217;
  *      modules/layers.py:31-47).  gb = [T,2D] fp32 per-token (gamma|beta).  bwd: dy bf16; dgamma/dbeta ACCUMULATED. */

@@ -559,22 +559,25 @@ BandWorkspace g_band_ws[16];
 float g_band_log2 = -1.f;   // < 0: not initialised (SPN_ATTN_BAND env, default 40); 0: off
 
 // fills a.band for this problem (no-op without ALiBi slopes); call release_band() after the consuming kernels are enqueued
-int prepare_band(AttnArgs& a, hipStream_t stream) {
+// `own`: caller-provided buffer of spn_attn_band_elems floats (the forward fills it, the backward of the same q / k / mask reuses it:
+// `reuse`), else the internal grow-only workspace
+int prepare_band(AttnArgs& a, hipStream_t stream, float* own = nullptr, bool reuse = false) {
     if (g_band_log2 < 0.f) g_band_log2 = getenv("SPN_ATTN_BAND") ? (float)atof(getenv("SPN_ATTN_BAND")) : 40.f;
     a.band = nullptr; a.band_log2 = g_band_log2; a.nqt64 = (a.nq + 63) / 64;
     if (!a.slopes || g_band_log2 <= 0.f) return SPN_OK;
     int dev = 0;
     hipGetDevice(&dev);
     const size_t nq_part = (size_t)a.b * a.h * a.nqt64, n = nq_part + (size_t)a.b * a.kvh;
-    float* ws = g_band_ws[dev & 15].get(n * 4, stream);
+    if (own && reuse) { a.band = own; return SPN_OK; }
+    float* ws = own ? own : g_band_ws[dev & 15].get(n * 4, stream);
     if (!ws) { spn_set_error("spn_attn: band workspace allocation failed"); return SPN_ERR_HIP; }
     hipMemsetAsync(ws + nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
     hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, ws);
     a.band = ws;
     return SPN_OK;
 }
-void release_band(const AttnArgs& a, hipStream_t stream) {
-    if (!a.band) return;
+void release_band(const AttnArgs& a, hipStream_t stream, const float* own = nullptr) {
+    if (!a.band || own) return;
     int dev = 0;
     hipGetDevice(&dev);
     g_band_ws[dev & 15].release(stream);
@@ -608,6 +611,9 @@ int check_common(const AttnArgs& a) {
 // Default 40, or the SPN_ATTN_BAND environment variable.  Process-wide; meant for tests and ablations.
 extern "C" void spn_attn_set_band(float log2_threshold) { g_band_log2 = log2_threshold < 0.f ? 0.f : log2_threshold; }
 
+// floats of a caller-owned band buffer (spn_attn_fwd fills it, spn_attn_bwd of the same problem reuses it instead of recomputing)
+extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return (long)b * h * ((nq + 63) / 64) + (long)b * kvh; }
+
 // uint16 words of the dropout keep-bit buffer for a [b, h, nq, nk] attention (1 bit per score, whole 128x128 blocks)
 extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {
     return (long)b * h * dropbits_nqt16(nq) * dropbits_nkt64(nk) * 64;
@@ -615,7 +621,7 @@ extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {
 
 extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                             const float* slopes, int b, int h, int kvh, int nq, int nk, int causal, float scale,
-                            const long* strides, float p_drop, unsigned seed, void* dropbits, hipStream_t stream) {
+                            const long* strides, float p_drop, unsigned seed, void* dropbits, float* band, hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     set_dropout(a, p_drop, seed, dropbits, nq, nk);
@@ -631,12 +637,12 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     if (rc) return rc;
     SPN_REQUIRE(o && lse, "spn_attn_fwd: null output");
     SPN_REQUIRE((a.o_ns % 4) == 0 && (a.o_hs % 4) == 0 && (a.o_bs % 4) == 0, "spn_attn_fwd: o strides must be multiples of 4");
-    rc = prepare_band(a, stream);
+    rc = prepare_band(a, stream, band, false);
     if (rc) return rc;
     dim3 grid(cdiv(nq, 128), h, b);
     if (a.thr8) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
-    release_band(a, stream);
+    release_band(a, stream, band);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -646,7 +652,8 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
 extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                             const float* lse, float* delta, void* dq, void* dk, void* dv, float* dslope,
                             const uint8_t* kmask, const float* slopes, int b, int h, int kvh, int nq, int nk,
-                            int causal, float scale, const long* strides, float p_drop, const void* dropbits, hipStream_t stream) {
+                            int causal, float scale, const long* strides, float p_drop, const void* dropbits, const float* band,
+                            hipStream_t stream) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     set_dropout(a, p_drop, 0, const_cast<void*>(dropbits), nq, nk);
@@ -667,14 +674,14 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE(o && d_o && lse && delta && dq && dk && dv, "spn_attn_bwd: null tensor");
     SPN_REQUIRE((a.o_ns % 8) == 0 && (a.o_hs % 8) == 0 && (a.o_bs % 8) == 0, "spn_attn_bwd: o/dO strides must be multiples of 8");
     SPN_REQUIRE((((uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "spn_attn_bwd: o/dO must be 16-byte aligned");
-    rc = prepare_band(a, stream);
+    rc = prepare_band(a, stream, const_cast<float*>(band), true);   // band != null: the bounds the forward computed for this q / k / mask
     if (rc) return rc;
     const long total = (long)b * nq * h;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total * 8, 256)), dim3(256), 0, stream, a, delta);
     launch_attn_dkv(a, stream);
     if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
-    release_band(a, stream);
+    release_band(a, stream, band);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -355,7 +355,8 @@ class SelfAttnFn(Function):
         v = qkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
-        o, lse, *bits = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        ctx.band = ops.attn_band_buffer(q, k) if sl is not None else None   # ALiBi band bounds: computed once, reused by the backward
+        o, lse, *bits = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed, band=ctx.band)
         ctx.dropbits = bits[0] if bits else None
         ctx.save_for_backward(qkv, o, lse, sl, kmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
@@ -376,7 +377,7 @@ class SelfAttnFn(Function):
         dv = dqkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, n, heads, 64)
         dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=sl, causal=causal, scale=scale,
-                           want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, dropbits=ctx.dropbits)
+                           want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, dropbits=ctx.dropbits, band=ctx.band)
         return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 
@@ -391,7 +392,8 @@ class CrossAttnFn(Function):
         v = kv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
-        o, lse, *bits = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed)
+        ctx.band = ops.attn_band_buffer(q4, k) if sl is not None else None
+        o, lse, *bits = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed, band=ctx.band)
         ctx.dropbits = bits[0] if bits else None
         ctx.save_for_backward(q, kv, o, lse, sl, kmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
@@ -413,7 +415,7 @@ class CrossAttnFn(Function):
         d_o = to_bf16(d_o).contiguous().view(b, nq, heads, 64)
         dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, slopes=sl,
                            causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2], p_drop=p_drop,
-                           dropbits=ctx.dropbits)
+                           dropbits=ctx.dropbits, band=ctx.band)
         return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
 
 

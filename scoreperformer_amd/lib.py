@@ -33,6 +33,7 @@ def load() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.spn_last_error.restype = ctypes.c_char_p
         _lib.spn_attn_dropbits_elems.restype = ctypes.c_long
+        _lib.spn_attn_band_elems.restype = ctypes.c_long
     return _lib
 
 

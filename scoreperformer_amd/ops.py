@@ -188,10 +188,11 @@ def _mask_u8(m: Optional[torch.Tensor]):
     return m.view(torch.uint8) if m.dtype == torch.bool else m
 
 
-def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0):
+def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0, band=None):
     """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq].
 
-    With p_drop > 0 a third value is returned: the dropout keep bits (int16 words, 1 bit per score) that `attn_bwd` needs."""
+    With p_drop > 0 a third value is returned: the dropout keep bits (int16 words, 1 bit per score) that `attn_bwd` needs.
+    `band`: optional fp32 buffer from `attn_band_buffer` that receives the ALiBi band bounds, for `attn_bwd` to reuse."""
     require_gpu(q, k, v)
     b, nq, h, dh = q.shape
     nk, kvh = k.shape[1], k.shape[2]
@@ -207,8 +208,15 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_dr
         bits = torch.empty(load().spn_attn_dropbits_elems(c_int(b), c_int(h), c_int(nq), c_int(nk)), device=q.device, dtype=torch.int16)
     call("spn_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh),
          c_int(nq), c_int(nk), c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides,
-         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(bits), stream_ptr())
+         c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(bits), ptr(band), stream_ptr())
     return (o, lse) if bits is None else (o, lse, bits)
+
+
+def attn_band_buffer(q, k) -> torch.Tensor:
+    """Buffer for the band bounds of a [b,nq,h,64] x [b,nk,kvh,64] attention (filled by attn_fwd, reused by attn_bwd)."""
+    b, nq, h, _ = q.shape
+    n = load().spn_attn_band_elems(c_int(b), c_int(h), c_int(k.shape[2]), c_int(nq))
+    return torch.empty(n, device=q.device, dtype=F32)
 
 
 def attn_set_band(log2_threshold: float) -> None:
@@ -217,7 +225,7 @@ def attn_set_band(log2_threshold: float) -> None:
 
 
 def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
-             p_drop: float = 0.0, dropbits=None):
+             p_drop: float = 0.0, dropbits=None, band=None):
     """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None.
     `dropbits`: the keep bits returned by `attn_fwd` when p_drop > 0."""
     if p_drop > 0 and dropbits is None:
@@ -238,7 +246,7 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
     call("spn_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
          ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
          c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, c_float(p_drop),
-         ptr(dropbits), stream_ptr())
+         ptr(dropbits), ptr(band), stream_ptr())
     return dslope
 
 
