@@ -172,7 +172,7 @@ def roofline_leg(ops, step, args):
     for name, f, t, tag in gemm:
         _, lay, dt = tag.split(":")
         a = by_inst.setdefault(f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
-                               f"{'float' if dt == 'f32' else 'unsigned short'}>", [0, 0.0, 0.0])
+                               f"{'float' if dt == 'f32' else 'unsigned short'}, {1 if dt.endswith('+glu') else 0}>", [0, 0.0, 0.0])
         a[0] += 1; a[1] += f; a[2] += t
     attn = [r for r in recs if r[0].startswith("attn")]
     traffic, traffic_note = None, None
@@ -181,8 +181,9 @@ def roofline_leg(ops, step, args):
         with open(tpath) as fh:
             tj = json.load(fh)
         traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("note")
-    return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
-                                       "of a step, a split-K launch includes its reduce kernel)",
+    return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT, GLU> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
+                                       "of a step, a split-K launch includes its reduce kernel; GLU = 1: the gated FFN input projection "
+                                       "with activation + dropout in its epilogue, counted at the GEMM's 2MNK only)",
             "achieved": flops / (ms * 1e-3) / 1e12 if ms else None, "peak": 2500.0, "unit": "TFLOP/s",
             "frac": (flops / (ms * 1e-3) / 1e12 / 2500.0) if ms else None, "traffic": traffic, "traffic_note": traffic_note,
             "launches_per_step": len(gemm) // 2, "avg_launch_ms": ms / max(len(gemm), 1),

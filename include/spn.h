@@ -76,6 +76,14 @@ int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy,
                            const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx,
                            void* dx16, long lddx16, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
 
+/* ---- gated feed-forward input projection, activation fused into the GEMM epilogue (feedforward.py:13-21 GLU.forward and the
+ * nn.Dropout of feedforward.py:57-60):  u[M,2I] = x W^T + bias (bf16, value | gate, kept for the backward);
+ * g[M,I] = dropout(u[:, :I] * act(u[:, I:])) with the mask of spn_act_fwd(seed): spn_act_bwd(u, dg, ...) is its backward.
+ * g equals spn_act_fwd(u) bit for bit.  spn_gemm_glu_ok: 1 when the shape is taken (M >= 128, I % 128 == 0, K % 64 == 0, K >= 256) */
+int spn_gemm_glu_ok(int M, int I, int K);
+int spn_gemm_glu(const void* x, const void* W /* [2I, K] */, void* u, void* g, const float* bias /* [2I] or null */, int M, int I, int K,
+                 int lda, int ldb, int ldu, int ldg, int act /* 0 SiLU, 1 GELU */, float p_drop, unsigned seed, spn_stream_t s);
+
 /* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
 /* p_drop > 0: nn.Dropout on the activation output (feedforward.py:57-60); the mask is a pure function of (seed, index) */
 int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int act, int glu, float p_drop, unsigned seed,

@@ -9,12 +9,10 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float silu_grad(float x) {
     const float s = 1.f / (1.f + __expf(-x));
     return s * (1.f + x * (1.f - s));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
     const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);

@@ -51,6 +51,11 @@ struct GemmArgs {
     int ngroup;               // n-tiles per column group of the tile order
     int pp_addr_ok;           // both operands span < 2^31 bytes (the ping-pong kernel addresses them with 32-bit offsets)
     int tx, ty;               // ping-pong kernel: tile grid (n-tiles, m-tiles); a launch with fewer blocks walks it persistently
+    // gated-linear-unit epilogue (spn_gemm_glu): N = I gated outputs, B = [2I, K] (value rows | gate rows), C = u [M, 2I]
+    bf16_t* G;                // [M, ldg]: dropout(value * act(gate))
+    int ldg;
+    uint32_t thr16, seed;     // dropout threshold (0 = none) and seed, as in spn_act_fwd
+    float keep_scale;
 #ifdef SPN_GEMM_TIMING
     long long* dbg;
 #endif
@@ -418,7 +423,16 @@ __device__ __forceinline__ uint32_t pp_voffset(int ld, int row0, int R, int h, i
     }
 }
 
-template <bool TA, bool TB, typename OutT>
+// GLU mode: half-tile row x of BX is weight row row0 + x (value rows), of BY row I + row0 + x (gate rows): wave column group wc then
+// holds value AND gate of the same 32 outputs in acc[.][0] / acc[.][1] -- the pairing costs an address, not a weight permutation
+__device__ __forceinline__ uint32_t pp_voffset_lin(int ld, int row0, int wave, int lane, int i) {
+    const int L = (wave * 2 + i) * 64 + lane;
+    const int x = L >> 3, kc = (L & 7) ^ ((x >> 1) & 7);
+    return (uint32_t)(((long)(row0 + x) * ld + kc * 8) * 2);
+}
+
+// GLU: 0 = plain GEMM; 1 = SiLU, 2 = GELU gated epilogue (TA = TB = false, bf16 out)
+template <bool TA, bool TB, typename OutT, int GLU = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // slot of half-tile kind c (0 AX, 1 BX, 2 BY, 3 AY) of K tile t
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const int c = wg / per, within = wg - c * per;
         const int gw = min(G, g.tx - c * G);
         tm = (within / gw) * PP_BM;
-        tn = (c * G + within % gw) * PP_BN;
+        tn = (c * G + within % gw) * (GLU ? PP_BN / 2 : PP_BN);
     };
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
@@ -466,8 +480,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             vo[0][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 0, wave, lane, i);
-            vo[1][i] = pp_voffset<TB, 32>(g.ldb, tn, g.N, 0, wave, lane, i);
-            vo[2][i] = pp_voffset<TB, 32>(g.ldb, tn, g.N, 1, wave, lane, i);
+            vo[1][i] = GLU ? pp_voffset_lin(g.ldb, tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 0, wave, lane, i);
+            vo[2][i] = GLU ? pp_voffset_lin(g.ldb, g.N + tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 1, wave, lane, i);
             vo[3][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 1, wave, lane, i);
         }
     };
@@ -620,9 +634,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     char* stg = smem + 8 * PP_HALF + wave * 4096;
     f32x4 bv[8];
 #pragma unroll
-    for (int jq = 0; jq < 8; ++jq)
-        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4))
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int jq = 0; jq < 8; ++jq) {
+        // GLU: bv[0..3] = bias of the value columns, bv[4..7] = bias of the gate columns (N = I is a multiple of 128: no edge)
+        const int bn = GLU ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
+                           : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
+        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();   // every wave is done with the operand ring
     const int cm0 = m0, cn0 = n0;
     const bool has_next = vid + stride < nwg;
@@ -633,7 +650,67 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         prologue();
     }
     // interior tiles issue exactly NS store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-    extra = (has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0;
+    extra = (!GLU && has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0;
+    if constexpr (GLU != 0) {
+        // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
+        // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
+        bf16_t* U = reinterpret_cast<bf16_t*>(g.C);
+        const int chunks = g.N >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lane & 31;
+            const int m = cm0 + wr * 128 + 32 * i + row;
+            uint2 go[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]} + bv[q];
+                const f32x4 t = f32x4{acc[i][1][4 * q], acc[i][1][4 * q + 1], acc[i][1][4 * q + 2], acc[i][1][4 * q + 3]} + bv[4 + q];
+                uint2 pa, pt;
+                pa.x = pack_bf2(a[0], a[1]); pa.y = pack_bf2(a[2], a[3]);
+                pt.x = pack_bf2(t[0], t[1]); pt.y = pack_bf2(t[2], t[3]);
+                const int slot = 2 * q + (lane >> 5);   // 8-byte slot of the 64-byte value half; the gate half is slots 8..15
+                *reinterpret_cast<uint2*>(stg + row * 128 + (((slot ^ row) & 15) << 3)) = pa;
+                *reinterpret_cast<uint2*>(stg + row * 128 + ((((8 + slot) ^ row) & 15) << 3)) = pt;
+                const float ar[4] = {bf2f(pa.x & 0xffff), bf2f(pa.x >> 16), bf2f(pa.y & 0xffff), bf2f(pa.y >> 16)};
+                const float tr[4] = {bf2f(pt.x & 0xffff), bf2f(pt.x >> 16), bf2f(pt.y & 0xffff), bf2f(pt.y >> 16)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
+                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd: chunk idx = t * (I/8) + col/8, pair e/2 of the chunk
+                    const int col = cn0 + wc * 32 + 8 * q + (lane >> 5) * 4;
+                    const long idx = (long)m * chunks + (col >> 3);
+                    const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
+                    const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
+                    o[0] = (h0 & 0xffffu) >= g.thr16 ? o[0] * g.keep_scale : 0.f;
+                    o[1] = (h0 >> 16) >= g.thr16 ? o[1] * g.keep_scale : 0.f;
+                    o[2] = (h1 & 0xffffu) >= g.thr16 ? o[2] * g.keep_scale : 0.f;
+                    o[3] = (h1 >> 16) >= g.thr16 ? o[3] * g.keep_scale : 0.f;
+                }
+                go[q].x = pack_bf2(o[0], o[1]); go[q].y = pack_bf2(o[2], o[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
+                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                const int mo = cm0 + wr * 128 + 32 * i + r;
+                const int no = (chunk >> 2) * g.N + cn0 + wc * 32 + (chunk & 3) * 8;
+                if (mo < g.M) *reinterpret_cast<uint4*>(U + (long)mo * g.ldc + no) = val;
+            }
+            // the gated output through the same slab: 64-byte rows, 8 slots
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint2*>(stg + row * 64 + ((((2 * q + (lane >> 5)) ^ row) & 7) << 3)) = go[q];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + (lane >> 2), chunk = lane & 3;
+                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 64 + (((chunk ^ (r >> 1)) & 3) << 4));
+                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                const int mo = cm0 + wr * 128 + 32 * i + r;
+                if (mo < g.M) *reinterpret_cast<uint4*>(g.G + (long)mo * g.ldg + cn0 + wc * 32 + chunk * 8) = val;
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = lane & 31;
@@ -684,6 +761,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             }
         }
     }
+    }   // !GLU
     }
 #ifdef SPN_GEMM_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -856,6 +934,24 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     return launch_bk<TA, TB, OutT, 32, 2>(g, stream);
 }
 
+template <int GLU>
+int launch_pp_glu(GemmArgs g, hipStream_t stream) {
+    constexpr int LDS_BYTES = 8 * PP_HALF + 8 * 4096;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<false, false, bf16_t, GLU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    dim3 grid(g.N / (PP_BN / 2), cdiv(g.M, PP_BM), 1);
+    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
+    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
+    g.tx = grid.x; g.ty = grid.y;
+    hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU>), grid, dim3(512), LDS_BYTES, stream, g);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 }  // namespace
 
 // C-ABI ---------------------------------------------------------------------------------------------------
@@ -878,6 +974,7 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.residual = residual; g.rowmask = rowmask;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.G = nullptr; g.ldg = 0; g.thr16 = 0; g.seed = 0; g.keep_scale = 1.f;
     {
         const long a_span = (long)(ta ? K : M) * lda * 2, b_span = (long)(tb ? K : N) * ldb * 2;
         g.pp_addr_ok = (a_span < (1L << 31) && b_span < (1L << 31)) ? 1 : 0;
@@ -896,6 +993,38 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
         if (ta && !tb) return launch<true, false, bf16_t>(g, stream);
         return launch<true, true, bf16_t>(g, stream);
     }
+}
+
+// Input projection of a gated feed-forward with its activation fused into the GEMM epilogue (feedforward.py:17-20,57-60):
+//   u[M, 2I] = x[M, K] . W[2I, K]^T + bias[2I]   (bf16, kept for the backward: value columns 0..I-1, gate columns I..2I-1)
+//   g[M, I]  = dropout(u[:, :I] * act(u[:, I:]))  with the mask of spn_act_fwd(seed), so spn_act_bwd is its backward unchanged
+// act: 0 = SiLU, 1 = GELU(erf).  Returns SPN_ERR_ARG for shapes the ping-pong kernel does not take (spn_gemm_glu_ok says which):
+// the caller then runs spn_gemm_bf16 + spn_act_fwd.
+extern "C" int spn_gemm_glu_ok(int M, int I, int K) {
+    return (M >= 128 && M % 8 == 0 && I >= 128 && I % (PP_BN / 2) == 0 && K % PP_BK == 0 && K >= 4 * PP_BK) ? 1 : 0;
+}
+
+extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, const float* bias, int M, int I, int K, int lda, int ldb,
+                            int ldu, int ldg, int act, float p_drop, unsigned seed, hipStream_t stream) {
+    SPN_REQUIRE(x && W && u && gout, "spn_gemm_glu: null operand");
+    SPN_REQUIRE(spn_gemm_glu_ok(M, I, K), "spn_gemm_glu: shape not supported (M >= 128, I a multiple of 128, K a multiple of 64 and >= 256)");
+    SPN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldu % 8 == 0 && ldg % 8 == 0, "spn_gemm_glu: leading dimensions must be multiples of 8");
+    SPN_REQUIRE(((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)u) | ((uintptr_t)gout)) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
+                "spn_gemm_glu: operands must be 16-byte aligned");
+    SPN_REQUIRE((long)M * lda * 2 < (1L << 31) && 2l * I * ldb * 2 < (1L << 31), "spn_gemm_glu: operand spans 2 GiB or more");
+    SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu: act is 0 (SiLU) or 1 (GELU)");
+    GemmArgs g;
+    g.A = (const bf16_t*)x; g.B = (const bf16_t*)W; g.C = u; g.bias = bias; g.residual = nullptr; g.rowmask = nullptr;
+    g.M = M; g.N = I; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldu; g.ldr = 0; g.alpha = 1.f;
+    g.accumulate = 0; g.batch = 1; g.sA = g.sB = g.sC = 0; g.splitk = 1; g.kt_per_split = K / PP_BK; g.pp_addr_ok = 1;
+    g.G = (bf16_t*)gout; g.ldg = ldg; g.seed = seed;
+    const float t = p_drop * 65536.f;   // thr16_of of elementwise.hip
+    g.thr16 = t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)(t + 0.5f));
+    g.keep_scale = 1.f / (1.f - (float)g.thr16 / 65536.f);
+#ifdef SPN_GEMM_TIMING
+    g.dbg = g_dbg;
+#endif
+    return act == 0 ? launch_pp_glu<1>(g, stream) : launch_pp_glu<2>(g, stream);
 }
 
 #ifdef SPN_GEMM_TIMING

@@ -452,6 +452,61 @@ class ActFn(Function):
         return du, None, None, None, None, None
 
 
+class LinearGLUFn(Function):
+    """GLU input projection with the activation and the FFN dropout inside the GEMM epilogue (`spn_gemm_glu`): the projection u is
+    written once and never re-read in the forward.  Backward = ActFn.backward then LinearFn.backward on the saved u."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act: int, p_drop: float, seed: int):
+        x2 = to_bf16(x).reshape(-1, x.shape[-1])
+        u, g = ops.gemm_glu(x2, bf16_weight(weight), bias.detach() if bias is not None else None, act=act, p_drop=p_drop, seed=seed)
+        ctx.save_for_backward(x2, u)
+        ctx.weight_ref, ctx.bias_ref, ctx.cfg = weight, bias, (act, p_drop, seed)
+        ctx.x_dtype, ctx.x_shape = x.dtype, x.shape
+        if weight.requires_grad:
+            _pend(weight)
+        if bias is not None and bias.requires_grad:
+            _pend(bias)
+        return g.view(*x.shape[:-1], g.shape[-1])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dg):
+        x2, u = ctx.saved_tensors
+        weight, bias = ctx.weight_ref, ctx.bias_ref
+        act, p_drop, seed = ctx.cfg
+        main = getattr(bias, "_spn_main_grad", None) if bias is not None and bias.requires_grad else None
+        fused_sum = main is not None and ops.act_bwd_can_fuse_colsum(u.shape[-1], True)
+        du = ops.act_bwd(u, to_bf16(dg).reshape(-1, dg.shape[-1]), act=act, glu=True, p_drop=p_drop, seed=seed,
+                         colsum=main if fused_sum else None)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(du, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.x_dtype == BF16 else F32).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(du, x2, ta=True, tb=True, out=out, accumulate=acc), weight.shape)
+        if bias is not None and ctx.needs_input_grad[2]:
+            if main is not None:
+                if not fused_sum:
+                    ops.colsum(du, out=main)
+                hook = getattr(bias, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            else:
+                db = ops.colsum(du)
+        return dx, dw, db, None, None, None
+
+
+GLU_FUSE = _os.environ.get("SPN_GLU_FUSE", "1") != "0"
+
+
+def linear_glu(x, weight, bias, *, act=ACT_SILU, p_drop: float = 0.0):
+    """glu_act(linear(x, weight, bias)) -- one kernel when the shape allows it (ops.gemm_glu_ok), else the two-kernel path."""
+    rows = x.numel() // x.shape[-1]
+    if GLU_FUSE and x.is_cuda and weight.shape[0] % 2 == 0 and ops.gemm_glu_ok(rows, weight.shape[0] // 2, x.shape[-1]):
+        return LinearGLUFn.apply(x, weight, bias, act, float(p_drop), next_seed() if p_drop > 0 else 0)
+    return glu_act(linear(x, weight, bias), act=act, glu=True, p_drop=p_drop, bias=bias)
+
+
 def glu_act(u, *, act=ACT_SILU, glu=True, p_drop: float = 0.0, bias=None):
     return ActFn.apply(u, act, glu, float(p_drop), next_seed() if p_drop > 0 else 0, bias)
 

@@ -14,9 +14,8 @@ class GLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x, p_drop: float = 0.0):
-        u = F_.linear(x, self.proj.weight, self.proj.bias)
-        return F_.glu_act(u, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU, glu=True, p_drop=p_drop,
-                          bias=self.proj.bias)
+        return F_.linear_glu(x, self.proj.weight, self.proj.bias, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU,
+                            p_drop=p_drop)
 
 
 @dataclass

@@ -297,6 +297,23 @@ def act_fwd(u: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: 
     return out
 
 
+def gemm_glu_ok(M: int, I: int, K: int) -> bool:
+    return bool(load().spn_gemm_glu_ok(c_int(M), c_int(I), c_int(K)))
+
+
+def gemm_glu(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, act: int, p_drop: float = 0.0, seed: int = 0):
+    """(u, g): u = x @ w.T + bias as bf16 [M, 2I]; g = dropout(u[:, :I] * act(u[:, I:])) written by the same kernel."""
+    M, K = x.shape
+    I = w.shape[0] // 2
+    assert x.dtype == BF16 and w.dtype == BF16 and x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K
+    u = torch.empty((M, 2 * I), device=x.device, dtype=BF16)
+    g = torch.empty((M, I), device=x.device, dtype=BF16)
+    b = bias if bias is None or bias.dtype == F32 else bias.float()
+    call("spn_gemm_glu", ptr(x), ptr(w), ptr(u), ptr(g), ptr(b), c_int(M), c_int(I), c_int(K), c_int(x.stride(0)), c_int(w.stride(0)),
+         c_int(2 * I), c_int(I), c_int(act), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
+    return u, g
+
+
 def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0,
             colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`colsum` (fp32 [W]): the column sums of the result are accumulated into it (bias gradient of the Linear that produced u)."""
@@ -656,6 +673,17 @@ def gemm(a, b, *, ta=False, tb=False, **kw):  # noqa: F811
     f32 = (out.dtype if out is not None else kw.get("out_dtype", BF16)) == F32
     return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:{'T' if ta else 'N'}{'T' if tb else 'N'}:{'f32' if f32 else 'bf16'}",
                         lambda: _gemm_raw(a, b, ta=ta, tb=tb, **kw))
+
+
+_gemm_glu_raw = gemm_glu
+
+
+def gemm_glu(x, w, bias, **kw):  # noqa: F811
+    if not PROFILE.enabled:
+        return _gemm_glu_raw(x, w, bias, **kw)
+    M, K = x.shape
+    N = w.shape[0]
+    return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:NN:bf16+glu", lambda: _gemm_glu_raw(x, w, bias, **kw))
 
 
 def attn_fwd(q, k, v, **kw):  # noqa: F811

@@ -134,3 +134,55 @@ def test_cross_entropy_forward_backward():
     coef = torch.ones(1, device=DEV)
     dl = ops.ce_bwd(logits, V, lab, lse, coef)
     assert rel_err(dl[:, :V], lr.grad) < 1e-2 and float(dl[:, V:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,I,K,act,p", [(256, 128, 256, 0, 0.0), (1000, 256, 512, 0, 0.1), (4096, 2048, 512, 1, 0.0),
+                                         (8192 + 8, 2048, 512, 0, 0.1), (131072, 2048, 512, 0, 0.1)])
+def test_gemm_glu_equals_gemm_then_activation(M, I, K, act, p):
+    """Fused GLU projection: u is the plain GEMM's output and g the stand-alone activation kernel's output on that u, bit for bit
+    (same rounding point, same dropout mask), at edge row counts and at the benchmark's FFN shape."""
+    from scoreperformer_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(M + I)
+    x = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).bfloat16()
+    w = (torch.randn(2 * I, K, device="cuda", generator=gen) * K ** -0.5).bfloat16()
+    b = torch.randn(2 * I, device="cuda", generator=gen) * 0.1
+    assert ops.gemm_glu_ok(M, I, K)
+    u, g = ops.gemm_glu(x, w, b, act=act, p_drop=p, seed=1234)
+    u_ref = ops.gemm(x, w, tb=False, out_dtype=torch.bfloat16, bias=b)
+    assert torch.equal(u.view(torch.int16), u_ref.view(torch.int16))
+    g_ref = ops.act_fwd(u_ref, act=act, glu=True, p_drop=p, seed=1234)
+    assert torch.equal(g.view(torch.int16), g_ref.view(torch.int16))
+    if p > 0:
+        kept = (g != 0).float().mean().item()
+        assert abs(kept - (1 - p)) < 0.01
+
+
+def test_gemm_glu_rejects_unsupported_shapes():
+    from scoreperformer_amd import ops
+    assert not ops.gemm_glu_ok(64, 128, 256) and not ops.gemm_glu_ok(256, 192, 256) and not ops.gemm_glu_ok(256, 128, 200)
+    x = torch.zeros(256, 200, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(256, 200, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(ops.SpnError):
+        ops.gemm_glu(x, w, None, act=0)
+
+
+def test_feedforward_fused_glu_matches_two_kernel_path(monkeypatch):
+    """FeedForward(glu) forward and every gradient are identical with the fused projection and with GEMM + activation kernels."""
+    import scoreperformer_amd.functional as F_
+    from scoreperformer_amd.modules.transformer.feedforward import FeedForward
+    torch.manual_seed(0)
+    ff = FeedForward(dim=512, mult=4, glu=True, swish=True, dropout=0.1, no_bias=False).cuda().train()
+    x0 = torch.randn(4, 256, 512, device="cuda")
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(F_, "GLU_FUSE", fuse)
+        F_._seed_state["base"] = None   # same dropout seeds in both runs
+        ff.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = ff(x.bfloat16())
+        y.float().square().mean().backward()
+        outs.append((y.detach().float(), x.grad.clone(), [p.grad.clone() for p in ff.parameters()]))
+    (y1, dx1, g1), (y2, dx2, g2) = outs
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)

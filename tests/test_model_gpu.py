@@ -70,7 +70,11 @@ def test_forward_backward_matches_reference_golden(dev, name):
     for k, v in fix.items():
         if k.startswith("grad/"):
             g = named[k[5:]].grad.float().cpu().numpy()
-            assert np.abs(g - v).max() <= 0.06 * np.abs(v).max() + 1e-4, k
+            # the ALiBi log-slope gradient is a signed sum of distance-weighted score gradients over every query/key pair: what
+            # survives the cancellation is ~5e-4 here and the bf16 noise on it measures 1.4e-4 .. 2.2e-4 (tools history: a 1-ulp
+            # fp32 change in SiLU moves it by 2e-5), so its absolute floor is 3e-4; every other tensor sits below 0.25 of its bound
+            floor = 3e-4 if k.endswith("learned_logslopes") else 1e-4
+            assert np.abs(g - v).max() <= 0.06 * np.abs(v).max() + floor, k
 
 
 def test_optimizer_step_matches_torch_adamw(dev):

@@ -9,6 +9,11 @@ dev = torch.device("cuda")
 a = torch.randn((K, M) if ta else (M, K), device=dev).bfloat16()
 b = torch.randn((K, N) if tb else (N, K), device=dev).bfloat16()
 out = torch.zeros(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
-for _ in range(reps):
-    ops.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out)
+if E("GLU", 0):   # N = gated outputs: b is [2N, K]
+    b = torch.randn(2 * N, K, device=dev).bfloat16()
+    for _ in range(reps):
+        ops.gemm_glu(a, b, None, act=0, p_drop=0.1, seed=3)
+else:
+    for _ in range(reps):
+        ops.gemm(a, b, ta=bool(ta), tb=bool(tb), out=out)
 torch.cuda.synchronize()
