@@ -502,7 +502,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     auto wait_landed = [&](int p) {
         const int younger = min(p + PP_LEAD + 1, total) - (p + 3);
         if (extra && p <= 3) {   // younger == 4 here (total >= 16)
-            if (NS == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (GLU) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // 16 stores of u + 8 of g
+            else if (NS == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
             return;
         }
@@ -650,7 +651,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         prologue();
     }
     // interior tiles issue exactly NS store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-    extra = (!GLU && has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0;
+    extra = GLU ? ((has_next && cm0 + PP_BM <= g.M) ? 24 : 0)
+                : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0);
     if constexpr (GLU != 0) {
         // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
         // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
@@ -947,6 +949,10 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y;
+    // one block per CU walking the tile list: the next tile's first DMA is in flight while this tile's (long, VALU-bound) epilogue runs
+    // (811 -> 783 us at 131072 x 2048 x 512)
+    static const int persist_env = getenv("SPN_GLU_PERSIST") ? atoi(getenv("SPN_GLU_PERSIST")) : 2;   // 0 off, else min rounds
+    if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
