@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     int* full_flag = reinterpret_cast<int*>(smem + 16384 + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bi = blockIdx.z, hi = blockIdx.y, q0 = qtile_of(blockIdx.x, gridDim.x, a.causal) * 128;
+    int bi = blockIdx.z, hi = blockIdx.y, qt;
+    if (!causal_order(a, true, bi, hi, qt)) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
+    const int q0 = qt * 128;
     const int kh = (a.kvh == 1) ? 0 : hi;
     const int off = a.nk - a.nq;
     const bf16_t* qp = a.q + bi * a.q_bs + hi * a.q_hs;
@@ -345,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     int* full_flag = reinterpret_cast<int*>(smem + 24576 + 64);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bi = blockIdx.z, hi = blockIdx.y, q0 = qtile_of(blockIdx.x, gridDim.x, a.causal) * 128;
+    int bi = blockIdx.z, hi = blockIdx.y, qt;
+    if (!causal_order(a, true, bi, hi, qt)) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
+    const int q0 = qt * 128;
     const int kh = (a.kvh == 1) ? 0 : hi;
     const int off = a.nk - a.nq;
     const bf16_t* qp = a.q + bi * a.q_bs + hi * a.q_hs;
@@ -564,6 +568,8 @@ float g_band_log2 = -1.f;   // < 0: not initialised (SPN_ATTN_BAND env, default 
 int prepare_band(AttnArgs& a, hipStream_t stream, float* own = nullptr, bool reuse = false) {
     if (g_band_log2 < 0.f) g_band_log2 = getenv("SPN_ATTN_BAND") ? (float)atof(getenv("SPN_ATTN_BAND")) : 40.f;
     a.band = nullptr; a.band_log2 = g_band_log2; a.nqt64 = (a.nq + 63) / 64;
+    static const int order_env = getenv("SPN_ATTN_ORDER") ? atoi(getenv("SPN_ATTN_ORDER")) : 1;   // tuning aid, see causal_order
+    a.order = order_env;
     if (!a.slopes || g_band_log2 <= 0.f) return SPN_OK;
     int dev = 0;
     hipGetDevice(&dev);

@@ -36,6 +36,7 @@ struct AttnArgs {
     // ALiBi band (attention.hip, "band skipping"): band[(b*h + head)*nqt64 + i/64] = max ||q_i||^2 over the 64-row tile (+inf if
     // the tile must never be skipped), then band[b*h*nqt64 + b_*kvh + kv_head] = max ||k_j||^2.  null / band_log2 <= 0: off.
     const float* band; int nqt64; float band_log2;
+    int order;   // causal launches: longest-first block order (causal_order below); SPN_ATTN_ORDER=0 keeps the interleaved one
 };
 
 // Largest |j - i - off| that can still matter for a query tile: with |q.k * scale * log2e| <= B every score obeys
@@ -170,6 +171,25 @@ __device__ __forceinline__ int qtile_of(int x, int n, int causal) {
     if (!causal || n < 16 || (n & 15)) return x;
     const int half = n >> 1;
     return x < half ? x : (n - 1 - (x - half));
+}
+
+// Causal launches, block -> (batch, head, tile).  Work per query tile grows with its index (per key block it shrinks), so the order
+// in which blocks reach the CUs matters at the END of the launch: with heavy and light tiles interleaved, a heavy block that starts
+// late finishes alone (fwd: up to 8 % of the launch; dK/dV, with 4 blocks per CU in all, up to 40 % on the XCD that owns key
+// block 0).  Workgroups go to XCDs round-robin (linear id % 8); XCD k owns tiles {k + 8m} and their mirror images {n-1-k-8m}
+// (equal totals), and runs them heaviest first -- longest-processing-time order -- with all (head, batch) pairs of one tile
+// consecutive, heads fastest (MQA: 8 consecutive blocks share K/V).  `heavy_high`: work grows with the tile index (query tiles)
+// or shrinks (key blocks).  Any bijection is correct; this one is a speed-only remap.
+__device__ __forceinline__ bool causal_order(const AttnArgs& a, bool heavy_high, int& bi, int& hi, int& tile) {
+    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z;
+    if (!a.causal || !a.order || (nx & 15)) return false;
+    const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int k = L & 7, idx = L >> 3, per_tile = ny * nz;
+    const int seq = idx / per_tile, rest = idx - seq * per_tile, half = nx >> 4;
+    hi = rest % ny; bi = rest / ny;
+    const int light_first = seq < half ? k + 8 * seq : nx - 1 - k - 8 * (2 * half - 1 - seq);   // ascending tile index
+    tile = heavy_high ? nx - 1 - light_first : light_first;
+    return true;
 }
 
 // Tile classes for a wave's block of query rows [i_lo, i_hi] (in key coordinates, i + nk - nq) against keys [j0, j0+63]:

@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     float* dl_s = nl2_s + 64;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int bi = blockIdx.z, kh = blockIdx.y, j0 = blockIdx.x * 128;
+    int bi = blockIdx.z, kh = blockIdx.y, jt = blockIdx.x;
+    causal_order(a, false, bi, kh, jt);
+    const int j0 = jt * 128;
     const int off = a.nk - a.nq;
     const int heads_per_kv = a.h / a.kvh;
     const bf16_t* kp = a.k + bi * a.k_bs + kh * a.k_hs;

@@ -11,6 +11,10 @@ def main():
     qkv = torch.randn(b, n, (h + 2) * 64, device=dev).bfloat16()
     q = qkv[..., :h * 64].unflatten(-1, (h, 64)); k = qkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); v = qkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
     slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(h)], device=dev)
+    if os.environ.get("SLOPES") == "0":
+        slopes = None
+    elif os.environ.get("SLOPES") == "flat":   # no head reaches the band limit: isolates the diagonal-tile cost from the band skip
+        slopes = torch.full((h,), 2.0 ** -9, device=dev)
     d_o = torch.randn(b, n, h, 64, device=dev).bfloat16()
     dqkv = torch.empty_like(qkv)
     dq = dqkv[..., :h * 64].unflatten(-1, (h, 64)); dk = dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); dv = dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
@@ -23,11 +27,11 @@ def main():
             o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal)
         torch.cuda.synchronize()
         tf = (time.perf_counter() - t0) / reps
-        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=True)
+        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=True)
+            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None)
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t0) / reps
         print(f"causal={causal}: fwd {tf*1e3:.3f} ms {fl/tf/1e12:.0f} TF/s | bwd {tb*1e3:.3f} ms {2.5*fl/tb/1e12:.0f} TF/s (5-matmul flops)")
