@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, hi = blockIdx.y, qt;
-    if (!causal_order(a, true, bi, hi, qt)) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
+    if (!causal_order(a, true, bi, hi, qt) && (a.causal || !xcd_batch_coords(a, bi, hi, qt))) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
     const int q0 = qt * 128;
     const int kh = (a.kvh == 1) ? 0 : hi;
     const int off = a.nk - a.nq;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, hi = blockIdx.y, qt;
-    if (!causal_order(a, true, bi, hi, qt)) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
+    if (!causal_order(a, true, bi, hi, qt) && (a.causal || !xcd_batch_coords(a, bi, hi, qt))) qt = qtile_of(blockIdx.x, gridDim.x, a.causal);
     const int q0 = qt * 128;
     const int kh = (a.kvh == 1) ? 0 : hi;
     const int off = a.nk - a.nq;

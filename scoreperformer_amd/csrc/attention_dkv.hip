@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, kh = blockIdx.y, jt = blockIdx.x;
-    causal_order(a, false, bi, kh, jt);
+    if (!causal_order(a, false, bi, kh, jt) && !a.causal) xcd_batch_coords(a, bi, kh, jt);
     const int j0 = jt * 128;
     const int off = a.nk - a.nq;
     const int heads_per_kv = a.h / a.kvh;

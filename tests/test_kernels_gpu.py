@@ -151,7 +151,10 @@ def attn_reference(q, k, v, kmask, slopes, causal, scale):
 
 @pytest.mark.parametrize("mqa", [True, False])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("b,h,nq,nk", [(2, 4, 128, 128), (3, 8, 200, 200), (2, 2, 47, 48), (1, 8, 300, 333)])
+@pytest.mark.parametrize("b,h,nq,nk", [(2, 4, 128, 128), (3, 8, 200, 200), (2, 2, 47, 48), (1, 8, 300, 333),
+                                        # block-order remaps (attention_common.h): batch a multiple of 8 (XCD-per-batch order, causal
+                                        # longest-first), 16 query tiles with batch 1 (mirror-pair causal order), nq != nk with batch 8
+                                        (8, 2, 256, 256), (16, 2, 384, 384), (1, 2, 2048, 2048), (8, 4, 300, 333)])
 def test_attention_fwd_bwd(dev, mqa, causal, b, h, nq, nk):
     from scoreperformer_amd import ops
     g = torch.Generator().manual_seed(b * 1000 + h * 100 + nq + nk + int(mqa) * 7 + int(causal))
