@@ -50,6 +50,7 @@ struct GemmArgs {
     int kt_per_split;         // K tiles per slice
     int ngroup;               // n-tiles per column group of the tile order
     int pp_addr_ok;           // both operands span < 2^31 bytes (the ping-pong kernel addresses them with 32-bit offsets)
+    int slice_xcd;            // ping-pong kernel, split-K: remap blocks so that an XCD runs whole K slices (see the kernel)
     int tx, ty;               // ping-pong kernel: tile grid (n-tiles, m-tiles); a launch with fewer blocks walks it persistently
     // gated-linear-unit epilogue (spn_gemm_glu): N = I gated outputs, B = [2I, K] (value rows | gate rows), C = u [M, 2I]
     bf16_t* G;                // [M, ldg]: dropout(value * act(gate))
@@ -449,7 +450,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     // the tile grid is g.tx x g.ty; a launch of exactly that many blocks runs one tile per block, a smaller one (256 blocks, one per CU)
     // walks the tile ids block, block + 256, ... : no workgroup launch between tiles, and the next tile's first DMA goes out while the
     // stores of the previous one drain
-    const int nwg = g.tx * g.ty, first = blockIdx.y * gridDim.x + blockIdx.x, stride = gridDim.x * gridDim.y;
+    const int nwg = g.tx * g.ty, stride = gridDim.x * gridDim.y;
+    int first = blockIdx.y * gridDim.x + blockIdx.x, zid = blockIdx.z;
+    if (g.slice_xcd) {   // split-K with a multiple of 8 slices: XCD k (linear id % 8) runs whole K slices, so the A / B panels of a slice
+                         // are fetched into ONE L2 (each B panel is shared by every m-tile of the slice)
+        const int L = first + nwg * (int)blockIdx.z;
+        zid = (L & 7) + 8 * (L / (8 * nwg));
+        first = (L >> 3) % nwg;
+    }
     // tile id -> tile: XCD-contiguous (id % 8 = XCD), then column groups of `ngroup` n-tiles, m-tiles down each group (see
     // gemm_kernel): the 32 tiles an XCD runs together share few B panels and few A panels
     auto tile_of = [&](int id, int& tm, int& tn) {
@@ -462,10 +470,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         tn = (c * G + within % gw) * (GLU ? PP_BN / 2 : PP_BN);
     };
     const bool split = g.splitk > 1;
-    const bf16_t* A = g.A + (split ? 0 : (long)blockIdx.z * g.sA);
-    const bf16_t* B = g.B + (split ? 0 : (long)blockIdx.z * g.sB);
+    const bf16_t* A = g.A + (split ? 0 : (long)zid * g.sA);
+    const bf16_t* B = g.B + (split ? 0 : (long)zid * g.sB);
     const int nt_all = g.K / PP_BK;
-    const int t_begin = split ? blockIdx.z * g.kt_per_split : 0;
+    const int t_begin = split ? zid * g.kt_per_split : 0;
     const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
     if (nt <= 0 || first >= nwg) return;
     const int kbase = t_begin * PP_BK;
@@ -627,8 +635,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 
     // ---- epilogue: through the wave's own 4 KiB slab of the 32 KiB the ring leaves free, so that C leaves as whole 128-byte row
     //      segments (see gemm_kernel) while the ring already receives the NEXT tile's first half-tiles ----
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)blockIdx.z * g.sC;
-    const bool lead = !split || blockIdx.z == 0;
+    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)zid * g.sC;
+    const bool lead = !split || zid == 0;
     constexpr int ES = sizeof(OutT);
     constexpr int JP = ES == 2 ? 2 : 1;                 // 32-column halves of the wave's 128x64 block staged per pass
     constexpr int ROWB = 32 * JP * ES, CPR = ROWB / 16; // 128-byte rows, 8 chunks: a pass = 32 rows = 4 KiB
@@ -876,6 +884,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y;
+    // (weight gradients at C3: 4096x512x131072 609 -> 590 us, 512x2048x131072 335 -> 323 us)
+    static const int slice_env = getenv("SPN_GEMM_SLICE_XCD") ? atoi(getenv("SPN_GEMM_SLICE_XCD")) : 1;   // tuning aid: 0 = grid order
+    g.slice_xcd = (slice_env && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
     static const int persist_env = getenv("SPN_GEMM_PERSIST") ? atoi(getenv("SPN_GEMM_PERSIST")) : 0;   // tuning aid: 0 off, else min rounds
     if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
@@ -948,7 +959,7 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
     g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
-    g.tx = grid.x; g.ty = grid.y;
+    g.tx = grid.x; g.ty = grid.y; g.slice_xcd = 0;
     // one block per CU walking the tile list: the next tile's first DMA is in flight while this tile's (long, VALU-bound) epilogue runs
     // (811 -> 783 us at 131072 x 2048 x 512)
     static const int persist_env = getenv("SPN_GLU_PERSIST") ? atoi(getenv("SPN_GLU_PERSIST")) : 2;   // 0 off, else min rounds
