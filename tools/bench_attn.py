@@ -18,20 +18,24 @@ def main():
     d_o = torch.randn(b, n, h, 64, device=dev).bfloat16()
     dqkv = torch.empty_like(qkv)
     dq = dqkv[..., :h * 64].unflatten(-1, (h, 64)); dk = dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); dv = dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    p_drop = float(os.environ.get("DROP", 0))   # attention dropout (the benchmark's 0.1)
+    dkw = {"p_drop": p_drop, "seed": 7} if p_drop > 0 else {}
     for causal in (False, True):
         fl = 4.0 * b * h * n * n * 64 * (0.5 if causal else 1.0)
-        o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal)
+        res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, **dkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            o, lse = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal)
+            res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, **dkw)
         torch.cuda.synchronize()
         tf = (time.perf_counter() - t0) / reps
-        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None)
+        o, lse = res[0], res[1]
+        bkw = {"p_drop": p_drop, "dropbits": res[2]} if p_drop > 0 else {}
+        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None, **bkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None)
+            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None, **bkw)
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t0) / reps
         print(f"causal={causal}: fwd {tf*1e3:.3f} ms {fl/tf/1e12:.0f} TF/s | bwd {tb*1e3:.3f} ms {2.5*fl/tb/1e12:.0f} TF/s (5-matmul flops)")
