@@ -887,7 +887,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     // (weight gradients at C3: 4096x512x131072 609 -> 590 us, 512x2048x131072 335 -> 323 us)
     static const int slice_env = getenv("SPN_GEMM_SLICE_XCD") ? atoi(getenv("SPN_GEMM_SLICE_XCD")) : 1;   // tuning aid: 0 = grid order
     g.slice_xcd = (slice_env && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
-    static const int persist_env = getenv("SPN_GEMM_PERSIST") ? atoi(getenv("SPN_GEMM_PERSIST")) : 0;   // tuning aid: 0 off, else min rounds
+    // one block per CU walking the tile list: the K = 512 projections gain 1-4 % per launch under HIP events, the step does not
+    // (170.8 vs 171.5 ms: the next kernel can no longer start under the last round), so it stays a tuning aid
+    static const int persist_env = getenv("SPN_GEMM_PERSIST") ? atoi(getenv("SPN_GEMM_PERSIST")) : 0;   // 0 off, else min rounds
     if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();

@@ -452,3 +452,24 @@ def test_embedding_forward_backward_match_torch(E, V, with_ln, pad_rows):
         assert rel_err(dts[k], ref_tabs[k].grad) < tol, (k, rel_err(dts[k], ref_tabs[k].grad))
     if with_ln:
         assert rel_err(dgamma, rg.grad) < 2e-3 and rel_err(dbeta, rb.grad) < 2e-3
+
+
+@pytest.mark.parametrize("out_f32,tb", [(False, False), (True, False), (False, True)])
+def test_gemm_persistent_tile_walk(dev, out_f32, tb):
+    """A launch of > 512 output tiles with ragged M and a bias against fp32 matmul, and written exactly once.  With SPN_GEMM_PERSIST=2 in
+    the environment this is the one-block-per-CU tile walk (next tile's loads in flight during the epilogue, store credits in the wait
+    counts, edge tiles on the stronger wait); by default it is the plain grid."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 16384 + 8, 2304, 512
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).bfloat16()
+    bias = torch.randn(N, generator=g).to(dev)
+    b = w.t().contiguous() if tb else w
+    out = ops.gemm(a, b, tb=tb, out_dtype=torch.float32 if out_f32 else torch.bfloat16, bias=bias)
+    ref = a.float() @ w.float().t() + bias
+    assert rel_err(out, ref) < (2e-5 if out_f32 else 6e-3)
+    # every row was written exactly once: a second call into a poisoned buffer gives the same result
+    out2 = torch.full_like(out, float("nan"))
+    ops.gemm(a, b, tb=tb, out=out2, bias=bias)
+    assert torch.equal(out.view(torch.int32 if out_f32 else torch.int16), out2.view(torch.int32 if out_f32 else torch.int16))
