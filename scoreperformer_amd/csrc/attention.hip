@@ -263,33 +263,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ==========================================================================================================
-// delta[b,h,i] = sum_d o * dO      grid: ceil(b*nq*h / 256) threads, one (b,i,h) per thread
-// ==========================================================================================================
-// delta[b, h, i] = sum_d O[b, i, h, d] * dO[b, i, h, d]: 8 lanes per (row, head), 16 bytes each -> a wave reads whole 128-byte lines
-__global__ void attn_delta_kernel(AttnArgs a, float* delta) {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned grp = t >> 3, ch = t & 7;
-    const unsigned total = (unsigned)a.b * a.nq * a.h;
-    const bool live = grp < total;
-    const unsigned gi = live ? grp : total - 1;
-    const unsigned hi = gi % (unsigned)a.h, bi_i = gi / (unsigned)a.h;
-    const unsigned i = bi_i % (unsigned)a.nq, bi = bi_i / (unsigned)a.nq;
-    const long off = (long)bi * a.o_bs + (long)i * a.o_ns + (long)hi * a.o_hs + ch * 8;
-    const uint4 x = *reinterpret_cast<const uint4*>(a.o + off), y = *reinterpret_cast<const uint4*>(a.d_o + off);
-    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-    float acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        acc += bf2f(xs[e] & 0xffff) * bf2f(ys[e] & 0xffff);
-        acc += bf2f(xs[e] >> 16) * bf2f(ys[e] >> 16);
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    if (live && ch == 0) delta[((long)bi * a.h + hi) * a.nq + i] = acc;
-}
-
-// ==========================================================================================================
 // dQ (+ d slope): same decomposition as the forward
 // ==========================================================================================================
 // d slope_h = sum_ij dS_ij * (-|j - i - off|).  delta is computed from the bf16-rounded O, so each row's dS carries a
@@ -377,7 +350,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         // output the caller zeroes), get p = 0
         const float lse_i = i < a.nq ? a.lse[si] : NEG_FILL;
         l2[qb] = lse_i > -1e37f ? lse_i * LOG2E : 1e30f;
-        dl[qb] = i < a.nq ? a.delta[si] : 0.f;
+        // delta_i = sum_d O[i, d] * dO[i, d] (bf16 inputs, fp32 sum): this lane holds 16 of the row's 64 dO values, its three
+        // lane-group peers the rest.  Computed here, once per row, and stored for the dK/dV kernel that runs after this one
+        // (a separate 47 us pass over O and dO per layer before).
+        float dsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 of = load_row_frag(a.o + bi * a.o_bs + hi * a.o_hs, a.o_ns, i, a.nq, ks, lane);
+            const uint4 x = __builtin_bit_cast(uint4, of), y = __builtin_bit_cast(uint4, dof[qb][ks]);
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dsum += bf2f(xs[e] & 0xffff) * bf2f(ys[e] & 0xffff);
+                dsum += bf2f(xs[e] >> 16) * bf2f(ys[e] >> 16);
+            }
+        }
+        dl[qb] = group_sum(dsum);
+        if (g == 0 && i < a.nq) const_cast<float*>(a.delta)[si] = dl[qb];
     }
     const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
     const long bstride = (long)a.nkt64 * 64;
@@ -682,11 +671,10 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE((((uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "spn_attn_bwd: o/dO must be 16-byte aligned");
     rc = prepare_band(a, stream, const_cast<float*>(band), true);   // band != null: the bounds the forward computed for this q / k / mask
     if (rc) return rc;
-    const long total = (long)b * nq * h;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total * 8, 256)), dim3(256), 0, stream, a, delta);
-    launch_attn_dkv(a, stream);
+    // dQ first: it computes delta = rowsum(O * dO) in its prologue and stores it for dK/dV
     if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    launch_attn_dkv(a, stream);
     release_band(a, stream, band);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
