@@ -963,8 +963,10 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y; g.slice_xcd = 0;
     // one block per CU walking the tile list: the next tile's first DMA is in flight while this tile's (long, VALU-bound) epilogue runs
-    // (811 -> 783 us at 131072 x 2048 x 512)
-    static const int persist_env = getenv("SPN_GLU_PERSIST") ? atoi(getenv("SPN_GLU_PERSIST")) : 2;   // 0 off, else min rounds
+    // (811 -> 783 us at 131072 x 2048 x 512 on an otherwise idle chip).  Off by default: with a static tile list per block, a CU that
+    // a concurrent kernel holds (the RCCL all-reduce of the data-parallel step) delays ITS whole share of tiles by one block
+    // lifetime, while the plain grid just hands those tiles to the other CUs.
+    static const int persist_env = getenv("SPN_GLU_PERSIST") ? atoi(getenv("SPN_GLU_PERSIST")) : 0;   // 0 off, else min rounds
     if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
