@@ -5,16 +5,23 @@
  * with ctypes exactly as scoreperformer_amd/lib.py does.
  *
  * Conventions
- *  - plain pointers / sizes / strides; no torch types.  All device buffers are owned by the caller; kernels never
- *    allocate, free, or retain pointers.  Pointer-table arguments (`const float* const*`) are HOST arrays of device
- *    pointers, copied into the kernel argument block.
- *  - every call is asynchronous on `stream`; no device/stream synchronisation, no host reads: safe under hipGraph capture.
+ *  - plain pointers / sizes / strides; no torch types.  All device buffers -- inputs, outputs, saved-for-backward tensors AND
+ *    workspaces -- are owned by the caller; the library never allocates, frees or retains device memory (no hipMalloc / hipFree
+ *    anywhere in csrc/).  Ops that want scratch take `void* workspace, size_t workspace_bytes` and have a
+ *    `spn_<op>_workspace_bytes(shape...)` query (GEMM split-K) or a documented element count (attention band, dropout bits, delta).
+ *    Pointer-table arguments (`const float* const*`) are HOST arrays of device pointers, copied into the kernel argument block.
+ *  - every call is asynchronous on `stream`; no device/stream synchronisation, no host reads: safe under hipGraph capture
+ *    (tests/test_abi_gpu.py captures a GEMM + attention + LayerNorm sequence in a fresh process), and re-entrant across host
+ *    threads: the only mutable process state is the tuning table below (atomics) and the per-kernel "LDS opt-in done" bit masks.
+ *  - the library never reads the environment.  Tuning knobs are set with spn_set_tuning(name, value) (names: csrc/tuning.h;
+ *    spn_tuning_count / spn_tuning_name enumerate them); the Python binding maps SPN_<NAME> variables onto it at load.
  *  - returns 0 on success, <0 on error (spn_last_error() gives a thread-local message).  No C++ exceptions cross the ABI.
  *  - dtype codes: 0 = fp32, 1 = bf16.  "bf16" buffers are raw 16-bit bfloat16.  Strides/leading dimensions in ELEMENTS.
  *  - ACCUMULATED outputs (documented per function) must be zeroed by the caller first.
  */
 #ifndef SPN_H
 #define SPN_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -22,19 +29,27 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void);
+int spn_abi_version(void); /* 2 */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
+int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
+int spn_get_tuning(const char* name, double* value);
+int spn_tuning_count(void);
+const char* spn_tuning_name(int i);
 
 /* ---- GEMM (nn.Linear / F.linear everywhere on the path: modules/transformer/attention.py:135-142,210-218;
  *      feedforward.py:13-21,51-64; models/scoreperformer/embeddings.py:104,139,211,255,345-349; transformer.py:131,185;
  *      modules/layers.py:37,46) and their backward contractions.
  *      C[M,N] = residual + rowmask[m] * (alpha * A.B + bias[n]);  bf16 operands, fp32 accumulate.
  *      flags: bit0 A stored [K,M] (M contiguous); bit1 B stored [K,N] (N contiguous; default is nn.Linear's [N,K]);
- *             bit2 C fp32 (else bf16); bit3 C += (fp32 only). lda/ldb multiples of 8, 16-byte aligned bases. */
+ *             bit2 C fp32 (else bf16); bit3 C += (fp32 only). lda/ldb multiples of 8, 16-byte aligned bases.
+ *      workspace: weight-gradient shapes (fp32 C, small M x N, K = all tokens) are split over K through `workspace`
+ *      (spn_gemm_workspace_bytes(M, N, K, flags, batch) bytes, 16-byte aligned; 0 = this shape is never split); with a null or
+ *      smaller workspace the product runs unsplit (same result up to fp32 summation order, slower). */
+size_t spn_gemm_workspace_bytes(int M, int N, int K, int flags, int batch);
 int spn_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual, const uint8_t* rowmask,
                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, float alpha, int flags, int batch, long strideA,
-                  long strideB, long strideC, spn_stream_t stream);
+                  long strideB, long strideC, void* workspace, size_t workspace_bytes, spn_stream_t stream);
 /* exact fp32 GEMM with arbitrary strides: A(m,k)=a[m*sam+k*sak], B(k,n)=b[k*sbk+n*sbn]  (VAE heads
  * models/scoreperformer/mmd_transformer.py:53-56; embedding value MLP modules/transformer/embeddings.py:202-213) */
 int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, long sbn, float* c, long ldc, const float* bias,
@@ -53,8 +68,9 @@ long spn_attn_dropbits_elems(int b, int h, int nq, int nk);
 /* ALiBi band skipping: key tiles whose probabilities are provably below 2^-log2_threshold of the row maximum (Cauchy-Schwarz
  * bound on q.k plus the linear distance penalty) are not visited, forward and backward alike.  Default 40; 0 = visit all. */
 void spn_attn_set_band(float log2_threshold);
-/* `band` (optional, spn_attn_band_elems floats): caller-owned buffer of the band bounds; spn_attn_fwd fills it and spn_attn_bwd of
- * the same q / k / mask reuses it instead of recomputing them (null: internal workspace, recomputed) */
+/* `band` (spn_attn_band_elems floats): caller-owned buffer of the band bounds; spn_attn_fwd fills it and spn_attn_bwd of the same
+ * q / k / mask reads it back.  null (or no slopes): every tile is visited -- skipped tiles contribute below fp32 resolution, so the
+ * result does not depend on it. */
 long spn_attn_band_elems(int b, int h, int kvh, int nq);
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
@@ -143,9 +159,11 @@ int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, in
 
 /* ---- optimizer (experiments/optimizers.py:151-169: clip_grad_norm_ + torch.optim.AdamW) over the flat arena */
 int spn_sumsq(const float* g, long n, float* out /* ACCUMULATED */, spn_stream_t s);
-int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* normsq,
-                   float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
-                   int step, spn_stream_t s);
+/* slot_mask: optional uint8 [n / 8], one flag per 8-element arena slot; 0 = the slot's parameter has no gradient this step (frozen or
+ * unused: torch.optim.AdamW skips grad-is-None parameters -- no decay, no moments) and is left untouched; null = update everything */
+int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* slot_mask, long n,
+                   const float* normsq, float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, spn_stream_t s);
 
 /* ---- decode, b = 1 (per-note body of ScorePerformerMixedLMWrapper.unmask_tokens, models/scoreperformer/wrappers.py:325-407;
  *      cache protocol modules/transformer/transformer.py:159-181,219-221; attention.py:155-156; sampling.py:28-59).

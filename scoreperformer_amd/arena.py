@@ -47,6 +47,7 @@ class ParamArena:
         self.shadow = torch.zeros(total, device=device, dtype=BF16)
         self._normsq = torch.zeros(1, device=device, dtype=F32)
         self.step_count = 0
+        self._mask_key, self._slot_mask = None, None   # which parameters the last optimizer step updated, and its device mask
         with torch.no_grad():
             for p, off in zip(params, offsets):
                 n = p.numel()
@@ -57,6 +58,9 @@ class ParamArena:
                 p._spn_main_grad = p.grad
                 p._spn_shadow = self.shadow[off:off + n].view(p.shape)
                 p._spn_offset = off
+                p._spn_touched = False
+                # gradients that arrive through autograd's own accumulation (p.grad is the arena view) count as produced too
+                p.register_post_accumulate_grad_hook(lambda q: setattr(q, "_spn_touched", True))
         # buffers follow the model to the device
         for mod in model.modules():
             for bname, buf in list(mod._buffers.items()):
@@ -118,14 +122,41 @@ class ParamArena:
         self._normsq.zero_()
         return ops.sumsq(self.grads, out=self._normsq)
 
+    def active_params(self) -> List[bool]:
+        """Parameters torch.optim.AdamW would update now: `requires_grad` and a gradient was produced since the last step
+        (the reference wraps AdamW over model.parameters(), which skips grad-is-None parameters: frozen by Model.freeze,
+        models/base.py:95-102, or unused in the forward -- no weight decay, no moments; experiments/optimizers.py:151-169)."""
+        touched = [bool(getattr(p, "_spn_touched", False)) for p in self.param_list]
+        if not any(touched):   # gradients written into the arena out of band (no backward ran): every trainable parameter has one
+            touched = [True] * len(touched)
+        return [bool(p.requires_grad and t) for p, t in zip(self.param_list, touched)]
+
+    def _mask_for(self, active: List[bool]) -> Optional[torch.Tensor]:
+        if all(active):
+            return None
+        key = tuple(active)
+        if key != self._mask_key:   # rebuilt only when the set changes (freeze / unfreeze), not every step
+            m = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
+            bounds = self.offsets[1:] + [self.total]
+            for on, s, e in zip(active, self.offsets, bounds):
+                if on:
+                    m[s // ALIGN:e // ALIGN] = 1
+            self._mask_key, self._slot_mask = key, m.to(self.device)
+        return self._slot_mask
+
     def step(self, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
              max_norm: Optional[float] = None, grad_scale: float = 1.0) -> torch.Tensor:
-        """clip_grad_norm_(max_norm) + AdamW over the whole arena; returns the (unclipped) grad norm as a device scalar."""
+        """clip_grad_norm_(max_norm) + AdamW over the arena; returns the (unclipped) grad norm as a device scalar.
+        Parameters without a gradient this step (see `active_params`) are left untouched, as torch.optim.AdamW leaves them."""
         self.step_count += 1
+        active = self.active_params()
+        self.updated = [a or u for a, u in zip(active, getattr(self, "updated", [False] * len(active)))]
         normsq = self.grad_norm_sq()
         ops.adamw_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, normsq,
                        max_norm=max_norm or 0.0, grad_scale=grad_scale, lr=lr, betas=betas, eps=eps,
-                       weight_decay=weight_decay, step=self.step_count)
+                       weight_decay=weight_decay, step=self.step_count, slot_mask=self._mask_for(active))
+        for p in self.param_list:
+            p._spn_touched = False
         return normsq.sqrt() * grad_scale
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
@@ -158,7 +189,10 @@ class FusedAdamW:
         a = self.arena
         state = {}
         if a.step_count > 0:
+            updated = getattr(a, "updated", None)
             for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
+                if updated is not None and not updated[i]:
+                    continue   # torch.optim.AdamW holds no state for a parameter it never stepped (frozen / unused)
                 n = p.numel()
                 state[i] = {"step": torch.tensor(float(a.step_count)),
                             "exp_avg": a.exp_avg[off:off + n].view(p.shape).clone(),
@@ -191,3 +225,4 @@ class FusedAdamW:
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ; the fused update keeps one step counter")
         a.step_count = steps.pop() if steps else 0
+        a.updated = [sd["state"].get(g["params"][i]) is not None for i in range(len(a.param_list))]

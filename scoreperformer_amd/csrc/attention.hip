@@ -532,50 +532,21 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
     }
 }
 
-// grow-only scratch for the band bounds; reuse is ordered by the stream, a different stream waits for the previous user
-struct BandWorkspace {
-    float* ptr = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false;
-    float* get(size_t need, hipStream_t stream) {
-        if (!done) hipEventCreateWithFlags(&done, hipEventDisableTiming);
-        if (need > bytes) {
-            if (ptr) { hipDeviceSynchronize(); hipFree(ptr); }
-            bytes = need * 2;
-            if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; bytes = 0; return nullptr; }
-            used = false;
-        }
-        if (used && last != stream) hipStreamWaitEvent(stream, done, 0);
-        return ptr;
-    }
-    void release(hipStream_t stream) { hipEventRecord(done, stream); last = stream; used = true; }
-};
-BandWorkspace g_band_ws[16];
-float g_band_log2 = -1.f;   // < 0: not initialised (SPN_ATTN_BAND env, default 40); 0: off
-
-// fills a.band for this problem (no-op without ALiBi slopes); call release_band() after the consuming kernels are enqueued
-// `own`: caller-provided buffer of spn_attn_band_elems floats (the forward fills it, the backward of the same q / k / mask reuses it:
-// `reuse`), else the internal grow-only workspace
-int prepare_band(AttnArgs& a, hipStream_t stream, float* own = nullptr, bool reuse = false) {
-    if (g_band_log2 < 0.f) g_band_log2 = getenv("SPN_ATTN_BAND") ? (float)atof(getenv("SPN_ATTN_BAND")) : 40.f;
-    a.band = nullptr; a.band_log2 = g_band_log2; a.nqt64 = (a.nq + 63) / 64;
-    static const int order_env = getenv("SPN_ATTN_ORDER") ? atoi(getenv("SPN_ATTN_ORDER")) : 1;   // tuning aid, see causal_order
-    a.order = order_env;
-    if (!a.slopes || g_band_log2 <= 0.f) return SPN_OK;
-    int dev = 0;
-    hipGetDevice(&dev);
-    const size_t nq_part = (size_t)a.b * a.h * a.nqt64, n = nq_part + (size_t)a.b * a.kvh;
-    if (own && reuse) { a.band = own; return SPN_OK; }
-    float* ws = own ? own : g_band_ws[dev & 15].get(n * 4, stream);
-    if (!ws) { spn_set_error("spn_attn: band workspace allocation failed"); return SPN_ERR_HIP; }
-    hipMemsetAsync(ws + nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
-    hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, ws);
-    a.band = ws;
+// fills a.band for this problem.  The band buffer is the CALLER's (spn_attn_band_elems floats): the forward fills it (`reuse` = false),
+// the backward of the same q / k / mask reads it back (`reuse` = true).  Without a buffer (or without ALiBi slopes, or with the knob
+// at 0) every tile is visited -- the skipped tiles contribute below fp32 resolution, so results do not depend on it.  Nothing is
+// allocated or synchronised here.
+int prepare_band(AttnArgs& a, hipStream_t stream, float* own, bool reuse) {
+    const float band_log2 = (float)spn_tune(SPN_TUNE_ATTN_BAND);
+    a.band = nullptr; a.band_log2 = band_log2; a.nqt64 = (a.nq + 63) / 64;
+    a.order = spn_tune_i(SPN_TUNE_ATTN_ORDER);
+    if (!a.slopes || band_log2 <= 0.f || !own) return SPN_OK;
+    a.band = own;
+    if (reuse) return SPN_OK;
+    const size_t nq_part = (size_t)a.b * a.h * a.nqt64;
+    hipMemsetAsync(own + nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
+    hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, own);
     return SPN_OK;
-}
-void release_band(const AttnArgs& a, hipStream_t stream, const float* own = nullptr) {
-    if (!a.band || own) return;
-    int dev = 0;
-    hipGetDevice(&dev);
-    g_band_ws[dev & 15].release(stream);
 }
 
 void set_dropout(AttnArgs& a, float p_drop, unsigned seed, void* dropbits, int nq, int nk) {
@@ -603,8 +574,9 @@ int check_common(const AttnArgs& a) {
 
 // strides: 12 longs = {q_bs,q_ns,q_hs, k_bs,k_ns,k_hs, v_bs,v_ns,v_hs, o_bs,o_ns,o_hs} in elements; head dim 64.
 // probabilities below 2^-log2_threshold of their row's largest one may be skipped by the ALiBi band (0 = visit everything).
-// Default 40, or the SPN_ATTN_BAND environment variable.  Process-wide; meant for tests and ablations.
-extern "C" void spn_attn_set_band(float log2_threshold) { g_band_log2 = log2_threshold < 0.f ? 0.f : log2_threshold; }
+// Default 40.  Process-wide (the "attn_band" knob of spn_set_tuning); meant for tests and ablations.
+extern "C" int spn_set_tuning(const char* name, double value);
+extern "C" void spn_attn_set_band(float log2_threshold) { spn_set_tuning("attn_band", log2_threshold < 0.f ? 0.f : log2_threshold); }
 
 // floats of a caller-owned band buffer (spn_attn_fwd fills it, spn_attn_bwd of the same problem reuses it instead of recomputing)
 extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return (long)b * h * ((nq + 63) / 64) + (long)b * kvh; }
@@ -637,7 +609,6 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     dim3 grid(cdiv(nq, 128), h, b);
     if (a.thr8) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
-    release_band(a, stream, band);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -669,13 +640,12 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE(o && d_o && lse && delta && dq && dk && dv, "spn_attn_bwd: null tensor");
     SPN_REQUIRE((a.o_ns % 8) == 0 && (a.o_hs % 8) == 0 && (a.o_bs % 8) == 0, "spn_attn_bwd: o/dO strides must be multiples of 8");
     SPN_REQUIRE((((uintptr_t)o | (uintptr_t)d_o) & 15) == 0, "spn_attn_bwd: o/dO must be 16-byte aligned");
-    rc = prepare_band(a, stream, const_cast<float*>(band), true);   // band != null: the bounds the forward computed for this q / k / mask
+    rc = prepare_band(a, stream, const_cast<float*>(band), true);   // the bounds the forward computed for this q / k / mask (null: visit all)
     if (rc) return rc;
     // dQ first: it computes delta = rowsum(O * dO) in its prologue and stores it for dK/dV
     if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     launch_attn_dkv(a, stream);
-    release_band(a, stream, band);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

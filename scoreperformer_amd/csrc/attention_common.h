@@ -1,6 +1,7 @@
 // Shared definitions of the attention kernels (see attention.hip for the design notes).
 #pragma once
 #include "common.h"
+#include "tuning.h"
 
 namespace spn_attn {
 

@@ -12,6 +12,7 @@
 //     LDS-privatised copy of the (tiny, heavily contended) table: ds_add_f32 per element, one global atomic per
 //     table element per block.  Rows with token == padding_idx receive no gradient (F.embedding semantics).
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -573,7 +574,7 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
     if (gamma) {
         SPN_REQUIRE(mean && rstd && dgamma && dbeta && ws, "spn_embed_bwd: LayerNorm buffers required with gamma");
         const int nv = round_nv((D + 255) / 256);
-        static const int stats_blocks = getenv("SPN_EMBED_STATS_BLOCKS") ? atoi(getenv("SPN_EMBED_STATS_BLOCKS")) : 2048;   // tuning aid (2048: -5 % over 1024; 256 or 16384: slower)
+        const int stats_blocks = spn_tune_i(SPN_TUNE_EMBED_STATS_BLOCKS) > 0 ? spn_tune_i(SPN_TUNE_EMBED_STATS_BLOCKS) : 2048;   // tuning aid (2048: -5 % over 1024; 256 or 16384: slower)
         int rpb = cdiv(T, stats_blocks); rpb = ((rpb + 3) / 4) * 4;
         dim3 grid(cdiv(T, rpb));
 #define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_bwd_stats_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, (const bf16_t*)dy, lddy, gamma, mean, rstd, s1, s2, dgamma, dbeta, T, rpb); break;
@@ -582,9 +583,9 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
     }
     bool mfma_ok = lddy % 8 == 0 && (((uintptr_t)dy) & 15) == 0;
     for (int i = 0; i < nkeys; ++i) mfma_ok = mfma_ok && E[i] == 128 && V[i] <= 512;
-    static const int mfma_env = getenv("SPN_EMBED_SCATTER_MFMA") ? atoi(getenv("SPN_EMBED_SCATTER_MFMA")) : 1;   // 0: LDS-atomic kernel
+    const int mfma_env = spn_tune_i(SPN_TUNE_EMBED_SCATTER_MFMA);   // 0: LDS-atomic kernel
     if (mfma_ok && mfma_env) {
-        static const int mfma_blocks = getenv("SPN_EMBED_SCATTER_BLOCKS") ? atoi(getenv("SPN_EMBED_SCATTER_BLOCKS")) : 256;   // tuning aid
+        const int mfma_blocks = spn_tune_i(SPN_TUNE_EMBED_SCATTER_BLOCKS) > 0 ? spn_tune_i(SPN_TUNE_EMBED_SCATTER_BLOCKS) : 256;   // tuning aid
         int chunks = mfma_blocks / nkeys;
         if (chunks > cdiv(T, 256)) chunks = cdiv(T, 256);
         if (chunks < 1) chunks = 1;
@@ -598,11 +599,8 @@ extern "C" int spn_embed_bwd(int nkeys, const float* const* tables, float* const
     for (int i = 0; i < nkeys; ++i) maxve = V[i] * E[i] > maxve ? V[i] * E[i] : maxve;
     const int lds_bytes = maxve * 4;
     const int use_lds = lds_bytes <= 150 * 1024;
-    static bool attr_set = false;
-    if (use_lds && !attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static std::atomic<unsigned> optin{0};
+    if (use_lds) spn_lds_optin(optin, reinterpret_cast<const void*>(embed_bwd_scatter_kernel<true>), 160 * 1024);
     // one block per CU when the table copy fills the LDS, a few more when it is small
     int chunks = (lds_bytes > 72 * 1024 ? 256 : 512) / nkeys;
     if (chunks > cdiv(T, 512)) chunks = cdiv(T, 512);

@@ -27,7 +27,7 @@
 // shapes (tiny MxN, K = all tokens) split K over blocks that write fp32 partials to a workspace; one small kernel reduces them.
 // Tile order: XCD-contiguous (workgroup id % 8 = XCD), column groups of 8 n-tiles, m-tiles down each group.
 #include "common.h"
-#include <stdlib.h>
+#include "tuning.h"
 
 namespace {
 
@@ -53,6 +53,8 @@ struct GemmArgs {
     int slice_xcd;            // ping-pong kernel, split-K: remap blocks so that an XCD runs whole K slices (see the kernel)
     int tx, ty;               // ping-pong kernel: tile grid (n-tiles, m-tiles); a launch with fewer blocks walks it persistently
     // gated-linear-unit epilogue (spn_gemm_glu): N = I gated outputs, B = [2I, K] (value rows | gate rows), C = u [M, 2I]
+    void* ws;                 // caller-owned split-K workspace (or null) and its size
+    size_t ws_bytes;
     bf16_t* G;                // [M, ldg]: dropout(value * act(gate))
     int ldg;
     uint32_t thr16, seed;     // dropout threshold (0 = none) and seed, as in spn_act_fwd
@@ -798,46 +800,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// grow-only workspace.  Reuse is ordered by the stream; a call from another stream waits for the previous user's reduce.
-struct SplitWorkspace {
-    float* ptr = nullptr;
-    size_t bytes = 0;
-    hipEvent_t done = nullptr;
-    hipStream_t last = nullptr;
-    bool used = false;
-    float* get(size_t need, hipStream_t stream) {
-        if (!done) hipEventCreateWithFlags(&done, hipEventDisableTiming);
-        if (need > bytes) {
-            if (ptr) { hipDeviceSynchronize(); hipFree(ptr); }
-            bytes = need + need / 4;
-            if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; bytes = 0; return nullptr; }
-            used = false;
-        }
-        if (used && last != stream) hipStreamWaitEvent(stream, done, 0);
-        return ptr;
-    }
-    void release(hipStream_t stream) { hipEventRecord(done, stream); last = stream; used = true; }
-};
-static SplitWorkspace g_split_ws[16];   // per device
-
 // decide the K split of a tiny-MxN / long-K product, redirect the kernel's output to the workspace; returns the final C description
+// The workspace [splits][M][N] fp32 is the CALLER's (spn_gemm_workspace_bytes says how much this shape wants): nothing is allocated,
+// freed or synchronised here, so a call is capturable and re-entrant.  A null / too small workspace simply runs the product unsplit.
 struct SplitPlan { float* C; int ldc; int accumulate; float* ws; };
-static int plan_split(GemmArgs& g, int tiles, int nt, int max_tiles, int want_blocks, int min_kt, hipStream_t stream, SplitPlan& plan) {
-    g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
-    if (g.batch != 1 || tiles >= max_tiles || nt < 4 * min_kt || g.N % 4 != 0 || g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0)
-        return SPN_OK;
+static void split_shape(const GemmArgs& g, int tiles, int nt, int max_tiles, int want_blocks, int min_kt, int& splitk, int& kt_per_split) {
+    splitk = 1; kt_per_split = nt;
+    if (g.batch != 1 || tiles >= max_tiles || nt < 4 * min_kt || g.N % 4 != 0) return;
     int want = want_blocks < 0 ? (-want_blocks) / tiles : cdiv(want_blocks, tiles);   // negative target: round down
     if (want > nt / min_kt) want = nt / min_kt;
-    if (want <= 1) return SPN_OK;
-    g.kt_per_split = cdiv(nt, want);
-    g.splitk = cdiv(nt, g.kt_per_split);
-    int dev = 0;
-    hipGetDevice(&dev);
-    float* ws = g_split_ws[dev & 15].get((size_t)g.splitk * g.M * g.N * 4, stream);
-    if (!ws) { spn_set_error("spn_gemm_bf16: split-K workspace allocation failed"); return SPN_ERR_HIP; }
-    plan = SplitPlan{reinterpret_cast<float*>(g.C), g.ldc, g.accumulate, ws};
-    g.C = ws; g.ldc = g.N; g.sC = (long)g.M * g.N; g.accumulate = 0;
-    return SPN_OK;
+    if (want <= 1) return;
+    kt_per_split = cdiv(nt, want);
+    splitk = cdiv(nt, kt_per_split);
+}
+static void plan_split(GemmArgs& g, int tiles, int nt, int max_tiles, int want_blocks, int min_kt, SplitPlan& plan) {
+    g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
+    if (g.ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(g.C) & 15) != 0) return;
+    int splitk, kt;
+    split_shape(g, tiles, nt, max_tiles, want_blocks, min_kt, splitk, kt);
+    if (splitk <= 1) return;
+    const size_t need = (size_t)splitk * g.M * g.N * 4;
+    if (!g.ws || g.ws_bytes < need || (reinterpret_cast<uintptr_t>(g.ws) & 15) != 0) return;   // unsplit: slower, still correct
+    g.splitk = splitk; g.kt_per_split = kt;
+    plan = SplitPlan{reinterpret_cast<float*>(g.C), g.ldc, g.accumulate, reinterpret_cast<float*>(g.ws)};
+    g.C = g.ws; g.ldc = g.N; g.sC = (long)g.M * g.N; g.accumulate = 0;
 }
 static void finish_split(const GemmArgs& g, const SplitPlan& plan, hipStream_t stream) {
     if (!plan.ws) return;
@@ -846,10 +832,12 @@ static void finish_split(const GemmArgs& g, const SplitPlan& plan, hipStream_t s
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, plan.ws, g.splitk, (long)g.M * g.N, plan.C, plan.ldc, g.N,
                        total4, plan.accumulate);
-    int dev = 0;
-    hipGetDevice(&dev);
-    g_split_ws[dev & 15].release(stream);
 }
+
+// split-K policy of the ping-pong kernel: one block per CU, aim for ONE full round of 256 blocks (floor, so that no second, nearly
+// empty round appears); products with >= 192 tiles or fewer than 64 K tiles are not split
+constexpr int PP_SPLIT_MAX_TILES = 192, PP_SPLIT_MIN_KT = 16;
+static int pp_split_want() { const int w = spn_tune_i(SPN_TUNE_GEMM_SPLIT_BLOCKS); return w > 0 ? w : -256; }
 
 // shapes the ping-pong kernel takes: K in whole 64-tiles, rows in multiples of 8, vector-aligned epilogue operands
 static bool pp_eligible(const GemmArgs& g) {
@@ -866,30 +854,22 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     const int tiles = cdiv(g.N, PP_BN) * cdiv(g.M, PP_BM), nt = g.K / PP_BK;
     SplitPlan plan;
     if (sizeof(OutT) == 4) {
-        static const int want_env = getenv("SPN_GEMM_PP_SPLIT_BLOCKS") ? atoi(getenv("SPN_GEMM_PP_SPLIT_BLOCKS")) : 0;   // tuning aid
-        // one block per CU: aim for ONE full round of 256 blocks (floor, so that no second, nearly empty round appears)
-        const int rc = plan_split(g, tiles, nt, 192, want_env > 0 ? want_env : -256, 16, stream, plan);
-        if (rc != SPN_OK) return rc;
+        plan_split(g, tiles, nt, PP_SPLIT_MAX_TILES, pp_split_want(), PP_SPLIT_MIN_KT, plan);
     } else {
         g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
     constexpr int LDS_BYTES = 8 * PP_HALF + 8 * 4096;   // operand ring + epilogue staging
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_done = true;
-    }
+    static std::atomic<unsigned> optin{0};
+    spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT>), LDS_BYTES);
     dim3 grid(cdiv(g.N, PP_BN), cdiv(g.M, PP_BM), g.splitk > 1 ? g.splitk : g.batch);
-    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
-    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y;
     // (weight gradients at C3: 4096x512x131072 609 -> 590 us, 512x2048x131072 335 -> 323 us)
-    static const int slice_env = getenv("SPN_GEMM_SLICE_XCD") ? atoi(getenv("SPN_GEMM_SLICE_XCD")) : 1;   // tuning aid: 0 = grid order
-    g.slice_xcd = (slice_env && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
+    g.slice_xcd = (spn_tune_i(SPN_TUNE_GEMM_SLICE_XCD) && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
     // one block per CU walking the tile list: the K = 512 projections gain 1-4 % per launch under HIP events, the step does not
     // (170.8 vs 171.5 ms: the next kernel can no longer start under the last round), so it stays a tuning aid
-    static const int persist_env = getenv("SPN_GEMM_PERSIST") ? atoi(getenv("SPN_GEMM_PERSIST")) : 0;   // 0 off, else min rounds
+    const int persist_env = spn_tune_i(SPN_TUNE_GEMM_PERSIST);   // 0 off, else min rounds
     if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
@@ -904,23 +884,17 @@ int launch_bk(GemmArgs g, hipStream_t stream) {
     const int tiles = cdiv(g.N, BN) * cdiv(g.M, BM), nt = cdiv(g.K, BK);
     SplitPlan plan;
     if (sizeof(OutT) == 4) {
-        const int rc = plan_split(g, tiles, nt, 384, 768, 8, stream, plan);
-        if (rc != SPN_OK) return rc;
+        plan_split(g, tiles, nt, 384, 768, 8, plan);
     } else {
         g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
     dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM), g.splitk > 1 ? g.splitk : g.batch);
     constexpr int LDS_BYTES = STAGES * 2 * 128 * BK * 2;
-    if (LDS_BYTES > 64 * 1024) {
-        static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        if (!attr_done) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OutT, BK, STAGES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            attr_done = true;
-        }
+    if (LDS_BYTES > 64 * 1024) {   // > 64 KiB of dynamic LDS needs the opt-in attribute (once per instantiation and device)
+        static std::atomic<unsigned> optin{0};
+        spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_kernel<TA, TB, OutT, BK, STAGES>), LDS_BYTES);
     }
-    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
-    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     hipLaunchKernelGGL((gemm_kernel<TA, TB, OutT, BK, STAGES>), grid, dim3(256), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
@@ -933,7 +907,7 @@ template <bool TA, bool TB, typename OutT>
 int launch(const GemmArgs& g, hipStream_t stream) {
     // short contractions (K <= 1024: every projection with d_model = 512 on the input side) are latency-bound per block:
     // BK = 32 halves the LDS footprint (32 KiB) so that 4 blocks stay resident per CU and hide each other's pipeline fill
-    static const int variant = getenv("SPN_GEMM_VARIANT") ? atoi(getenv("SPN_GEMM_VARIANT")) : 0;   // tuning aid
+    const int variant = spn_tune_i(SPN_TUNE_GEMM_VARIANT);   // tuning aid
     if (variant == 1) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
     if (variant == 2) return launch_bk<TA, TB, OutT, 64, 3>(g, stream);
     if (variant == 3) return launch_bk<TA, TB, OutT, 32, 4>(g, stream);
@@ -952,21 +926,17 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 template <int GLU>
 int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     constexpr int LDS_BYTES = 8 * PP_HALF + 8 * 4096;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<false, false, bf16_t, GLU>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_done = true;
-    }
+    static std::atomic<unsigned> optin{0};
+    spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pp_kernel<false, false, bf16_t, GLU>), LDS_BYTES);
     dim3 grid(g.N / (PP_BN / 2), cdiv(g.M, PP_BM), 1);
-    static const int ngroup_env = getenv("SPN_GEMM_NGROUP") ? atoi(getenv("SPN_GEMM_NGROUP")) : 0;   // tuning aid
-    g.ngroup = ngroup_env > 0 ? ngroup_env : 8;
+    g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y; g.slice_xcd = 0;
     // one block per CU walking the tile list: the next tile's first DMA is in flight while this tile's (long, VALU-bound) epilogue runs
     // (811 -> 783 us at 131072 x 2048 x 512 on an otherwise idle chip).  Off by default: with a static tile list per block, a CU that
     // a concurrent kernel holds (the RCCL all-reduce of the data-parallel step) delays ITS whole share of tiles by one block
     // lifetime, while the plain grid just hands those tiles to the other CUs.
-    static const int persist_env = getenv("SPN_GLU_PERSIST") ? atoi(getenv("SPN_GLU_PERSIST")) : 0;   // 0 off, else min rounds
+    const int persist_env = spn_tune_i(SPN_TUNE_GLU_PERSIST);   // 0 off, else min rounds
     if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
     hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
@@ -978,10 +948,32 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
 // C-ABI ---------------------------------------------------------------------------------------------------
 // flags: bit0 = A is M-contiguous (transposed storage), bit1 = B is N-contiguous, bit2 = C is fp32 (else bf16),
 //        bit3 = accumulate into C (fp32 C only).
+//
+// Weight-gradient shapes (fp32 C, tiny M x N, K = all tokens) are split over K through a CALLER-OWNED fp32 workspace:
+// spn_gemm_workspace_bytes(M, N, K, flags, batch) is the size this shape can use (0: never split).  With workspace == null or fewer
+// bytes the product runs unsplit (correct, slower).  The call never allocates, frees or synchronises.
+extern "C" size_t spn_gemm_workspace_bytes(int M, int N, int K, int flags, int batch) {
+    if (!(flags & 4) || M <= 0 || N <= 0 || K <= 0) return 0;   // only fp32 outputs are split
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K; g.batch = batch;
+    size_t need = 0;
+    int splitk, kt;
+    if (M >= 128 && N >= 128 && M % 8 == 0 && N % 8 == 0 && K % PP_BK == 0 && K >= 4 * PP_BK) {
+        split_shape(g, cdiv(N, PP_BN) * cdiv(M, PP_BM), K / PP_BK, PP_SPLIT_MAX_TILES, pp_split_want(), PP_SPLIT_MIN_KT, splitk, kt);
+        if (splitk > 1) need = (size_t)splitk * M * N * 4;
+    }
+    for (int bk = 32; bk <= 64; bk *= 2) {   // the 128x128 kernels (whichever K tile the dispatch picks)
+        split_shape(g, cdiv(N, BN) * cdiv(M, BM), cdiv(K, bk), 384, 768, 8, splitk, kt);
+        if (splitk > 1 && (size_t)splitk * M * N * 4 > need) need = (size_t)splitk * M * N * 4;
+    }
+    return need;
+}
+
 extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
                              const uint8_t* rowmask, int M, int N, int K, int lda, int ldb, int ldc, int ldr,
                              float alpha, int flags, int batch, long strideA, long strideB, long strideC,
-                             hipStream_t stream) {
+                             void* workspace, size_t workspace_bytes, hipStream_t stream) {
     SPN_REQUIRE(A && B && C, "spn_gemm_bf16: null operand");
     SPN_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "spn_gemm_bf16: empty problem");
     SPN_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "spn_gemm_bf16: lda/ldb must be multiples of 8 elements");
@@ -996,6 +988,7 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.G = nullptr; g.ldg = 0; g.thr16 = 0; g.seed = 0; g.keep_scale = 1.f;
+    g.ws = workspace; g.ws_bytes = workspace ? workspace_bytes : 0;
     {
         const long a_span = (long)(ta ? K : M) * lda * 2, b_span = (long)(tb ? K : N) * ldb * 2;
         g.pp_addr_ok = (a_span < (1L << 31) && b_span < (1L << 31)) ? 1 : 0;
@@ -1038,7 +1031,7 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)W; g.C = u; g.bias = bias; g.residual = nullptr; g.rowmask = nullptr;
     g.M = M; g.N = I; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldu; g.ldr = 0; g.alpha = 1.f;
     g.accumulate = 0; g.batch = 1; g.sA = g.sB = g.sC = 0; g.splitk = 1; g.kt_per_split = K / PP_BK; g.pp_addr_ok = 1;
-    g.G = (bf16_t*)gout; g.ldg = ldg; g.seed = seed;
+    g.G = (bf16_t*)gout; g.ldg = ldg; g.seed = seed; g.ws = nullptr; g.ws_bytes = 0;
     const float t = p_drop * 65536.f;   // thr16_of of elementwise.hip
     g.thr16 = t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)(t + 0.5f));
     g.keep_scale = 1.f / (1.f - (float)g.thr16 / 65536.f);

@@ -6,6 +6,7 @@
 // (gamma_t, beta_t) = Linear(cond).chunk(2) supplied as a [T, 2D] fp32 tensor.
 // Statistics are fp32 two-pass (mean, then centred variance) like ATen's CPU kernel.
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -222,7 +223,7 @@ int ln_bwd_impl(const void* x, int x_dtype, long ldx, const void* dy, long lddy,
     SPN_REQUIRE(D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldgb % 4 == 0 && lddgb % 4 == 0 &&
                 lddres % 4 == 0 && lddx16 % 4 == 0, "spn_layernorm_bwd: D must be a multiple of 4 and <= 2048; leading dims multiples of 4");
     const int nv = round_nv((D + 255) / 256);
-    static const int bwd_blocks = getenv("SPN_LN_BWD_BLOCKS") ? atoi(getenv("SPN_LN_BWD_BLOCKS")) : 2048;   // tuning aid
+    const int bwd_blocks = spn_tune_i(SPN_TUNE_LN_BWD_BLOCKS) > 0 ? spn_tune_i(SPN_TUNE_LN_BWD_BLOCKS) : 2048;   // tuning aid
     int rpb = cdiv(T, bwd_blocks);
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));

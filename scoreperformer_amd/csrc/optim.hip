@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 // normsq: device scalar (sum of squares of ALL grads, already reduced across whatever the caller wants);
 // grad_scale multiplies g before clipping (1/world_size for data-parallel sums, 1/loss_scale ...).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow,
+                                                    const uint8_t* __restrict__ slot_mask, long n,
                                                     const float* __restrict__ normsq, float max_norm, float grad_scale, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt) {
     float coef = grad_scale;
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        // torch.optim.AdamW skips a parameter whose grad is None (frozen by Model.freeze, or never used): no decay, no moments
+        if (slot_mask && slot_mask[i >> 1] == 0) continue;
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
 #pragma unroll
@@ -68,14 +71,18 @@ extern "C" int spn_sumsq(const float* g, long n, float* out, hipStream_t s) {
 }
 
 // n must be a multiple of 4 (the arena pads); step >= 1.
-extern "C" int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* normsq,
+// slot_mask: optional uint8 [n / 8], one flag per 8-element slot (the arena aligns every parameter to 8 elements): 0 = the slot belongs
+// to a parameter torch.optim.AdamW would skip this step (grad is None: frozen or unused) and is left untouched; null = update all.
+extern "C" int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* slot_mask, long n,
+                              const float* normsq,
                               float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int step, hipStream_t s) {
     SPN_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "spn_adamw_step: bad arguments (n multiple of 4)");
+    SPN_REQUIRE(!slot_mask || n % 8 == 0, "spn_adamw_step: a slot mask needs n to be a multiple of 8");
     SPN_REQUIRE(max_norm <= 0.f || normsq, "spn_adamw_step: normsq required when clipping");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow_bf16, n, normsq, max_norm,
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16_t*)shadow_bf16, slot_mask, n, normsq, max_norm,
                        grad_scale, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

@@ -1,0 +1,37 @@
+// Process-wide tuning knobs of libspn.so.  The library never reads the environment: the host binding sets knobs explicitly through
+// spn_set_tuning() (scoreperformer_amd/lib.py maps SPN_* environment variables onto them once, at load).  Reads are relaxed atomic
+// loads of plain doubles: a knob changed while kernels are being enqueued from another thread takes effect for later launches only.
+#pragma once
+
+enum SpnTune {
+    SPN_TUNE_ATTN_BAND = 0,        // log2 of the smallest probability ratio still visited by the ALiBi band (0 = visit everything); 40
+    SPN_TUNE_ATTN_ORDER,           // attention block order: 1 = XCD per batch element + heaviest-first causal tiles, 0 = grid order; 1
+    SPN_TUNE_GEMM_VARIANT,         // 0 = measured dispatch; 1..6 force a 128x128 variant; 9 = ping-pong wherever eligible; 0
+    SPN_TUNE_GEMM_NGROUP,          // n-tiles per column group of the tile order; 8
+    SPN_TUNE_GEMM_SLICE_XCD,       // split-K: an XCD runs whole K slices; 1
+    SPN_TUNE_GEMM_SPLIT_BLOCKS,    // split-K block target of the ping-pong kernel (0 = one full round of 256); 0
+    SPN_TUNE_GEMM_PERSIST,         // plain GEMM: 256 persistent blocks when the grid has at least this many rounds (0 = off); 0
+    SPN_TUNE_GLU_PERSIST,          // gated GEMM: the same; 0
+    SPN_TUNE_EMBED_STATS_BLOCKS,   // 2048
+    SPN_TUNE_EMBED_SCATTER_MFMA,   // 1 = one-hot MFMA scatter, 0 = LDS-atomic scatter; 1
+    SPN_TUNE_EMBED_SCATTER_BLOCKS, // 256
+    SPN_TUNE_LN_BWD_BLOCKS,        // 2048
+    SPN_TUNE_GEMM_DUO,             // 1 = two 4-wave workgroups per CU (256x128 tiles) for the short-K projections; see gemm.hip
+    SPN_TUNE_COUNT
+};
+
+double spn_tune(SpnTune k);
+static inline int spn_tune_i(SpnTune k) { return (int)spn_tune(k); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device); `mask` is the call site's static word.
+// Two host threads may both find the bit clear and both set the attribute: harmless (idempotent).
+#include <atomic>
+#include <hip/hip_runtime.h>
+static inline void spn_lds_optin(std::atomic<unsigned>& mask, const void* fn, int bytes) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (mask.load(std::memory_order_acquire) & bit) return;
+    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    mask.fetch_or(bit, std::memory_order_release);
+}

@@ -98,10 +98,23 @@ def _with_shadow(dx: torch.Tensor, shape) -> torch.Tensor:
     return out
 
 
+def _main_grad(p):
+    """The arena's fp32 gradient view of a parameter (None outside an arena).  Asking for it in backward means a gradient is being
+    produced for `p` this step: torch.optim.AdamW skips parameters whose grad is None, and the fused step does the same for
+    parameters that were never marked (arena.ParamArena.step)."""
+    if p is None:
+        return None
+    main = getattr(p, "_spn_main_grad", None)
+    if main is not None:
+        for q in getattr(p, "_spn_parts", None) or (p,):
+            q._spn_touched = True
+    return main
+
+
 def _accumulate_wgrad(w: torch.Tensor, compute, shape):
     """Weight gradient: accumulate straight into the arena's fp32 grad view when there is one (returns None to
     autograd), else return a fresh fp32 gradient."""
-    main = getattr(w, "_spn_main_grad", None)
+    main = _main_grad(w)
     if main is not None:
         compute(main, True)
         hook = getattr(w, "_spn_grad_ready", None)
@@ -167,7 +180,7 @@ class LinearFn(Function):
                                        weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             bias = ctx.bias_ref
-            main = getattr(bias, "_spn_main_grad", None)
+            main = _main_grad(bias)
             if main is not None:
                 if not getattr(dy, "_spn_bias_done", False):   # else: the activation backward that produced dy summed it already
                     ops.colsum(dyb, out=main)
@@ -214,8 +227,8 @@ class LayerNormFn(Function):
         dres = _fork_grad(dres, x)
         dyb = to_bf16(dy.reshape(-1, D))
         dgamma = dbeta = None
-        g_main = getattr(gamma, "_spn_main_grad", None) if gamma is not None else None
-        b_main = getattr(beta, "_spn_main_grad", None) if beta is not None else None
+        g_main = _main_grad(gamma) if gamma is not None else None
+        b_main = _main_grad(beta) if beta is not None else None
         fused = g_main is not None and b_main is not None
         if gamma is not None:
             dgamma = g_main if fused else torch.zeros(D, device=x.device, dtype=F32)
@@ -324,7 +337,7 @@ class AdaLayerNormFn(Function):
             dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
             dcond = dcond.view(ctx.cond_shape)
         dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(dgb, c2, ta=True, tb=True, out=out, accumulate=acc), weight.shape)
-        main = getattr(bias, "_spn_main_grad", None)
+        main = _main_grad(bias)
         db = None
         if main is not None:
             ops.colsum(dgb, out=main)
@@ -442,7 +455,7 @@ class ActFn(Function):
         (u,) = ctx.saved_tensors
         act, glu, p_drop, seed = ctx.cfg
         bias = ctx.bias_ref
-        main = getattr(bias, "_spn_main_grad", None) if bias is not None and bias.requires_grad else None
+        main = _main_grad(bias) if bias is not None and bias.requires_grad else None
         if main is not None and not ops.act_bwd_can_fuse_colsum(u.shape[-1], glu):
             main = None
         du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu, p_drop=p_drop, seed=seed, colsum=main)
@@ -475,7 +488,7 @@ class LinearGLUFn(Function):
         x2, u = ctx.saved_tensors
         weight, bias = ctx.weight_ref, ctx.bias_ref
         act, p_drop, seed = ctx.cfg
-        main = getattr(bias, "_spn_main_grad", None) if bias is not None and bias.requires_grad else None
+        main = _main_grad(bias) if bias is not None and bias.requires_grad else None
         fused_sum = main is not None and ops.act_bwd_can_fuse_colsum(u.shape[-1], True)
         du = ops.act_bwd(u, to_bf16(dg).reshape(-1, dg.shape[-1]), act=act, glu=True, p_drop=p_drop, seed=seed,
                          colsum=main if fused_sum else None)
@@ -667,7 +680,7 @@ class EmbedFn(Function):
         dgamma = dbeta = None
         fused = False
         if gamma is not None:
-            g_main, b_main = getattr(gamma, "_spn_main_grad", None), getattr(beta, "_spn_main_grad", None)
+            g_main, b_main = _main_grad(gamma), _main_grad(beta)
             fused = g_main is not None and b_main is not None
             dgamma = g_main if fused else torch.zeros(D, device=dy.device, dtype=F32)
             dbeta = b_main if fused else torch.zeros(D, device=dy.device, dtype=F32)

@@ -10,6 +10,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from . import lib as _lib_mod
 from .lib import load,  call, ptr, stream_ptr, require_gpu, c_int, c_long, c_float, SpnError
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -104,10 +105,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, ta: bool = False, tb: bool = False
             raise SpnError("gemm: rowmask must have M entries")
     if bias is not None and (bias.dtype != F32 or bias.numel() != N):
         raise SpnError("gemm: bias must be fp32 [N]")
+    ws, ws_bytes = None, _gemm_ws_bytes(M, N, K, flags)
+    if ws_bytes:   # split-K partial products: the workspace is the caller's (PyTorch's caching allocator, stream-ordered reuse)
+        ws = torch.empty(ws_bytes, device=a.device, dtype=torch.uint8)
     call("spn_gemm_bf16", ptr(a), ptr(b), ptr(out), ptr(bias), ptr(residual), ptr(rowmask), c_int(M), c_int(N), c_int(K),
          c_int(a.stride(0)), c_int(b.stride(0)), c_int(out.stride(0)), c_int(residual.stride(0) if residual is not None else 0),
-         c_float(alpha), c_int(flags), c_int(1), c_long(0), c_long(0), c_long(0), stream_ptr())
+         c_float(alpha), c_int(flags), c_int(1), c_long(0), c_long(0), c_long(0), ptr(ws), ctypes.c_size_t(ws_bytes), stream_ptr())
     return out
+
+
+_WS_CACHE = {}
+
+
+def _gemm_ws_bytes(M: int, N: int, K: int, flags: int) -> int:
+    """spn_gemm_workspace_bytes, memoised per shape (a pure function of the shape and the split knobs)."""
+    key = (M, N, K, flags & 4, _lib_mod.TUNING_EPOCH)
+    n = _WS_CACHE.get(key)
+    if n is None:
+        n = int(load().spn_gemm_workspace_bytes(c_int(M), c_int(N), c_int(K), c_int(flags), c_int(1)))
+        _WS_CACHE[key] = n
+    return n
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -192,7 +209,10 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_dr
     """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq].
 
     With p_drop > 0 a third value is returned: the dropout keep bits (int16 words, 1 bit per score) that `attn_bwd` needs.
-    `band`: optional fp32 buffer from `attn_band_buffer` that receives the ALiBi band bounds, for `attn_bwd` to reuse."""
+    `band`: fp32 buffer from `attn_band_buffer` that receives the ALiBi band bounds, for `attn_bwd` to reuse; with slopes and
+    no buffer one is allocated here (the library owns no memory), without slopes there is no band."""
+    if band is None and slopes is not None:
+        band = attn_band_buffer(q, k)
     require_gpu(q, k, v)
     b, nq, h, dh = q.shape
     nk, kvh = k.shape[1], k.shape[2]
@@ -624,8 +644,11 @@ def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 
 
 def adamw_step(p, g, m, v, shadow, normsq, *, max_norm: float, grad_scale: float, lr: float, betas=(0.9, 0.999), eps=1e-8,
-               weight_decay: float = 0.0, step: int = 1):
-    call("spn_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), c_long(p.numel()), ptr(normsq), c_float(max_norm or 0.0),
+               weight_decay: float = 0.0, step: int = 1, slot_mask: Optional[torch.Tensor] = None):
+    """`slot_mask`: uint8 [n / 8]; slots with 0 belong to parameters without a gradient this step and are left untouched."""
+    if slot_mask is not None and (slot_mask.dtype != torch.uint8 or slot_mask.numel() * 8 != p.numel()):
+        raise SpnError("adamw_step: slot_mask must be uint8 with one entry per 8 parameters")
+    call("spn_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), ptr(slot_mask), c_long(p.numel()), ptr(normsq), c_float(max_norm or 0.0),
          c_float(grad_scale), c_float(lr), c_float(betas[0]), c_float(betas[1]), c_float(eps), c_float(weight_decay), c_int(step),
          stream_ptr())
 

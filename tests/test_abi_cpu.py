@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(handle, s)]
     assert not missing, missing
-    assert handle.spn_abi_version() == 1
+    assert handle.spn_abi_version() == 2
 
 
 def test_python_bindings_call_only_declared_symbols():
@@ -44,3 +44,43 @@ def test_product_has_no_cpu_fallback():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_library_owns_no_memory_and_reads_no_environment():
+    """include/spn.h's contract: no allocation, no device/stream synchronisation, no getenv anywhere in csrc/."""
+    banned = ("hipMalloc", "hipFree", "hipDeviceSynchronize", "hipStreamSynchronize", "hipEventSynchronize", "getenv")
+    csrc = os.path.join(ROOT, "scoreperformer_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            for word in banned:
+                assert word not in text, f"{f} uses {word}"
+
+
+def test_tuning_table_round_trip():
+    """spn_set_tuning / spn_get_tuning are host-only: every knob of csrc/tuning.h is enumerable, settable and readable."""
+    from scoreperformer_amd import build, lib
+    build.build()
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    handle.spn_tuning_name.restype = ctypes.c_char_p
+    names = [handle.spn_tuning_name(ctypes.c_int(i)).decode() for i in range(handle.spn_tuning_count())]
+    assert "attn_band" in names and "gemm_variant" in names and len(set(names)) == len(names)
+    out = ctypes.c_double(0)
+    assert handle.spn_get_tuning(b"attn_band", ctypes.byref(out)) == 0 and out.value == 40.0
+    assert handle.spn_set_tuning(b"attn_band", ctypes.c_double(0.0)) == 0
+    assert handle.spn_get_tuning(b"attn_band", ctypes.byref(out)) == 0 and out.value == 0.0
+    assert handle.spn_set_tuning(b"attn_band", ctypes.c_double(40.0)) == 0
+    assert handle.spn_set_tuning(b"no_such_knob", ctypes.c_double(1.0)) != 0
+
+
+def test_gemm_workspace_query_is_pure():
+    """spn_gemm_workspace_bytes: 0 for bf16 outputs and for big tile grids, > 0 for the weight-gradient shapes (no GPU needed)."""
+    from scoreperformer_amd import build, lib
+    build.build()
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    handle.spn_gemm_workspace_bytes.restype = ctypes.c_size_t
+    q = lambda M, N, K, flags: handle.spn_gemm_workspace_bytes(ctypes.c_int(M), ctypes.c_int(N), ctypes.c_int(K), ctypes.c_int(flags), ctypes.c_int(1))
+    assert q(131072, 4096, 512, 0) == 0 and q(131072, 512, 2048, 4) == 0
+    need = q(4096, 512, 131072, 1 | 2 | 4 | 8)
+    assert need > 0 and need % (4096 * 512 * 4) == 0
+    assert q(512, 2048, 131072, 1 | 2 | 4) > 0

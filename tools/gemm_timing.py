@@ -14,13 +14,13 @@ if hasattr(lib, "spn_gemm_set_debug"):
 P = ctypes.c_void_p
 for _ in range(2):
     rc = lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
-                           ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None)
+                           ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
     lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
-                      ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None)
+                      ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 if LDA == K and LDB == K:

@@ -8,7 +8,7 @@ for M, N in [(4096, 512), (512, 2048), (640, 512), (512, 512), (1536, 512)]:
     c = torch.zeros(M, N, device=dev)
     def run():
         return lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, T, M, N, N, 0,
-                                 ctypes.c_float(1.0), 1 | 2 | 4 | 8, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None)
+                                 ctypes.c_float(1.0), 1 | 2 | 4 | 8, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
