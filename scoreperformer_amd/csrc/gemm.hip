@@ -434,6 +434,130 @@ __device__ __forceinline__ uint32_t pp_voffset_lin(int ld, int row0, int wave, i
     return (uint32_t)(((long)(row0 + x) * ld + kc * 8) * 2);
 }
 
+// ---- tile epilogue shared by the 256x256 ping-pong kernel and the 256x128 duo kernel -----------------------------------------
+// A wave holds 128 rows x 64 columns of C as acc[i][j] (32-row block i, 32-column block j; operand-swapped MFMA: lane l owns row
+// l & 31 and, per register quad q, the 4 consecutive columns 8q + 4(l >> 5) ..).  Rows start at cm0 + 128 wr; plain GEMM: columns
+// cn0 + 64 wc + 32 j; gated (GLU): j = 0 / 1 are the VALUE / GATE columns of the outputs cn0 + 32 wc ...  The block goes through the
+// wave's own 4 KiB LDS slab `stg` and leaves as whole 128-byte row segments (partial-line writes make the L2 fetch C first).
+template <typename OutT, int GLU>
+__device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4][2], const f32x4 (&bv)[8], OutT* C, bool lead,
+                                              int cm0, int cn0, int wr, int wc, int lane, char* stg) {
+    constexpr int ES = sizeof(OutT);
+    constexpr int JP = ES == 2 ? 2 : 1;                 // 32-column halves of the wave's 128x64 block staged per pass
+    constexpr int ROWB = 32 * JP * ES, CPR = ROWB / 16; // 128-byte rows, 8 chunks: a pass = 32 rows = 4 KiB
+    if constexpr (GLU != 0) {
+        // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
+        // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
+        bf16_t* U = reinterpret_cast<bf16_t*>(g.C);
+        const int chunks = g.N >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = lane & 31;
+            const int m = cm0 + wr * 128 + 32 * i + row;
+            uint2 go[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]} + bv[q];
+                const f32x4 t = f32x4{acc[i][1][4 * q], acc[i][1][4 * q + 1], acc[i][1][4 * q + 2], acc[i][1][4 * q + 3]} + bv[4 + q];
+                uint2 pa, pt;
+                pa.x = pack_bf2(a[0], a[1]); pa.y = pack_bf2(a[2], a[3]);
+                pt.x = pack_bf2(t[0], t[1]); pt.y = pack_bf2(t[2], t[3]);
+                const int slot = 2 * q + (lane >> 5);   // 8-byte slot of the 64-byte value half; the gate half is slots 8..15
+                *reinterpret_cast<uint2*>(stg + row * 128 + (((slot ^ row) & 15) << 3)) = pa;
+                *reinterpret_cast<uint2*>(stg + row * 128 + ((((8 + slot) ^ row) & 15) << 3)) = pt;
+                const float ar[4] = {bf2f(pa.x & 0xffff), bf2f(pa.x >> 16), bf2f(pa.y & 0xffff), bf2f(pa.y >> 16)};
+                const float tr[4] = {bf2f(pt.x & 0xffff), bf2f(pt.x >> 16), bf2f(pt.y & 0xffff), bf2f(pt.y >> 16)};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
+                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd: chunk idx = t * (I/8) + col/8, pair e/2 of the chunk
+                    const int col = cn0 + wc * 32 + 8 * q + (lane >> 5) * 4;
+                    const long idx = (long)m * chunks + (col >> 3);
+                    const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
+                    const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
+                    o[0] = (h0 & 0xffffu) >= g.thr16 ? o[0] * g.keep_scale : 0.f;
+                    o[1] = (h0 >> 16) >= g.thr16 ? o[1] * g.keep_scale : 0.f;
+                    o[2] = (h1 & 0xffffu) >= g.thr16 ? o[2] * g.keep_scale : 0.f;
+                    o[3] = (h1 >> 16) >= g.thr16 ? o[3] * g.keep_scale : 0.f;
+                }
+                go[q].x = pack_bf2(o[0], o[1]); go[q].y = pack_bf2(o[2], o[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
+                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                const int mo = cm0 + wr * 128 + 32 * i + r;
+                const int no = (chunk >> 2) * g.N + cn0 + wc * 32 + (chunk & 3) * 8;
+                if (mo < g.M) *reinterpret_cast<uint4*>(U + (long)mo * g.ldc + no) = val;
+            }
+            // the gated output through the same slab: 64-byte rows, 8 slots
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint2*>(stg + row * 64 + ((((2 * q + (lane >> 5)) ^ row) & 7) << 3)) = go[q];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + (lane >> 2), chunk = lane & 3;
+                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 64 + (((chunk ^ (r >> 1)) & 3) << 4));
+                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                const int mo = cm0 + wr * 128 + 32 * i + r;
+                if (mo < g.M) *reinterpret_cast<uint4*>(g.G + (long)mo * g.ldg + cn0 + wc * 32 + chunk * 8) = val;
+            }
+        }
+    } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = lane & 31;
+        const int m = cm0 + wr * 128 + 32 * i + row;
+        const float rs = g.rowmask ? (g.rowmask[min(m, g.M - 1)] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int jh = 0; jh < 2 / JP; ++jh) {
+#pragma unroll
+            for (int jj = 0; jj < JP; ++jj) {
+                const int j = jh * JP + jj;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = cn0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
+                    f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[j * 4 + q]) * rs;
+                    if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
+                    const int colb = (32 * jj + 8 * q + (lane >> 5) * 4) * ES;
+                    if constexpr (ES == 4) {
+                        *reinterpret_cast<f32x4*>(stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4)) = v;
+                    } else {
+                        // 8-byte pieces: the 32 rows of a half-wave share one column, so the XOR key works on 8-byte slots with 4 row
+                        // bits (rows r and r + 16 collide, which 256 bytes per half-wave cannot avoid); keyed on 16-byte chunks
+                        // with 3 row bits the write was a 4-way bank conflict (SQ_LDS_BANK_CONFLICT: 5 k cycles per tile)
+                        uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(stg + row * ROWB + ((((colb >> 3) ^ row) & 15) << 3)) = pk;
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                uint4 val;
+                if constexpr (ES == 4) {
+                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ r) & (CPR - 1)) << 4));
+                } else {   // slots 2c, 2c+1 of row r live in chunk c ^ (r >> 1), swapped when r is odd
+                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ (r >> 1)) & (CPR - 1)) << 4));
+                    if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                }
+                const int mo = cm0 + wr * 128 + 32 * i + r, no = cn0 + wc * 64 + jh * JP * 32 + chunk * (16 / ES);
+                if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
+                OutT* dst = C + (long)mo * g.ldc + no;
+                if constexpr (ES == 4) {
+                    f32x4 v = __builtin_bit_cast(f32x4, val);
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = val;
+                }
+            }
+        }
+    }
+    }   // !GLU
+}
+
 // GLU: 0 = plain GEMM; 1 = SiLU, 2 = GELU gated epilogue (TA = TB = false, bf16 out)
 template <bool TA, bool TB, typename OutT, int GLU = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
@@ -663,117 +787,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     // interior tiles issue exactly NS store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
     extra = GLU ? ((has_next && cm0 + PP_BM <= g.M) ? 24 : 0)
                 : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0);
-    if constexpr (GLU != 0) {
-        // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
-        // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
-        bf16_t* U = reinterpret_cast<bf16_t*>(g.C);
-        const int chunks = g.N >> 3;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = lane & 31;
-            const int m = cm0 + wr * 128 + 32 * i + row;
-            uint2 go[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 a = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]} + bv[q];
-                const f32x4 t = f32x4{acc[i][1][4 * q], acc[i][1][4 * q + 1], acc[i][1][4 * q + 2], acc[i][1][4 * q + 3]} + bv[4 + q];
-                uint2 pa, pt;
-                pa.x = pack_bf2(a[0], a[1]); pa.y = pack_bf2(a[2], a[3]);
-                pt.x = pack_bf2(t[0], t[1]); pt.y = pack_bf2(t[2], t[3]);
-                const int slot = 2 * q + (lane >> 5);   // 8-byte slot of the 64-byte value half; the gate half is slots 8..15
-                *reinterpret_cast<uint2*>(stg + row * 128 + (((slot ^ row) & 15) << 3)) = pa;
-                *reinterpret_cast<uint2*>(stg + row * 128 + ((((8 + slot) ^ row) & 15) << 3)) = pt;
-                const float ar[4] = {bf2f(pa.x & 0xffff), bf2f(pa.x >> 16), bf2f(pa.y & 0xffff), bf2f(pa.y >> 16)};
-                const float tr[4] = {bf2f(pt.x & 0xffff), bf2f(pt.x >> 16), bf2f(pt.y & 0xffff), bf2f(pt.y >> 16)};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
-                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd: chunk idx = t * (I/8) + col/8, pair e/2 of the chunk
-                    const int col = cn0 + wc * 32 + 8 * q + (lane >> 5) * 4;
-                    const long idx = (long)m * chunks + (col >> 3);
-                    const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
-                    const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
-                    o[0] = (h0 & 0xffffu) >= g.thr16 ? o[0] * g.keep_scale : 0.f;
-                    o[1] = (h0 >> 16) >= g.thr16 ? o[1] * g.keep_scale : 0.f;
-                    o[2] = (h1 & 0xffffu) >= g.thr16 ? o[2] * g.keep_scale : 0.f;
-                    o[3] = (h1 >> 16) >= g.thr16 ? o[3] * g.keep_scale : 0.f;
-                }
-                go[q].x = pack_bf2(o[0], o[1]); go[q].y = pack_bf2(o[2], o[3]);
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
-                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
-                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                const int mo = cm0 + wr * 128 + 32 * i + r;
-                const int no = (chunk >> 2) * g.N + cn0 + wc * 32 + (chunk & 3) * 8;
-                if (mo < g.M) *reinterpret_cast<uint4*>(U + (long)mo * g.ldc + no) = val;
-            }
-            // the gated output through the same slab: 64-byte rows, 8 slots
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint2*>(stg + row * 64 + ((((2 * q + (lane >> 5)) ^ row) & 7) << 3)) = go[q];
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int r = it * 16 + (lane >> 2), chunk = lane & 3;
-                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 64 + (((chunk ^ (r >> 1)) & 3) << 4));
-                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                const int mo = cm0 + wr * 128 + 32 * i + r;
-                if (mo < g.M) *reinterpret_cast<uint4*>(g.G + (long)mo * g.ldg + cn0 + wc * 32 + chunk * 8) = val;
-            }
-        }
-    } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = lane & 31;
-        const int m = cm0 + wr * 128 + 32 * i + row;
-        const float rs = g.rowmask ? (g.rowmask[min(m, g.M - 1)] ? 1.f : 0.f) : 1.f;
-#pragma unroll
-        for (int jh = 0; jh < 2 / JP; ++jh) {
-#pragma unroll
-            for (int jj = 0; jj < JP; ++jj) {
-                const int j = jh * JP + jj;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = cn0 + wc * 64 + 32 * j + 8 * q + (lane >> 5) * 4;
-                    f32x4 v = (f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * g.alpha + bv[j * 4 + q]) * rs;
-                    if (g.residual && lead && m < g.M && n < g.N) v += *reinterpret_cast<const f32x4*>(g.residual + (long)m * g.ldr + n);
-                    const int colb = (32 * jj + 8 * q + (lane >> 5) * 4) * ES;
-                    if constexpr (ES == 4) {
-                        *reinterpret_cast<f32x4*>(stg + row * ROWB + ((((colb >> 4) ^ row) & (CPR - 1)) << 4)) = v;
-                    } else {
-                        // 8-byte pieces: the 32 rows of a half-wave share one column, so the XOR key works on 8-byte slots with 4 row
-                        // bits (rows r and r + 16 collide, which 256 bytes per half-wave cannot avoid); keyed on 16-byte chunks
-                        // with 3 row bits the write was a 4-way bank conflict (SQ_LDS_BANK_CONFLICT: 5 k cycles per tile)
-                        uint2 pk; pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]);
-                        *reinterpret_cast<uint2*>(stg + row * ROWB + ((((colb >> 3) ^ row) & 15) << 3)) = pk;
-                    }
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
-                uint4 val;
-                if constexpr (ES == 4) {
-                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ r) & (CPR - 1)) << 4));
-                } else {   // slots 2c, 2c+1 of row r live in chunk c ^ (r >> 1), swapped when r is odd
-                    val = *reinterpret_cast<const uint4*>(stg + r * ROWB + (((chunk ^ (r >> 1)) & (CPR - 1)) << 4));
-                    if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                }
-                const int mo = cm0 + wr * 128 + 32 * i + r, no = cn0 + wc * 64 + jh * JP * 32 + chunk * (16 / ES);
-                if (mo >= g.M || no >= g.N) continue;   // edge tiles: N is a multiple of 8, so a 16-byte chunk is in or out as a whole
-                OutT* dst = C + (long)mo * g.ldc + no;
-                if constexpr (ES == 4) {
-                    f32x4 v = __builtin_bit_cast(f32x4, val);
-                    if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    *reinterpret_cast<uint4*>(dst) = val;
-                }
-            }
-        }
-    }
-    }   // !GLU
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg);
     }
 #ifdef SPN_GEMM_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -783,6 +797,135 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         g.dbg[17] = t_end - t_loop_end;     // epilogue until the stores are acknowledged
     }
 #endif
+}
+
+// ---- 256x128 "duo" kernel: TWO independent 4-wave workgroups per CU -----------------------------------------------------
+// The projections with d_model = 512 on the contraction side (K = 512: 8 K-tiles of 64) spend a third of a 256x256 tile's life in the
+// prologue (first DMA latency) and the epilogue (128-256 KiB of C per CU through a 64 B/clk store path) with the matrix pipe idle, and
+// one workgroup per CU has nothing to overlap them with.  Here a workgroup is 4 waves (one per SIMD) with a 256x128 tile, <= 80 KiB of
+// LDS and <= 256 registers, so TWO of them are resident per CU and run out of phase: while one drains its accumulators and refills
+// its pipeline, the other one owns the matrix pipe; inside the K loop the two waves of a SIMD interleave LDS reads and MFMAs the way
+// the ping-pong kernel's two groups do, without a barrier between them.
+//   * K tile 32, three stages of (A 256x32 = 16 KiB, B 128x32 = 8 KiB): stage t+2 is requested right after the barrier that opens
+//     iteration t (it overwrites stage t-1, which every wave has finished reading), so two stages = 48 KiB per workgroup are in flight
+//     while stage t is multiplied; ONE barrier per K tile (512 MFMA cycles per wave)
+//   * a wave owns 128x64 of C (acc[4][2] 32x32 blocks, v_mfma_f32_32x32x16_bf16, operands swapped as in the ping-pong kernel) and shares
+//     its epilogue (pp_store_tile): after the loop the ring is dead and each wave stages through its own 4 KiB of it
+//   * K-contiguous stage image [rows][32 k]: 64-byte rows, 16-byte chunk index XOR (row >> 2) & 3 (the 16 rows of a ds_read_b128 lane
+//     group then cover all 16 slots of the 256-byte bank row); N-contiguous B image [32 k][128 n] as the ping-pong kernel's
+// A must be K-contiguous (TA = false: forward projections and input gradients); M / N edges by clamped loads + guarded stores.
+constexpr int DU_BM = 256, DU_BN = 128, DU_BK = 32, DU_STAGES = 3;
+constexpr int DU_A_BYTES = DU_BM * DU_BK * 2, DU_B_BYTES = DU_BN * DU_BK * 2, DU_STAGE_BYTES = DU_A_BYTES + DU_B_BYTES;
+constexpr int DU_LDS_BYTES = DU_STAGES * DU_STAGE_BYTES;   // 72 KiB
+
+__device__ __forceinline__ int du_kc_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <bool TB, typename OutT, int GLU = 0>
+__global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // tile order as in the ping-pong kernel: XCD-contiguous, column groups of `ngroup` n-tiles, m-tiles down each group
+    int m0, n0;
+    {
+        const int nwg = g.tx * g.ty, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        const int G = g.ngroup, per = G * g.ty;
+        const int c = wg / per, within = wg - c * per;
+        const int gw = min(G, g.tx - c * G);
+        m0 = (within / gw) * DU_BM;
+        n0 = (c * G + within % gw) * (GLU ? DU_BN / 2 : DU_BN);
+    }
+    const int nt = g.K / DU_BK;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+    // per-lane source offsets of this wave's DMA pieces (loop invariant): LDS chunk L of a stage image <- inverse-swizzled source chunk
+    uint32_t voA[4], voB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = (wave * 4 + i) * 64 + lane, row = L >> 2, kc = (L & 3) ^ ((row >> 2) & 3);
+        voA[i] = (uint32_t)(((long)min(m0 + row, g.M - 1) * g.lda + kc * 8) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wave * 2 + i) * 64 + lane;
+        if (!TB) {
+            const int row = L >> 2, kc = (L & 3) ^ ((row >> 2) & 3);
+            // gated: image rows 0..63 are the VALUE rows n0.. of W, rows 64..127 the GATE rows I + n0..
+            const int src = GLU ? (row < 64 ? n0 + row : g.N + n0 + row - 64) : min(n0 + row, g.N - 1);
+            voB[i] = (uint32_t)(((long)src * g.ldb + kc * 8) * 2);
+        } else {
+            const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
+            voB[i] = (uint32_t)(((long)krow * g.ldb + min(n0 + rc * 8, g.N - 8)) * 2);
+        }
+    }
+    auto issue = [&](int t) {
+        char* dst = smem + (t % DU_STAGES) * DU_STAGE_BYTES;
+        const uint32_t k0 = (uint32_t)t * DU_BK;
+        const uint32_t soA = k0 * 2u, soB = TB ? k0 * (uint32_t)g.ldb * 2u : k0 * 2u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dst + (wave * 4 + i) * 1024), 16, voA[i], soA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst + DU_A_BYTES + (wave * 2 + i) * 1024), 16, voB[i], soB, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0);
+    if (nt > 1) issue(1);
+    for (int t = 0; t < nt; ++t) {
+        // this wave's pieces of stage t have landed (stage t+1, 6 instructions, may stay in flight) ...
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... the barrier publishes everybody's pieces, and proves that every wave is done reading stage t-1 (its fragment reads were
+        // waited for before its MFMAs of iteration t-1)
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2);
+        const char* sa = smem + (t % DU_STAGES) * DU_STAGE_BYTES;
+        const char* sb = sa + DU_A_BYTES;
+        bf16x8 af[4][2], bf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int rb = GLU ? 64 * j + 32 * wc : 64 * wc + 32 * j;
+                if (!TB) bf[j][ks] = *reinterpret_cast<const bf16x8*>(sb + du_kc_off(rb + (lane & 31), ks * 2 + (lane >> 5)));
+                else bf[j][ks] = pp_read_frag<true>(sb, rb, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i][ks] = *reinterpret_cast<const bf16x8*>(sa + du_kc_off(wr * 128 + 32 * i + (lane & 31), ks * 2 + (lane >> 5)));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    OutT* C = reinterpret_cast<OutT*>(g.C);
+    f32x4 bv[8];
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {
+        const int bn = GLU ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
+                           : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
+        bv[jq] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();   // every wave is done with the operand ring: its first 16 KiB become the four staging slabs
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096);
 }
 
 // ---- split-K plumbing -------------------------------------------------------------------------------------
@@ -903,11 +1046,51 @@ int launch_bk(GemmArgs g, hipStream_t stream) {
     return SPN_OK;
 }
 
+// shapes the duo kernel takes: A K-contiguous, K in whole 32-tiles, enough tiles to give every CU its two workgroups
+static bool duo_eligible(const GemmArgs& g, bool ta) {
+    return !ta && g.batch == 1 && g.M >= 128 && g.N >= 64 && g.M % 8 == 0 && g.N % 8 == 0 && g.K % DU_BK == 0 && g.K >= 2 * DU_BK &&
+           g.ldc % 8 == 0 && g.pp_addr_ok && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+           (!g.residual || (g.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(g.residual) & 15) == 0)) &&
+           (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0) &&
+           (long)cdiv(g.N, DU_BN) * cdiv(g.M, DU_BM) >= 512;
+}
+
+// measured on MI355X (tools/bench_gemm.py, profiles/r02_gemm_shapes.txt): where the duo kernel beats the ping-pong kernel
+// (r02_gemm_ab.txt).  Two workgroups per CU overlap one tile's epilogue with the other's main loop, but a 256x128 tile moves 1.5x the
+// operand bytes per flop through the CU's 64 B/clk vector-memory path and issues 1.5x the LDS-DMA instructions per wave, so on every
+// wide projection the 256x256 ping-pong kernel stays ahead (K = 512, N = 4096: 855 vs 764 TF/s); duo wins only where a 256-wide
+// tile would be mostly padding (N <= 128: the 64-column condition gradients, 51 vs 73 us).
+static bool duo_preferred(const GemmArgs& g, bool tb, bool f32) {
+    (void)tb; (void)f32;
+    return g.N <= 128;
+}
+
+template <bool TB, typename OutT, int GLU>
+int launch_duo(GemmArgs g, hipStream_t stream) {
+    static std::atomic<unsigned> optin{0};
+    spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo_kernel<TB, OutT, GLU>), DU_LDS_BYTES);
+    g.tx = GLU ? g.N / (DU_BN / 2) : cdiv(g.N, DU_BN);
+    g.ty = cdiv(g.M, DU_BM);
+    g.splitk = 1; g.kt_per_split = g.K / DU_BK; g.slice_xcd = 0;
+    const int ng = spn_tune_i(SPN_TUNE_GEMM_DUO_NGROUP);
+    g.ngroup = ng > 0 ? ng : 8;
+    if (g.ngroup > g.tx) g.ngroup = g.tx;
+    hipLaunchKernelGGL((gemm_duo_kernel<TB, OutT, GLU>), dim3(g.tx * g.ty), dim3(256), DU_LDS_BYTES, stream, g);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 template <bool TA, bool TB, typename OutT>
 int launch(const GemmArgs& g, hipStream_t stream) {
     // short contractions (K <= 1024: every projection with d_model = 512 on the input side) are latency-bound per block:
     // BK = 32 halves the LDS footprint (32 KiB) so that 4 blocks stay resident per CU and hide each other's pipeline fill
     const int variant = spn_tune_i(SPN_TUNE_GEMM_VARIANT);   // tuning aid
+    if constexpr (!TA) {
+        // two 4-wave workgroups per CU: measured per shape (tools/bench_gemm.py), knob 2 forces it wherever it is eligible
+        const int duo = spn_tune_i(SPN_TUNE_GEMM_DUO);
+        if (variant == 0 && duo && duo_eligible(g, false) && (duo >= 2 || duo_preferred(g, TB, sizeof(OutT) == 4)))
+            return launch_duo<TB, OutT, 0>(g, stream);
+    }
     if (variant == 1) return launch_bk<TA, TB, OutT, 64, 2>(g, stream);
     if (variant == 2) return launch_bk<TA, TB, OutT, 64, 3>(g, stream);
     if (variant == 3) return launch_bk<TA, TB, OutT, 32, 4>(g, stream);
@@ -1038,6 +1221,9 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
 #ifdef SPN_GEMM_TIMING
     g.dbg = g_dbg;
 #endif
+    if (spn_tune_i(SPN_TUNE_GEMM_DUO) && I % (DU_BN / 2) == 0 && (long)(I / (DU_BN / 2)) * cdiv(M, DU_BM) >= 512 && K % DU_BK == 0 &&
+        spn_tune_i(SPN_TUNE_GEMM_DUO) >= 2)
+        return act == 0 ? launch_duo<false, bf16_t, 1>(g, stream) : launch_duo<false, bf16_t, 2>(g, stream);
     return act == 0 ? launch_pp_glu<1>(g, stream) : launch_pp_glu<2>(g, stream);
 }
 

@@ -16,7 +16,8 @@ enum SpnTune {
     SPN_TUNE_EMBED_SCATTER_MFMA,   // 1 = one-hot MFMA scatter, 0 = LDS-atomic scatter; 1
     SPN_TUNE_EMBED_SCATTER_BLOCKS, // 256
     SPN_TUNE_LN_BWD_BLOCKS,        // 2048
-    SPN_TUNE_GEMM_DUO,             // 1 = two 4-wave workgroups per CU (256x128 tiles) for the short-K projections; see gemm.hip
+    SPN_TUNE_GEMM_DUO,             // 0 off; 1 = two 4-wave workgroups per CU (256x128 tiles) where measured faster; 2 = wherever eligible; 1
+    SPN_TUNE_GEMM_DUO_NGROUP,      // n-tiles per column group of the duo kernel's tile order; 8
     SPN_TUNE_COUNT
 };
 
