@@ -315,7 +315,34 @@ def lm_head(sd: SD, prefix: str, x: Tensor, te_cfg, keys: List[str], head_cfg,
         e = layer_norm(x @ sd[prefix + "project_emb.weight"], sd[prefix + "norm.weight"], sd[prefix + "norm.bias"])
         parts = e.split(split, dim=-1)
         return {k: parts[i] @ tables[i].t() for i, k in enumerate(keys) if want(i, k)}
+    if target == "lm-tied-split":   # per key: LayerNorm(Linear(x)) against that key's table (embeddings.py:364-390)
+        out = {}
+        for i, k in enumerate(keys):
+            if want(i, k) and f"{prefix}to_embs.{k}.0.weight" in sd:
+                e = x @ sd[f"{prefix}to_embs.{k}.0.weight"].t() + sd[f"{prefix}to_embs.{k}.0.bias"]
+                e = layer_norm(e, sd[f"{prefix}to_embs.{k}.1.weight"], sd[f"{prefix}to_embs.{k}.1.bias"])
+                out[k] = e @ table_weight(sd, f"{prefix}embs.{k}.", te_cfg).t()
+        return out
     raise NotImplementedError(target)
+
+
+def regression_values(sd: SD, prefix: str, x: Tensor) -> Dict[str, Tensor]:
+    """`TupleTokenRegressionHead.forward` (models/scoreperformer/embeddings.py:400-420): one Linear(dim, 1) per regression key."""
+    keys = sorted({k[len(prefix) + len("layers."):].split(".")[0] for k in sd if k.startswith(prefix + "layers.")},
+                  key=lambda k: [q for q in sd if q.startswith(prefix + "layers.")].index(f"{prefix}layers.{k}.weight"))
+    return {k: x @ sd[f"{prefix}layers.{k}.weight"].t() + sd[f"{prefix}layers.{k}.bias"] for k in keys}
+
+
+def regression_losses(sd: SD, emb_prefix: str, logits: Dict[str, Tensor], reg_values: Dict[str, Tensor], labels: Tensor):
+    """L1 between the regression value and the label's token value over non-special labels (wrappers.py:61-78)."""
+    out = {}
+    for i, key in enumerate(logits.keys()):
+        if key not in reg_values:
+            continue
+        sel = labels[..., i] > 3
+        targets = F.embedding(labels[..., i][sel], sd[f"{emb_prefix}embs.{key}.token_values"])
+        out[f"{key}/l1"] = F.l1_loss(reg_values[key][sel], targets)
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -491,10 +518,35 @@ def score_performer_forward(
     out, logits = tuple_transformer(sd, dec_prefix, dcfg, seqs, causal=True, mask=pmask[:, :-1], context=ctx,
                                     context_mask=batch.get("score_mask"), style=style, with_logits=True)
     ce, losses = lm_losses(logits, labels)
+    if any(k.startswith(dec_prefix + "regression_head.") for k in sd):
+        reg = regression_losses(sd, dec_prefix + "token_emb.", logits, regression_values(sd, dec_prefix + "regression_head.", out), labels)
+        ce = ce + sum(reg.values()) / len(reg)
+        losses = dict(losses, **reg)
     loss = ce + enc["loss"]
     losses = dict(losses, **enc["losses"])
     return dict(loss=loss, losses=losses, logits=logits, hidden_state=out, perf_embeddings=enc["embeddings"],
                 score_embeddings=score_emb, latents=enc["latents"])
+
+
+# --------------------------------------------------------------------------------------
+# decoder-only `Performer` (models/scoreperformer/model.py:62-122) under the three LM wrappers (wrappers.py:87-99,290-307,409-431)
+# --------------------------------------------------------------------------------------
+
+def performer_forward(sd: SD, cfg, inputs: Dict[str, Tensor]):
+    """cfg = {transformer: <TupleTransformer config>, mode}; inputs = perf, mask, labels[, masked_perf] as `Performer.forward` takes."""
+    mode, tcfg = cfg["mode"], cfg["transformer"]
+    prefix = "transformer.model." if any(k.startswith("transformer.model.") for k in sd) else "transformer."
+    perf, mask, labels = inputs["perf"], inputs["mask"], inputs["labels"]
+    if mode == "mlm":        # no shift: every position predicts its own masked dims
+        seqs, causal = [perf], False
+    else:                    # next-note prediction: inputs lose the last position, targets the first
+        labels, mask = labels[:, 1:], mask[:, :-1]
+        seqs = [perf[:, :-1]] + ([inputs["masked_perf"][:, 1:]] if mode == "mixlm" else [])
+        causal = True
+    causal = _get(tcfg["transformer"], "_target_", "default") == "decoder"
+    out, logits = tuple_transformer(sd, prefix, tcfg, seqs, causal=causal, mask=mask, with_logits=True)
+    loss, losses = lm_losses(logits, labels)
+    return dict(loss=loss, losses=losses, logits=logits, hidden_state=out)
 
 
 # --------------------------------------------------------------------------------------

@@ -14,6 +14,10 @@ _TIED = [
     (re.compile(r"^(perf_decoder\.model|perf_decoder)\.lm_head\.embs\."), "EMBS."),
     (re.compile(r"^(perf_decoder\.model|perf_decoder)\.lm_head\.project_emb\."), "DEC.token_emb.project_emb."),
     (re.compile(r"^(perf_decoder\.model|perf_decoder)\."), "DEC."),
+    # decoder-only `Performer` (model.py:62-122): its single TupleTransformer lives under `transformer.` (wrapped: `transformer.model.`)
+    (re.compile(r"^(transformer\.model|transformer)\.(token_emb|lm_head)\.embs\."), "PERFORMER.EMBS."),
+    (re.compile(r"^(transformer\.model|transformer)\.lm_head\.project_emb\."), "PERFORMER.token_emb.project_emb."),
+    (re.compile(r"^(transformer\.model|transformer)\."), "PERFORMER."),
 ]
 
 

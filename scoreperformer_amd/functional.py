@@ -75,6 +75,10 @@ def _bf16_grad(dy: torch.Tensor, n: int, rowmask: Optional[torch.Tensor] = None)
     masked IN PLACE (only the padded rows are written; the fp32 `dy`, which continues down the residual path, is untouched) and
     remembers the mask, so that a consumer with another mask (or none) falls back to the cast."""
     shadow = getattr(dy, "_spn_bf16", None)
+    # autograd may accumulate a second gradient into `dy` IN PLACE (InputBuffer does when the first arrival is uniquely owned): the
+    # attribute would survive on the object while the copy goes stale, so the copy is trusted only at the version it was made for
+    if shadow is not None and getattr(dy, "_spn_bf16_ver", None) != dy._version:
+        shadow = None
     if shadow is not None and shadow.numel() == dy.numel() and n % 8 == 0:
         applied = getattr(dy, "_spn_bf16_mask", None)
         if rowmask is None and applied is None:
@@ -92,6 +96,7 @@ def _with_shadow(dx: torch.Tensor, shape) -> torch.Tensor:
     shadow = getattr(dx, "_spn_bf16", None)
     if shadow is not None:
         out._spn_bf16 = shadow
+        out._spn_bf16_ver = getattr(dx, "_spn_bf16_ver", None)   # a view shares its base's version counter
         mask = getattr(dx, "_spn_bf16_mask", None)
         if mask is not None:
             out._spn_bf16_mask = mask
@@ -182,7 +187,7 @@ class LinearFn(Function):
             bias = ctx.bias_ref
             main = _main_grad(bias)
             if main is not None:
-                if not getattr(dy, "_spn_bias_done", False):   # else: the activation backward that produced dy summed it already
+                if getattr(dy, "_spn_bias_done", None) != dy._version:   # else: the activation backward that produced dy summed it already
                     ops.colsum(dyb, out=main)
                 hook = getattr(bias, "_spn_grad_ready", None)
                 if hook is not None:
@@ -461,7 +466,7 @@ class ActFn(Function):
         du = ops.act_bwd(u, to_bf16(dout), act=act, glu=glu, p_drop=p_drop, seed=seed, colsum=main)
         du = du.view(u.shape)
         if main is not None:
-            du._spn_bias_done = True
+            du._spn_bias_done = du._version   # valid for this content only (see _bf16_grad)
         return du, None, None, None, None, None
 
 
@@ -611,6 +616,23 @@ class LinearF32Fn(Function):
 
 def linear_f32(x, weight, bias=None, rowmask=None):
     return LinearF32Fn.apply(x, weight, bias, rowmask)
+
+
+class MishFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.mish_fwd(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.mish_bwd(x, dy.to(F32))
+
+
+def mish(x):
+    return MishFn.apply(x)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -345,12 +345,10 @@ class TupleTokenTiedLMHead(_HeadBase, Constructor):
 
     def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
                 label_counts=None):
-        # `x @ project_emb.weight` uses the [dim, total] weight UNtransposed (embeddings.py:346)
-        if self.reuse_projection:
-            e = F_.linear(x, self.project_emb.weight, kn_layout=True)
-        else:
-            e = F_.linear(x, self.project_emb.weight)
-        e = self.norm(e)
+        # `x @ project_emb.weight` uses the weight UNtransposed (embeddings.py:346) -- the embeddings' [dim, total] projection when
+        # it is reused, and equally the head's own Linear(dim, total) weight [total, dim] otherwise: like the reference, that second
+        # form only multiplies when dim == total, and a checkpoint of it gives the same logits here
+        e = self.norm(F_.linear(x, self.project_emb.weight, kn_layout=True))
         tables = build_tables(list(self.embs.values()))
         parts = F_.split_cols(e, self.split_dims) if e.requires_grad else torch.split(e, self.split_dims, dim=-1)
         items = [(i, key, parts[i], tables[i], None) for i, key in enumerate(self.embs.keys()) if _wanted(i, key, keys)]
@@ -403,3 +401,46 @@ class TupleTokenRegressionHead(nn.Module, Constructor):
     def forward(self, x: Tensor, keys=None):
         return {key: F_.linear_f32(F_.cast(x, torch.float32), layer.weight, layer.bias)
                 for i, (key, layer) in enumerate(self.layers.items()) if _wanted(i, key, keys)}
+
+
+@dataclass
+class TupleTokenEmbeddingHeadConfig(TupleTokenHeadsConfig):
+    _target_: str = "embedding"
+    emb_dim: int = MISSING
+    hidden_dim: Optional[int] = None
+    depth: int = 2
+    detach_inputs: Union[bool, float] = True
+
+
+@TupleTokenHeadsRegistry.register("embedding")
+class TupleTokenEmbeddingHead(nn.Module, Constructor):
+    """Hidden state -> an embedding vector through a Mish MLP (`models/scoreperformer/embeddings.py:424-462`); `detach_inputs` blends
+    the detached and the attached input (1 / True: no gradient reaches the transformer).  state_dict keys `layers.<2i>.{weight,bias}`
+    as in the reference's nn.Sequential of Linear / Mish pairs.  Small fp32 contractions: exact-fp32 GEMM + the Mish kernel."""
+
+    def __init__(self, dim: int, emb_dim: int, hidden_dim: Optional[int] = None, depth: int = 2,
+                 detach_inputs: Union[bool, float] = True):
+        super().__init__()
+        hidden_dim = hidden_dim or emb_dim
+        widths = [dim] + [hidden_dim] * (depth - 1) + [emb_dim]
+        stack = []
+        for level in range(depth):
+            stack.append(nn.Linear(widths[level], widths[level + 1]))
+            if level + 1 < depth:
+                stack.append(nn.Mish())
+        self.layers = nn.Sequential(*stack)
+        self.detach_inputs = detach_inputs
+
+    def forward(self, x: Tensor):
+        keep = float(self.detach_inputs)
+        x = F_.cast(x, torch.float32)
+        if keep >= 1.0:
+            h = x.detach()
+        elif keep <= 0.0:
+            h = x
+        else:
+            h = keep * x.detach() + (1.0 - keep) * x
+        for layer in self.layers:
+            h = F_.linear_f32(h, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else F_.mish(h)
+        return h
+

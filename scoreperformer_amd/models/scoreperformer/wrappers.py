@@ -99,13 +99,90 @@ class ScorePerformerLMWrapper(LMWrapper):
             per_key = sums[:, 0] / sums[:, 1].clamp_min(1.0)
             loss = (per_key * has).sum() / has.sum().clamp_min(1.0)
             losses = {k: per_key[i] for i, k in enumerate(keys)}
+            if exists(out.reg_values) and self.model.token_emb.continuous:
+                reg = self._regression_losses(out, labels)
+                if reg:
+                    loss = loss + sum(reg.values()) / len(reg)
+                    losses.update(reg)
             res.loss, res.losses = loss, losses
             res._ce_keys, res._ce_state = keys, getattr(self.model.lm_head, "ce_state", None)
-            if exists(out.reg_values) and self.model.token_emb.continuous:
-                raise NotImplementedError("regression head loss (disabled in every shipped recipe) is not implemented")
             if not _defer_sync:
                 finalize_lm_losses(res)
         return res
+
+    def _regression_losses(self, out, labels: Tensor) -> Dict[str, Tensor]:
+        """L1 distance between the regression head's scalar and the label's normalised token value, over non-special labels
+        (`wrappers.py:61-78`; the head is disabled in every shipped recipe, so this is device-side glue, not a kernel).  The reference
+        gathers the selected rows with a boolean mask (a host sync); the masked mean below is the same number without one."""
+        reg = {}
+        for i, key in enumerate(out.logits.keys()):      # the reference indexes the label column by the position in `logits`
+            values = out.reg_values.get(key)
+            if values is None:
+                continue
+            column = labels[..., i]
+            chosen = column > 3                           # special ids carry no value
+            targets = F.embedding(column.clamp_min(0), self.model.token_emb.embs[key].token_values)
+            err = (values.float() - targets).abs().squeeze(-1) * chosen
+            reg[f"{key}/l1"] = err.sum() / chosen.sum()
+        return reg
+
+
+class _decode_call:
+    """Shared frame of the decode entry points (`unmask_tokens`, `generate`): run the wrapped transformer in eval mode and hand the
+    caller back whatever mode it was in; token arrays given without a batch axis get one for the duration of the call."""
+
+    def __init__(self, wrapper: LMWrapper, *token_arrays: Tensor, mask: Optional[Tensor] = None):
+        self.net = wrapper.model
+        self.resume_training = self.net.training
+        self.unbatched = token_arrays[0].ndim == 2
+        self.arrays = [t.unsqueeze(0) if self.unbatched else t for t in token_arrays]
+        self.mask = mask
+
+    def __enter__(self):
+        if self.resume_training:
+            self.net.eval()
+        if self.mask is None:   # every position is a real note
+            first = self.arrays[0]
+            self.mask = torch.ones(first.shape[:2], dtype=torch.bool, device=first.device)
+        return self
+
+    def __exit__(self, *exc):
+        if self.resume_training:
+            self.net.train()
+        return False
+
+    def result(self, tokens: Tensor) -> Tensor:
+        return tokens[0] if self.unbatched else tokens
+
+
+def _forbid(logits: Tensor, ids) -> Tensor:
+    """A copy of `logits` [rows, V] in which the given ids (slice, list or int) can never be drawn."""
+    logits = logits.clone()
+    if ids is not None:
+        logits[:, ids] = -float("Inf")
+    return logits
+
+
+def _sample(logits_i, filter_logits_fn, filter_kwargs, temperature):
+    if is_greedy(filter_logits_fn, filter_kwargs):  # top-1 filter + multinomial over a one-hot == argmax
+        return logits_i.argmax(dim=-1, keepdim=True)
+    return filter_logits_and_sample(logits_i, filter_logits_fn, filter_kwargs=filter_kwargs, temperature=temperature)
+
+
+def _teacher_forcing_views(net: TupleTransformer, seq: Tensor, labels: Optional[Tensor], kwargs: dict):
+    """Next-note prediction: position t of the input predicts note t + 1, so inputs lose their last position and everything that
+    describes the TARGET note -- labels, per-note style embeddings, a channel-concatenated score context -- loses its first
+    (`wrappers.py:290-307,409-431`).  A context that is cross-attended is a whole sequence and stays as it is.  Edits `kwargs`."""
+    inputs = seq[:, :-1]
+    targets = labels[:, 1:] if exists(labels) else None
+    for name in ("context", "style_embeddings"):
+        cond = kwargs.get(name)
+        if exists(cond) and (name != "context" or net.context_emb_mode == "cat"):
+            kwargs[name] = cond[:, 1:]
+    mask = kwargs.get("mask")
+    if exists(mask) and mask.shape[1] == inputs.shape[1] + 1:
+        kwargs["mask"] = mask[:, :-1]
+    return inputs, targets
 
 
 class ScorePerformerMLMWrapper(ScorePerformerLMWrapper):
@@ -118,52 +195,28 @@ class ScorePerformerMLMWrapper(ScorePerformerLMWrapper):
     def unmask_tokens(self, tokens: Tensor, single_run: bool = True, temperature: float = 1., filter_logits_fn: Callable = top_k,
                       filter_kwargs: Optional[Dict[str, object]] = None, filter_key_ids: Optional[Dict[str, list]] = None,
                       disable_tqdm: bool = False, **kwargs):
+        """Fill every MASK sub-token (`wrappers.py:100-182`): in one pass by arg-max, or note by note with the chosen sampler."""
         assert callable(filter_logits_fn)
-        was_training = self.model.training
-        if was_training:
-            self.model.eval()
-        num_dims = len(tokens.shape)
-        if num_dims == 2:
-            tokens = tokens[None, :]
-        out = tokens.clone().detach()
-        mask = kwargs.pop('mask', None)
-        if mask is None:
-            mask = torch.full_like(out[..., 0], True, dtype=torch.bool, device=out.device)
-        filter_key_ids = filter_key_ids or dict()
-        unmask_mask = out == self.mask_token_id
-        with shared_tables():
+        banned = filter_key_ids or {}
+        with _decode_call(self, tokens, mask=kwargs.pop("mask", None)) as call, shared_tables():
+            filled = call.arrays[0].clone().detach()
+            holes = filled == self.mask_token_id
             if single_run:
                 warnings.warn("`single_run` unmasking with sampling is not yet implemented, using argmax.")
-                outputs = self.model(out, mask=mask, **kwargs)
-                samples = torch.cat([l.argmax(dim=-1, keepdim=True) for l in outputs.logits.values()], dim=-1)
-                out[unmask_mask] = samples[unmask_mask]
+                logits = self.model(filled, mask=call.mask, **kwargs).logits
+                best = torch.stack([l.argmax(dim=-1) for l in logits.values()], dim=-1)
+                filled[holes] = best[holes]
             else:
-                unmask_ids = torch.where(torch.any(unmask_mask, dim=2))[1]
-                for idx in unmask_ids.tolist():
-                    type_mask = unmask_mask[:, idx][0]
-                    logits_keys = torch.where(type_mask)[0].tolist()
-                    outputs = self(out[:, :idx + 1], mask=mask[:, :idx + 1], return_embeddings=True, **kwargs)
-                    logits = self.model.lm_head(outputs.hidden_state[:, idx - 1], keys=logits_keys)
-                    samples = []
-                    for key, logits_i in logits.items():
-                        logits_i = logits_i.clone()
-                        logits_i[:, :self.num_special_tokens] = -float("Inf")
-                        ids = filter_key_ids.get(key, None)
-                        if ids is not None:
-                            logits_i[:, ids] = -float("Inf")
-                        samples.append(_sample(logits_i, filter_logits_fn, filter_kwargs, temperature))
-                    out[:, idx, type_mask] = torch.cat(samples, dim=-1)
-        if num_dims == 2:
-            out = out.squeeze(0)
-        if was_training:
-            self.model.train(was_training)
-        return out
-
-
-def _sample(logits_i, filter_logits_fn, filter_kwargs, temperature):
-    if is_greedy(filter_logits_fn, filter_kwargs):  # top-1 filter + multinomial over a one-hot == argmax
-        return logits_i.argmax(dim=-1, keepdim=True)
-    return filter_logits_and_sample(logits_i, filter_logits_fn, filter_kwargs=filter_kwargs, temperature=temperature)
+                for idx in torch.where(holes.any(dim=2))[1].tolist():
+                    dims = holes[0, idx]
+                    hidden = self(filled[:, :idx + 1], mask=call.mask[:, :idx + 1], return_embeddings=True, **kwargs).hidden_state
+                    logits = self.model.lm_head(hidden[:, idx - 1], keys=torch.where(dims)[0].tolist())
+                    draws = []
+                    for key, logits_k in logits.items():
+                        logits_k = _forbid(_forbid(logits_k, slice(0, self.num_special_tokens)), banned.get(key))
+                        draws.append(_sample(logits_k, filter_logits_fn, filter_kwargs, temperature))
+                    filled[:, idx, dims] = torch.cat(draws, dim=-1)
+            return call.result(filled)
 
 
 class ScorePerformerARWrapper(ScorePerformerLMWrapper):
@@ -172,80 +225,58 @@ class ScorePerformerARWrapper(ScorePerformerLMWrapper):
         super().__init__(model=model, ignore_index=ignore_index)
         self.pad_token_id, self.eos_token_id, self.num_special_tokens = pad_token_id, eos_token_id, num_special_tokens
 
+    def _musical_constraint(self, key: str, logits_k: Tensor, previous: Tensor, drawn: Dict[str, Tensor], tokenizer):
+        """The reference's three repairs of a sampled note (`wrappers.py:246-259`): bars never run backwards; the tempo is frozen
+        inside a bar; the time signature is copied from the previous note.  Returns (forced token or None, logits to sample from)."""
+        column = tokenizer.vocab_types_idx
+        if key == "Bar":
+            earliest = previous[:, column["Bar"]]
+            return None, _forbid(logits_k, slice(4, earliest))
+        bar_unchanged = drawn.get("Bar", -1) == previous[:, column["Bar"]]
+        if key == "TimeSig" or (key == "Tempo" and bar_unchanged):
+            return previous[:, column[key]][None], logits_k
+        return None, logits_k
+
     @torch.inference_mode()
     def generate(self, start_tokens: Tensor, seq_len: int, max_bar: Optional[int] = None, temperature: float = 1.,
                  filter_logits_fn: Callable = top_k, filter_kwargs: Optional[Dict[str, object]] = None,
                  caches: Optional[TupleTransformerCaches] = None, return_caches: bool = False, tokenizer=None,
                  fix_errors: bool = True, disable_tqdm: bool = False, **kwargs):
+        """Autoregressive continuation with key/value caches (`wrappers.py:200-288`)."""
         assert callable(filter_logits_fn)
-        was_training = self.model.training
-        if was_training:
-            self.model.eval()
-        num_dims = len(start_tokens.shape)
-        if num_dims == 2:
-            start_tokens = start_tokens[None, :]
-        b, t = start_tokens.shape[:2]
-        out = start_tokens
-        mask = kwargs.pop('mask', None)
-        if mask is None:
-            mask = torch.full_like(out[..., 0], True, dtype=torch.bool, device=out.device)
-        with shared_tables():
-            for _ in range(t, seq_len + 1):
-                x = out[:, -self.max_seq_len:]
-                mask = mask[:, -self.max_seq_len:]
-                # NOTE: like the reference, `self(...)` applies the CLM shift (forward drops the last position)
-                outputs = self(x, mask=mask, caches=caches, return_embeddings=True, return_caches=True, **kwargs)
-                logits = self.model.lm_head(outputs.hidden_state[:, -1])
-                caches = outputs.caches
-                samples = {}
-                for key, logits_i in logits.items():
-                    logits_i = logits_i.clone()
-                    do_sample = True
-                    if fix_errors and exists(tokenizer):
-                        if key == 'Bar':
-                            last_bar = out[:, -1, tokenizer.vocab_types_idx['Bar']]
-                            logits_i[:, 4:last_bar] = -float("Inf")
-                        same_bar = samples.get('Bar', -1) == out[:, -1, tokenizer.vocab_types_idx['Bar']]
-                        if (key == 'Tempo' and same_bar) or key == 'TimeSig':
-                            sample = out[:, -1, tokenizer.vocab_types_idx[key]][None]
-                            do_sample = False
-                    if do_sample:
-                        logits_i[:, :2] = -float("Inf")
-                        sample = _sample(logits_i, filter_logits_fn, filter_kwargs, temperature)
-                    samples[key] = sample
-                samples = torch.cat(list(samples.values()), dim=-1)[None]
-                out = torch.cat((out, samples), dim=1)
+        repair = fix_errors and exists(tokenizer)
+        with _decode_call(self, start_tokens, mask=kwargs.pop("mask", None)) as call, shared_tables():
+            notes, mask = call.arrays[0], call.mask
+            prompt_len = notes.shape[1]
+            for _ in range(prompt_len, seq_len + 1):
+                window, mask = notes[:, -self.max_seq_len:], mask[:, -self.max_seq_len:]
+                # like the reference, `self(...)` applies the CLM shift: forward drops the last position
+                step = self(window, mask=mask, caches=caches, return_embeddings=True, return_caches=True, **kwargs)
+                caches = step.caches
+                drawn: Dict[str, Tensor] = {}
+                for key, logits_k in self.model.lm_head(step.hidden_state[:, -1]).items():
+                    forced = None
+                    if repair:
+                        forced, logits_k = self._musical_constraint(key, logits_k, notes[:, -1], drawn, tokenizer)
+                    if forced is None:
+                        forced = _sample(_forbid(logits_k, slice(0, 2)), filter_logits_fn, filter_kwargs, temperature)
+                    drawn[key] = forced
+                notes = torch.cat((notes, torch.cat(list(drawn.values()), dim=-1)[None]), dim=1)
                 mask = F.pad(mask, (0, 1), value=True)
+                newest_first_dim = notes[..., -1, 0]
                 if exists(self.eos_token_id):
-                    if (out[..., -1, 0] == self.eos_token_id).any(dim=-1):
-                        out[:, -1, 1:] = self.pad_token_id
+                    if (newest_first_dim == self.eos_token_id).any(dim=-1):
+                        notes[:, -1, 1:] = self.pad_token_id      # an end-of-sequence note carries nothing else
                         break
-                elif exists(max_bar):
-                    if (out[..., -1, 0] > max_bar).any(dim=-1):
-                        out = out[:, :-1, :]
-                        break
-        out = out[:, t:]
-        if num_dims == 2:
-            out = out.squeeze(0)
-        if was_training:
-            self.model.train(was_training)
-        if return_caches:
-            return out, caches
-        return out
+                elif exists(max_bar) and (newest_first_dim > max_bar).any(dim=-1):
+                    notes = notes[:, :-1, :]                      # the note that opened a bar beyond the limit is dropped
+                    break
+            continuation = call.result(notes[:, prompt_len:])
+        return (continuation, caches) if return_caches else continuation
 
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, **kwargs):
-        seq = seq[:, :-1]
-        labels = labels[:, 1:] if exists(labels) else None
-        context = kwargs.get("context", None)
-        if exists(context) and self.model.context_emb_mode == "cat":
-            kwargs["context"] = context[:, 1:]
-        style_embeddings = kwargs.get("style_embeddings", None)
-        if exists(style_embeddings):
-            kwargs["style_embeddings"] = style_embeddings[:, 1:]
-        mask = kwargs.get('mask', None)
-        if exists(mask) and mask.shape[1] == seq.shape[1] + 1:
-            kwargs['mask'] = mask[:, :-1]
-        return super().forward(seq, labels=labels, **kwargs)
+        inputs, targets = _teacher_forcing_views(self.model, seq, labels, kwargs)
+        return super().forward(inputs, labels=targets, **kwargs)
 
 
 class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
@@ -254,84 +285,53 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         super().__init__(model=model, ignore_index=ignore_index)
         self.pad_token_id, self.mask_token_id, self.num_special_tokens = pad_token_id, mask_token_id, num_special_tokens
 
+    def _engine_for(self, filled: Tensor, mask: Tensor, caches, banned, filter_logits_fn, filter_kwargs):
+        """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, one sequence, fresh caches, no padding."""
+        usable = (filled.is_cuda and filled.shape[0] == 1 and caches is None and not banned
+                  and is_greedy(filter_logits_fn, filter_kwargs) and getattr(self, "use_decode_engine", True) and bool(mask.all()))
+        if not usable:
+            return None
+        try:
+            from ...decode import GreedyDecoder
+            return GreedyDecoder(self.model, filled.shape[1])
+        except NotImplementedError:
+            return None
+
     @torch.inference_mode()
     def unmask_tokens(self, tokens: Tensor, tokens_masked, temperature: float = 1., filter_logits_fn: Callable = top_k,
                       filter_kwargs: Optional[Dict[str, object]] = None, filter_key_ids: Optional[Dict[str, list]] = None,
                       caches: Optional[TupleTransformerCaches] = None, return_caches: bool = False, disable_tqdm: bool = False,
                       **kwargs):
+        """Cached note-by-note rendering of the MASK sub-tokens (`wrappers.py:325-407`): the decode hot loop."""
         assert callable(filter_logits_fn)
-        was_training = self.model.training
-        if was_training:
-            self.model.eval()
-        num_dims = len(tokens.shape)
-        if num_dims == 2:
-            tokens = tokens[None, :]
-            tokens_masked = tokens_masked[None, :]
-        out = tokens.clone().detach()
-        mask = kwargs.pop('mask', None)
-        if mask is None:
-            mask = torch.full_like(out[..., 0], True, dtype=torch.bool, device=out.device)
-        # fast path: greedy, one sequence, fresh caches -> hipGraph-replayed fp32 decode engine (decode.py)
-        if (out.is_cuda and out.shape[0] == 1 and caches is None and not filter_key_ids and is_greedy(filter_logits_fn, filter_kwargs)
-                and bool(mask.all()) and getattr(self, "use_decode_engine", True)):
-            try:
-                from ...decode import GreedyDecoder
-                eng = GreedyDecoder(self.model, out.shape[1])
-            except NotImplementedError:
-                eng = None
-            if eng is not None:
-                res, _ = eng.run(out, tokens_masked, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id)
-                res = res.squeeze(0) if num_dims == 2 else res
-                if was_training:
-                    self.model.train(was_training)
-                return (res, eng.caches()) if return_caches else res
-        filter_key_ids = filter_key_ids or dict()
-        unmask_mask = out == self.mask_token_id
-        # one host read of the mask layout for the whole window (the reference reads it per step: wrappers.py:385-390)
-        unmask_host = unmask_mask[0].cpu()
-        unmask_ids = torch.where(torch.any(unmask_host, dim=1))[0].tolist()
-        with shared_tables():
-            for idx in unmask_ids:
-                type_mask = unmask_mask[:, idx][0]
-                logits_keys = torch.where(unmask_host[idx])[0].tolist()
-                outputs = self(out[:, :idx + 1], seq_masked=tokens_masked[:, :idx + 1], mask=mask[:, :idx + 1],
-                               return_embeddings=True, return_caches=True, caches=caches, **kwargs)
-                caches = outputs.caches
-                logits = self.model.lm_head(outputs.hidden_state[:, idx - 1], keys=logits_keys)
-                samples = []
-                for key, logits_i in logits.items():
-                    logits_i = logits_i.clone()
-                    logits_i[:, self.pad_token_id] = -float("Inf")
-                    logits_i[:, self.mask_token_id] = -float("Inf")
-                    ids = filter_key_ids.get(key, None)
-                    if ids is not None:
-                        logits_i[:, ids] = -float("Inf")
-                    samples.append(_sample(logits_i, filter_logits_fn, filter_kwargs, temperature))
-                out[:, idx, type_mask] = torch.cat(samples, dim=-1)
-        if num_dims == 2:
-            out = out.squeeze(0)
-        if was_training:
-            self.model.train(was_training)
-        if return_caches:
-            return out, caches
-        return out
+        banned = filter_key_ids or {}
+        with _decode_call(self, tokens, tokens_masked, mask=kwargs.pop("mask", None)) as call:
+            filled, masked_view = call.arrays[0].clone().detach(), call.arrays[1]
+            engine = self._engine_for(filled, call.mask, caches, banned, filter_logits_fn, filter_kwargs)
+            if engine is not None:
+                filled, _ = engine.run(filled, masked_view, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id)
+                caches = engine.caches() if return_caches else None
+            else:
+                holes = filled == self.mask_token_id
+                holes_host = holes[0].cpu()   # ONE host read of the mask layout per window (the reference reads it per note: :385-390)
+                with shared_tables():
+                    for idx in torch.where(holes_host.any(dim=1))[0].tolist():
+                        step = self(filled[:, :idx + 1], seq_masked=masked_view[:, :idx + 1], mask=call.mask[:, :idx + 1],
+                                    return_embeddings=True, return_caches=True, caches=caches, **kwargs)
+                        caches = step.caches
+                        logits = self.model.lm_head(step.hidden_state[:, idx - 1], keys=torch.where(holes_host[idx])[0].tolist())
+                        draws = []
+                        for key, logits_k in logits.items():
+                            logits_k = _forbid(_forbid(logits_k, [self.pad_token_id, self.mask_token_id]), banned.get(key))
+                            draws.append(_sample(logits_k, filter_logits_fn, filter_kwargs, temperature))
+                        filled[:, idx, holes[0, idx]] = torch.cat(draws, dim=-1)
+            filled = call.result(filled)
+        return (filled, caches) if return_caches else filled
 
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, **kwargs):
-        seq = seq[:, :-1]
-        labels = labels[:, 1:] if exists(labels) else None
-        seq_masked = kwargs.pop("seq_masked", None)
-        if exists(seq_masked):
-            seq_masked = seq_masked[:, 1:]
-        context = kwargs.get("context", None)
-        if exists(context) and self.model.context_emb_mode == "cat":
-            kwargs["context"] = context[:, 1:]
-        style_embeddings = kwargs.get("style_embeddings", None)
-        if exists(style_embeddings):
-            kwargs["style_embeddings"] = style_embeddings[:, 1:]
-        mask = kwargs.get("mask", None)
-        if exists(mask) and mask.shape[1] == seq.shape[1] + 1:
-            kwargs["mask"] = mask[:, :-1]
-        return super().forward(seq, labels=labels, x_extra=seq_masked, **kwargs)
+        masked_view = kwargs.pop("seq_masked", None)
+        inputs, targets = _teacher_forcing_views(self.model, seq, labels, kwargs)
+        return super().forward(inputs, labels=targets, x_extra=masked_view[:, 1:] if exists(masked_view) else None, **kwargs)
 
 
 class ScorePerformerLMModes(ExplicitEnum):

@@ -64,20 +64,25 @@ class DiscreteContinuousEmbedding(nn.Module):
         if _weight is None:
             self.reset_parameters()
 
+    INIT_STD = 1e-2   # both parameter families start as N(0, 0.01) (modules/transformer/embeddings.py:76-81)
+
     def reset_parameters(self) -> None:
-        if self.has_discrete:
-            nn.init.normal_(self.index_weight, std=1e-2)
-        if self.continuous:
-            nn.init.normal_(self.value_layer.weight, std=1e-2)
+        for used, name in ((self.has_discrete, "index_weight"), (self.continuous, "value_layer")):
+            if used:
+                target = getattr(self, name)
+                nn.init.normal_(target if isinstance(target, Tensor) else target.weight, std=self.INIT_STD)
         self._fill_padding_idx_with_zero()
 
+    @torch.no_grad()
     def _fill_padding_idx_with_zero(self) -> None:
-        if self.padding_idx is not None:
-            with torch.no_grad():
-                if self.has_discrete:
-                    self.index_weight[self.padding_idx].fill_(0)
-                if self.continuous and self.token_values is not None:
-                    self.token_values[self.padding_idx].fill_(0)
+        """The padding id embeds to zero: its index row and its token value are cleared (embeddings.py:83-90)."""
+        pad = self.padding_idx
+        if pad is None:
+            return
+        if self.has_discrete:
+            self.index_weight[pad].zero_()
+        if self.continuous and self.token_values is not None:
+            self.token_values[pad].zero_()
 
     @property
     def has_discrete(self):
@@ -165,18 +170,19 @@ class AbsolutePositionalEmbedding(nn.Module):
 
 
 class FixedPositionalEmbedding(nn.Module):
+    """Sinusoidal table [sin(p w_k) | cos(p w_k)], w_k = 10000^(-2k/dim)  (modules/transformer/embeddings.py:245-265)."""
+
     def __init__(self, dim):
         super().__init__()
         self.dim = dim
-        inv_freq = 1. / (10000 ** (torch.arange(0, dim, 2).float() / dim))
-        self.register_buffer('inv_freq', inv_freq)
+        exponents = torch.arange(0, dim, 2, dtype=torch.float32) / dim
+        self.register_buffer('inv_freq', torch.reciprocal(torch.pow(10000.0, exponents)))
 
     def forward(self, x: Tensor, pos: Optional[Tensor] = None, seq_dim: int = 1, offset: int = 0):
-        if pos is None:
-            pos = torch.arange(x.shape[seq_dim], device=x.device)
-        pos = pos.type_as(self.inv_freq) + offset
-        sinusoid_inp = pos.unsqueeze(-1) * self.inv_freq
-        return torch.cat((sinusoid_inp.sin(), sinusoid_inp.cos()), dim=-1)
+        positions = torch.arange(x.shape[seq_dim], device=x.device) if pos is None else pos
+        angles = torch.outer(positions.to(self.inv_freq.dtype).reshape(-1) + offset, self.inv_freq)
+        angles = angles.reshape(*positions.shape, -1)
+        return torch.cat((torch.sin(angles), torch.cos(angles)), dim=-1)
 
     def extra_repr(self) -> str:
         return f'dim={self.dim}'
@@ -206,9 +212,11 @@ class ALiBiPositionalBias(nn.Module):
         return slopes_power_of_2(closest) + slopes_power_of_2(2 * closest)[0::2][:heads - closest]
 
     def get_bias(self, i: int, j: int, k: int = 0):
-        i_arange = torch.arange(k, i + k, dtype=torch.int, device=self.slopes.device)
-        j_arange = torch.arange(j, dtype=torch.int, device=self.slopes.device)
-        return -torch.abs(j_arange[None, None, :] - i_arange[None, :, None])
+        """-|key - query| for queries k .. k+i-1 against keys 0 .. j-1, shape [1, i, j] (embeddings.py:294-297)."""
+        dev = self.slopes.device
+        query = torch.arange(k, k + i, dtype=torch.int, device=dev).view(1, i, 1)
+        key = torch.arange(j, dtype=torch.int, device=dev).view(1, 1, j)
+        return (key - query).abs().neg()
 
     def get_slopes(self):
         return self.slopes

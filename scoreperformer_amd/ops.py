@@ -176,14 +176,14 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tenso
              c_long(gb.stride(0)), ptr(mean), ptr(rstd), ptr(dres), c_long(dres.stride(0) if dres is not None else 0), ptr(dx),
              c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D), ptr(dgb), c_long(2 * D), c_int(T), c_int(D), stream_ptr())
         if dx16 is not None:
-            dx._spn_bf16 = dx16
+            dx._spn_bf16, dx._spn_bf16_ver = dx16, dx._version
         return dx, dgb
     call("spn_layernorm_bwd", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gamma),
          ptr(gb), c_long(gb.stride(0) if gb is not None else 0), ptr(mean), ptr(rstd), ptr(dres),
          c_long(dres.stride(0) if dres is not None else 0), ptr(dx), c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D),
          ptr(dgamma), ptr(dbeta), ptr(dgb), c_long(2 * D), c_int(T), c_int(D), stream_ptr())
     if dx16 is not None:
-        dx._spn_bf16 = dx16
+        dx._spn_bf16, dx._spn_bf16_ver = dx16, dx._version   # functional._bf16_grad trusts the copy at this version only
     return dx, dgb
 
 
@@ -360,6 +360,24 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = torch.zeros(N, device=x.device, dtype=F32)
     call("spn_colsum", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(out), c_long(T), c_int(N), stream_ptr())
     return out
+
+
+def mish_fwd(x: torch.Tensor) -> torch.Tensor:
+    """y = x * tanh(softplus(x)), fp32 (nn.Mish of the embedding value MLP and of the embedding head)."""
+    require_gpu(x)
+    if x.dtype != F32:
+        raise SpnError("mish: fp32 only")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    call("spn_mish_fwd", ptr(x), ptr(y), c_long(x.numel()), stream_ptr())
+    return y
+
+
+def mish_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    x, dy = x.contiguous(), dy.contiguous()
+    dx = torch.empty_like(x)
+    call("spn_mish_bwd", ptr(x), ptr(dy), ptr(dx), c_long(x.numel()), stream_ptr())
+    return dx
 
 
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, *, ta=False, tb=False, bias=None, rowmask=None, out=None, alpha=1.0,
