@@ -223,9 +223,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         const float j0f = (float)j0;
-        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
-        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
-        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, a.thr8, bitbase + t * 64, bstride);
+        uint32_t thr_t = a.thr8;
+        if (DROP && a.thr_frac) {   // this block's threshold: thr8 + Bernoulli(frac16 / 65536), all-scalar (set_dropout)
+            const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * a.nkt64 + t));
+            thr_t += ((block_mix(blk ^ a.seed) & 0xffffu) < a.thr_frac) ? 1u : 0u;
+        }
+        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
+        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
+        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
 
         // O^T += V^T P^T
 #pragma unroll
@@ -549,11 +554,23 @@ int prepare_band(AttnArgs& a, hipStream_t stream, float* own, bool reuse) {
     return SPN_OK;
 }
 
+// Drop probability p as an 8-bit threshold PLUS a 16-bit fraction: a wave's 32x64 block of scores uses thr8 or thr8 + 1, chosen by a
+// (scalar) hash of the block's coordinates with probability frac16 / 65536, so every score is dropped with probability
+// (thr8 + frac16 / 65536) / 256 = p to within 2^-24 -- F.dropout(p)'s rate (attend.py:122), where a plain 8-bit threshold would
+// turn p = 0.1 into 26/256 = 0.1016 -- at no VALU cost: the bit-sliced Bernoulli draw below still folds eight random words.
+// Kept probabilities are scaled by 1 / (1 - p).  (Scores of one block share the choice: pairwise correlation < 2e-4.)
 void set_dropout(AttnArgs& a, float p_drop, unsigned seed, void* dropbits, int nq, int nk) {
-    const float t = p_drop * 256.f;
-    a.thr8 = t <= 0.f ? 0u : (t >= 255.f ? 255u : (uint32_t)(t + 0.5f));
+    const double t = (double)p_drop * 256.0;
+    if (t <= 0.0) { a.thr8 = 0u; a.thr_frac = 0u; a.inv_keep = 1.f; }
+    else if (t >= 255.0) { a.thr8 = 255u; a.thr_frac = 0u; a.inv_keep = 256.f; }
+    else {
+        a.thr8 = (uint32_t)t;
+        a.thr_frac = (uint32_t)((t - (double)a.thr8) * 65536.0 + 0.5);
+        if (a.thr_frac > 65535u) { a.thr_frac = 0u; a.thr8 += 1u; }
+        a.inv_keep = (float)(1.0 / (1.0 - ((double)a.thr8 + (double)a.thr_frac / 65536.0) / 256.0));
+    }
     a.seed = seed;
-    a.inv_keep = 1.f / (1.f - (float)a.thr8 / 256.f);
+    a.drop_on = (a.thr8 | a.thr_frac) ? 1 : 0;
     a.dropbits = (uint16_t*)dropbits;
     a.nqt16 = dropbits_nqt16(nq);
     a.nkt64 = dropbits_nkt64(nk);
@@ -592,7 +609,7 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     set_dropout(a, p_drop, seed, dropbits, nq, nk);
-    SPN_REQUIRE(a.thr8 == 0 || dropbits, "spn_attn_fwd: dropout needs the keep-bit buffer (spn_attn_dropbits_elems uint16 words)");
+    SPN_REQUIRE(!a.drop_on || dropbits, "spn_attn_fwd: dropout needs the keep-bit buffer (spn_attn_dropbits_elems uint16 words)");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
     a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk; a.causal = causal;
     a.scale = scale;
@@ -607,7 +624,7 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     rc = prepare_band(a, stream, band, false);
     if (rc) return rc;
     dim3 grid(cdiv(nq, 128), h, b);
-    if (a.thr8) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
+    if (a.drop_on) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, stream, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
@@ -623,7 +640,7 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     set_dropout(a, p_drop, 0, const_cast<void*>(dropbits), nq, nk);
-    SPN_REQUIRE(a.thr8 == 0 || dropbits, "spn_attn_bwd: dropout needs the keep bits written by spn_attn_fwd");
+    SPN_REQUIRE(!a.drop_on || dropbits, "spn_attn_bwd: dropout needs the keep bits written by spn_attn_fwd");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.d_o = (const bf16_t*)d_o;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
     a.dslope = dslope; a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk;
@@ -643,7 +660,7 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     rc = prepare_band(a, stream, const_cast<float*>(band), true);   // the bounds the forward computed for this q / k / mask (null: visit all)
     if (rc) return rc;
     // dQ first: it computes delta = rowsum(O * dO) in its prologue and stores it for dK/dV
-    if (a.thr8) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    if (a.drop_on) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
     launch_attn_dkv(a, stream);
     SPN_LAUNCH_CHECK();

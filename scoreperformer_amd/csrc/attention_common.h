@@ -32,7 +32,7 @@ struct AttnArgs {
     // read them back instead of re-hashing (they are VALU-bound; a bit test is 3x cheaper per element than hash + compare).
     // Word [bh][query tile of 16][key tile of 64][forward lane]: bit 4*kb + r = key 16*kb + 4*(lane>>4) + r of query lane&15,
     // i.e. exactly the forward's (and dQ's) S^T register layout.
-    uint32_t thr8, seed; float inv_keep;
+    uint32_t thr8, thr_frac, seed; int drop_on; float inv_keep;   // p = (thr8 + thr_frac / 65536) / 256: see set_dropout (attention.hip)
     uint16_t* dropbits; int nqt16, nkt64;
     // ALiBi band (attention.hip, "band skipping"): band[(b*h + head)*nqt64 + i/64] = max ||q_i||^2 over the 64-row tile (+inf if
     // the tile must never be skipped), then band[b*h*nqt64 + b_*kvh + kv_head] = max ||k_j||^2.  null / band_log2 <= 0: off.
@@ -148,6 +148,11 @@ __device__ __forceinline__ uint32_t drop_bits(uint32_t row_const, int j_half) { 
 // from it) are folded digit by digit along the binary expansion of thr8 / 256 -- AND for a 0 digit, OR for a 1 digit, least
 // significant first -- which leaves every bit set with probability exactly thr8 / 256 (the drop mask).  ~2 VALU ops per score
 // instead of a byte compare per score; the backward kernels read the bits the forward stored, so only this function defines the mask.
+// scalar mixer for wave-uniform counters (plain 32-bit multiplies: stays on the SALU)
+__device__ __forceinline__ uint32_t block_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ uint32_t drop_light(uint32_t x) { x ^= x >> 11; return __umul24(x, 0xD35A2Du) + (x >> 8); }
 __device__ __forceinline__ uint32_t drop_keep32(uint32_t counter, uint32_t thr8) {
     uint32_t w = drop_hash(counter), acc = 0u;

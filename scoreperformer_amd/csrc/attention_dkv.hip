@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 }  // namespace
 
 int launch_attn_dkv(const AttnArgs& a, hipStream_t stream) {
-    if (a.thr8) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
+    if (a.drop_on) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(cdiv(a.nk, 128), a.kvh, a.b), dim3(256), 0, stream, a);
     return 0;
 }

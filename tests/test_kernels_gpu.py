@@ -329,7 +329,7 @@ def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
     p0 = dots.softmax(-1)
     visible = p0 > 1e-3
     mask = (pd > 0)
-    thr = round(p * 256) / 256
+    thr = p   # the drop rate is p itself (8-bit threshold + dithered 16-bit fraction), kept scores scaled by 1 / (1 - p)
     assert abs(mask[visible].float().mean().item() - (1 - thr)) < 0.02
     assert rel_err(pd[mask & visible], (p0 / (1 - thr))[mask & visible]) < 3e-2
     # 2. forward + backward with random V against the reference using the extracted mask
@@ -349,6 +349,28 @@ def test_attention_dropout_forward_backward_share_one_mask(dev, causal):
     assert rel_err(dq, qr.grad) < 4e-2
     assert rel_err(dk, kr.grad) < 4e-2
     assert rel_err(dv, vr.grad) < 4e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [0.1, 0.25, 0.003])
+def test_attention_dropout_rate_is_p(p):
+    """F.dropout(p) drops with probability p (attend.py:122).  8.4 M keep bits of a full (unmasked, bidirectional, bias-free) launch:
+    the observed rate is p within 5 standard errors -- for p = 0.1 that separates 0.1 from the 26/256 = 0.1016 a bare 8-bit
+    threshold would give -- and every block of 32 x 64 scores sits at one of the two neighbouring 8-bit rates."""
+    from scoreperformer_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    b, h, n = 2, 4, 1024
+    q = torch.randn(b, n, h, 64, generator=g).to(dev).bfloat16()
+    kv = torch.randn(b, n, 1, 64, generator=g).to(dev).bfloat16()
+    _, _, bits = ops.attn_fwd(q, kv, kv, p_drop=p, seed=4242)
+    words = bits.view(torch.int16).to(torch.int32) & 0xffff
+    kept = sum(((words >> i) & 1).sum().item() for i in range(16))
+    total = words.numel() * 16
+    assert total == b * h * n * n
+    rate = 1.0 - kept / total
+    se = (p * (1 - p) / total) ** 0.5
+    assert abs(rate - p) < 5 * se + 2e-5, (rate, p, se)   # (+ the block-level dither's own sampling noise)
 
 
 @pytest.mark.gpu
