@@ -14,15 +14,23 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, arena, group=None, bucket_mb: float = 32.0, force: bool = False):
-        """`force=True` keeps the bucketed all-reduce path active on a one-rank group (single-GPU tests of the RCCL path)."""
+    def __init__(self, arena, group=None, bucket_mb: float = 32.0, force: bool = False, grad_dtype: torch.dtype = torch.float32,
+                 dry_run: bool = False):
+        """`force=True` keeps the bucketed all-reduce path active on a one-rank group (single-GPU tests of the RCCL path).
+        `grad_dtype=torch.bfloat16` sends every bucket as bf16 (half the bytes over xGMI: 144 MB instead of 288 MB per step at C3;
+        the sum over ranks is then formed in bf16 -- about 3 significant digits per element -- so fp32 stays the default).
+        `dry_run=True` runs the whole readiness protocol without a process group: buckets are "launched" into `self.events`
+        (tools/record_grad_events.py records the real model's pending / ready order that way)."""
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if group is not None else 1
-        self.active = self.world > 1 or (force and group is not None)
+        self.dry_run = dry_run
+        self.active = dry_run or self.world > 1 or (force and group is not None)
+        self.grad_dtype = grad_dtype
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
         self.pending: List[int] = []
+        self.events: List[tuple] = []    # dry_run: ("pending" | "ready" | "autograd" | "launch", index) in program order
         if not self.active:
             return
         # buckets in REVERSE arena order (decoder parameters come last in the arena and first in backward)
@@ -71,15 +79,21 @@ class GradSync:
         raise KeyError
 
     def _pending(self, i):
+        if self.dry_run:
+            self.events.append(("pending", i))
         self.counts[i] += 1
 
     def _ready(self, i):
+        if self.dry_run:
+            self.events.append(("ready", i))
         self.counts[i] -= 1
         if self.counts[i] == 0:
             self._param_done(i)
 
     def _autograd_ready(self, i):
         # autograd accumulated a returned gradient into p.grad; such parameters are not counted in forward
+        if self.dry_run:
+            self.events.append(("autograd", i))
         if self.counts[i] == 0:
             self._param_done(i)
 
@@ -95,12 +109,29 @@ class GradSync:
     def _launch(self, b):
         s, e = self.buckets[b]
         self.launched.add(b)
-        self.handles.append(dist.all_reduce(self.arena.grads[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.dry_run:
+            self.events.append(("launch", b))
+            return
+        grads = self.arena.grads[s:e]
+        if self.grad_dtype == grads.dtype:
+            self.handles.append((dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            return
+        # reduced-precision transport: the bucket is cast into a staging buffer (stream-ordered behind the kernels that produced
+        # the gradients), reduced there, and cast back into the fp32 arena in finish()
+        staged = self._staging(b, e - s, grads.device)
+        staged.copy_(grads)
+        self.handles.append((dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=self.group, async_op=True), staged, grads))
+
+    def _staging(self, b, n, device):
+        bufs = self.__dict__.setdefault("_stage_bufs", {})
+        if b not in bufs:
+            bufs[b] = torch.empty(n, dtype=self.grad_dtype, device=device)
+        return bufs[b]
 
     def begin_step(self):
         if not self.active:
             return
-        self.handles, self.done, self.launched = [], set(), set()
+        self.handles, self.done, self.launched, self.events = [], set(), set(), []
         self.counts = [0] * len(self.arena.param_list)
         left = [0] * len(self.buckets)
         for i in range(len(self.arena.param_list)):
@@ -114,6 +145,8 @@ class GradSync:
         for b in range(len(self.buckets)):
             if b not in self.launched:
                 self._launch(b)
-        for h in self.handles:
+        for h, staged, grads in self.handles:
             h.wait()
+            if staged is not None:
+                grads.copy_(staged)
         self.handles = []

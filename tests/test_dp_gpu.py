@@ -19,13 +19,14 @@ def test_gradsync_nccl_single_rank_matches_plain_step(dev):
     try:
         batch = synthetic_batch(2, 64, seed=3, ragged=True, device=dev)
         results = []
-        for use_sync in (False, True):
+        for use_sync in (False, True, "bf16"):
             model = ScorePerformer.init(model_config("tiny", dropout=0.0))
             model.load_state_dict(filled_state_dict(model, seed=5))
             arena = ParamArena(model, dev)
             model.train()
             opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
-            sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, force=True) if use_sync else None
+            sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, force=True,
+                            grad_dtype=torch.bfloat16 if use_sync == "bf16" else torch.float32) if use_sync else None
             torch.manual_seed(11)
             first = None
             for it in range(2):
@@ -42,7 +43,11 @@ def test_gradsync_nccl_single_rank_matches_plain_step(dev):
                 opt.step()
             torch.cuda.synchronize()
             results.append((float(out.loss.detach()), first, grads, arena.params.clone()))
-        (l0, f0, g0, p0), (l1, f1, g1, p1) = results
+        (l0, f0, g0, p0), (l1, f1, g1, p1), (l2, f2, g2, p2) = results
+        # bf16 transport (one rank: the all-reduce is the identity): the arena holds the bf16-rounded fp32 gradients
+        assert (f2 - f1).abs().max() <= 2.0 ** -8 * f1.abs().max()
+        assert bool(((f2 - f1).abs() <= 2.0 ** -8 * f1.abs() + 1e-30).all())
+        assert float((f2 != f1).float().mean()) > 0.5   # (it really went through bf16)
         # split-K weight gradients add with fp32 atomics: equal up to summation order on the first step, and up to that noise
         # carried through one optimizer step on the second
         assert (f0 - f1).abs().max() <= 2e-5 * f0.abs().max()
