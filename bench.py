@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--dropout", type=float, default=0.1, help="attention / FFN dropout (recipes/scoreperformer/base.yaml:167,176)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the C5 decode object (N = 1 only)")
+    ap.add_argument("--decode-seq", type=int, default=4096)
     return ap.parse_args()
 
 
@@ -136,6 +138,12 @@ def main():
             result["roofline"] = roof
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 measurement
         result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args, model, dev)
+    if rank == 0 and world == 1 and not args.no_decode:         # secondary object: C5 greedy render, outside the timed region
+        del out
+        try:
+            result["decode_c5"] = decode_leg(args, dev)
+        except Exception as exc:  # noqa: BLE001 -- the headline line must not depend on the secondary object
+            result["decode_c5"] = {"error": repr(exc)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -150,15 +158,23 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def roofline_leg(ops, step, args):
-    """Dominant kernel = the bf16 MFMA GEMM.  Every GEMM launch of a few instrumented steps is bracketed by HIP events on
-    the launch stream; achieved = algorithmic FLOPs (2*M*N*K) / measured duration, summed over the step's GEMM launches."""
+def _collect(ops, step, n=2):
     ops.PROFILE.enable()
-    for _ in range(2):
+    for _ in range(n):
         step()
     torch.cuda.synchronize()
     recs = ops.PROFILE.collect()
     ops.PROFILE.disable()
+    return recs
+
+
+def roofline_leg(ops, step, args):
+    """Dominant kernel = the bf16 MFMA GEMM.  Every GEMM / attention / LayerNorm / activation launch of two instrumented steps is
+    bracketed by HIP events on the launch stream; achieved = algorithmic work (2*M*N*K flop, or operand bytes) / measured duration.
+    Sub-objects give each third of the step its own fraction: `attention` (MFMA-bound, SURVEY.md §8(d) floors) and `elementwise`
+    (HBM-bound, algorithmic bytes vs 8 TB/s)."""
+    from scoreperformer_amd import lib
+    recs = _collect(ops, step)
     gemm = [r for r in recs if r[0] == "gemm_bf16"]
     flops = sum(r[1] for r in gemm)
     ms = sum(r[2] for r in gemm)
@@ -174,13 +190,56 @@ def roofline_leg(ops, step, args):
         a = by_inst.setdefault(f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
                                f"{'float' if dt == 'f32' else 'unsigned short'}, {1 if dt.endswith('+glu') else 0}>", [0, 0.0, 0.0])
         a[0] += 1; a[1] += f; a[2] += t
-    attn = [r for r in recs if r[0].startswith("attn")]
+
+    # ---- attention: MFMA-bound.  Work is counted two ways: "dense" = 4 n^2 h dh flop per layer forward (x 2.5 backward) with the
+    # causal half discounted -- tiles the ALiBi band never visits included -- and "executed" = the same count with the band switched
+    # off (attn_band = 0: every tile of the mask is visited), measured in two more instrumented steps.
+    def attn_summary(rs):
+        rs = [r for r in rs if r[0].startswith("attn")]
+        t = sum(r[2] for r in rs)
+        return {"ms_per_step": t / 2, "tflops_dense_counted": (sum(r[1] for r in rs) / (t * 1e-3) / 1e12) if t else None,
+                "fwd_ms_per_step": sum(r[2] for r in rs if r[0] == "attn_fwd") / 2, "bwd_ms_per_step": sum(r[2] for r in rs if r[0] == "attn_bwd") / 2,
+                "launches_per_step": len(rs) // 2}
+    band_default = lib.get_tuning("attn_band")
+    attn_on = attn_summary(recs)
+    lib.set_tuning("attn_band", 0.0)
+    attn_off = attn_summary(_collect(ops, step))
+    lib.set_tuning("attn_band", band_default)
+    layers = max(1, attn_on["launches_per_step"] // 2)
+    attention = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s",
+                 "band_log2": band_default, "with_band": attn_on, "band_off": attn_off,
+                 "achieved": attn_on["tflops_dense_counted"], "frac": (attn_on["tflops_dense_counted"] or 0.0) / 2500.0,
+                 "achieved_executed_only": attn_off["tflops_dense_counted"], "frac_executed_only": (attn_off["tflops_dense_counted"] or 0.0) / 2500.0,
+                 "floor_us_per_layer_fwd": {"bidirectional": 220, "causal": 110},
+                 "note": "dense-counted flops / time; `band_off` visits every unmasked tile, so its figure is executed flops / time; "
+                         f"{layers} attention layers per step (fwd + bwd launches each)"}
+
+    # ---- element-wise tail: HBM-bound kernels, algorithmic bytes (every operand once) / time against 8 TB/s
+    ew = {}
+    for name, work, t, tag in recs:
+        if name in ("ln_fwd", "ln_bwd", "act_fwd", "act_bwd"):
+            a = ew.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += work; a[2] += t
+    ew_bytes, ew_ms = sum(v[1] for v in ew.values()), sum(v[2] for v in ew.values())
+    elementwise = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": (ew_bytes / (ew_ms * 1e-3) / 1e9) if ew_ms else None,
+                   "frac": (ew_bytes / (ew_ms * 1e-3) / 1e9 / 8000.0) if ew_ms else None, "ms_per_step": ew_ms / 2,
+                   "per_kernel": [{"kernel": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2, "GB_per_s": v[1] / (v[2] * 1e-3) / 1e9}
+                                  for k, v in sorted(ew.items(), key=lambda kv: -kv[1][2])],
+                   "note": "LayerNorm / AdaLN forward+backward and the activation backward (the FFN activation forward lives in the GEMM "
+                           "epilogue); algorithmic bytes, each operand counted once"}
+
     traffic, traffic_note = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
-        with open(tpath) as fh:
-            tj = json.load(fh)
-        traffic, traffic_note = tj.get("hbm_bytes_per_launch"), tj.get("note")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for fname in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+        tpath = os.path.join(here, "profiles", fname)
+        if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_note = (f"STORED PROFILE profiles/{fname} (measured {tj.get('measured', 'in round 1')}, kernel source "
+                            f"{tj.get('commit', 'of that round')}), not re-measured by this run: counters need their own rocprofv3 --pmc "
+                            f"passes.  " + (tj.get("note") or ""))
+            break
     return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT, GLU> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
                                        "of a step, a split-K launch includes its reduce kernel; GLU = 1: the gated FFN input projection "
                                        "with activation + dropout in its epilogue, counted at the GEMM's 2MNK only)",
@@ -192,8 +251,51 @@ def roofline_leg(ops, step, args):
                             "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in sorted(by_inst.items(), key=lambda kv: -kv[1][2])],
             "top_shapes": [{"MNK_layout": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2,
                             "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in top],
-            "attention_ms_per_step": sum(r[2] for r in attn) / 2,
-            "attention_tflops": (sum(r[1] for r in attn) / (sum(r[2] for r in attn) * 1e-3) / 1e12) if attn else None}
+            "attention_ms_per_step": attn_on["ms_per_step"], "attention_tflops": attn_on["tflops_dense_counted"],
+            "attention": attention, "elementwise": elementwise}
+
+
+def decode_leg(args, dev):
+    """C5 (BASELINE config 5): greedy performance render of ONE 4096-note sequence through the hipGraph-replayed decode engine, outside
+    the timed train region.  HBM-bound: every note streams the decoder's weights and its caches once."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.modules.sampling import top_k
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    L = args.decode_seq
+    torch.manual_seed(0)
+    model = ScorePerformer.init(model_config("c5", max_seq_len=L))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=7, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    tokens = batch["masked_perf"].clone()
+    tokens[:, 0] = batch["perf"][:, 0]
+    dec = model.perf_decoder
+    best = None
+    for _ in range(2):   # the second run replays warm graphs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = dec.unmask_tokens(tokens, batch["masked_perf"], context=enc.score_embeddings, style_embeddings=enc.perf_embeddings,
+                                filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    notes = L - 1
+    # algorithmic bytes per note: the decoder's weights once (fp32 engine) + on average half of the K/V caches (6 layers, MQA, fp32)
+    dec_params = sum(p.numel() for n, p in model.named_parameters() if n.startswith("perf_decoder."))
+    tables = sum(p.numel() for n, p in model.named_parameters() if ".embs." in n and n.startswith("score_encoder."))
+    wbytes = (dec_params + tables) * 4
+    cache_bytes = 6 * 2 * 64 * 4 * (L / 2)
+    per_note = wbytes + cache_bytes
+    return {"workload": f"C5 greedy render, seq {L}, batch 1, hipGraph-replayed decode engine (fp32), tokens bit-exact vs the fp32 reference on the fixtures",
+            "notes": notes, "us_per_note": best / notes * 1e6, "notes_per_s": notes / best, "masks_left": int((out == 1).sum()),
+            "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": per_note / (best / notes) / 1e9,
+                         "frac": per_note / (best / notes) / 1e9 / 8000.0, "algorithmic_bytes_per_note": per_note,
+                         "note": "decoder weights (fp32) + mean K/V cache bytes per note; launch-latency bound today (DESIGN.md)"}}
 
 
 def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):

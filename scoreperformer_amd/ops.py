@@ -745,6 +745,50 @@ def attn_bwd(q, k, v, o, d_o, lse, **kw):  # noqa: F811
                         lambda: _attn_bwd_raw(q, k, v, o, d_o, lse, **kw))
 
 
+# HBM-bound kernels: the "work" of a record is ALGORITHMIC BYTES (every operand once), for the element-wise roofline object of bench.py
+_ln_fwd_raw, _ln_bwd_raw, _act_bwd_raw, _act_fwd_raw = layernorm_fwd, layernorm_bwd, act_bwd, act_fwd
+
+
+def _esz(t) -> int:
+    return 0 if t is None else t.element_size()
+
+
+def layernorm_fwd(x, gamma, beta, gb=None, out_dtype=BF16, eps=1e-5, out=None):  # noqa: F811
+    if not PROFILE.enabled:
+        return _ln_fwd_raw(x, gamma, beta, gb, out_dtype, eps, out)
+    n = x.numel()
+    ysz = out.element_size() if out is not None else (2 if out_dtype == BF16 else 4)
+    by = n * (x.element_size() + ysz) + (2 * n * gb.element_size() if gb is not None else 0)
+    return PROFILE.wrap("ln_fwd", float(by), f"T{n // x.shape[-1]} D{x.shape[-1]} {'ada' if gb is not None else 'ln'}",
+                        lambda: _ln_fwd_raw(x, gamma, beta, gb, out_dtype, eps, out))
+
+
+def layernorm_bwd(x, dy, gamma, gb, mean, rstd, *, dres=None, dx_dtype=F32, dgamma=None, dbeta=None, want_dgb=False, want_dx16=False):  # noqa: F811
+    run = lambda: _ln_bwd_raw(x, dy, gamma, gb, mean, rstd, dres=dres, dx_dtype=dx_dtype, dgamma=dgamma, dbeta=dbeta,   # noqa: E731
+                              want_dgb=want_dgb, want_dx16=want_dx16)
+    if not PROFILE.enabled:
+        return run()
+    n = x.numel()
+    dxsz = 4 if dx_dtype == F32 else 2
+    by = n * (x.element_size() + 2 + dxsz + (2 if (want_dx16 and dx_dtype == F32) else 0) + (4 if dres is not None else 0))
+    by += (2 * n * gb.element_size() if gb is not None else 0) + (2 * n * 2 if want_dgb else 0)
+    return PROFILE.wrap("ln_bwd", float(by), f"T{n // x.shape[-1]} D{x.shape[-1]} {'ada' if gb is not None else 'ln'}", run)
+
+
+def act_bwd(u, dout, *, act, glu, p_drop=0.0, seed=0, colsum=None):  # noqa: F811
+    run = lambda: _act_bwd_raw(u, dout, act=act, glu=glu, p_drop=p_drop, seed=seed, colsum=colsum)   # noqa: E731
+    if not PROFILE.enabled:
+        return run()
+    return PROFILE.wrap("act_bwd", float(2 * u.numel() * 2 + dout.numel() * 2), f"T{u.numel() // u.shape[-1]} W{u.shape[-1]}", run)
+
+
+def act_fwd(u, *, act, glu, p_drop=0.0, seed=0):  # noqa: F811
+    run = lambda: _act_fwd_raw(u, act=act, glu=glu, p_drop=p_drop, seed=seed)   # noqa: E731
+    if not PROFILE.enabled:
+        return run()
+    return PROFILE.wrap("act_fwd", float(u.numel() * 2 + (u.numel() // (2 if glu else 1)) * 2), f"T{u.numel() // u.shape[-1]} W{u.shape[-1]}", run)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # decode (b = 1) kernels: fp32, position read from a device scalar so that one captured step can be replayed
 # ---------------------------------------------------------------------------------------------------------

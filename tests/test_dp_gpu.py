@@ -56,3 +56,53 @@ def test_gradsync_nccl_single_rank_matches_plain_step(dev):
         assert (g0 - g1).abs().max() <= 5e-3 * g0.abs().max()
     finally:
         dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_the_global_batch_step(dev):
+    """SURVEY.md §4 item 4 on one GPU: what two data-parallel ranks compute -- each rank the mean-loss gradient of ITS half of the batch,
+    the all-reduce their SUM, the optimizer a 1/world scale folded into its kernel -- equals the single-GPU step on the whole batch.
+    Holds exactly in exact arithmetic when every rank sees the same number of valid labels per key (full-length windows: SURVEY.md
+    §8(e)) and the loss is a mean over samples; the MMD term is a per-rank estimate by design (kernel means are not additive), so its
+    weight is 0 here.  The rank halves run one after the other on this GPU; their gradient arenas are summed as the all-reduce would."""
+    from scoreperformer_amd.arena import ParamArena, FusedAdamW
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    world = 2
+    batch = synthetic_batch(4, 96, seed=17, device=dev)                       # full-length windows: equal label counts per half
+    halves = [{k: v[r * 2:(r + 1) * 2] for k, v in batch.items()} for r in range(world)]
+
+    def fresh():
+        torch.manual_seed(5)
+        cfg = model_config("tiny", dropout=0.0)
+        cfg["perf_encoder"]["loss_weight"] = 0.0
+        model = ScorePerformer.init(cfg)
+        arena = ParamArena(model, dev)
+        model.train()
+        return model, arena, FusedAdamW(arena, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+
+    model, arena, opt = fresh()
+    arena.zero_grad()
+    model(**batch).loss.backward()
+    g_global = arena.grads.clone()
+    opt.step()
+    p_global = arena.params.clone()
+
+    model, arena, opt = fresh()
+    total = torch.zeros_like(arena.grads)
+    for half in halves:                      # rank r's backward ...
+        arena.zero_grad()
+        model(**half).loss.backward()
+        total += arena.grads                 # ... and the all-reduce(SUM) of the gradient arenas
+    arena.grads.copy_(total)
+    for p in arena.param_list:
+        p._spn_touched = True
+    opt.step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    g_dp = total / world
+    scale = g_global.abs().max()
+    assert (g_dp - g_global).abs().max() <= 2e-2 * scale, float((g_dp - g_global).abs().max() / scale)   # bf16 GEMMs, different row sets
+    rel = (g_dp - g_global).norm() / g_global.norm()
+    assert float(rel) <= 2e-2, float(rel)
+    # one Adam step (lr 1e-3) moves every entry by ~lr * sign(g): entries whose gradient is not at the noise level agree closely
+    dp = (arena.params - p_global).abs()
+    assert float(dp.max()) <= 2.5e-3 and float((dp > 2e-4).float().mean()) < 0.05, (float(dp.max()), float((dp > 2e-4).float().mean()))
