@@ -190,6 +190,10 @@ int spn_dec_cat(const float* x, int d, const float* gamma, const float* beta, fl
                 const float* style, long style_ld, int style_w, const int* pos, float* out, spn_stream_t s);
 int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part, int* counter,
                   float* kmax2, int h, int kvh, float scale, int splits, spn_stream_t s);
+/* cross-attention of the decoded position over a static context (decoder layer type 'c': modules/transformer/transformer.py:201 under
+ * the cache protocol :159-181; ALiBi distance from the END of the context as attention.py:193-197 gives it for a single query) */
+int spn_dec_xattn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask, int nk, float* o,
+                  float* part, int* counter, int h, int kvh, float scale, int splits, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);

@@ -93,7 +93,8 @@ def norm(sd: SD, prefix: str, x: Tensor, cond: Optional[Tensor], ada: bool) -> T
 def attention(
         sd: SD, prefix: str, x: Tensor, *, heads: int, causal: bool, alibi: bool = True,
         context: Optional[Tensor] = None, mask: Optional[Tensor] = None, context_mask: Optional[Tensor] = None,
-        cache_k: Optional[Tensor] = None, cache_v: Optional[Tensor] = None, return_kv: bool = False):
+        cache_k: Optional[Tensor] = None, cache_v: Optional[Tensor] = None, return_kv: bool = False,
+        single_query_bias: bool = False):
     """q/k/v projections (attention.py:135-142), key-padding + causal + ALiBi folded into one additive
     mask (attend.py:80-113), softmax(q k^T * dh^-0.5 + bias) v, out-proj and query-row masking
     (attention.py:210-218).  MQA when `to_k.weight` has dim_head rows (attention.py:67-73)."""
@@ -136,7 +137,9 @@ def attention(
     if has_alibi:
         if slopes.shape[0] < heads:  # embeddings.py:307-308
             slopes = F.pad(slopes, (0, 0, 0, 0, 0, heads - slopes.shape[0]))
-        dots = dots + slopes[None] * alibi_bias(n, j)[None]
+        # single_query_bias: the cached decode calls a cross-attention block with ONE query (transformer.py:159,201), so every position's
+        # bias row was computed as get_bias(i = 1, j, k = j - 1) = -|key - (j - 1)| when that position was the newest one
+        dots = dots + slopes[None] * (alibi_bias(1, j) if single_query_bias else alibi_bias(n, j))[None]
     neg = -torch.finfo(dots.dtype).max // 2  # attend.py:102,105
     dots = torch.where(allowed, dots, torch.full_like(dots, neg))
     attn = dots.softmax(dim=-1)
@@ -186,7 +189,7 @@ def layer_types(tcfg, cross_attend: bool) -> List[str]:
 
 def transformer(
         sd: SD, prefix: str, x: Tensor, tcfg, *, causal: bool, cross_attend: bool, ada: bool,
-        mask=None, context=None, context_mask=None, style=None, return_hiddens: bool = False):
+        mask=None, context=None, context_mask=None, style=None, return_hiddens: bool = False, cached_decode: bool = False):
     heads = int(_get(tcfg, "heads", 8))
     ff = _get(tcfg, "feed_forward", {})
     glu, swish = bool(_get(ff, "glu", False)), bool(_get(ff, "swish", False))
@@ -204,7 +207,7 @@ def transformer(
             kvs.append(kv)
         elif lt == "c":
             out, kv = attention(sd, lp + "1.", h, heads=heads, causal=False, alibi=alibi, context=context,
-                                mask=mask, context_mask=context_mask, return_kv=True)
+                                mask=mask, context_mask=context_mask, return_kv=True, single_query_bias=cached_decode)
             kvs.append(kv)
         else:
             out = feed_forward(sd, lp + "1.", h, glu=glu, swish=swish)
@@ -351,7 +354,7 @@ def regression_losses(sd: SD, emb_prefix: str, logits: Dict[str, Tensor], reg_va
 
 def tuple_transformer(
         sd: SD, prefix: str, cfg, seqs: List[Tensor], *, causal: bool, mask=None, context=None, context_mask=None,
-        style=None, with_logits: bool = False, return_hiddens: bool = False):
+        style=None, with_logits: bool = False, return_hiddens: bool = False, cached_decode: bool = False):
     te = cfg["token_embeddings"]
     keys = _emb_keys(sd, prefix + "token_emb.")
     x = tuple_embed(sd, prefix + "token_emb.", seqs, te, keys)
@@ -375,7 +378,7 @@ def tuple_transformer(
     res = transformer(sd, prefix + "transformer.", x, cfg["transformer"], causal=causal,
                       cross_attend=context is not None, ada=style_mode == "adanorm" and style is not None,
                       mask=mask, context=context, context_mask=context_mask, style=style,
-                      return_hiddens=return_hiddens)
+                      return_hiddens=return_hiddens, cached_decode=cached_decode)
     out = res[0] if return_hiddens else res
     logits = None
     if with_logits:
@@ -555,14 +558,22 @@ def performer_forward(sd: SD, cfg, inputs: Dict[str, Tensor]):
 
 @torch.no_grad()
 def greedy_unmask(sd: SD, cfg, tokens: Tensor, tokens_masked: Tensor, context: Tensor, style: Tensor,
-                  mask_token_id: int = 1, pad_token_id: int = 0) -> Tensor:
+                  mask_token_id: int = 1, pad_token_id: int = 0, context_mask: Optional[Tensor] = None,
+                  reference_hidden_row_defect: bool = False) -> Tensor:
     """Full-prefix recomputation per step (no caches): for each position idx holding MASK tokens, run the
     shifted decoder on out[:, :idx+1], take logits at idx-1 for the masked dims, ban PAD/MASK ids
     (wrappers.py:368-369) and take the argmax (top_k k=1 + multinomial == argmax, sampling.py:28-59)."""
+    # reference_hidden_row_defect (cross-attending decoders only): under the cache protocol the reference calls a 'c' block with ONE
+    # query but the whole-prefix `mask` (modules/transformer/transformer.py:201), and `out * mask[..., None]` (attention.py:216-218,
+    # has_cache is False there) broadcasts that row to s identical rows; they are appended to the cached final hiddens, whose length
+    # after step s is s(s+1)/2 instead of s, and `hidden_state[:, idx - 1]` (wrappers.py:364) then reads the hidden of position t - 1
+    # with t the smallest integer with t(t+1)/2 >= s -- a STALE position from s = 3 on.  The flag reproduces exactly that (it pins this
+    # oracle to the reference's own tokens, tests/golden/tiny_greedy_xattn.npz); the product implements the evident intent, row idx - 1.
     dec_prefix = "perf_decoder.model." if any(k.startswith("perf_decoder.model.") for k in sd) else "perf_decoder."
     dcfg = cfg["perf_decoder"]
     keys = _emb_keys(sd, dec_prefix + "token_emb.")
     out = tokens.clone()
+    first_step = None
     unmask = out == mask_token_id
     ids = torch.where(unmask.any(dim=2))[1]
     for idx in ids.tolist():
@@ -572,9 +583,17 @@ def greedy_unmask(sd: SD, cfg, tokens: Tensor, tokens_masked: Tensor, context: T
         if ctx is not None and _get(dcfg, "context_emb_mode", "attention") == "cat":
             ctx = ctx[:, 1:]
         hidden, _ = tuple_transformer(sd, dec_prefix, dcfg, [seq, seq_m], causal=True,
-                                      mask=torch.ones(seq.shape[:2], dtype=torch.bool), context=ctx,
-                                      style=style[:, 1:])
-        lg = lm_head(sd, dec_prefix + "lm_head.", hidden[:, idx - 1], dcfg["token_embeddings"], keys,
+                                      mask=torch.ones(seq.shape[:2], dtype=torch.bool), context=ctx, context_mask=context_mask,
+                                      style=style[:, 1:], cached_decode=True)
+        row = idx - 1
+        if reference_hidden_row_defect:
+            first_step = idx if first_step is None else first_step
+            step = idx - first_step + 1                       # 1 = the cache-free first call
+            t = 1
+            while t * (t + 1) // 2 < step:
+                t += 1
+            row = first_step - 1 + (t - 1)
+        lg = lm_head(sd, dec_prefix + "lm_head.", hidden[:, row], dcfg["token_embeddings"], keys,
                      _get(dcfg, "lm_head", {"_target_": "lm"}), only=dims)
         for d, (key, l) in zip(dims, lg.items()):
             l = l.clone()

@@ -439,6 +439,80 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
     }
 }
 
+// Cross-attention of ONE query over a static context (decoder layer type 'c', modules/transformer/transformer.py:201 with the cache
+// protocol of :159-181): the reference calls the block with the last position only and NO cache, so keys / values are the whole
+// context every step (here: projected once per render, kctx / vctx [nk, kvh*64]) and the ALiBi distance is measured from the END of the
+// context -- get_bias(i = 1, j = nk, k = nk - 1), attention.py:193-197 -- whatever the decoded position is.  Masked context keys get
+// the reference's fill value (attend.py:102-108).  Same split-key scheme as dec_attn2_kernel; nothing is appended.
+__global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict__ q, const float* __restrict__ kctx, const float* __restrict__ vctx,
+                                                        const float* __restrict__ slopes, const uint8_t* __restrict__ kmask, int nk,
+                                                        float* __restrict__ o, float* __restrict__ part, int* __restrict__ counter,
+                                                        int h, int kvh, float scale) {
+    __shared__ float sm[16], sl[16];
+    __shared__ __attribute__((aligned(16))) float so[16][64];
+    __shared__ int is_last;
+    const int hi = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, l16 = lane & 15;
+    const int kh = kvh == 1 ? 0 : hi;
+    const long cw = (long)kvh * 64;
+    const float slope = slopes ? slopes[hi] : 0.f;
+    const int chunk = (nk + S - 1) / S;
+    const int j0 = sp * chunk, j1 = min(nk, j0 + chunk);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + hi * 64 + l16 * 4) * scale;
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = j0 + w * 4 + grp; j < j1; j += 16) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kctx + j * cw + kh * 64 + l16 * 4);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vctx + j * cw + kh * 64 + l16 * 4);
+        float sc = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+        sc -= slope * (float)(nk - 1 - j);
+        if (kmask && kmask[j] == 0) sc = -1.7014118e38f;
+        const float m_new = fmaxf(m, sc);
+        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
+        l = l * alpha + pj;
+        acc = acc * alpha + v4 * pj;
+        m = m_new;
+    }
+    const int gi = w * 4 + grp;
+    if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
+    *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+    __syncthreads();
+    float* mine = part + ((long)hi * S + sp) * 66;
+    if (tid < 64) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) mm = fmaxf(mm, sm[x]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            const float f = (sm[x] == -INFINITY) ? 0.f : __expf(sm[x] - mm);
+            num += so[x][tid] * f; den += sl[x] * f;
+        }
+        mine[2 + tid] = num;
+        if (tid == 0) { mine[0] = mm; mine[1] = den; }
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(counter + hi, 1) == S - 1);
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (tid < 64) {
+        const float* ph = part + (long)hi * S * 66;
+        float mm = -INFINITY;
+        for (int x = 0; x < S; ++x) mm = fmaxf(mm, ph[x * 66]);
+        float num = 0.f, den = 0.f;
+        for (int x = 0; x < S; ++x) {
+            const float mq = ph[x * 66];
+            const float f = (mq == -INFINITY) ? 0.f : __expf(mq - mm);
+            num += ph[x * 66 + 2 + tid] * f; den += ph[x * 66 + 1] * f;
+        }
+        o[hi * 64 + tid] = num / den;
+        if (tid == 0) counter[hi] = 0;   // ready for the next step
+    }
+}
+
 // LM head of one position for all candidate dims in one launch (grid = dims): LayerNorm(e) slice . table_dim^T -> arg-max with
 // banned ids -> written where the next position holds MASK.  e: [D] head embedding (models/scoreperformer/embeddings.py:345-353).
 struct DecHeadDesc {
@@ -656,6 +730,17 @@ extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, con
     SPN_REQUIRE(qkv && kcache && vcache && pos && o && part && counter && kmax2 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
                 "spn_dec_attn2: bad arguments");
     hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(256), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// q: [h*64] fp32; kctx / vctx: [nk, kvh*64] fp32 (projected context, constant over the render); kmask: [nk] uint8 or null;
+// part: h * splits * 66 floats scratch; counter: h ints, zero before the first step (the kernel resets it)
+extern "C" int spn_dec_xattn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask, int nk, float* o,
+                             float* part, int* counter, int h, int kvh, float scale, int splits, hipStream_t s) {
+    SPN_REQUIRE(q && kctx && vctx && o && part && counter && nk > 0 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
+                "spn_dec_xattn: bad arguments");
+    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, nk, o, part, counter, h, kvh, scale);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -33,8 +33,11 @@ class GreedyDecoder:
         self.head_slabs = int(os.environ.get("SPN_DEC_HEAD_SLABS", 8))
         self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
         tr = m.transformer
-        if any(t != ('a', 'f')[i % 2] for i, t in enumerate(tr.layer_types)) or not tr.pre_norm:
-            raise NotImplementedError("decode engine: pre-norm self-attention decoder only (context_emb_mode='cat')")
+        types = tuple(tr.layer_types)
+        self.cross = 'c' in types
+        block = ('a', 'c', 'f') if self.cross else ('a', 'f')
+        if types != block * (len(types) // len(block)) or not tr.pre_norm:
+            raise NotImplementedError("decode engine: pre-norm decoder with ('a','f') or ('a','c','f') layer blocks")
         if getattr(m.token_emb, "multiseq_mode", None) != "post-cat" or m.pos_emb is not None:
             raise NotImplementedError("decode engine: multi-seq post-cat token embeddings without absolute positions")
         self.dev = next(m.parameters()).device
@@ -58,15 +61,18 @@ class GreedyDecoder:
         att0 = m.transformer.layers[0][1]
         self.heads, self.kvh = att0.heads, att0.kv_heads
         self.qkv = z((self.heads + 2 * self.kvh) * 64)
-        inner2 = m.transformer.layers[1][1].ff[0].proj.weight.shape[0] if m.transformer.layers[1][1].glu else \
-            m.transformer.layers[1][1].ff[0][0].weight.shape[0]
+        ffn = next(blk for lt, (_n, blk, _r) in zip(m.transformer.layer_types, m.transformer.layers) if lt == 'f')
+        inner2 = ffn.ff[0].proj.weight.shape[0] if ffn.glu else ffn.ff[0][0].weight.shape[0]
         self.u = z(inner2)
-        self.g = z(inner2 // 2 if m.transformer.layers[1][1].glu else inner2)
+        self.g = z(inner2 // 2 if ffn.glu else inner2)
         self.gb = z(2 * d)
         n_attn = m.transformer.num_attn_layers
-        self.kc = [z(L, self.kvh * 64) for _ in range(n_attn)]
-        self.vc = [z(L, self.kvh * 64) for _ in range(n_attn)]
-        self.hid = [z(L, d) for _ in range(n_attn + 1)]
+        n_self = sum(1 for t in m.transformer.layer_types if t == 'a')
+        self.kc = [z(L, self.kvh * 64) for _ in range(n_self)]
+        self.vc = [z(L, self.kvh * 64) for _ in range(n_self)]
+        self.hid = [z(L, d) for _ in range(n_self + 1)]
+        self.q_only = z(self.heads * 64)                      # query of a cross-attention layer
+        self.xk, self.xv, self.xmask = [], [], None            # projected context per 'c' layer: filled by _project_context
         self.e_head = z(te.total_emb_dim)
         self.e_head_n = z(te.total_emb_dim)
         self.logits = z(max(te.num_tokens.values()) + 8)
@@ -79,7 +85,7 @@ class GreedyDecoder:
         self.head_counter = torch.zeros(16, device=dev, dtype=torch.int32)
         self.head_logits = z(16, 1024)
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
-        self.kmax2 = [z(self.kvh) for _ in range(n_attn)]
+        self.kmax2 = [z(self.kvh) for _ in range(n_self)]
         tr = m.transformer
         self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
         self.ada_rows = {}
@@ -93,6 +99,36 @@ class GreedyDecoder:
         head = m.lm_head
         if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection:
             self.head_Wt = head.project_emb.weight.data.float().t().contiguous()   # [total_emb, d]: row-major GEMV operand
+
+    def _project_context(self, context: torch.Tensor, context_mask: Optional[torch.Tensor]):
+        """Keys / values of every cross-attention layer over the WHOLE context, once per render: the reference recomputes them from the
+        context at every note (the 'c' block gets no cache: modules/transformer/transformer.py:201), the values are the same."""
+        ctx = context.float().contiguous()
+        self.xk, self.xv = [], []
+        for lt, (_n, block, _r) in zip(self.m.transformer.layer_types, self.m.transformer.layers):
+            if lt == 'c':
+                self.xk.append(ops.gemm_f32(ctx, block.to_k.weight.data))
+                self.xv.append(ops.gemm_f32(ctx, block.to_v.weight.data))
+        self.xmask = None
+        if context_mask is not None:
+            cm = context_mask.reshape(-1).contiguous()
+            self.xmask = cm.view(torch.uint8) if cm.dtype == torch.bool else cm.to(torch.uint8)
+
+    def _cross_layer(self, ci: int, norm, block, fused: bool):
+        """x += to_out(attend(to_q(norm(x)), K_ctx, V_ctx)) for the current position."""
+        if fused:
+            mode, g_, b_, eps_ = self._norm_args(norm)
+            ops.dec_fused_gemv(block.to_q.weight.data, self.x, self.q_only, norm=mode, gamma=g_, beta=b_, eps=eps_)
+        else:
+            self._ln(self.x, norm, self.h, True)
+            ops.dec_gemv(block.to_q.weight.data, self.h, self.q_only)
+        slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+        ops.dec_xattn(self.q_only, self.xk[ci], self.xv[ci], slopes, self.xmask, self.o, self.att_part, self.att_counter,
+                      h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
+        if fused:
+            ops.dec_fused_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+        else:
+            ops.dec_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
 
     # -- one decoder step at position t = *pos (predicts the MASKed dims of position t + 1) -----------------
     def _ln(self, x, norm, out, cond_row: bool):
@@ -128,9 +164,12 @@ class GreedyDecoder:
             ops.dec_gemv(m.project_emb.weight.data, self.xcat, self.x, bias=m.project_emb.bias.data)
         else:
             ops.dec_copy_row(self.xcat, self.x, pos, d)
-        ai = 0
+        ai = ci = 0
         for lt, (norms, block, _res) in zip(m.transformer.layer_types, m.transformer.layers):
-            if lt == 'a':
+            if lt == 'c':
+                self._cross_layer(ci, norms[0], block, False)
+                ci += 1
+            elif lt == 'a':
                 ops.dec_copy_row(self.x, self.hid[ai], pos, d, dst_ld=d)
                 self._ln(self.x, norms[0], self.h, True)
                 wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
@@ -219,11 +258,14 @@ class GreedyDecoder:
         else:
             ops.dec_copy_row(self.xcat, self.x, pos, d)
             ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
-        ai = 0
+        ai = ci = 0
         n_layers = len(tr.layers)
         for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
             mode, g_, b_, eps_ = self._norm_args(norms[0])
-            if lt == 'a':
+            if lt == 'c':
+                self._cross_layer(ci, norms[0], block, True)
+                ci += 1
+            elif lt == 'a':
                 wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
                 ops.dec_fused_gemv(wqkv, self.x, self.qkv, norm=mode, gamma=g_, beta=b_, eps=eps_)
                 slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
@@ -275,14 +317,20 @@ class GreedyDecoder:
     # -- public ----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, tokens: torch.Tensor, tokens_masked: torch.Tensor, context: Optional[torch.Tensor],
-            style: Optional[torch.Tensor], mask_token_id: int = 1):
-        """tokens / tokens_masked: [1, L, K] int64 on the GPU; returns (filled tokens, number of decoded positions)."""
+            style: Optional[torch.Tensor], mask_token_id: int = 1, context_mask: Optional[torch.Tensor] = None):
+        """tokens / tokens_masked: [1, L, K] int64 on the GPU; returns (filled tokens, number of decoded positions).
+        context: [1, L, d] rows concatenated per note (context_emb_mode 'cat') or [1, n_ctx, d] attended as a whole ('attention',
+        with its key mask `context_mask` [1, n_ctx])."""
         m = self.m
         L = tokens.shape[1]
         self._alloc(L)
+        if self.cross:
+            if context is None:
+                raise ValueError("decode engine: a cross-attending decoder needs its context")
+            self._project_context(context[0], context_mask[0] if context_mask is not None else None)
         self.seq2d = tokens[0].clone().contiguous()
         self.masked2d = tokens_masked[0].contiguous()
-        self.ctx2d = context[0].float().contiguous() if context is not None else None
+        self.ctx2d = context[0].float().contiguous() if (context is not None and not self.cross) else None
         self.style2d = style[0].float().contiguous() if style is not None else None
         unmask = (self.seq2d == mask_token_id)
         rows = unmask.any(dim=1).nonzero().flatten()
@@ -314,9 +362,16 @@ class GreedyDecoder:
         """Caches in the reference's layout (TupleTransformerCaches fields) for the decoded prefix."""
         from .models.scoreperformer.transformer import TupleTransformerCaches
         n = self.n_steps
-        att = [AttentionIntermediates(keys=k[None, :n] if self.kvh == 1 else k[:n].view(1, n, self.kvh, 64).permute(0, 2, 1, 3),
-                                      values=v[None, :n] if self.kvh == 1 else v[:n].view(1, n, self.kvh, 64).permute(0, 2, 1, 3))
-               for k, v in zip(self.kc, self.vc)]
+        def view(t, rows):   # reference layouts: [1, n, 64] multi-query, [1, h, n, 64] otherwise
+            return t[None, :rows] if self.kvh == 1 else t[:rows].view(1, rows, self.kvh, 64).permute(0, 2, 1, 3)
+        att, ai, ci = [], 0, 0
+        for lt in self.m.transformer.layer_types:   # one entry per attention layer, in layer order ('c': the whole context)
+            if lt == 'a':
+                att.append(AttentionIntermediates(keys=view(self.kc[ai], n), values=view(self.vc[ai], n)))
+                ai += 1
+            elif lt == 'c':
+                att.append(AttentionIntermediates(keys=view(self.xk[ci], self.xk[ci].shape[0]), values=view(self.xv[ci], self.xv[ci].shape[0])))
+                ci += 1
         return TupleTransformerCaches(token_emb=self.tok_emb[None, :n],
                                       transformer=TransformerIntermediates(hiddens=[h[None, :n] for h in self.hid], attention=att))
 
@@ -332,6 +387,8 @@ class RenderSession(GreedyDecoder):
 
     def __init__(self, decoder, max_len: int, dims: List[int], mask_token_id: int = 1, **kw):
         super().__init__(decoder, max_len, **kw)
+        if self.cross:
+            raise NotImplementedError("render session: cross-attending decoders render through GreedyDecoder / the module path")
         m, dev = self.m, self.dev
         self._alloc(max_len)
         K = len(m.token_emb.embs)

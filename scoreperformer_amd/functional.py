@@ -298,9 +298,12 @@ def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5, fork=False):
     return LayerNormFn.apply(x, gamma, beta, out_fp32, eps, fork)
 
 
-# dtype of the per-token (gamma | beta) rows of an adaptive norm: the largest tensor of the norm ([T, 2D]); SPN_ADALN_GB=bf16 halves it
+# dtype of the per-token (gamma | beta) rows of an adaptive norm: the largest tensor of the norm ([T, 2D], written by a GEMM, read by
+# the LayerNorm forward and backward).  bf16 by default since round 2: -1.7 ms per C3 step for |loss_HIP - loss_CPU| 3.8e-4 -> 4.4e-4
+# at C3 scale, inside the 1e-3 budget that tests/test_parity_c2_gpu.py asserts together with the gradient bounds; SPN_ADALN_GB=fp32
+# restores the fp32 rows.
 import os as _os
-ADALN_GB_DTYPE = BF16 if _os.environ.get("SPN_ADALN_GB", "fp32") == "bf16" else F32
+ADALN_GB_DTYPE = F32 if _os.environ.get("SPN_ADALN_GB", "bf16") == "fp32" else BF16
 
 
 class AdaLayerNormFn(Function):

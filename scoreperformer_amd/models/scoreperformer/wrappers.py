@@ -309,7 +309,8 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
             filled, masked_view = call.arrays[0].clone().detach(), call.arrays[1]
             engine = self._engine_for(filled, call.mask, caches, banned, filter_logits_fn, filter_kwargs)
             if engine is not None:
-                filled, _ = engine.run(filled, masked_view, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id)
+                filled, _ = engine.run(filled, masked_view, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id,
+                                       context_mask=kwargs.get("context_mask"))
                 caches = engine.caches() if return_caches else None
             else:
                 holes = filled == self.mask_token_id

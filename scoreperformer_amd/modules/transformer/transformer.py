@@ -129,7 +129,12 @@ class Transformer(nn.Module, Constructor):
             if layer_type == 'a':
                 out, inter, _ = block(h, mask=mask, cache=cache, residual=res_arg)
             elif layer_type == 'c':
-                out, inter, _ = block(h, context=ctx_b, mask=mask, context_mask=context_mask, residual=res_arg)
+                # under the cache protocol the block sees ONE query: its row mask is the last column.  (The reference passes the
+                # whole-prefix mask here, transformer.py:201, and attention.py:216-218 then BROADCASTS the single output row to the
+                # prefix length -- the rows pile up in its caches and `hidden_state[:, idx - 1]` reads a stale position from the third
+                # decoded note on; oracle/ref_cpu.py greedy_unmask reproduces that defect to pin itself, the product does not.)
+                qmask = mask[:, -1:] if (has_cache and mask is not None) else mask
+                out, inter, _ = block(h, context=ctx_b, mask=qmask, context_mask=context_mask, residual=res_arg)
             else:
                 out = block(h, residual=res_arg)
             x = out if fuse else residual_fn(out, residual)

@@ -853,6 +853,13 @@ def dec_attn2(qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, *, h, k
     return o
 
 
+def dec_xattn(q, kctx, vctx, slopes, kmask, o, part, counter, *, h, kvh, scale, splits):
+    """Single-query cross-attention over the projected context rows (see spn_dec_xattn); kmask: uint8 [nk] or None."""
+    call("spn_dec_xattn", ptr(q), ptr(kctx), ptr(vctx), ptr(slopes), ptr(kmask), c_int(kctx.shape[0]), ptr(o), ptr(part), ptr(counter),
+         c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
+    return o
+
+
 def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1):
     V = [t.shape[0] for t in tables]
     W = [t.shape[1] for t in tables]

@@ -109,3 +109,23 @@ def test_oracle_greedy_matches_reference_cached_decode():
     out = ref_cpu.greedy_unmask(sd, cfg, tokens, torch.from_numpy(fix["in/masked_perf"]),
                                 torch.from_numpy(fix["out/score_embeddings"]), torch.from_numpy(fix["out/perf_embeddings"]))
     np.testing.assert_array_equal(out.numpy(), fix["out/tokens"])
+
+
+def test_oracle_greedy_matches_reference_cached_decode_with_cross_attention():
+    """Decoder layer blocks ('a','c','f') (context_emb_mode='attention'): the reference's cached `unmask_tokens` over a padded score
+    (tests/golden/tiny_greedy_xattn.npz, oracle/refimport/make_golden_greedy_xattn.py) equals the oracle's greedy loop token for token
+    -- INCLUDING the reference's defect in that mode (it reads a stale hidden row from the third decoded note on: see
+    ref_cpu.greedy_unmask); with the intended row the two agree exactly on the notes decoded before the defect bites."""
+    fix = load("tiny_greedy_xattn")
+    kw = dict(preset="tiny", context_emb_mode="attention", num_tokens=SMALL_VOCAB)
+    cfg = model_config(**kw)
+    sd = filled_state_dict(ScorePerformer.init(model_config(**kw)), seed=4)
+    out = ref_cpu.greedy_unmask(sd, cfg, torch.from_numpy(fix["in/tokens"]), torch.from_numpy(fix["in/masked_perf"]),
+                                torch.from_numpy(fix["out/score_embeddings"]), torch.from_numpy(fix["out/perf_embeddings"]),
+                                context_mask=torch.from_numpy(fix["in/score_mask"]), reference_hidden_row_defect=True)
+    np.testing.assert_array_equal(out.numpy(), fix["out/tokens"])
+    intended = ref_cpu.greedy_unmask(sd, cfg, torch.from_numpy(fix["in/tokens"]), torch.from_numpy(fix["in/masked_perf"]),
+                                     torch.from_numpy(fix["out/score_embeddings"]), torch.from_numpy(fix["out/perf_embeddings"]),
+                                     context_mask=torch.from_numpy(fix["in/score_mask"]))
+    np.testing.assert_array_equal(intended.numpy()[:, :3], fix["out/tokens"][:, :3])
+    assert (intended.numpy() != fix["out/tokens"]).any()
