@@ -86,8 +86,12 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
                     tmax = fmaxf(tmax, t);
                 }
         }
-        tmax = group_max(tmax) + u;
+        // The running maximum only has to be the SAME for the 4 lanes of a row and within 2^RESCALE_THR of the true one.  So the test uses
+        // each lane's OWN maximum (no cross-lane traffic); the two swizzles of the row reduction -- LDS-crossbar round trips in the
+        // middle of the dependency chain max -> exp -> P V -- run only in the rare iteration that actually raises a maximum.
+        tmax += u;
         if (__any(tmax > m_run[qb] + RESCALE_THR)) {   // wave-uniform: rescale only when some row's max really grew
+            tmax = group_max(tmax);
             const float m_new = fmaxf(m_run[qb], tmax);
             const float alpha = fast_exp2(m_run[qb] - m_new);
             m_run[qb] = m_new;
@@ -123,11 +127,15 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 8192 + 64 + 16];
-    char* k_tile = smem;            // "a" layout
-    char* v_tile = smem + 8192;     // "t" layout
-    uint8_t* m_tile = reinterpret_cast<uint8_t*>(smem + 16384);
-    int* full_flag = reinterpret_cast<int*>(smem + 16384 + 64);
+    // K / V tiles arrive by LDS DMA (buffer_load ... lds: no VGPR round trip, no ds_write, no address arithmetic in the loop) into
+    // two alternating stages, so ONE barrier per key tile both publishes tile t and proves that the stage tile t+1 is about to
+    // overwrite is no longer read.  The DMA writes LDS linearly (wave base + lane * 16): the XOR swizzles of the "a" / "t" layouts sit
+    // on the SOURCE address.  Rows past the end of the sequence lie outside the buffer resource and read as zero.
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384 + 2 * 64 + 16];
+    char* k_stage = smem;             // [2][8 KiB] "a" layout
+    char* v_stage = smem + 16384;     // [2][8 KiB] "t" layout
+    uint8_t* m_stage = reinterpret_cast<uint8_t*>(smem + 32768);    // [2][64] key mask bytes
+    int* full_flags = reinterpret_cast<int*>(smem + 32768 + 128);   // [2]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, hi = blockIdx.y, qt;
@@ -183,27 +191,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
     }
 
-    TileRegs kr, vr;
+    const int wv = __builtin_amdgcn_readfirstlane(w);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
+    uint32_t voK[2], voV[2];   // this wave's two 1 KiB pieces of a tile: LDS chunk L = piece * 64 + lane <- source chunk (inverse swizzle)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wv * 2 + i) * 64 + lane, row = L >> 3, ch = L & 7;
+        voK[i] = (uint32_t)(((long)row * a.k_ns + ((ch ^ (row & 7)) << 3)) * 2);
+        voV[i] = (uint32_t)(((long)row * a.v_ns + ((ch ^ (((row >> 1) & 3) << 1)) << 3)) * 2);
+    }
+    auto issue_tile = [&](int t) {
+        char* kd = k_stage + (t & 1) * 8192 + wv * 2048;
+        char* vd = v_stage + (t & 1) * 8192 + wv * 2048;
+        const uint32_t sk = (uint32_t)(t * 64) * (uint32_t)a.k_ns * 2u, sv = (uint32_t)(t * 64) * (uint32_t)a.v_ns * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(kd + i * 1024), 16, voK[i], sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(vd + i * 1024), 16, voV[i], sv, 0, 0);
+        }
+    };
     uint8_t mreg = 1;
     if (nt > t_lo) {
-        kr.load(kp, a.k_ns, t_lo * 64, a.nk, tid);
-        vr.load(vp, a.v_ns, t_lo * 64, a.nk, tid);
+        issue_tile(t_lo);
         if (tid < 64) { const int j = t_lo * 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
     }
     for (int t = t_lo; t < nt; ++t) {
         const int j0 = t * 64;
-        __syncthreads();
-        kr.store<false>(k_tile, tid);
-        vr.store<true>(v_tile, tid);
+        const char* k_tile = k_stage + (t & 1) * 8192;
+        const char* v_tile = v_stage + (t & 1) * 8192;
+        const uint8_t* m_tile = m_stage + (t & 1) * 64;
+        const int* full_flag = full_flags + (t & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t (requested a whole iteration ago) have landed
         if (tid < 64) {
-            m_tile[tid] = mreg;
+            m_stage[(t & 1) * 64 + tid] = mreg;
             const unsigned long long all = __ballot(mreg != 0);
-            if (tid == 0) *full_flag = (all == ~0ull) ? 1 : 0;
+            if (tid == 0) full_flags[t & 1] = (all == ~0ull) ? 1 : 0;
         }
-        __syncthreads();
+        __syncthreads();   // tile t visible to all; everybody is done with the other stage (read in iteration t - 1)
         if (t + 1 < nt) {
-            kr.load(kp, a.k_ns, j0 + 64, a.nk, tid);
-            vr.load(vp, a.v_ns, j0 + 64, a.nk, tid);
+            issue_tile(t + 1);
             if (tid < 64) { const int j = j0 + 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
         }
         const int cls = classify(j0, i_lo, i_hi, *full_flag != 0, a.causal != 0);

@@ -30,9 +30,9 @@ static inline int spn_tune_i(SpnTune k) { return (int)spn_tune(k); }
 #include <hip/hip_runtime.h>
 static inline void spn_lds_optin(std::atomic<unsigned>& mask, const void* fn, int bytes) {
     int dev = 0;
-    hipGetDevice(&dev);
+    (void)hipGetDevice(&dev);
     const unsigned bit = 1u << (dev & 31);
     if (mask.load(std::memory_order_acquire) & bit) return;
-    hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     mask.fetch_or(bit, std::memory_order_release);
 }
