@@ -344,12 +344,11 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * 8192 + 64 + 16];
-    char* k_tile = smem;              // "a": A operand of S^T
-    char* kt_tile = smem + 8192;      // "t": K^T A operand of dQ^T
-    char* v_tile = smem + 16384;      // "a": A operand of dP^T = V dO^T
-    uint8_t* m_tile = reinterpret_cast<uint8_t*>(smem + 24576);
-    int* full_flag = reinterpret_cast<int*>(smem + 24576 + 64);
+    // three images per key tile -- K "a" (A operand of S^T), K "t" (K^T, A operand of dQ^T), V "a" (A operand of dP^T = V dO^T) -- by LDS
+    // DMA into two alternating stages, one barrier per tile (see attn_fwd_kernel); K is fetched twice (it comes from the L2)
+    __shared__ __attribute__((aligned(16))) char smem[2 * 24576 + 2 * 64 + 16];
+    uint8_t* m_stage = reinterpret_cast<uint8_t*>(smem + 49152);
+    int* full_flags = reinterpret_cast<int*>(smem + 49152 + 128);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, hi = blockIdx.y, qt;
@@ -424,30 +423,50 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
         }
     }
-    TileRegs kr, vr;
+    const int wv = __builtin_amdgcn_readfirstlane(w);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
+    uint32_t voKa[2], voKt[2], voV[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wv * 2 + i) * 64 + lane, row = L >> 3, ch = L & 7;
+        voKa[i] = (uint32_t)(((long)row * a.k_ns + ((ch ^ (row & 7)) << 3)) * 2);
+        voKt[i] = (uint32_t)(((long)row * a.k_ns + ((ch ^ (((row >> 1) & 3) << 1)) << 3)) * 2);
+        voV[i] = (uint32_t)(((long)row * a.v_ns + ((ch ^ (row & 7)) << 3)) * 2);
+    }
+    auto issue_tile = [&](int t) {
+        char* base = smem + (t & 1) * 24576 + wv * 2048;
+        const uint32_t sk = (uint32_t)(t * 64) * (uint32_t)a.k_ns * 2u, sv = (uint32_t)(t * 64) * (uint32_t)a.v_ns * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, voKa[i], sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(base + 8192 + i * 1024), 16, voKt[i], sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(base + 16384 + i * 1024), 16, voV[i], sv, 0, 0);
+        }
+    };
     uint8_t mreg = 1;
     if (nt > t_lo) {
-        kr.load(kp, a.k_ns, t_lo * 64, a.nk, tid);
-        vr.load(vp, a.v_ns, t_lo * 64, a.nk, tid);
+        issue_tile(t_lo);
         if (tid < 64) { const int j = t_lo * 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
         if (DROP) { kwn[0] = bitbase[t_lo * 64]; kwn[1] = bitbase[bstride + t_lo * 64]; }
     }
     for (int t = t_lo; t < nt; ++t) {
         const int j0 = t * 64;
-        __syncthreads();
+        const char* k_tile = smem + (t & 1) * 24576;
+        const char* kt_tile = k_tile + 8192;
+        const char* v_tile = k_tile + 16384;
+        const uint8_t* m_tile = m_stage + (t & 1) * 64;
+        const int* full_flag = full_flags + (t & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t's pieces (and its keep-bit words) have landed
         kw[0] = kwn[0]; kw[1] = kwn[1];
-        kr.store<false>(k_tile, tid);
-        kr.store<true>(kt_tile, tid);
-        vr.store<false>(v_tile, tid);
         if (tid < 64) {
-            m_tile[tid] = mreg;
+            m_stage[(t & 1) * 64 + tid] = mreg;
             const unsigned long long all = __ballot(mreg != 0);
-            if (tid == 0) *full_flag = (all == ~0ull) ? 1 : 0;
+            if (tid == 0) full_flags[t & 1] = (all == ~0ull) ? 1 : 0;
         }
         __syncthreads();
         if (t + 1 < nt) {
-            kr.load(kp, a.k_ns, j0 + 64, a.nk, tid);
-            vr.load(vp, a.v_ns, j0 + 64, a.nk, tid);
+            issue_tile(t + 1);
             if (tid < 64) { const int j = j0 + 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
             if (DROP) { kwn[0] = bitbase[(t + 1) * 64]; kwn[1] = bitbase[bstride + (t + 1) * 64]; }
         }

@@ -82,13 +82,11 @@ __device__ __forceinline__ void dkv_tile(const char* q_tile, const char* qt_tile
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 8192 + 512];
-    char* q_tile = smem;               // "a": A operand of S
-    char* qt_tile = smem + 8192;       // "t": Q^T A operand of dK^T
-    char* do_tile = smem + 16384;      // "a": A operand of dP
-    char* dot_tile = smem + 24576;     // "t": dO^T A operand of dV^T
-    float* nl2_s = reinterpret_cast<float*>(smem + 32768);   // -lse * log2e per row (NEG_FILL for dead rows: p = 0)
-    float* dl_s = nl2_s + 64;
+    // per (head, query tile): Q "a" (A operand of S), Q "t" (Q^T, A operand of dK^T), dO "a" (A operand of dP), dO "t" (dO^T, A operand
+    // of dV^T) -- four 8 KiB images by LDS DMA into two alternating stages, one barrier per tile (see attn_fwd_kernel); the XOR swizzles
+    // sit on the source address, rows past nq lie outside the buffer resource and read as zero
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32768 + 2 * 512];
+    float* stat_s = reinterpret_cast<float*>(smem + 65536);   // [2][-lse * log2e per row (NEG_FILL for dead rows: p = 0) | delta per row]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     int bi = blockIdx.z, kh = blockIdx.y, jt = blockIdx.x;
@@ -141,8 +139,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) { bw[qb] = make_uint2(0, 0); bwn[qb] = make_uint2(0, 0); }
 
-    TileRegs qr, dor;
+    const int wv = __builtin_amdgcn_readfirstlane(w);
+    uint32_t voQa[2], voQt[2], voDa[2], voDt[2];   // this wave's two 1 KiB pieces of each image: LDS chunk <- inverse-swizzled source chunk
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wv * 2 + i) * 64 + lane, row = L >> 3, ch = L & 7;
+        const int ca = (ch ^ (row & 7)) << 3, ct = (ch ^ (((row >> 1) & 3) << 1)) << 3;
+        voQa[i] = (uint32_t)(((long)row * a.q_ns + ca) * 2); voQt[i] = (uint32_t)(((long)row * a.q_ns + ct) * 2);
+        voDa[i] = (uint32_t)(((long)row * a.o_ns + ca) * 2); voDt[i] = (uint32_t)(((long)row * a.o_ns + ct) * 2);
+    }
     float lreg = 0.f, dreg = 0.f;
+    int n_issued = 0;   // stage of the next issue = n_issued & 1
     auto issue = [&](int it) {
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
@@ -151,8 +158,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb) bwn[qb] = *reinterpret_cast<const uint2*>(bp + qb * bstride);
         }
-        qr.load(a.q + bi * a.q_bs + hh * a.q_hs, a.q_ns, i0, a.nq, tid);
-        dor.load(a.d_o + bi * a.o_bs + hh * a.o_hs, a.o_ns, i0, a.nq, tid);
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + bi * a.q_bs + hh * a.q_hs), 0,
+                                                                              (int)(((long)(a.nq - 1) * a.q_ns + 64) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.d_o + bi * a.o_bs + hh * a.o_hs), 0,
+                                                                              (int)(((long)(a.nq - 1) * a.o_ns + 64) * 2), 0x00020000);
+        char* base = smem + (n_issued & 1) * 32768 + wv * 2048;
+        const uint32_t sq = (uint32_t)i0 * (uint32_t)a.q_ns * 2u, sd = (uint32_t)i0 * (uint32_t)a.o_ns * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, voQa[i], sq, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(base + 8192 + i * 1024), 16, voQt[i], sq, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(base + 16384 + i * 1024), 16, voDa[i], sd, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (__attribute__((address_space(3))) void*)(base + 24576 + i * 1024), 16, voDt[i], sd, 0, 0);
+        }
+        ++n_issued;
         if (tid < 64) {
             const int i = i0 + tid;
             const long si = ((long)bi * a.h + hh) * a.nq + i;
@@ -180,15 +199,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
         const float slope2 = a.slopes ? a.slopes[hh] * LOG2E : 0.f;
-        __syncthreads();
-        qr.store<false>(q_tile, tid);
-        qr.store<true>(qt_tile, tid);
-        dor.store<false>(do_tile, tid);
-        dor.store<true>(dot_tile, tid);
+        const int stage = (n_issued - 1) & 1;   // the stage the tile of THIS iteration was requested into
+        const char* q_tile = smem + stage * 32768;
+        const char* qt_tile = q_tile + 8192;
+        const char* do_tile = q_tile + 16384;
+        const char* dot_tile = q_tile + 24576;
+        float* nl2_s = stat_s + stage * 128;
+        float* dl_s = nl2_s + 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces, the row statistics and the keep-bit words have landed
         if (tid < 64) { nl2_s[tid] = lreg; dl_s[tid] = dreg; }
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) bw[qb] = bwn[qb];
-        __syncthreads();
+        __syncthreads();   // tile visible to all; everybody is done with the other stage
         if (it_next < n_iter) issue(it_next);
 
         // tile class of this wave's 32 keys against the 64 rows (key coordinates i + off)
