@@ -172,6 +172,10 @@ int spn_dec_gemv(const float* W, long ldw, const float* x, long x_ld, int x_off,
                  long y_ld, int y_off, const int* pos, int N, int K, int kn_layout, spn_stream_t s);
 int spn_dec_embed(int nkeys, const float* const* tables, const int* E, const long* tokens, long tok_ld, int row_off, const int* pos,
                   const float* gamma, const float* beta, float* y, float eps, spn_stream_t s);
+/* spn_dec_embed + the embeddings' projection GEMV for both sequences of a multi-sequence decoder in one launch (bit-identical values) */
+int spn_dec_embed_proj(int nkeys, const float* const* tables, const int* E, const long* tokens_a, const long* tokens_b, long tok_ld,
+                       const int* pos, const float* gamma, const float* beta, float eps, const float* W, long ldw, const float* bias, float* y,
+                       int N, spn_stream_t s);
 int spn_dec_copy_row(const float* src, long src_ld, int src_off, float* dst, long dst_ld, int dst_off, const int* pos, int D,
                      spn_stream_t s);
 int spn_dec_glu(const float* u, float* out, int I, int act, int glu, spn_stream_t s);
@@ -186,6 +190,8 @@ int spn_dec_add_pos(int* pos, int delta, spn_stream_t s);
 int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const float* x, long x_ld, int x_off, int norm, const float* gamma,
                        const float* beta, float eps, const float* bias, const float* residual, float* y, long y_ld, int y_off, float* y2,
                        long y2_ld, int y2_off, float* xn_out, long xn_ld, int xn_off, int glu, int act, const int* pos, spn_stream_t s);
+/* o = null in spn_dec_attn2 / spn_dec_xattn leaves only the split-key partials; this GEMV merges them in its prologue */
+int spn_dec_attn_out(const float* W, long ldw, int N, const float* part, int h, int splits, const float* residual, float* y, spn_stream_t s);
 int spn_dec_cat(const float* x, int d, const float* gamma, const float* beta, float eps, const float* ctx, long ctx_ld, int ctx_w,
                 const float* style, long style_ld, int style_w, const int* pos, float* out, spn_stream_t s);
 int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part, int* counter,

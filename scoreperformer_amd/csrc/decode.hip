@@ -97,6 +97,62 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedDesc d, const lo
     for (int c = threadIdx.x; c < d.D; c += 256) y[c] = (buf[c] - mu) * rs * gamma[c] + beta[c];
 }
 
+// Token-tuple embedding AND its projection for BOTH sequences of a multi-sequence decoder in one launch (blockIdx.y = sequence:
+// 0 = the tokens at row *pos, 1 = the masked copy at row *pos + 1):  y[seq * N + n] = W[n, :] . LN(concat_k table_k[token_k]) + bias[n].
+// Every block rebuilds the (<= 2048-wide) embedding in LDS -- the same gather, statistics and normalisation as dec_embed_kernel -- and
+// then runs the row products of gemv_nk_kernel, so the values equal dec_embed + gemv bit for bit (4 launches of a decode step become 1).
+__global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, const long* __restrict__ tok_a, const long* __restrict__ tok_b,
+                                                             long tok_ld, const int* __restrict__ pos, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, const float* __restrict__ W, long ldw,
+                                                             const float* __restrict__ bias, float* __restrict__ y, int N) {
+    __shared__ __attribute__((aligned(16))) float buf[2048];
+    __shared__ float red[8];
+    const int seq = blockIdx.y;
+    const long* tok = (seq ? tok_b : tok_a) + (long)(*pos + seq) * tok_ld;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < d.D; c += 256) {
+        int kk = 0;
+        for (int q = 1; q < d.nkeys; ++q) if (c >= d.col0[q]) kk = q;
+        const float v = d.table[kk][tok[kk] * d.width[kk] + (c - d.col0[kk])];
+        buf[c] = v;
+        s += v;
+    }
+    if (gamma) {
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
+        float q2 = 0.f;
+        for (int c = threadIdx.x; c < d.D; c += 256) { const float t = buf[c] - mu; q2 += t * t; }
+        q2 = wave_sum(q2);
+        if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q2;
+        __syncthreads();
+        const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+        for (int c = threadIdx.x; c < d.D; c += 256) buf[c] = (buf[c] - mu) * rs * gamma[c] + beta[c];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = W + (long)n * ldw;
+    const int K = d.D;
+    float acc = 0.f;
+    if ((K & 3) == 0 && (ldw & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(buf + k);
+            acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) acc = fmaf(w[k], buf[k], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (bias) acc += bias[n];
+        y[seq * N + n] = acc;
+    }
+}
+
 // dst[(*pos + dst_off) * dst_ld + c] = src[(*pos + src_off) * src_ld + c]   (ld = 0: fixed row)
 __global__ void dec_copy_row_kernel(const float* __restrict__ src, long src_ld, int src_off, float* __restrict__ dst, long dst_ld,
                                     int dst_off, const int* __restrict__ pos, int D) {
@@ -256,6 +312,10 @@ struct DecGemvArgs {
     float* xn_out; long xn_ld; int xn_off;
     int glu, act;
     const int* pos;
+    // x = the attention output merged from the split-key partials of dec_attn2 / dec_xattn (launched with merge = 0): [h][S] records of
+    // (running max, normaliser, 64 weighted value sums).  Every block redoes the 8 KiB merge in its prologue; the kernel boundary in
+    // front of this launch orders it behind the partials, so the attention kernel needs neither fences nor a last-block tail.
+    const float* att_part; int att_h, att_S;
 };
 __device__ __forceinline__ float dec_act(float g, int act) {
     return act == 0 ? g / (1.f + __expf(-g)) : 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
@@ -265,9 +325,45 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
     __shared__ float red[8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int p = a.pos ? *a.pos : 0;
-    const float* x = a.x + (long)(p + a.x_off) * a.x_ld;
     float s = 0.f;
-    for (int k = threadIdx.x; k < a.K; k += 256) { const float v = x[k]; xs[k] = v; s += v; }
+    if (a.att_part) {
+        // K = h * 64.  Same expression order as the in-kernel merge of dec_attn2_kernel (bit-identical o), but the loads of a 16-record
+        // chunk are issued together: a dependent load per record made this prologue 15 us long
+        for (int k = threadIdx.x; k < a.K; k += 256) {
+            const float* ph = a.att_part + (long)(k >> 6) * a.att_S * 66;
+            const int dcol = 2 + (k & 63);
+            float mm = -INFINITY;
+            for (int q0 = 0; q0 < a.att_S; q0 += 16) {
+                float mv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mv[q] = (q0 + q < a.att_S) ? ph[(q0 + q) * 66] : -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
+            }
+            float num = 0.f, den = 0.f;
+            for (int q0 = 0; q0 < a.att_S; q0 += 16) {
+                float mv[16], lv[16], nv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool in = q0 + q < a.att_S;
+                    mv[q] = in ? ph[(q0 + q) * 66] : -INFINITY;
+                    lv[q] = in ? ph[(q0 + q) * 66 + 1] : 0.f;
+                    nv[q] = in ? ph[(q0 + q) * 66 + dcol] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (q0 + q < a.att_S) {
+                        const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
+                        num += nv[q] * f; den += lv[q] * f;
+                    }
+                }
+            }
+            xs[k] = num / den;
+        }
+    } else {
+        const float* x = a.x + (long)(p + a.x_off) * a.x_ld;
+        for (int k = threadIdx.x; k < a.K; k += 256) { const float v = x[k]; xs[k] = v; s += v; }
+    }
     if (a.norm) {
         s = wave_sum(s);
         if (lane == 0) red[w] = s;
@@ -353,7 +449,7 @@ __global__ __launch_bounds__(256) void dec_cat_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict__ qkv, float* __restrict__ kcache, float* __restrict__ vcache,
                                                         const float* __restrict__ slopes, const int* __restrict__ pos, float* __restrict__ o,
                                                         float* __restrict__ part, int* __restrict__ counter, float* __restrict__ kmax2,
-                                                        int h, int kvh, float scale) {
+                                                        int h, int kvh, float scale, int merge) {
     __shared__ float sm[16], sl[16];
     __shared__ __attribute__((aligned(16))) float so[16][64];
     __shared__ int is_last;
@@ -418,6 +514,7 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
         mine[2 + tid] = num;
         if (tid == 0) { mine[0] = mm; mine[1] = den; }
     }
+    if (!merge) return;   // the consumer GEMV merges the partials (DecGemvArgs::att_part)
     __threadfence();
     __syncthreads();
     if (tid == 0) is_last = (atomicAdd(counter + hi, 1) == S - 1);
@@ -447,7 +544,7 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict__ q, const float* __restrict__ kctx, const float* __restrict__ vctx,
                                                         const float* __restrict__ slopes, const uint8_t* __restrict__ kmask, int nk,
                                                         float* __restrict__ o, float* __restrict__ part, int* __restrict__ counter,
-                                                        int h, int kvh, float scale) {
+                                                        int h, int kvh, float scale, int merge) {
     __shared__ float sm[16], sl[16];
     __shared__ __attribute__((aligned(16))) float so[16][64];
     __shared__ int is_last;
@@ -492,6 +589,7 @@ __global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict_
         mine[2 + tid] = num;
         if (tid == 0) { mine[0] = mm; mine[1] = den; }
     }
+    if (!merge) return;   // the consumer GEMV merges the partials (DecGemvArgs::att_part)
     __threadfence();
     __syncthreads();
     if (tid == 0) is_last = (atomicAdd(counter + hi, 1) == S - 1);
@@ -664,6 +762,23 @@ extern "C" int spn_dec_embed(int nkeys, const float* const* tables, const int* E
     return SPN_OK;
 }
 
+// both sequences' tuple embeddings + projection in one launch: y [2, N] (tokens_a at row *pos, tokens_b at row *pos + 1)
+extern "C" int spn_dec_embed_proj(int nkeys, const float* const* tables, const int* E, const long* tokens_a, const long* tokens_b, long tok_ld,
+                                  const int* pos, const float* gamma, const float* beta, float eps, const float* W, long ldw, const float* bias,
+                                  float* y, int N, hipStream_t s) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= 16 && tokens_a && tokens_b && pos && W && y && N > 0, "spn_dec_embed_proj: bad arguments");
+    DecEmbedDesc d;
+    memset(&d, 0, sizeof(d));
+    int col = 0;
+    for (int i = 0; i < nkeys; ++i) { d.table[i] = tables[i]; d.width[i] = E[i]; d.col0[i] = col; col += E[i]; }
+    d.nkeys = nkeys; d.D = col;
+    SPN_REQUIRE(col <= 2048, "spn_dec_embed_proj: total width <= 2048");
+    hipLaunchKernelGGL(dec_embed_proj_kernel, dim3(cdiv(N, 4), 2), dim3(256), 0, s, d, tokens_a, tokens_b, tok_ld, pos, gamma, beta, eps, W, ldw,
+                       bias, y, N);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 extern "C" int spn_dec_copy_row(const float* src, long src_ld, int src_off, float* dst, long dst_ld, int dst_off, const int* pos, int D,
                                 hipStream_t s) {
     SPN_REQUIRE(src && dst && pos && D > 0, "spn_dec_copy_row: bad arguments");
@@ -710,7 +825,19 @@ extern "C" int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const 
     SPN_REQUIRE(W && x && y && N > 0 && K > 0 && K <= 2048, "spn_dec_fused_gemv: bad arguments (K <= 2048)");
     SPN_REQUIRE(norm >= 0 && norm <= 2 && (norm != 2 || gamma), "spn_dec_fused_gemv: bad norm mode");
     DecGemvArgs a{W, ldw, N, K, x, x_ld, x_off, norm, gamma, beta, eps, bias, residual, y, y_ld, y_off, y2, y2_ld, y2_off,
-                  xn_out, xn_ld, xn_off, glu, act, pos};
+                  xn_out, xn_ld, xn_off, glu, act, pos, nullptr, 0, 0};
+    hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// Attention output projection whose input is merged on the fly from the split-key partials `part` [h][splits][66] that spn_dec_attn2 /
+// spn_dec_xattn leave when called with o = null:  y = residual + W . merge(part)   (W: [N, h*64]; attention.py:210-218 for one query)
+extern "C" int spn_dec_attn_out(const float* W, long ldw, int N, const float* part, int h, int splits, const float* residual, float* y,
+                                hipStream_t s) {
+    SPN_REQUIRE(W && part && y && N > 0 && h > 0 && h * 64 <= 2048 && splits > 0 && splits <= 64, "spn_dec_attn_out: bad arguments");
+    DecGemvArgs a{W, ldw, N, h * 64, nullptr, 0, 0, 0, nullptr, nullptr, 0.f, nullptr, residual, y, 0, 0, nullptr, 0, 0,
+                  nullptr, 0, 0, 0, -1, nullptr, part, h, splits};
     hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
@@ -725,11 +852,13 @@ extern "C" int spn_dec_cat(const float* x, int d, const float* gamma, const floa
 }
 
 // part: h * splits * 66 floats scratch; counter: h ints, zero before the first step (the kernel resets it); kmax2: kvh floats, zero at start
+// o == null: partials only (no fences, no last-block merge); the consumer spn_dec_fused_gemv merges them (att_part argument)
 extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part,
                              int* counter, float* kmax2, int h, int kvh, float scale, int splits, hipStream_t s) {
-    SPN_REQUIRE(qkv && kcache && vcache && pos && o && part && counter && kmax2 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
+    SPN_REQUIRE(qkv && kcache && vcache && pos && part && counter && kmax2 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
                 "spn_dec_attn2: bad arguments");
-    hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(256), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale);
+    hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(256), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale,
+                       o ? 1 : 0);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -738,9 +867,9 @@ extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, con
 // part: h * splits * 66 floats scratch; counter: h ints, zero before the first step (the kernel resets it)
 extern "C" int spn_dec_xattn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask, int nk, float* o,
                              float* part, int* counter, int h, int kvh, float scale, int splits, hipStream_t s) {
-    SPN_REQUIRE(q && kctx && vctx && o && part && counter && nk > 0 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
+    SPN_REQUIRE(q && kctx && vctx && part && counter && nk > 0 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
                 "spn_dec_xattn: bad arguments");
-    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, nk, o, part, counter, h, kvh, scale);
+    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, nk, o, part, counter, h, kvh, scale, o ? 1 : 0);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

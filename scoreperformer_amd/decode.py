@@ -31,6 +31,7 @@ class GreedyDecoder:
         import os
         attn_splits = int(os.environ.get("SPN_DEC_SPLITS", attn_splits))   # tuning aid
         self.head_slabs = int(os.environ.get("SPN_DEC_HEAD_SLABS", 8))
+        self.legacy_launches = os.environ.get("SPN_DEC_LEGACY", "0") == "1"   # A/B aid: round-1 launch list (separate embed / merge kernels)
         self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
         tr = m.transformer
         types = tuple(tr.layer_types)
@@ -100,6 +101,15 @@ class GreedyDecoder:
         if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection:
             self.head_Wt = head.project_emb.weight.data.float().t().contiguous()   # [total_emb, d]: row-major GEMV operand
 
+    def _slopes(self, block):
+        """ALiBi slopes of an attention block as a contiguous fp32 [h] tensor, computed ONCE per engine: the weights do not change during a
+        render, and `learned_logslopes.exp()` inside the captured step was six extra launches per note (28 us of 329)."""
+        cache = self.__dict__.setdefault("_slope_cache", {})
+        key = id(block)
+        if key not in cache:
+            cache[key] = block.rel_pos.padded_slopes().detach().float().contiguous().clone() if block.rel_pos is not None else None
+        return cache[key]
+
     def _project_context(self, context: torch.Tensor, context_mask: Optional[torch.Tensor]):
         """Keys / values of every cross-attention layer over the WHOLE context, once per render: the reference recomputes them from the
         context at every note (the 'c' block gets no cache: modules/transformer/transformer.py:201), the values are the same."""
@@ -122,11 +132,11 @@ class GreedyDecoder:
         else:
             self._ln(self.x, norm, self.h, True)
             ops.dec_gemv(block.to_q.weight.data, self.h, self.q_only)
-        slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
-        ops.dec_xattn(self.q_only, self.xk[ci], self.xv[ci], slopes, self.xmask, self.o, self.att_part, self.att_counter,
+        slopes = self._slopes(block)
+        ops.dec_xattn(self.q_only, self.xk[ci], self.xv[ci], slopes, self.xmask, None if fused else self.o, self.att_part, self.att_counter,
                       h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
-        if fused:
-            ops.dec_fused_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+        if fused:   # the output projection merges the split-key partials in its prologue: no fences / last-block tail in the attention kernel
+            ops.dec_attn_out(block.to_out.weight.data, self.att_part, self.x, h=self.heads, splits=self.attn_splits, residual=self.x)
         else:
             ops.dec_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
 
@@ -174,7 +184,7 @@ class GreedyDecoder:
                 self._ln(self.x, norms[0], self.h, True)
                 wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
                 ops.dec_gemv(wqkv, self.h, self.qkv)
-                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+                slopes = self._slopes(block)
                 ops.dec_attn(self.qkv, self.kc[ai], self.vc[ai], slopes, pos, self.o, h=self.heads, kvh=self.kvh, scale=block.scale)
                 ops.dec_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
                 ai += 1
@@ -242,9 +252,13 @@ class GreedyDecoder:
         te, tr = m.token_emb, m.transformer
         has_norm = isinstance(te.norm, nn.LayerNorm)
         gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
-        for si, (toks, off) in enumerate(((self.seq2d, 0), (self.masked2d, 1))):
-            ops.dec_embed(self.tables, toks, pos, self.e_cat, row_off=off, gamma=gam, beta=bet, eps=eps)
-            ops.dec_gemv(te.project_emb.weight.data, self.e_cat, self.proj_cat[si * d:(si + 1) * d], bias=te.project_emb.bias.data)
+        if self.legacy_launches:
+            for si, (toks, off) in enumerate(((self.seq2d, 0), (self.masked2d, 1))):
+                ops.dec_embed(self.tables, toks, pos, self.e_cat, row_off=off, gamma=gam, beta=bet, eps=eps)
+                ops.dec_gemv(te.project_emb.weight.data, self.e_cat, self.proj_cat[si * d:(si + 1) * d], bias=te.project_emb.bias.data)
+        else:   # both sequences' tuple embeddings and their projection: one launch (4 before)
+            ops.dec_embed_proj(self.tables, self.seq2d, self.masked2d, pos, te.project_emb.weight.data, te.project_emb.bias.data, self.proj_cat,
+                               gamma=gam, beta=bet, eps=eps)
         ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x, bias=te.project_multiemb.bias.data, pos=pos,
                            y2=self.tok_emb, y2_ld=d)
         en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
@@ -268,10 +282,13 @@ class GreedyDecoder:
             elif lt == 'a':
                 wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
                 ops.dec_fused_gemv(wqkv, self.x, self.qkv, norm=mode, gamma=g_, beta=b_, eps=eps_)
-                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
-                ops.dec_attn2(self.qkv, self.kc[ai], self.vc[ai], slopes, pos, self.o, self.att_part, self.att_counter, self.kmax2[ai],
-                              h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
-                ops.dec_fused_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+                slopes = self._slopes(block)
+                ops.dec_attn2(self.qkv, self.kc[ai], self.vc[ai], slopes, pos, self.o if self.legacy_launches else None, self.att_part,
+                              self.att_counter, self.kmax2[ai], h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
+                if self.legacy_launches:
+                    ops.dec_fused_gemv(block.to_out.weight.data, self.o, self.x, residual=self.x)
+                else:
+                    ops.dec_attn_out(block.to_out.weight.data, self.att_part, self.x, h=self.heads, splits=self.attn_splits, residual=self.x)
                 ai += 1
             else:
                 lin = block.ff[0].proj if block.glu else block.ff[0][0]

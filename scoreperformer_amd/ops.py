@@ -807,6 +807,16 @@ def dec_embed(tables, tokens2d, pos, y, *, row_off=0, gamma=None, beta=None, eps
     return y
 
 
+def dec_embed_proj(tables, tokens_a, tokens_b, pos, W, bias, y, *, gamma=None, beta=None, eps=1e-5):
+    """y[0:N] / y[N:2N] = W . LN(tuple embedding of tokens_a[*pos] / tokens_b[*pos + 1]) + bias: dec_embed + dec_gemv for both sequences."""
+    if tokens_a.stride(0) != tokens_b.stride(0):
+        raise SpnError("dec_embed_proj: the two token arrays must share their row stride")
+    E = [t.shape[1] for t in tables]
+    call("spn_dec_embed_proj", c_int(len(tables)), _ptr_array(tables), _int_array(E), ptr(tokens_a), ptr(tokens_b), c_long(tokens_a.stride(0)),
+         ptr(pos), ptr(gamma), ptr(beta), c_float(eps), ptr(W), c_long(W.stride(0)), ptr(bias), ptr(y), c_int(W.shape[0]), stream_ptr())
+    return y
+
+
 def dec_copy_row(src, dst, pos, D, *, src_ld=0, src_off=0, dst_ld=0, dst_off=0):
     call("spn_dec_copy_row", ptr(src), c_long(src_ld), c_int(src_off), ptr(dst), c_long(dst_ld), c_int(dst_off), ptr(pos), c_int(D),
          stream_ptr())
@@ -851,6 +861,13 @@ def dec_attn2(qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, *, h, k
     call("spn_dec_attn2", ptr(qkv), ptr(kcache), ptr(vcache), ptr(slopes), ptr(pos), ptr(o), ptr(part), ptr(counter), ptr(kmax2),
          c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
     return o
+
+
+def dec_attn_out(W, part, y, *, h, splits, residual=None):
+    """y = residual + W . (attention output merged from the partials left by dec_attn2 / dec_xattn with o=None)."""
+    call("spn_dec_attn_out", ptr(W), c_long(W.stride(0)), c_int(W.shape[0]), ptr(part), c_int(h), c_int(splits), ptr(residual), ptr(y),
+         stream_ptr())
+    return y
 
 
 def dec_xattn(q, kctx, vctx, slopes, kmask, o, part, counter, *, h, kvh, scale, splits):
