@@ -72,4 +72,38 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- LDS DMA through inline asm ----------------------------------------------------------------------------------------------
+// `buffer_load_dwordx4 ... offen lds` copies 16 bytes per lane from a buffer resource straight into LDS (wave-uniform LDS base in M0
+// + lane * 16).  Issued through the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) hipcc tracks the copy as a pending LDS write on
+// the VM counter and puts `s_waitcnt vmcnt(0)` in front of every later ds_read_b64_tr_b16 (and in front of LDS traffic of an epilogue):
+// a software pipeline that keeps several tiles in flight is drained once per phase.  Issued through asm the compiler knows nothing
+// about it: completion is counted by hand (`s_waitcnt vmcnt(N)` in asm, then a barrier, then the reads), which these kernels did
+// anyway.  M0 is written in the statement that uses it.  The leading s_nop covers a resource / offset operand that the compiler has
+// just moved into SGPRs with v_readlane / v_readfirstlane (VALU write of an SGPR -> VMEM read: 5 wait states; hipcc pads nothing
+// inside or in front of an asm statement).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 spn_buffer_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);   // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);                           // raw buffer: bounds check in bytes, out of range reads 0
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ uint32_t spn_lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// one 1 KiB piece: LDS [lds .. lds + 1023] <- lane l: 16 bytes at resource offset voff(l) + soff
+__device__ __forceinline__ void spn_dma16(const u32x4 rs, uint32_t lds, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// two pieces into consecutive KiB of LDS (the second piece's per-lane offset in voff1)
+__device__ __forceinline__ void spn_dma16x2(const u32x4 rs, uint32_t lds, uint32_t voff0, uint32_t voff1, uint32_t soff) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds"
+                 :: "s"(lds), "v"(voff0), "v"(voff1), "s"(rs), "s"(soff) : "memory", "scc");
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

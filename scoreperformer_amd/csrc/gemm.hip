@@ -28,6 +28,7 @@
 // Tile order: XCD-contiguous (workgroup id % 8 = XCD), column groups of 8 n-tiles, m-tiles down each group.
 #include "common.h"
 #include "tuning.h"
+#include <type_traits>
 
 namespace {
 
@@ -51,6 +52,7 @@ struct GemmArgs {
     int ngroup;               // n-tiles per column group of the tile order
     int pp_addr_ok;           // both operands span < 2^31 bytes (the ping-pong kernel addresses them with 32-bit offsets)
     int slice_xcd;            // ping-pong kernel, split-K: remap blocks so that an XCD runs whole K slices (see the kernel)
+    int stagger;              // persistent launch: start delay per CU slot (shader cycles)
     int tx, ty;               // ping-pong kernel: tile grid (n-tiles, m-tiles); a launch with fewer blocks walks it persistently
     // gated-linear-unit epilogue (spn_gemm_glu): N = I gated outputs, B = [2I, K] (value rows | gate rows), C = u [M, 2I]
     void* ws;                 // caller-owned split-K workspace (or null) and its size
@@ -559,7 +561,16 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
 }
 
 // GLU: 0 = plain GEMM; 1 = SiLU, 2 = GELU gated epilogue (TA = TB = false, bf16 out)
-template <bool TA, bool TB, typename OutT, int GLU = 0>
+// PERSIST: the launch has fewer blocks than tiles and every block walks the tile ids block, block + stride, ...: no workgroup launch
+// between tiles, the next tile's first half-tiles are requested before the epilogue and the stores of the epilogue drain under the next
+// main loop (its first waits credit them: the VM counter retires in order).
+//
+// The LDS DMA is issued through inline asm (spn_dma16x2, common.h): through the builtin hipcc fenced every ds_read_b64_tr_b16 (and the
+// LDS staging of the epilogue) behind `s_waitcnt vmcnt(0)`, which drained the four half-tiles in flight once per phase in every
+// kernel with a transposed operand (dX and dW GEMMs), and with the descriptors pushed out of the SGPR file (fp32-output
+// instantiations) wrapped each DMA instruction in a readfirstlane waterfall loop.  The K loop is peeled into a steady-state body (every
+// phase issues, every wait is vmcnt(8): no scalar branches between the barriers), the last-but-one and the last K tile.
+template <bool TA, bool TB, typename OutT, int GLU = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // slot of half-tile kind c (0 AX, 1 BX, 2 BY, 3 AY) of K tile t
@@ -571,11 +582,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const long long t_start = __builtin_amdgcn_s_memtime();
     long long t_loop_end = t_start;
 #endif
-    // workgroup id -> tile: XCD-contiguous (id % 8 = XCD), then column groups of `ngroup` n-tiles, m-tiles down each group (see
-    // gemm_kernel): the 32 tiles an XCD runs together share few B panels and few A panels
-    // the tile grid is g.tx x g.ty; a launch of exactly that many blocks runs one tile per block, a smaller one (256 blocks, one per CU)
-    // walks the tile ids block, block + 256, ... : no workgroup launch between tiles, and the next tile's first DMA goes out while the
-    // stores of the previous one drain
+    // the tile grid is g.tx x g.ty; a launch of exactly that many blocks runs one tile per block, a PERSIST one (256 blocks, one per CU)
+    // walks the tile ids block, block + 256, ...
     const int nwg = g.tx * g.ty, stride = gridDim.x * gridDim.y;
     int first = blockIdx.y * gridDim.x + blockIdx.x, zid = blockIdx.z;
     if (g.slice_xcd) {   // split-K with a multiple of 8 slices: XCD k (linear id % 8) runs whole K slices, so the A / B panels of a slice
@@ -603,12 +611,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
     if (nt <= 0 || first >= nwg) return;
     const int kbase = t_begin * PP_BK;
-    const int total = 4 * nt;   // half-tiles in the stream
     int m0, n0;
     tile_of(first, m0, n0);
-    int extra = 0;              // VMEM stores of the previous tile's epilogue that are younger than this tile's prologue DMA
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    int extra = 0;              // PERSIST: the previous tile's epilogue left its stores between S[5] and S[6] of this tile in the VM counter
+    const u32x4 rsA = spn_buffer_rsrc(A, 0x7fffffffu), rsB = spn_buffer_rsrc(B, 0x7fffffffu);
+    const uint32_t ring = spn_lds_addr(smem) + (uint32_t)wave * 2048u;   // this wave's 2 KiB of every half-tile slot
     uint32_t vo[4][2];   // [kind][piece]
     auto set_tile = [&](int tm, int tn) {
 #pragma unroll
@@ -620,33 +627,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         }
     };
     set_tile(m0, n0);
-    auto issue = [&](int c, int t) {   // c is a compile-time constant at every call site
-        const int k0 = kbase + t * PP_BK;
+    if (PERSIST && g.stagger > 0) {   // tuning aid: CU slot s of an XCD starts s * stagger cycles late (tile boundaries spread in time)
+        const long long t_go = __builtin_amdgcn_s_memtime() + (long long)((first >> 3) & 31) * g.stagger;
+        while (__builtin_amdgcn_s_memtime() < t_go) __builtin_amdgcn_s_sleep(8);
+    }
+    const uint32_t kstepA = TA ? (uint32_t)PP_BK * g.lda * 2u : (uint32_t)PP_BK * 2u;   // bytes per K tile along the operand
+    const uint32_t kstepB = TB ? (uint32_t)PP_BK * g.ldb * 2u : (uint32_t)PP_BK * 2u;
+    const uint32_t kbaseA = TA ? (uint32_t)kbase * g.lda * 2u : (uint32_t)kbase * 2u;
+    const uint32_t kbaseB = TB ? (uint32_t)kbase * g.ldb * 2u : (uint32_t)kbase * 2u;
+    auto issue = [&](int c, int t) __attribute__((always_inline)) {   // c is a compile-time constant at every call site
         const bool isA = (c == 0 || c == 3);
-        const uint32_t soff = isA ? (TA ? (uint32_t)k0 * g.lda * 2u : (uint32_t)k0 * 2u) : (TB ? (uint32_t)k0 * g.ldb * 2u : (uint32_t)k0 * 2u);
-        char* dst = PP_SLOT(c, t) + wave * 2048;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? rsA : rsB, (lptr_t)(dst + i * 1024), 16, vo[c][i], soff, 0, 0);
+        const uint32_t soff = isA ? kbaseA + (uint32_t)t * kstepA : kbaseB + (uint32_t)t * kstepB;
+        spn_dma16x2(isA ? rsA : rsB, ring + (uint32_t)((c * 2 + (t & 1)) * PP_HALF), vo[c][0], vo[c][1], soff);
     };
-    // after the issue of phase p (S[<= p+6] issued): everything up to S[p+2] must have landed
-    // Stores of the previous tile's epilogue sit between S[5] and S[6] of this tile in the (in-order) VM counter: while the awaited
-    // half-tile is one of S[0..5] (phases <= 3) they count among the younger operations.
+    // S[p+6] has been issued in phase p; everything up to S[p+2] must have landed: 4 half-tiles = 8 DMA instructions stay in flight
+    // (fewer at the end of the stream).  PERSIST, first K tile: the stores of the previous tile's epilogue are younger than S[<= 5].
     constexpr int NS = sizeof(OutT) == 2 ? 16 : 32;   // store instructions per wave of one interior-tile epilogue
-    auto wait_landed = [&](int p) {
-        const int younger = min(p + PP_LEAD + 1, total) - (p + 3);
-        if (extra && p <= 3) {   // younger == 4 here (total >= 16)
-            if (GLU) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // 16 stores of u + 8 of g
-            else if (NS == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-            return;
-        }
-        if (younger >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
+    constexpr int NSX = GLU ? 24 : NS;                // (gated: 16 stores of u + 8 of g)
+#define PP_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n_) : "memory")
 #define PP_SYNC_MFMA_BEGIN()                                   \
     TSTAMP(2);                                                  \
     __builtin_amdgcn_sched_barrier(0);                          \
@@ -663,10 +661,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();                               \
     TSTAMP(6)
 
-    // prologue: S[0..5] = K tile 0 and AX, BX of K tile 1
-    auto prologue = [&]() {
+    // prologue: S[0..5] = K tile 0 and AX, BX of K tile 1 (nt >= 4)
+    auto prologue = [&]() __attribute__((always_inline)) {
         issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
-        if (nt > 1) { issue(0, 1); issue(1, 1); }
+        issue(0, 1); issue(1, 1);
     };
     prologue();
     for (int vid = first; vid < nwg; vid += stride) {
@@ -678,7 +676,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    wait_landed(-1);
+    if (PERSIST && extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8);   // AX(0), BX(0) have landed
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind the first
 
@@ -686,7 +684,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-    for (int t = 0; t < nt; ++t) {
+    // one K tile = four phases.  MODE 0: steady state (t <= nt - 3), 1: t = nt - 2, 2: t = nt - 1, 3: t = 0 of a PERSIST launch
+    // (steady, but the waits may have to credit the previous epilogue's stores)
+    auto ktile = [&](auto mode_c, const int t) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
+        constexpr bool ISSUE_01 = MODE != 2, ISSUE_23 = (MODE == 0 || MODE == 3);
         bf16x8 af[2][4], b0[4], b1[4];
         // ---- p0: reads A0, B0; issues BY(t+1) = S[4t+6] ----
 #pragma unroll
@@ -696,9 +698,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) af[i][ks] = pp_read_frag<TA>(PP_SLOT(0, t), wr * 64 + 32 * i, ks, lane);
         TSTAMP(0);
-        if (t + 1 < nt) issue(2, t + 1);
+        if (ISSUE_01) issue(2, t + 1);
         TSTAMP(1);
-        wait_landed(4 * t);
+        if (MODE == 3) { if (extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8); }
+        else if (MODE == 2) PP_VMWAIT(2);
+        else PP_VMWAIT(8);
         PP_SYNC_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -710,9 +714,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b1[ks] = pp_read_frag<TB>(PP_SLOT(2, t), wc * 32, ks, lane);
         TSTAMP(0);
-        if (t + 1 < nt) issue(3, t + 1);
+        if (ISSUE_01) issue(3, t + 1);
         TSTAMP(1);
-        wait_landed(4 * t + 1);
+        if (MODE == 3) { if (extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8); }
+        else if (MODE == 2) PP_VMWAIT(0);
+        else PP_VMWAIT(8);
         PP_SYNC_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -726,9 +732,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) af[i][ks] = pp_read_frag<TA>(PP_SLOT(3, t), wr * 64 + 32 * i, ks, lane);
         TSTAMP(0);
-        if (t + 2 < nt) issue(0, t + 2);
+        if (ISSUE_23) issue(0, t + 2);
         TSTAMP(1);
-        wait_landed(4 * t + 2);
+        if (MODE == 3) { if (extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8); }
+        else if (MODE == 1) PP_VMWAIT(6);
+        else if (MODE == 0) PP_VMWAIT(8);
         PP_SYNC_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -738,9 +746,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         PP_SYNC_MFMA_END();
         // ---- p3: no reads (B0 is still in registers); issues BX(t+2) = S[4t+9] ----
         TSTAMP(0);
-        if (t + 2 < nt) issue(1, t + 2);
+        if (ISSUE_23) issue(1, t + 2);
         TSTAMP(1);
-        wait_landed(4 * t + 3);
+        if (MODE == 3) { if (extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8); }
+        else if (MODE == 1) PP_VMWAIT(4);
+        else if (MODE == 0) PP_VMWAIT(8);
         PP_SYNC_MFMA_BEGIN();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -748,6 +758,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i) acc[2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[ks], af[i][ks], acc[2 + i][0], 0, 0, 0);
         }
         PP_SYNC_MFMA_END();
+    };
+    {
+        int t = 0;
+        if (PERSIST) { ktile(std::integral_constant<int, 3>{}, 0); t = 1; }
+        for (; t < nt - 2; ++t) ktile(std::integral_constant<int, 0>{}, t);
+        ktile(std::integral_constant<int, 1>{}, nt - 2);
+        ktile(std::integral_constant<int, 2>{}, nt - 1);
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();   // balances the second group's extra barrier
 #ifdef SPN_GEMM_TIMING
@@ -755,17 +772,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 4) && lane == 0)
         for (int k = 0; k < 8; ++k) g.dbg[(wave >> 2) * 8 + k] = seg[k];
 #endif
-#undef PP_SYNC_MFMA_BEGIN
-#undef PP_SYNC_MFMA_END
-#undef PP_SLOT
 
     // ---- epilogue: through the wave's own 4 KiB slab of the 32 KiB the ring leaves free, so that C leaves as whole 128-byte row
-    //      segments (see gemm_kernel) while the ring already receives the NEXT tile's first half-tiles ----
+    //      segments (see gemm_kernel) while (PERSIST) the ring already receives the NEXT tile's first half-tiles ----
     OutT* C = reinterpret_cast<OutT*>(g.C) + (long)zid * g.sC;
     const bool lead = !split || zid == 0;
-    constexpr int ES = sizeof(OutT);
-    constexpr int JP = ES == 2 ? 2 : 1;                 // 32-column halves of the wave's 128x64 block staged per pass
-    constexpr int ROWB = 32 * JP * ES, CPR = ROWB / 16; // 128-byte rows, 8 chunks: a pass = 32 rows = 4 KiB
     char* stg = smem + 8 * PP_HALF + wave * 4096;
     f32x4 bv[8];
 #pragma unroll
@@ -777,18 +788,25 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     }
     __syncthreads();   // every wave is done with the operand ring
     const int cm0 = m0, cn0 = n0;
-    const bool has_next = vid + stride < nwg;
-    if (has_next) {    // the next tile's prologue DMA goes out now: its latency hides behind this epilogue
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads above; nothing else is outstanding)
-        tile_of(vid + stride, m0, n0);
-        set_tile(m0, n0);
-        prologue();
+    if (PERSIST) {
+        const bool has_next = vid + stride < nwg;
+        if (has_next) {    // the next tile's prologue DMA goes out now: its latency hides behind this epilogue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads above; nothing else is outstanding)
+            tile_of(vid + stride, m0, n0);
+            set_tile(m0, n0);
+            prologue();
+        }
+        // interior tiles issue exactly NSX store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
+        extra = GLU ? ((has_next && cm0 + PP_BM <= g.M) ? 1 : 0)
+                    : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? 1 : 0);
     }
-    // interior tiles issue exactly NS store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-    extra = GLU ? ((has_next && cm0 + PP_BM <= g.M) ? 24 : 0)
-                : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? NS : 0);
     pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg);
+    if (!PERSIST) break;
     }
+#undef PP_SYNC_MFMA_BEGIN
+#undef PP_SYNC_MFMA_END
+#undef PP_VMWAIT
+#undef PP_SLOT
 #ifdef SPN_GEMM_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
     const long long t_end = __builtin_amdgcn_s_memtime();
@@ -839,8 +857,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
         n0 = (c * G + within % gw) * (GLU ? DU_BN / 2 : DU_BN);
     }
     const int nt = g.K / DU_BK;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, 0x7fffffff, 0x00020000);
+    const u32x4 rsA = spn_buffer_rsrc(g.A, 0x7fffffffu), rsB = spn_buffer_rsrc(g.B, 0x7fffffffu);
+    const uint32_t lds0 = spn_lds_addr(smem);
     // per-lane source offsets of this wave's DMA pieces (loop invariant): LDS chunk L of a stage image <- inverse-swizzled source chunk
     uint32_t voA[4], voB[2];
 #pragma unroll
@@ -861,16 +879,13 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
             voB[i] = (uint32_t)(((long)krow * g.ldb + min(n0 + rc * 8, g.N - 8)) * 2);
         }
     }
-    auto issue = [&](int t) {
-        char* dst = smem + (t % DU_STAGES) * DU_STAGE_BYTES;
+    auto issue = [&](int t) {   // asm DMA (common.h): the compiler neither counts it nor fences the transposed reads behind it
+        const uint32_t dst = lds0 + (uint32_t)((t % DU_STAGES) * DU_STAGE_BYTES);
         const uint32_t k0 = (uint32_t)t * DU_BK;
         const uint32_t soA = k0 * 2u, soB = TB ? k0 * (uint32_t)g.ldb * 2u : k0 * 2u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dst + (wave * 4 + i) * 1024), 16, voA[i], soA, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst + DU_A_BYTES + (wave * 2 + i) * 1024), 16, voB[i], soB, 0, 0);
+        spn_dma16x2(rsA, dst + (uint32_t)(wave * 4) * 1024u, voA[0], voA[1], soA);
+        spn_dma16x2(rsA, dst + (uint32_t)(wave * 4 + 2) * 1024u, voA[2], voA[3], soA);
+        spn_dma16x2(rsB, dst + DU_A_BYTES + (uint32_t)(wave * 2) * 1024u, voB[0], voB[1], soB);
     };
 
     f32x16 acc[4][2];
@@ -955,6 +970,8 @@ static void split_shape(const GemmArgs& g, int tiles, int nt, int max_tiles, int
     if (want <= 1) return;
     kt_per_split = cdiv(nt, want);
     splitk = cdiv(nt, kt_per_split);
+    // the ping-pong kernel's peeled K loop wants >= 4 K tiles in every slice, the last one included
+    while (splitk > 1 && nt - (splitk - 1) * kt_per_split < 4) { ++kt_per_split; splitk = cdiv(nt, kt_per_split); }
 }
 static void plan_split(GemmArgs& g, int tiles, int nt, int max_tiles, int want_blocks, int min_kt, SplitPlan& plan) {
     g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
@@ -1013,7 +1030,12 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     // one block per CU walking the tile list: the K = 512 projections gain 1-4 % per launch under HIP events, the step does not
     // (170.8 vs 171.5 ms: the next kernel can no longer start under the last round), so it stays a tuning aid
     const int persist_env = spn_tune_i(SPN_TUNE_GEMM_PERSIST);   // 0 off, else min rounds
-    if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
+    g.stagger = spn_tune_i(SPN_TUNE_GEMM_STAGGER) * 1024 / 32;
+    if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) {
+        static std::atomic<unsigned> optin_p{0};
+        spn_lds_optin(optin_p, reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT, 0, true>), LDS_BYTES);
+        hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT, 0, true>), dim3(256, 1, 1), dim3(512), LDS_BYTES, stream, g);
+    } else
     hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);
@@ -1071,7 +1093,7 @@ int launch_duo(GemmArgs g, hipStream_t stream) {
     spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo_kernel<TB, OutT, GLU>), DU_LDS_BYTES);
     g.tx = GLU ? g.N / (DU_BN / 2) : cdiv(g.N, DU_BN);
     g.ty = cdiv(g.M, DU_BM);
-    g.splitk = 1; g.kt_per_split = g.K / DU_BK; g.slice_xcd = 0;
+    g.splitk = 1; g.kt_per_split = g.K / DU_BK; g.slice_xcd = 0; g.stagger = 0;
     const int ng = spn_tune_i(SPN_TUNE_GEMM_DUO_NGROUP);
     g.ngroup = ng > 0 ? ng : 8;
     if (g.ngroup > g.tx) g.ngroup = g.tx;
@@ -1120,7 +1142,12 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     // a concurrent kernel holds (the RCCL all-reduce of the data-parallel step) delays ITS whole share of tiles by one block
     // lifetime, while the plain grid just hands those tiles to the other CUs.
     const int persist_env = spn_tune_i(SPN_TUNE_GLU_PERSIST);   // 0 off, else min rounds
-    if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) grid = dim3(256, 1, 1);
+    g.stagger = spn_tune_i(SPN_TUNE_GEMM_STAGGER) * 1024 / 32;
+    if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) {
+        static std::atomic<unsigned> optin_p{0};
+        spn_lds_optin(optin_p, reinterpret_cast<const void*>(&gemm_pp_kernel<false, false, bf16_t, GLU, true>), LDS_BYTES);
+        hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU, true>), dim3(256, 1, 1), dim3(512), LDS_BYTES, stream, g);
+    } else
     hipLaunchKernelGGL((gemm_pp_kernel<false, false, bf16_t, GLU>), grid, dim3(512), LDS_BYTES, stream, g);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
@@ -1170,7 +1197,7 @@ extern "C" int spn_gemm_bf16(const void* A, const void* B, void* C, const float*
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.residual = residual; g.rowmask = rowmask;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.accumulate = accum ? 1 : 0; g.batch = batch; g.sA = strideA; g.sB = strideB; g.sC = strideC;
-    g.G = nullptr; g.ldg = 0; g.thr16 = 0; g.seed = 0; g.keep_scale = 1.f;
+    g.G = nullptr; g.ldg = 0; g.thr16 = 0; g.seed = 0; g.keep_scale = 1.f; g.stagger = 0;
     g.ws = workspace; g.ws_bytes = workspace ? workspace_bytes : 0;
     {
         const long a_span = (long)(ta ? K : M) * lda * 2, b_span = (long)(tb ? K : N) * ldb * 2;
@@ -1214,7 +1241,7 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)W; g.C = u; g.bias = bias; g.residual = nullptr; g.rowmask = nullptr;
     g.M = M; g.N = I; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldu; g.ldr = 0; g.alpha = 1.f;
     g.accumulate = 0; g.batch = 1; g.sA = g.sB = g.sC = 0; g.splitk = 1; g.kt_per_split = K / PP_BK; g.pp_addr_ok = 1;
-    g.G = (bf16_t*)gout; g.ldg = ldg; g.seed = seed; g.ws = nullptr; g.ws_bytes = 0;
+    g.G = (bf16_t*)gout; g.ldg = ldg; g.seed = seed; g.ws = nullptr; g.ws_bytes = 0; g.stagger = 0;
     const float t = p_drop * 65536.f;   // thr16_of of elementwise.hip
     g.thr16 = t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)(t + 0.5f));
     g.keep_scale = 1.f / (1.f - (float)g.thr16 / 65536.f);

@@ -5,25 +5,27 @@ lib = ctypes.CDLL(os.path.join(root, "tools/_bin", os.environ.get("LIB", "libspn
 E = lambda k, d: int(os.environ.get(k, d))
 M, N, K = E("M", 8192), E("N", 8192), E("K", 8192)
 dev = torch.device("cuda")
-LDA, LDB = E("LDA", K), E("LDB", K)
-a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
-c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+FLAGS = E("FLAGS", 0)   # bit0: A stored [K][M], bit1: B stored [K][N], bit2: fp32 C
+TA, TB, F32 = FLAGS & 1, FLAGS & 2, FLAGS & 4
+LDA, LDB = E("LDA", M if TA else K), E("LDB", N if TB else K)
+a = torch.randn((K, M) if TA else (M, K), device=dev).bfloat16(); b = torch.randn((K, N) if TB else (N, K), device=dev).bfloat16()
+c = torch.empty(M, N, device=dev, dtype=torch.float32 if F32 else torch.bfloat16)
 dbg = torch.zeros(32, device=dev, dtype=torch.int64)
 if hasattr(lib, "spn_gemm_set_debug"):
     lib.spn_gemm_set_debug(ctypes.c_void_p(dbg.data_ptr()))
 P = ctypes.c_void_p
 for _ in range(2):
     rc = lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
-                           ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
+                           ctypes.c_float(1.0), FLAGS, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
     lib.spn_gemm_bf16(P(a.data_ptr()), P(b.data_ptr()), P(c.data_ptr()), None, None, None, M, N, K, LDA, LDB, N, 0,
-                      ctypes.c_float(1.0), 0, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
+                      ctypes.c_float(1.0), FLAGS, 1, ctypes.c_long(0), ctypes.c_long(0), ctypes.c_long(0), None, ctypes.c_size_t(0), None)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
-if LDA == K and LDB == K:
+if FLAGS == 0 and LDA == K and LDB == K:
     ref = a[:512].float() @ b.float().t()
     err = ((c[:512].float() - ref).abs().max() / ref.abs().max()).item()
     ref2 = a[-256:].float() @ b[-256:].float().t()
