@@ -679,6 +679,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     if (PERSIST && extra) PP_VMWAIT(8 + NSX); else PP_VMWAIT(8);   // AX(0), BX(0) have landed
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) __builtin_amdgcn_s_barrier();   // second group runs one barrier behind the first
+    bf16x8 apre[4];   // first 32 rows of the current tile's A0 fragments, read one phase ahead
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) apre[ks] = pp_read_frag<TA>(PP_SLOT(0, 0), wr * 64, ks, lane);
 
 #ifdef SPN_GEMM_TIMING
     long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -690,13 +693,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         constexpr int MODE = decltype(mode_c)::value;
         constexpr bool ISSUE_01 = MODE != 2, ISSUE_23 = (MODE == 0 || MODE == 3);
         bf16x8 af[2][4], b0[4], b1[4];
-        // ---- p0: reads A0, B0; issues BY(t+1) = S[4t+6] ----
+        // ---- p0: reads B0 and the second 32 rows of A0 (the first 32 were read in the previous tile's read-free p3); issues BY(t+1) ----
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) b0[ks] = pp_read_frag<TB>(PP_SLOT(1, t), wc * 32, ks, lane);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int ks = 0; ks < 4; ++ks) af[1][ks] = pp_read_frag<TA>(PP_SLOT(0, t), wr * 64 + 32, ks, lane);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) af[i][ks] = pp_read_frag<TA>(PP_SLOT(0, t), wr * 64 + 32 * i, ks, lane);
+        for (int ks = 0; ks < 4; ++ks) af[0][ks] = apre[ks];
         TSTAMP(0);
         if (ISSUE_01) issue(2, t + 1);
         TSTAMP(1);
@@ -744,7 +747,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i) acc[2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[ks], af[i][ks], acc[2 + i][1], 0, 0, 0);
         }
         PP_SYNC_MFMA_END();
-        // ---- p3: no reads (B0 is still in registers); issues BX(t+2) = S[4t+9] ----
+        // ---- p3: B0 is still in registers; reads the first 32 rows of the NEXT tile's A0 (AX(t+1) = S[4t+4] was published by the
+        //      barrier of phase 4t+2): the reads are 8 / 4 / 8 / 4 per phase instead of 12 / 4 / 8 / 0; issues BX(t+2) = S[4t+9] ----
+        if (MODE != 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) apre[ks] = pp_read_frag<TA>(PP_SLOT(0, t + 1), wr * 64, ks, lane);
+        }
         TSTAMP(0);
         if (ISSUE_23) issue(1, t + 2);
         TSTAMP(1);
