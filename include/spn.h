@@ -99,6 +99,15 @@ int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy,
 int spn_gemm_glu_ok(int M, int I, int K);
 int spn_gemm_glu(const void* x, const void* W /* [2I, K] */, void* u, void* g, const float* bias /* [2I] or null */, int M, int I, int K,
                  int lda, int ldb, int ldu, int ldg, int act /* 0 SiLU, 1 GELU */, float p_drop, unsigned seed, spn_stream_t s);
+/* backward through the same block (feedforward.py:57-64 output projection, then :13-21): the input gradient of the OUTPUT projection
+ * with the activation backward in the GEMM epilogue:  dg = dy[M,K] . W2[K,I] is never stored;
+ * du[M,2I] = (d * act(gate) | d * value * act'(gate)),  d = dropout_mask(seed)(bf16(dg)),  value | gate = u.
+ * Equals spn_gemm_bf16 (flags bit1) + spn_act_bwd bit for bit.  colsum_partial: null, or fp32 [ceil(M/128), 2I]: row r receives the
+ * column sums of du rows 128r.. (bias gradient of the input projection = the sum of the rows).
+ * spn_gemm_glu_bwd_ok: 1 when the shape is taken (M >= 128, M % 8 == 0, I % 256 == 0, K % 64 == 0, K >= 256) */
+int spn_gemm_glu_bwd_ok(int M, int I, int K);
+int spn_gemm_glu_bwd(const void* dy, const void* W2 /* [K, I] */, const void* u /* [M, 2I] */, void* du, float* colsum_partial,
+                     int M, int I, int K, int lddy, int ldw, int ldu, int lddu, int act, float p_drop, unsigned seed, spn_stream_t s);
 
 /* ---- element-wise (feedforward.py:13-21 GLU/act; attention.py:216-218 & mmd_transformer.py:213-214 row masks) */
 /* p_drop > 0: nn.Dropout on the activation output (feedforward.py:57-60); the mask is a pure function of (seed, index) */

@@ -59,6 +59,15 @@ __device__ __forceinline__ uint32_t spn_hash32(uint32_t x) {
 // v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the GEMM epilogue that applies it is VALU-bound (-70 us per FFN at C3)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.f + __expf(-x));   // the sigmoid of silu_f: one exp + one rcp serve both in a gated backward
+    return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

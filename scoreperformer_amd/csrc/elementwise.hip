@@ -9,15 +9,7 @@
 
 namespace {
 
-__device__ __forceinline__ float silu_grad(float x) {
-    const float s = 1.f / (1.f + __expf(-x));
-    return s * (1.f + x * (1.f - s));
-}
-__device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
+// silu_grad / gelu_grad: common.h (shared with the gated-backward GEMM epilogue, which must agree bit for bit)
 template <int ACT> __device__ __forceinline__ float act_f(float x) { return ACT == 0 ? silu_f(x) : gelu_f(x); }
 template <int ACT> __device__ __forceinline__ float act_g(float x) { return ACT == 0 ? silu_grad(x) : gelu_grad(x); }
 

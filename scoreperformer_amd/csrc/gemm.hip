@@ -443,11 +443,135 @@ __device__ __forceinline__ uint32_t pp_voffset_lin(int ld, int row0, int wave, i
 // wave's own 4 KiB LDS slab `stg` and leaves as whole 128-byte row segments (partial-line writes make the L2 fetch C first).
 template <typename OutT, int GLU>
 __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4][2], const f32x4 (&bv)[8], OutT* C, bool lead,
-                                              int cm0, int cn0, int wr, int wc, int lane, char* stg) {
+                                              int cm0, int cn0, int wr, int wc, int lane, char* stg, char* ring = nullptr) {
     constexpr int ES = sizeof(OutT);
     constexpr int JP = ES == 2 ? 2 : 1;                 // 32-column halves of the wave's 128x64 block staged per pass
     constexpr int ROWB = 32 * JP * ES, CPR = ROWB / 16; // 128-byte rows, 8 chunks: a pass = 32 rows = 4 KiB
-    if constexpr (GLU != 0) {
+    if constexpr (GLU >= 3) {
+        // GATED BACKWARD (spn_gemm_glu_bwd): the accumulators are dg = dy W2 (input gradient of the FFN's output projection) for the
+        // outputs cn0 + 64 wc .. of 128 rows; instead of storing dg for a separate pass the epilogue applies the activation backward:
+        //   d = dropout_mask(bf16(dg)),  du[:, c] = d * act(gate),  du[:, I + c] = d * value * act'(gate)
+        // with value / gate read from u [M, 2I] (g.G) and du written to g.C -- rounded exactly where GEMM + spn_act_bwd round, so the
+        // result is bit-identical to the two-kernel path.  The u blocks come in and the du blocks leave through the wave's LDS slab
+        // as whole 128-byte row segments; the column sums of du (the bias gradient of the input projection) are taken from the
+        // staged du blocks (bf16-rounded, as the consumer GEMMs see them) and left in row cm0/128 + wr of the partial buffer g.ws.
+        constexpr int ACT = GLU - 3;
+        bf16_t* DU = reinterpret_cast<bf16_t*>(g.C);
+        const int I = g.N, chunks = I >> 3;
+        const int colw = cn0 + wc * 64;                       // first of this wave's 64 gated outputs
+        const int rl = lane & 31, hl = lane >> 5;
+        // The u blocks (32 rows x 64 value columns, 32 x 64 gate columns per 32-row block i) arrive by LDS DMA into this wave's 16 KiB
+        // of the (now dead) operand ring: no registers, two 32-row blocks (4 x 4 KiB) in flight while one is processed.  LDS image of a
+        // block: [32 rows][8 chunks of 16 B], chunk position = source chunk ^ ((row >> 1) & 7) (swizzle on the SOURCE address).
+        const u32x4 rsU = spn_buffer_rsrc(g.G, 0x7fffffffu);
+        const uint32_t ring_w = spn_lds_addr(ring);
+        auto issue_u = [&](int i) __attribute__((always_inline)) {   // block i -> ring slots 2 (i & 1) (value), 2 (i & 1) + 1 (gate)
+            const int mrow0 = cm0 + wr * 128 + 32 * i;
+            uint32_t vo[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+                vo[it] = (uint32_t)(((long)min(mrow0 + r, g.M - 1) * g.ldg + colw + c * 8) * 2);
+            }
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const uint32_t dst = ring_w + (uint32_t)((2 * (i & 1) + part) * 4096);
+                spn_dma16x2(rsU, dst, vo[0], vo[1], (uint32_t)(part * I) * 2u);
+                spn_dma16x2(rsU, dst + 2048u, vo[2], vo[3], (uint32_t)(part * I) * 2u);
+            }
+        };
+        issue_u(0); issue_u(1);
+        float csum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // [value / gate][column 2c, 2c + 1], c = lane & 31; rows 16 hl .. of every block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mrow0 = cm0 + wr * 128 + 32 * i;
+            // VM counter, oldest first (DMA = 8 instructions per block, S = the 8 stores of a block):
+            //   block 0: DMA0 DMA1 | block 1: DMA1 S0 DMA2 | block 2: DMA2 S1 DMA3 | block 3: DMA3 S2
+            // A row tile that hangs over M may skip store instructions (all lanes off): it waits for everything instead of counting.
+            if (cm0 + PP_BM > g.M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (i == 0 || i == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            uint2 uv[2][4], ug[2][4];                          // this lane's value / gate pieces: row rl, columns 32 j + 8 q + 4 hl ..
+            const char* blk = ring + (2 * (i & 1)) * 4096;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s_ = 8 * j + 2 * q + hl;
+                    const int o = rl * 128 + ((((s_ >> 1) ^ ((rl >> 1) & 7)) & 7) << 4) + (s_ & 1) * 8;
+                    uv[j][q] = *reinterpret_cast<const uint2*>(blk + o);
+                    ug[j][q] = *reinterpret_cast<const uint2*>(blk + 4096 + o);
+                }
+            if (i + 2 < 4) {   // the slots of block i are free once the reads above have returned
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_u(i + 2);
+            }
+            const int m = mrow0 + rl;
+            const bool row_ok = m < g.M;
+            uint2 pa[2][4], pg[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 pd;   // dg rounded to bf16 first: what the unfused GEMM stores and spn_act_bwd reads
+                    pd.x = pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]); pd.y = pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    float d[4] = {bf2f(pd.x & 0xffff), bf2f(pd.x >> 16), bf2f(pd.y & 0xffff), bf2f(pd.y >> 16)};
+                    if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (drop8 of elementwise.hip)
+                        const int col = colw + 32 * j + 8 * q + 4 * hl;
+                        const long idx = (long)m * chunks + (col >> 3);
+                        const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
+                        const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
+                        d[0] = (h0 & 0xffffu) >= g.thr16 ? d[0] * g.keep_scale : 0.f;
+                        d[1] = (h0 >> 16) >= g.thr16 ? d[1] * g.keep_scale : 0.f;
+                        d[2] = (h1 & 0xffffu) >= g.thr16 ? d[2] * g.keep_scale : 0.f;
+                        d[3] = (h1 >> 16) >= g.thr16 ? d[3] * g.keep_scale : 0.f;
+                    }
+                    const float a[4] = {bf2f(uv[j][q].x & 0xffff), bf2f(uv[j][q].x >> 16), bf2f(uv[j][q].y & 0xffff), bf2f(uv[j][q].y >> 16)};
+                    const float t[4] = {bf2f(ug[j][q].x & 0xffff), bf2f(ug[j][q].x >> 16), bf2f(ug[j][q].y & 0xffff), bf2f(ug[j][q].y >> 16)};
+                    float da[4], dt[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        da[e] = row_ok ? d[e] * (ACT == 0 ? silu_f(t[e]) : gelu_f(t[e])) : 0.f;
+                        dt[e] = row_ok ? d[e] * a[e] * (ACT == 0 ? silu_grad(t[e]) : gelu_grad(t[e])) : 0.f;
+                    }
+                    pa[j][q].x = pack_bf2(da[0], da[1]); pa[j][q].y = pack_bf2(da[2], da[3]);
+                    pg[j][q].x = pack_bf2(dt[0], dt[1]); pg[j][q].y = pack_bf2(dt[2], dt[3]);
+                }
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<uint2*>(stg + rl * 128 + ((((8 * j + 2 * q + hl) ^ rl) & 15) << 3)) = part == 0 ? pa[j][q] : pg[j][q];
+                if (g.ws) {   // column sums of the staged block: lane c = lane & 31 owns columns 2c, 2c + 1 and rows 16 hl .. 16 hl + 15
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const int r = 16 * hl + rr;
+                        const uint32_t w = *reinterpret_cast<const uint32_t*>(stg + r * 128 + (((((rl >> 1)) ^ r) & 15) << 3) + (rl & 1) * 4);
+                        csum[part][0] += bf2f(w & 0xffff); csum[part][1] += bf2f(w >> 16);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                    uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
+                    if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
+                    const int mo = mrow0 + r;
+                    // interior row tiles issue exactly 8 store instructions per block and wave (the vmcnt counts above rely on it)
+                    if (mo < g.M) *reinterpret_cast<uint4*>(DU + (long)mo * g.ldc + part * I + colw + chunk * 8) = val;
+                }
+            }
+        }
+        if (g.ws) {
+            float* P = reinterpret_cast<float*>(g.ws) + (long)(cm0 / 128 + wr) * (2 * I);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const float s0 = csum[part][0] + __shfl_xor(csum[part][0], 32, 64), s1 = csum[part][1] + __shfl_xor(csum[part][1], 32, 64);
+                if (hl == 0) *reinterpret_cast<f32x2*>(P + part * I + colw + 2 * rl) = f32x2{s0, s1};
+            }
+        }
+    } else if constexpr (GLU != 0) {
         // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
         // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
         bf16_t* U = reinterpret_cast<bf16_t*>(g.C);
@@ -572,6 +696,7 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
 // phase issues, every wait is vmcnt(8): no scalar branches between the barriers), the last-but-one and the last K tile.
 template <bool TA, bool TB, typename OutT, int GLU = 0, bool PERSIST = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
+    constexpr bool GLUF = (GLU == 1 || GLU == 2);   // gated FORWARD epilogue: B half-tiles are value / gate rows, 128 outputs per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // slot of half-tile kind c (0 AX, 1 BX, 2 BY, 3 AY) of K tile t
 #define PP_SLOT(c_, t_) (smem + ((c_) * 2 + ((t_) & 1)) * PP_HALF)
@@ -601,7 +726,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         const int c = wg / per, within = wg - c * per;
         const int gw = min(G, g.tx - c * G);
         tm = (within / gw) * PP_BM;
-        tn = (c * G + within % gw) * (GLU ? PP_BN / 2 : PP_BN);
+        tn = (c * G + within % gw) * (GLUF ? PP_BN / 2 : PP_BN);
     };
     const bool split = g.splitk > 1;
     const bf16_t* A = g.A + (split ? 0 : (long)zid * g.sA);
@@ -621,8 +746,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             vo[0][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 0, wave, lane, i);
-            vo[1][i] = GLU ? pp_voffset_lin(g.ldb, tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 0, wave, lane, i);
-            vo[2][i] = GLU ? pp_voffset_lin(g.ldb, g.N + tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 1, wave, lane, i);
+            vo[1][i] = GLUF ? pp_voffset_lin(g.ldb, tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 0, wave, lane, i);
+            vo[2][i] = GLUF ? pp_voffset_lin(g.ldb, g.N + tn, wave, lane, i) : pp_voffset<TB, 32>(g.ldb, tn, g.N, 1, wave, lane, i);
             vo[3][i] = pp_voffset<TA, 64>(g.lda, tm, g.M, 1, wave, lane, i);
         }
     };
@@ -643,7 +768,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     // S[p+6] has been issued in phase p; everything up to S[p+2] must have landed: 4 half-tiles = 8 DMA instructions stay in flight
     // (fewer at the end of the stream).  PERSIST, first K tile: the stores of the previous tile's epilogue are younger than S[<= 5].
     constexpr int NS = sizeof(OutT) == 2 ? 16 : 32;   // store instructions per wave of one interior-tile epilogue
-    constexpr int NSX = GLU ? 24 : NS;                // (gated: 16 stores of u + 8 of g)
+    constexpr int NSX = GLUF ? 24 : NS;               // (gated: 16 stores of u + 8 of g)
 #define PP_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n_) : "memory")
 #define PP_SYNC_MFMA_BEGIN()                                   \
     TSTAMP(2);                                                  \
@@ -790,8 +915,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq) {
         // GLU: bv[0..3] = bias of the value columns, bv[4..7] = bias of the gate columns (N = I is a multiple of 128: no edge)
-        const int bn = GLU ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
-                           : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
+        const int bn = GLUF ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
+                            : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
         bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();   // every wave is done with the operand ring
@@ -805,10 +930,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             prologue();
         }
         // interior tiles issue exactly NSX store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-        extra = GLU ? ((has_next && cm0 + PP_BM <= g.M) ? 1 : 0)
+        extra = GLUF ? ((has_next && cm0 + PP_BM <= g.M) ? 1 : 0)
                     : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? 1 : 0);
     }
-    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg);
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, smem + wave * 16384);
     if (!PERSIST) break;
     }
 #undef PP_SYNC_MFMA_BEGIN
@@ -848,6 +973,7 @@ __device__ __forceinline__ int du_kc_off(int row, int chunk) { return row * 64 +
 
 template <bool TB, typename OutT, int GLU = 0>
 __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
+    constexpr bool GLUF = (GLU == 1 || GLU == 2);   // gated forward (value / gate rows of W paired in one tile); GLU >= 3: gated backward epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -862,7 +988,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
         const int c = wg / per, within = wg - c * per;
         const int gw = min(G, g.tx - c * G);
         m0 = (within / gw) * DU_BM;
-        n0 = (c * G + within % gw) * (GLU ? DU_BN / 2 : DU_BN);
+        n0 = (c * G + within % gw) * (GLUF ? DU_BN / 2 : DU_BN);
     }
     const int nt = g.K / DU_BK;
     const u32x4 rsA = spn_buffer_rsrc(g.A, 0x7fffffffu), rsB = spn_buffer_rsrc(g.B, 0x7fffffffu);
@@ -880,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
         if (!TB) {
             const int row = L >> 2, kc = (L & 3) ^ ((row >> 2) & 3);
             // gated: image rows 0..63 are the VALUE rows n0.. of W, rows 64..127 the GATE rows I + n0..
-            const int src = GLU ? (row < 64 ? n0 + row : g.N + n0 + row - 64) : min(n0 + row, g.N - 1);
+            const int src = GLUF ? (row < 64 ? n0 + row : g.N + n0 + row - 64) : min(n0 + row, g.N - 1);
             voB[i] = (uint32_t)(((long)src * g.ldb + kc * 8) * 2);
         } else {
             const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
@@ -921,7 +1047,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int rb = GLU ? 64 * j + 32 * wc : 64 * wc + 32 * j;
+                const int rb = GLUF ? 64 * j + 32 * wc : 64 * wc + 32 * j;
                 if (!TB) bf[j][ks] = *reinterpret_cast<const bf16x8*>(sb + du_kc_off(rb + (lane & 31), ks * 2 + (lane >> 5)));
                 else bf[j][ks] = pp_read_frag<true>(sb, rb, ks, lane);
             }
@@ -943,12 +1069,13 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
     f32x4 bv[8];
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq) {
-        const int bn = GLU ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
-                           : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
+        const int bn = GLUF ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
+                            : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
         bv[jq] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();   // every wave is done with the operand ring: its first 16 KiB become the four staging slabs
-    pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096);
+    // gated backward: the four staging slabs, then 16 KiB per wave for the u blocks that arrive by LDS DMA (80 KiB in all)
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096, smem + 16384 + wave * 16384);
 }
 
 // ---- split-K plumbing -------------------------------------------------------------------------------------
@@ -1260,6 +1387,75 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
         spn_tune_i(SPN_TUNE_GEMM_DUO) >= 2)
         return act == 0 ? launch_duo<false, bf16_t, 1>(g, stream) : launch_duo<false, bf16_t, 2>(g, stream);
     return act == 0 ? launch_pp_glu<1>(g, stream) : launch_pp_glu<2>(g, stream);
+}
+
+// Input gradient of a gated feed-forward's output projection with the activation backward in its epilogue (feedforward.py:17-20,57-64):
+//   dg = dy[M, K] . W2[K, I]              (never stored)
+//   d  = dropout_mask(bf16(dg)),  du[:, :I] = d * act(u[:, I:]),  du[:, I:] = d * u[:, :I] * act'(u[:, I:])      (bf16 [M, 2I])
+// = spn_gemm_bf16 (N-contiguous B) followed by spn_act_bwd, bit for bit, without the 2 x M x I x 2 bytes of dg between them.
+// colsum_partial (fp32 [ceil(M / 128), 2I] or null): row r receives the column sums of du rows 128 r .. (bias gradient of the input
+// projection: sum the rows).  W2 is the nn.Linear weight [K, I] of the output projection (row stride ldw).
+extern "C" int spn_gemm_glu_bwd_ok(int M, int I, int K) {
+    return (M >= 128 && M % 8 == 0 && I >= 256 && I % PP_BN == 0 && K % PP_BK == 0 && K >= 4 * PP_BK) ? 1 : 0;
+}
+
+extern "C" int spn_gemm_glu_bwd(const void* dy, const void* W2, const void* u, void* du, float* colsum_partial, int M, int I, int K,
+                                int lddy, int ldw, int ldu, int lddu, int act, float p_drop, unsigned seed, hipStream_t stream) {
+    SPN_REQUIRE(dy && W2 && u && du, "spn_gemm_glu_bwd: null operand");
+    SPN_REQUIRE(spn_gemm_glu_bwd_ok(M, I, K), "spn_gemm_glu_bwd: shape not supported (M >= 128, I a multiple of 256, K a multiple of 64 and >= 256)");
+    SPN_REQUIRE(lddy % 8 == 0 && ldw % 8 == 0 && ldu % 8 == 0 && lddu % 8 == 0, "spn_gemm_glu_bwd: leading dimensions must be multiples of 8");
+    SPN_REQUIRE(((((uintptr_t)dy) | ((uintptr_t)W2) | ((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && (!colsum_partial || (((uintptr_t)colsum_partial) & 7) == 0),
+                "spn_gemm_glu_bwd: operands must be 16-byte aligned");
+    SPN_REQUIRE((long)M * lddy * 2 < (1L << 31) && (long)K * ldw * 2 < (1L << 31), "spn_gemm_glu_bwd: operand spans 2 GiB or more");
+    SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu_bwd: act is 0 (SiLU) or 1 (GELU)");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t*)dy; g.B = (const bf16_t*)W2; g.C = du;
+    g.M = M; g.N = I; g.K = K; g.lda = lddy; g.ldb = ldw; g.ldc = lddu; g.alpha = 1.f;
+    g.batch = 1; g.splitk = 1; g.kt_per_split = K / PP_BK; g.pp_addr_ok = 1;
+    g.G = (bf16_t*)u; g.ldg = ldu; g.seed = seed; g.ws = colsum_partial;
+    const float t = p_drop * 65536.f;   // thr16_of of elementwise.hip
+    g.thr16 = t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)(t + 0.5f));
+    g.keep_scale = 1.f / (1.f - (float)g.thr16 / 65536.f);
+#ifdef SPN_GEMM_TIMING
+    g.dbg = g_dbg;
+#endif
+    // Two 4-wave workgroups per CU (256x128 tiles): this epilogue moves 4 bytes of u / du per output through HBM and takes twice as
+    // long as the K = 512 main loop, so what matters is that one workgroup's main loop runs under the other's epilogue
+    if (spn_tune_i(SPN_TUNE_GLU_BWD_DUO) && K % DU_BK == 0) {
+        constexpr int DUO_LDS = 16384 + 4 * 16384;
+        g.tx = I / DU_BN; g.ty = cdiv(M, DU_BM);
+        const int ng = spn_tune_i(SPN_TUNE_GEMM_DUO_NGROUP);
+        g.ngroup = ng > 0 ? ng : 8;
+        if (g.ngroup > g.tx) g.ngroup = g.tx;
+        if (act == 0) {
+            static std::atomic<unsigned> optin{0};
+            spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo_kernel<true, bf16_t, 3>), DUO_LDS);
+            hipLaunchKernelGGL((gemm_duo_kernel<true, bf16_t, 3>), dim3(g.tx * g.ty), dim3(256), DUO_LDS, stream, g);
+        } else {
+            static std::atomic<unsigned> optin{0};
+            spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo_kernel<true, bf16_t, 4>), DUO_LDS);
+            hipLaunchKernelGGL((gemm_duo_kernel<true, bf16_t, 4>), dim3(g.tx * g.ty), dim3(256), DUO_LDS, stream, g);
+        }
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
+    constexpr int LDS_BYTES = 8 * PP_HALF + 8 * 4096;
+    dim3 grid(I / PP_BN, cdiv(M, PP_BM), 1);
+    g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
+    if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
+    g.tx = grid.x; g.ty = grid.y;
+    if (act == 0) {
+        static std::atomic<unsigned> optin{0};
+        spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pp_kernel<false, true, bf16_t, 3>), LDS_BYTES);
+        hipLaunchKernelGGL((gemm_pp_kernel<false, true, bf16_t, 3>), grid, dim3(512), LDS_BYTES, stream, g);
+    } else {
+        static std::atomic<unsigned> optin{0};
+        spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pp_kernel<false, true, bf16_t, 4>), LDS_BYTES);
+        hipLaunchKernelGGL((gemm_pp_kernel<false, true, bf16_t, 4>), grid, dim3(512), LDS_BYTES, stream, g);
+    }
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
 }
 
 #ifdef SPN_GEMM_TIMING

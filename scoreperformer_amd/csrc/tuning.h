@@ -19,6 +19,7 @@ enum SpnTune {
     SPN_TUNE_GEMM_DUO,             // 0 off; 1 = two 4-wave workgroups per CU (256x128 tiles) where measured faster; 2 = wherever eligible; 1
     SPN_TUNE_GEMM_DUO_NGROUP,      // n-tiles per column group of the duo kernel's tile order; 8
     SPN_TUNE_GEMM_STAGGER,         // persistent GEMM: start delay spread over the 32 CU slots of an XCD, in units of 1024 shader cycles (0 = off); 0
+    SPN_TUNE_GLU_BWD_DUO,          // gated-backward GEMM (spn_gemm_glu_bwd): 1 = two workgroups per CU (256x128 tiles), 0 = ping-pong kernel; 1
     SPN_TUNE_COUNT
 };
 

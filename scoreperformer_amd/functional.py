@@ -532,6 +532,83 @@ def glu_act(u, *, act=ACT_SILU, glu=True, p_drop: float = 0.0, bias=None):
     return ActFn.apply(u, act, glu, float(p_drop), next_seed() if p_drop > 0 else 0, bias)
 
 
+class FeedForwardGLUFn(Function):
+    """The whole gated feed-forward  y = residual + (dropout(value * act(gate)) W2^T + b2),  value | gate = x W1^T + b1  as ONE autograd
+    node (feedforward.py:13-21,51-64).  Forward = `spn_gemm_glu` + the output GEMM; in the backward the input gradient of the output
+    projection never reaches HBM: `spn_gemm_glu_bwd` applies the activation backward in that GEMM's epilogue (du straight from dy),
+    which removes the 2 x M x I x 2 bytes of dg and the separate activation-backward pass over u, dg and du."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act: int, p_drop: float, seed: int):
+        lead, D = x.shape[:-1], w2.shape[0]
+        x2 = to_bf16(x).reshape(-1, x.shape[-1])
+        u, g = ops.gemm_glu(x2, bf16_weight(w1), b1.detach() if b1 is not None else None, act=act, p_drop=p_drop, seed=seed)
+        res2 = residual.reshape(-1, D) if residual is not None else None
+        y = ops.gemm(g, bf16_weight(w2), out_dtype=F32 if residual is not None else BF16, bias=b2.detach() if b2 is not None else None,
+                     residual=res2)
+        ctx.save_for_backward(x2, u, g)
+        ctx.refs = (w1, b1, w2, b2)
+        ctx.cfg = (act, p_drop, seed, residual is not None, x.dtype, x.shape)
+        for p in (w1, b1, w2, b2):
+            if p is not None and p.requires_grad:
+                _pend(p)
+        return y.view(*lead, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, u, g = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.refs
+        act, p_drop, seed, has_res, x_dtype, x_shape = ctx.cfg
+        D = w2.shape[0]
+        d_res = dy if has_res else None
+        dyb = _bf16_grad(dy, D, None)
+        # output projection: weight / bias gradients (same order as LinearFn.backward followed by LinearGLUFn.backward)
+        dw2 = db2 = None
+        if ctx.needs_input_grad[3]:
+            dw2 = _accumulate_wgrad(w2, lambda out, acc: ops.gemm(dyb, g, ta=True, tb=True, out=out, accumulate=acc), w2.shape)
+        if b2 is not None and ctx.needs_input_grad[4]:
+            main2 = _main_grad(b2)
+            if main2 is not None:
+                if getattr(dy, "_spn_bias_done", None) != dy._version:
+                    ops.colsum(dyb, out=main2)
+                hook = getattr(b2, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            else:
+                db2 = ops.colsum(dyb)
+        # dg = dy W2 and the activation backward in one kernel
+        main1 = _main_grad(b1) if b1 is not None and b1.requires_grad else None
+        du = ops.gemm_glu_bwd(dyb, bf16_weight(w2), u, act=act, p_drop=p_drop, seed=seed, colsum=main1)
+        dx = dw1 = db1 = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(du, bf16_weight(w1), tb=True, out_dtype=BF16 if x_dtype == BF16 else F32).view(x_shape)
+        if ctx.needs_input_grad[1]:
+            dw1 = _accumulate_wgrad(w1, lambda out, acc: ops.gemm(du, x2, ta=True, tb=True, out=out, accumulate=acc), w1.shape)
+        if b1 is not None and ctx.needs_input_grad[2]:
+            if main1 is not None:
+                hook = getattr(b1, "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+            else:
+                db1 = ops.colsum(du)
+        return dx, dw1, db1, dw2, db2, d_res, None, None, None
+
+
+FFN_FUSE = _os.environ.get("SPN_FFN_FUSE", "1") != "0"
+
+
+def feed_forward_glu(x, w1, b1, w2, b2, *, residual=None, act=ACT_SILU, p_drop: float = 0.0):
+    """Gated feed-forward block; the fully fused node when the shapes allow it, else linear_glu + linear."""
+    rows = x.numel() // x.shape[-1]
+    I, K, D = w1.shape[0] // 2, x.shape[-1], w2.shape[0]
+    if (FFN_FUSE and GLU_FUSE and x.is_cuda and w1.shape[0] % 2 == 0 and w2.shape[1] == I and ops.gemm_glu_ok(rows, I, K)
+            and ops.gemm_glu_bwd_ok(rows, I, D)):
+        return FeedForwardGLUFn.apply(x, w1, b1, w2, b2, residual, act, float(p_drop), next_seed() if p_drop > 0 else 0)
+    g = linear_glu(x, w1, b1, act=act, p_drop=p_drop)
+    return linear(g, w2, b2, residual=residual, out_fp32=residual is not None)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # concat-with-cast: bf16 [.., sum D_i] from parts of either dtype (strided [b, t, D] views allowed)
 # ---------------------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ class FeedForward(nn.Module, Constructor):
         has_ln = isinstance(self.ff[1], nn.LayerNorm)
         if has_ln and p > 0:
             raise NotImplementedError("post_act_ln together with dropout (not used by any recipe)")
+        out = self.ff[3]
+        if self.glu and not has_ln:   # one autograd node for the block (activation backward inside the output projection's dX GEMM)
+            proj = self.ff[0].proj
+            return F_.feed_forward_glu(x, proj.weight, proj.bias, out.weight, out.bias, residual=residual, act=self.act_code, p_drop=p)
         if self.glu:
             g = self.ff[0](x, p_drop=p)
         else:
@@ -53,5 +57,4 @@ class FeedForward(nn.Module, Constructor):
             g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p, bias=lin.bias)
         if has_ln:
             g = F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps)
-        out = self.ff[3]
         return F_.linear(g, out.weight, out.bias, residual=residual, out_fp32=residual is not None)

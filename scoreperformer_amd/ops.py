@@ -334,6 +334,27 @@ def gemm_glu(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, 
     return u, g
 
 
+def gemm_glu_bwd_ok(M: int, I: int, K: int) -> bool:
+    return bool(load().spn_gemm_glu_bwd_ok(c_int(M), c_int(I), c_int(K)))
+
+
+def gemm_glu_bwd(dy: torch.Tensor, w2: torch.Tensor, u: torch.Tensor, *, act: int, p_drop: float = 0.0, seed: int = 0,
+                 colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """du [M, 2I] = act_bwd(u, dy @ w2) in ONE kernel (w2: the output projection's weight [K, I]; dg is never stored).
+    `colsum` (fp32 [2I]): the column sums of du are accumulated into it (bias gradient of the input projection)."""
+    M, K = dy.shape
+    I = w2.shape[1]
+    assert dy.dtype == BF16 and w2.dtype == BF16 and u.dtype == BF16 and dy.stride(1) == 1 and w2.stride(1) == 1 and u.stride(1) == 1
+    assert w2.shape[0] == K and u.shape == (M, 2 * I)
+    du = torch.empty((M, 2 * I), device=dy.device, dtype=BF16)
+    part = torch.empty(((M + 127) // 128, 2 * I), device=dy.device, dtype=F32) if colsum is not None else None
+    call("spn_gemm_glu_bwd", ptr(dy), ptr(w2), ptr(u), ptr(du), ptr(part), c_int(M), c_int(I), c_int(K), c_int(dy.stride(0)),
+         c_int(w2.stride(0)), c_int(u.stride(0)), c_int(2 * I), c_int(act), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
+    if colsum is not None:
+        call("spn_colsum", ptr(part), c_int(0), c_long(2 * I), ptr(colsum), c_long(part.shape[0]), c_int(2 * I), stream_ptr())
+    return du
+
+
 def act_bwd(u: torch.Tensor, dout: torch.Tensor, *, act: int, glu: bool, p_drop: float = 0.0, seed: int = 0,
             colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """`colsum` (fp32 [W]): the column sums of the result are accumulated into it (bias gradient of the Linear that produced u)."""
@@ -725,6 +746,17 @@ def gemm_glu(x, w, bias, **kw):  # noqa: F811
     M, K = x.shape
     N = w.shape[0]
     return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:NN:bf16+glu", lambda: _gemm_glu_raw(x, w, bias, **kw))
+
+
+_gemm_glu_bwd_raw = gemm_glu_bwd
+
+
+def gemm_glu_bwd(dy, w2, u, **kw):  # noqa: F811
+    if not PROFILE.enabled:
+        return _gemm_glu_bwd_raw(dy, w2, u, **kw)
+    M, K = dy.shape
+    N = w2.shape[1]
+    return PROFILE.wrap("gemm_bf16", 2.0 * M * N * K, f"{M}x{N}x{K}:NT:bf16+glu_bwd", lambda: _gemm_glu_bwd_raw(dy, w2, u, **kw))
 
 
 def attn_fwd(q, k, v, **kw):  # noqa: F811

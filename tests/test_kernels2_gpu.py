@@ -157,6 +157,30 @@ def test_gemm_glu_equals_gemm_then_activation(M, I, K, act, p):
         assert abs(kept - (1 - p)) < 0.01
 
 
+@pytest.mark.parametrize("M,I,K,act,p", [(256, 256, 256, 0, 0.0), (904, 512, 512, 0, 0.1), (4096, 2048, 512, 1, 0.1),
+                                         (8192 + 8, 2048, 512, 0, 0.1), (131008, 2048, 512, 0, 0.1)])
+def test_gemm_glu_bwd_equals_gemm_then_activation_backward(M, I, K, act, p):
+    """Gated backward epilogue: du and the bias column sums equal the input-gradient GEMM followed by the stand-alone activation
+    backward, bit for bit (dg rounded to bf16 at the same point, same dropout mask), at edge row counts and at the benchmark's shape."""
+    from scoreperformer_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(M + I + 1)
+    dy = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).bfloat16()
+    w2 = (torch.randn(K, I, device="cuda", generator=gen) * K ** -0.5).bfloat16()
+    u = torch.randn(M, 2 * I, device="cuda", generator=gen).bfloat16()
+    assert ops.gemm_glu_bwd_ok(M, I, K)
+    cs = torch.zeros(2 * I, device="cuda")
+    du = ops.gemm_glu_bwd(dy, w2, u, act=act, p_drop=p, seed=4321, colsum=cs)
+    dg = ops.gemm(dy, w2, tb=True, out_dtype=torch.bfloat16)
+    cs_ref = torch.zeros(2 * I, device="cuda")
+    du_ref = ops.act_bwd(u, dg, act=act, glu=True, p_drop=p, seed=4321, colsum=cs_ref)
+    assert torch.equal(du.view(torch.int16), du_ref.view(torch.int16))
+    exact = du_ref.float().sum(0)
+    tol = 1e-3 * float(du_ref.float().abs().sum(0).max()) + 1e-3
+    assert float((cs - exact).abs().max()) < tol and float((cs_ref - exact).abs().max()) < tol
+    du2 = ops.gemm_glu_bwd(dy, w2, u, act=act, p_drop=p, seed=4321)   # without the column sums
+    assert torch.equal(du2.view(torch.int16), du.view(torch.int16))
+
+
 def test_gemm_glu_rejects_unsupported_shapes():
     from scoreperformer_amd import ops
     assert not ops.gemm_glu_ok(64, 128, 256) and not ops.gemm_glu_ok(256, 192, 256) and not ops.gemm_glu_ok(256, 128, 200)
@@ -174,15 +198,17 @@ def test_feedforward_fused_glu_matches_two_kernel_path(monkeypatch):
     ff = FeedForward(dim=512, mult=4, glu=True, swish=True, dropout=0.1, no_bias=False).cuda().train()
     x0 = torch.randn(4, 256, 512, device="cuda")
     outs = []
-    for fuse in (True, False):
+    for fuse, ffn in ((True, True), (True, False), (False, False)):   # whole-block node / fused projection only / separate kernels
         monkeypatch.setattr(F_, "GLU_FUSE", fuse)
+        monkeypatch.setattr(F_, "FFN_FUSE", ffn)
         F_._seed_state["base"] = None   # same dropout seeds in both runs
         ff.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(True)
         y = ff(x.bfloat16())
         y.float().square().mean().backward()
         outs.append((y.detach().float(), x.grad.clone(), [p.grad.clone() for p in ff.parameters()]))
-    (y1, dx1, g1), (y2, dx2, g2) = outs
-    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
-    for a, b in zip(g1, g2):
-        assert torch.equal(a, b)
+    (y1, dx1, g1) = outs[0]
+    for (y2, dx2, g2) in outs[1:]:
+        assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+        for a, b in zip(g1, g2):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)   # bias column sums: same values, another summation order

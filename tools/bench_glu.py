@@ -35,6 +35,18 @@ def main():
         act = timed(lambda: ops.act_fwd(u, act=0, glu=True, p_drop=p, seed=5))
         out[f"p{p}"] = {"fused_us": round(fused, 1), "gemm_us": round(gemm, 1), "act_us": round(act, 1),
                         "fused_tflops": round(2 * M * 2 * I * K / fused / 1e6, 1)}
+    # backward: input gradient of the output projection + activation backward (spn_gemm_glu_bwd) against the two kernels it replaces
+    dy = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
+    w2 = (torch.randn(K, I, device="cuda") * K ** -0.5).bfloat16()
+    uu = torch.randn(M, 2 * I, device="cuda").bfloat16()
+    cs = torch.zeros(2 * I, device="cuda")
+    for p in (0.0, 0.1):
+        fused = timed(lambda: ops.gemm_glu_bwd(dy, w2, uu, act=0, p_drop=p, seed=5, colsum=cs))
+        gemm = timed(lambda: ops.gemm(dy, w2, tb=True, out_dtype=torch.bfloat16))
+        dg = ops.gemm(dy, w2, tb=True, out_dtype=torch.bfloat16)
+        act = timed(lambda: ops.act_bwd(uu, dg, act=0, glu=True, p_drop=p, seed=5, colsum=cs))
+        out[f"bwd_p{p}"] = {"fused_us": round(fused, 1), "gemm_us": round(gemm, 1), "act_bwd_us": round(act, 1),
+                            "fused_tflops": round(2 * M * I * K / fused / 1e6, 1)}
     print(json.dumps(out))
 
 
