@@ -55,6 +55,19 @@ __device__ __forceinline__ uint32_t spn_hash32(uint32_t x) {
     return x;
 }
 
+// Dropout bits of the feed-forward (nn.Dropout behind the activation, feedforward.py:57-60): element (row t, column c) is kept iff the
+// 16-bit field (c & 1) of ffn_drop_bits(ffn_drop_rowc(t, seed), c >> 1) is >= thr16.  One definition for spn_act_fwd / spn_act_bwd and
+// the gated GEMM epilogues (forward and backward must see the same mask).  The mixer uses full-rate 24-bit multiplies only
+// (v_mul_u32_u24 / v_mad_u32_u24; a 32-bit v_mul_lo_u32 issues at quarter rate and the gated epilogues are VALU-bound): two rounds of
+// fold + multiply-add and a final fold, the mixer of the attention dropout (attention_common.h: per-byte chi^2 ~ 1, avalanche ~0.5).
+__device__ __forceinline__ uint32_t ffn_drop_rowc(long t, uint32_t seed) { return (uint32_t)t * 0x9E3779B1u + seed; }
+__device__ __forceinline__ uint32_t ffn_drop_bits(uint32_t rowc, uint32_t pair) {
+    uint32_t x = rowc + __umul24(pair, 0xEBCA77u);
+    x ^= x >> 11; x = __umul24(x, 0xD35A2Du) + (x >> 8);
+    x ^= x >> 13; x = __umul24(x, 0x9E3B35u) + (x >> 9);
+    return x ^ (x >> 15);
+}
+
 // activations of the feed-forward (one definition: the fused GEMM epilogue and the stand-alone kernels must agree bit for bit)
 // v_rcp_f32 (1 ulp) instead of the IEEE divide sequence: the GEMM epilogue that applies it is VALU-bound (-70 us per FFN at C3)
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }

@@ -25,12 +25,13 @@ __device__ __forceinline__ uint4 pack8f(const float* f) {
 }
 
 // out[t, i] = u[t, i] * act(u[t, I + i])     (GLU) ;  GLU=false: out[t,i] = act(u[t,i])
-// dropout of the activation output (nn.Dropout between activation and out-projection, feedforward.py:57-60): element e of
-// chunk idx is kept iff the e-th 16-bit field of hash(seed, 4*idx + e/2) >= thr16; kept values are scaled by 1/(1-p)
-__device__ __forceinline__ void drop8(float* o, long idx, uint32_t seed, uint32_t thr16, float keep_scale) {
+// dropout of the activation output (nn.Dropout between activation and out-projection, feedforward.py:57-60): the 8 elements of
+// chunk `chunk` (columns 8 chunk ..) of row t; mask definition in common.h (ffn_drop_bits); kept values are scaled by 1/(1-p)
+__device__ __forceinline__ void drop8(float* o, long t, int chunk, uint32_t seed, uint32_t thr16, float keep_scale) {
+    const uint32_t rowc = ffn_drop_rowc(t, seed);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t h = spn_hash32(((uint32_t)idx * 4u + q) * 0x9E3779B1u + seed);
+        const uint32_t h = ffn_drop_bits(rowc, (uint32_t)chunk * 4u + q);
         o[2 * q] = (h & 0xffffu) >= thr16 ? o[2 * q] * keep_scale : 0.f;
         o[2 * q + 1] = (h >> 16) >= thr16 ? o[2 * q + 1] * keep_scale : 0.f;
     }
@@ -55,7 +56,7 @@ __global__ void act_fwd_kernel(const bf16_t* __restrict__ u, long ldu, bf16_t* _
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = act_f<ACT>(g[e]);
         }
-        if (thr16) drop8(o, idx, seed, thr16, keep_scale);
+        if (thr16) drop8(o, t, c >> 3, seed, thr16, keep_scale);
         *reinterpret_cast<uint4*>(out + t * ldo + c) = pack8f(o);
     }
 }
@@ -75,7 +76,7 @@ __global__ void act_bwd_kernel(const bf16_t* __restrict__ u, long ldu, const bf1
         const int c = (idx % chunks) * 8;
         float a[8], g[8], d[8], da[8], dg[8];
         unpack8(*reinterpret_cast<const uint4*>(dout + t * lddo + c), d);
-        if (thr16) drop8(d, idx, seed, thr16, keep_scale);
+        if (thr16) drop8(d, t, c >> 3, seed, thr16, keep_scale);
         if (GLU) {
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + c), a);
             unpack8(*reinterpret_cast<const uint4*>(u + t * ldu + I + c), g);

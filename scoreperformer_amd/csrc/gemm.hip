@@ -457,7 +457,7 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
         // staged du blocks (bf16-rounded, as the consumer GEMMs see them) and left in row cm0/128 + wr of the partial buffer g.ws.
         constexpr int ACT = GLU - 3;
         bf16_t* DU = reinterpret_cast<bf16_t*>(g.C);
-        const int I = g.N, chunks = I >> 3;
+        const int I = g.N;
         const int colw = cn0 + wc * 64;                       // first of this wave's 64 gated outputs
         const int rl = lane & 31, hl = lane >> 5;
         // The u blocks (32 rows x 64 value columns, 32 x 64 gate columns per 32-row block i) arrive by LDS DMA into this wave's 16 KiB
@@ -508,6 +508,7 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
             }
             const int m = mrow0 + rl;
             const bool row_ok = m < g.M;
+            const uint32_t rowc = ffn_drop_rowc(m, g.seed);
             uint2 pa[2][4], pg[2][4];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -516,11 +517,9 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                     uint2 pd;   // dg rounded to bf16 first: what the unfused GEMM stores and spn_act_bwd reads
                     pd.x = pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]); pd.y = pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                     float d[4] = {bf2f(pd.x & 0xffff), bf2f(pd.x >> 16), bf2f(pd.y & 0xffff), bf2f(pd.y >> 16)};
-                    if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (drop8 of elementwise.hip)
+                    if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (common.h: ffn_drop_bits)
                         const int col = colw + 32 * j + 8 * q + 4 * hl;
-                        const long idx = (long)m * chunks + (col >> 3);
-                        const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
-                        const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
+                        const uint32_t h0 = ffn_drop_bits(rowc, (uint32_t)(col >> 1)), h1 = ffn_drop_bits(rowc, (uint32_t)(col >> 1) + 1u);
                         d[0] = (h0 & 0xffffu) >= g.thr16 ? d[0] * g.keep_scale : 0.f;
                         d[1] = (h0 >> 16) >= g.thr16 ? d[1] * g.keep_scale : 0.f;
                         d[2] = (h1 & 0xffffu) >= g.thr16 ? d[2] * g.keep_scale : 0.f;
@@ -596,11 +595,10 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
-                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd: chunk idx = t * (I/8) + col/8, pair e/2 of the chunk
+                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (common.h: ffn_drop_bits)
                     const int col = cn0 + wc * 32 + 8 * q + (lane >> 5) * 4;
-                    const long idx = (long)m * chunks + (col >> 3);
-                    const uint32_t pb = (uint32_t)idx * 4u + ((col & 7) >> 1);
-                    const uint32_t h0 = spn_hash32(pb * 0x9E3779B1u + g.seed), h1 = spn_hash32((pb + 1u) * 0x9E3779B1u + g.seed);
+                    const uint32_t rowc = ffn_drop_rowc(m, g.seed);
+                    const uint32_t h0 = ffn_drop_bits(rowc, (uint32_t)(col >> 1)), h1 = ffn_drop_bits(rowc, (uint32_t)(col >> 1) + 1u);
                     o[0] = (h0 & 0xffffu) >= g.thr16 ? o[0] * g.keep_scale : 0.f;
                     o[1] = (h0 >> 16) >= g.thr16 ? o[1] * g.keep_scale : 0.f;
                     o[2] = (h1 & 0xffffu) >= g.thr16 ? o[2] * g.keep_scale : 0.f;
