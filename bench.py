@@ -187,9 +187,19 @@ def roofline_leg(ops, step, args):
     by_inst = {}
     for name, f, t, tag in gemm:
         _, lay, dt = tag.split(":")
-        a = by_inst.setdefault(f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
-                               f"{'float' if dt == 'f32' else 'unsigned short'}, {1 if dt.endswith('+glu') else 0}>", [0, 0.0, 0.0])
+        if dt.endswith("+glu_bwd"):   # gated backward epilogue: the two-workgroups-per-CU kernel unless the knob says otherwise
+            kname = ("gemm_duo_kernel<true, unsigned short, 3>" if lib.get_tuning("glu_bwd_duo") else
+                     "gemm_pp_kernel<false, true, unsigned short, 3>")
+        else:
+            kname = (f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
+                     f"{'float' if dt == 'f32' else 'unsigned short'}, {1 if dt.endswith('+glu') else 0}>")
+        a = by_inst.setdefault(kname, [0, 0.0, 0.0])
         a[0] += 1; a[1] += f; a[2] += t
+    # launches whose epilogue also does the feed-forward's activation work (forward: GLU + dropout, backward: activation backward +
+    # dropout + bias column sums): their time contains HBM-bound element-wise work that `achieved` prices at zero flops
+    plain = [r for r in gemm if "+glu" not in r[3]]
+    fusedl = [r for r in gemm if "+glu" in r[3]]
+    plain_ms, fused_ms = sum(r[2] for r in plain), sum(r[2] for r in fusedl)
 
     # ---- attention: MFMA-bound.  Work is counted two ways: "dense" = 4 n^2 h dh flop per layer forward (x 2.5 backward) with the
     # causal half discounted -- tiles the ALiBi band never visits included -- and "executed" = the same count with the band switched
@@ -225,8 +235,8 @@ def roofline_leg(ops, step, args):
                    "frac": (ew_bytes / (ew_ms * 1e-3) / 1e9 / 8000.0) if ew_ms else None, "ms_per_step": ew_ms / 2,
                    "per_kernel": [{"kernel": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2, "GB_per_s": v[1] / (v[2] * 1e-3) / 1e9}
                                   for k, v in sorted(ew.items(), key=lambda kv: -kv[1][2])],
-                   "note": "LayerNorm / AdaLN forward+backward and the activation backward (the FFN activation forward lives in the GEMM "
-                           "epilogue); algorithmic bytes, each operand counted once"}
+                   "note": "LayerNorm / AdaLN forward+backward (and activation kernels of shapes the fused GEMM epilogues do not take: the "
+                           "FFN activation forward and backward live in GEMM epilogues); algorithmic bytes, each operand counted once"}
 
     traffic, traffic_note = None, None
     here = os.path.dirname(os.path.abspath(__file__))
@@ -241,12 +251,21 @@ def roofline_leg(ops, step, args):
                             f"passes.  " + (tj.get("note") or ""))
             break
     return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT, GLU> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
-                                       "of a step, a split-K launch includes its reduce kernel; GLU = 1: the gated FFN input projection "
-                                       "with activation + dropout in its epilogue, counted at the GEMM's 2MNK only)",
+                                       "of a step, a split-K launch includes its reduce kernel; GLU = 1 / 3: the gated FFN projections with "
+                                       "the activation (forward) / activation backward in the epilogue, counted at the GEMM's 2MNK only)",
             "achieved": flops / (ms * 1e-3) / 1e12 if ms else None, "peak": 2500.0, "unit": "TFLOP/s",
             "frac": (flops / (ms * 1e-3) / 1e12 / 2500.0) if ms else None, "traffic": traffic, "traffic_note": traffic_note,
             "launches_per_step": len(gemm) // 2, "avg_launch_ms": ms / max(len(gemm), 1),
             "gemm_ms_per_step": ms / 2,
+            "plain_gemm": {"launches_per_step": len(plain) // 2, "ms_per_step": plain_ms / 2,
+                           "tflops": (sum(r[1] for r in plain) / (plain_ms * 1e-3) / 1e12) if plain_ms else None,
+                           "frac": (sum(r[1] for r in plain) / (plain_ms * 1e-3) / 1e12 / 2500.0) if plain_ms else None,
+                           "note": "GEMM launches without a fused activation epilogue"},
+            "fused_activation_epilogues": {"launches_per_step": len(fusedl) // 2, "ms_per_step": fused_ms / 2,
+                                           "tflops_gemm_only": (sum(r[1] for r in fusedl) / (fused_ms * 1e-3) / 1e12) if fused_ms else None,
+                                           "note": "spn_gemm_glu (value * act(gate), dropout) and spn_gemm_glu_bwd (activation backward, "
+                                                   "dropout mask, bias column sums) launches: the element-wise kernels they replace "
+                                                   "(0.33 + 0.51 ms per FFN layer) no longer appear under `elementwise`"},
             "per_kernel": [{"kernel": k, "launches": v[0] // 2, "avg_launch_ms": v[2] / v[0], "ms_per_step": v[2] / 2,
                             "tflops": v[1] / (v[2] * 1e-3) / 1e12} for k, v in sorted(by_inst.items(), key=lambda kv: -kv[1][2])],
             "top_shapes": [{"MNK_layout": k, "launches": v[0] // 2, "ms_per_step": v[2] / 2,

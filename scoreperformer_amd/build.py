@@ -5,6 +5,7 @@ hipcc cross-compiles for gfx950 without a GPU; the ``.so`` travels to the GPU bo
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -22,12 +23,22 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
+def _digest(src):
+    """Content hash of everything an object depends on: compiler flags, the source and every header of csrc/ (a stale object --
+    older flags, a reverted header with an older mtime -- is rebuilt, not reused)."""
+    h = hashlib.sha256(" ".join([HIPCC] + FLAGS).encode())
+    for path in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")):
+        with open(path, "rb") as fh:
+            h.update(path.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def _stale(src, obj):
-    if not os.path.exists(obj):
+    stamp = obj + ".sha256"
+    if not (os.path.exists(obj) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(obj)
-    deps = [src] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as fh:
+        return fh.read().strip() != _digest(src)
 
 
 def _compile(name):
@@ -38,6 +49,8 @@ def _compile(name):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {name}:\n{r.stderr[-4000:]}")
+        with open(obj + ".sha256", "w") as fh:
+            fh.write(_digest(src))
     return obj
 
 
@@ -48,11 +61,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
             os.remove(os.path.join(OBJ, f))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, _sources()))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+    link_stamp = os.path.join(OBJ, "libspn.link.sha256")
+    want = hashlib.sha256("".join(open(o + ".sha256").read() for o in objs).encode()).hexdigest()
+    have = open(link_stamp).read().strip() if os.path.exists(link_stamp) else ""
+    if force or not os.path.exists(LIB) or have != want:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        with open(link_stamp, "w") as fh:
+            fh.write(want)
     if verbose:
         print("built", LIB)
     return LIB

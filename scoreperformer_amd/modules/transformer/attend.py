@@ -1,5 +1,4 @@
 """Attention core (`modules/transformer/attend.py:27-186`) on the fused HIP attention kernels."""
-import warnings
 from dataclasses import dataclass
 from typing import Optional
 
@@ -17,17 +16,6 @@ class AttentionIntermediates:
 
     def to_tuple(self):
         return self.keys, self.values, self.qk_similarities
-
-
-_warned_dropout = False
-
-
-def warn_dropout_once(what: str):
-    global _warned_dropout
-    if not _warned_dropout:
-        warnings.warn(f"{what}: dropout inside the fused HIP kernels is not implemented yet; running with p = 0 "
-                      f"(DESIGN.md 'known gaps')")
-        _warned_dropout = True
 
 
 class Attend(nn.Module):
