@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the bucketed RCCL all-reduce path on a one-rank group")
+    ap.add_argument("--dp-transport", choices=("torch", "spn"), default=os.environ.get("SPN_DP_TRANSPORT", "torch"),
+                    help="gradient all-reduce through torch.distributed (default) or libspn.so's own RCCL wrapper (spn_comm_allreduce)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048)
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -84,7 +86,7 @@ def main():
     model.train()
     model.sync_free = True
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
-    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp)
+    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp, transport=args.dp_transport)
     batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
     # segment-slot counts are known to the (host-side) input pipeline: pass them as python ints, no device read-back
     model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in

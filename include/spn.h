@@ -241,6 +241,20 @@ int spn_collate_mixlm(const int32_t* score_flat, const int32_t* perf_flat, const
 int spn_collate_pad_tokens(const int32_t* flat, const int32_t* off, int b, int K, int L, int pad_id, long long* out, uint8_t* mask,
                            long long* len, spn_stream_t stream);
 
+/* ---- data-parallel collective: thin wrappers over RCCL's ncclAllReduce on a dedicated communication stream, event-fenced against
+ *      the producer / consumer streams (replaces the gradient all-reduce a data-parallel trainer.py run
+ *      performs through torch.distributed; scoreperformer_amd/parallel.py launches one call per gradient bucket from inside backward).
+ *      RCCL is bound at run time (dlopen, RTLD_NOLOAD first: the copy PyTorch has loaded is reused; rccl_path null = "librccl.so").
+ *      id128: 128 bytes made by spn_comm_unique_id on one rank and handed to every rank out of band.  spn_comm_init is collective.
+ *      spn_comm_allreduce: in-place sum of buf[0 .. count) (dtype 0 fp32, 1 bf16) ordered behind everything enqueued on
+ *      producer_stream so far; returns at once.  spn_comm_wait: consumer_stream waits for every all-reduce enqueued so far.
+ *      No host synchronisation; streams / events are created in init and released in destroy. */
+int spn_comm_unique_id(void* id128, const char* rccl_path);
+int spn_comm_init(void** comm, int nranks, int rank, const void* id128, const char* rccl_path);
+int spn_comm_allreduce(void* comm, void* buf, size_t count, int dtype, spn_stream_t producer_stream);
+int spn_comm_wait(void* comm, spn_stream_t consumer_stream);
+int spn_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

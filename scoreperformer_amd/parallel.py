@@ -15,17 +15,25 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, arena, group=None, bucket_mb: float = 32.0, force: bool = False, grad_dtype: torch.dtype = torch.float32,
-                 dry_run: bool = False):
+                 dry_run: bool = False, transport: str = "torch"):
         """`force=True` keeps the bucketed all-reduce path active on a one-rank group (single-GPU tests of the RCCL path).
         `grad_dtype=torch.bfloat16` sends every bucket as bf16 (half the bytes over xGMI: 144 MB instead of 288 MB per step at C3;
         the sum over ranks is then formed in bf16 -- about 3 significant digits per element -- so fp32 stays the default).
         `dry_run=True` runs the whole readiness protocol without a process group: buckets are "launched" into `self.events`
-        (tools/record_grad_events.py records the real model's pending / ready order that way)."""
+        (tools/record_grad_events.py records the real model's pending / ready order that way).
+        `transport="spn"`: buckets go through libspn.so's own RCCL wrapper (`spn_comm_allreduce`: ncclAllReduce on a dedicated
+        communication stream, event-fenced; comm.NativeComm, created collectively over `group`) instead of `dist.all_reduce`."""
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.dry_run = dry_run
         self.active = dry_run or self.world > 1 or (force and group is not None)
         self.grad_dtype = grad_dtype
+        self.native = None
+        if transport == "spn" and not dry_run and group is not None and (self.world > 1 or force):
+            from .comm import NativeComm
+            self.native = NativeComm.from_group(group)
+        elif transport not in ("torch", "spn"):
+            raise ValueError(f"unknown transport {transport!r}")
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
@@ -114,13 +122,21 @@ class GradSync:
             return
         grads = self.arena.grads[s:e]
         if self.grad_dtype == grads.dtype:
-            self.handles.append((dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+            if self.native is not None:
+                self.native.all_reduce_(grads)
+                self.handles.append((None, None, None))
+            else:
+                self.handles.append((dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
             return
         # reduced-precision transport: the bucket is cast into a staging buffer (stream-ordered behind the kernels that produced
         # the gradients), reduced there, and cast back into the fp32 arena in finish()
         staged = self._staging(b, e - s, grads.device)
         staged.copy_(grads)
-        self.handles.append((dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=self.group, async_op=True), staged, grads))
+        if self.native is not None:
+            self.native.all_reduce_(staged)
+            self.handles.append((None, staged, grads))
+        else:
+            self.handles.append((dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=self.group, async_op=True), staged, grads))
 
     def _staging(self, b, n, device):
         bufs = self.__dict__.setdefault("_stage_bufs", {})
@@ -145,8 +161,11 @@ class GradSync:
         for b in range(len(self.buckets)):
             if b not in self.launched:
                 self._launch(b)
+        if self.native is not None:
+            self.native.wait()   # the current stream waits (on the device) for every bucket; no host synchronisation
         for h, staged, grads in self.handles:
-            h.wait()
+            if h is not None:
+                h.wait()
             if staged is not None:
                 grads.copy_(staged)
         self.handles = []

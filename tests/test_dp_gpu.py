@@ -19,13 +19,13 @@ def test_gradsync_nccl_single_rank_matches_plain_step(dev):
     try:
         batch = synthetic_batch(2, 64, seed=3, ragged=True, device=dev)
         results = []
-        for use_sync in (False, True, "bf16"):
+        for use_sync in (False, True, "bf16", "spn"):   # "spn": libspn.so's own RCCL wrapper (spn_comm_allreduce) instead of dist.all_reduce
             model = ScorePerformer.init(model_config("tiny", dropout=0.0))
             model.load_state_dict(filled_state_dict(model, seed=5))
             arena = ParamArena(model, dev)
             model.train()
             opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
-            sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, force=True,
+            sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, force=True, transport="spn" if use_sync == "spn" else "torch",
                             grad_dtype=torch.bfloat16 if use_sync == "bf16" else torch.float32) if use_sync else None
             torch.manual_seed(11)
             first = None
@@ -43,7 +43,9 @@ def test_gradsync_nccl_single_rank_matches_plain_step(dev):
                 opt.step()
             torch.cuda.synchronize()
             results.append((float(out.loss.detach()), first, grads, arena.params.clone()))
-        (l0, f0, g0, p0), (l1, f1, g1, p1), (l2, f2, g2, p2) = results
+        (l0, f0, g0, p0), (l1, f1, g1, p1), (l2, f2, g2, p2), (l3, f3, g3, p3) = results
+        # native transport on one rank: the same buckets through ncclAllReduce on libspn.so's communication stream
+        assert (f3 - f1).abs().max() <= 2e-5 * f1.abs().max() and (g3 - g1).abs().max() <= 5e-3 * g1.abs().max()
         # bf16 transport (one rank: the all-reduce is the identity): the arena holds the bf16-rounded fp32 gradients
         assert (f2 - f1).abs().max() <= 2.0 ** -8 * f1.abs().max()
         assert bool(((f2 - f1).abs() <= 2.0 ** -8 * f1.abs() + 1e-30).all())
@@ -106,3 +108,21 @@ def test_two_rank_data_parallel_step_equals_the_global_batch_step(dev):
     # one Adam step (lr 1e-3) moves every entry by ~lr * sign(g): entries whose gradient is not at the noise level agree closely
     dp = (arena.params - p_global).abs()
     assert float(dp.max()) <= 2.5e-3 and float((dp > 2e-4).float().mean()) < 0.05, (float(dp.max()), float((dp > 2e-4).float().mean()))
+
+
+def test_native_comm_allreduce_is_stream_ordered(dev):
+    """spn_comm_*: one-rank communicator bound to the RCCL copy PyTorch loaded; the all-reduce (identity on one rank, fp32 and bf16)
+    runs on the library's own stream, ordered behind the producer kernel and ahead of the consumer through events only."""
+    from scoreperformer_amd.comm import NativeComm, unique_id
+    comm = NativeComm(1, 0, unique_id())
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            x = torch.zeros(1 << 22, device=dev, dtype=dtype)
+            x.add_(3.0)                     # producer on the current stream
+            comm.all_reduce_(x)             # must see the 3.0
+            comm.wait()
+            y = x * 2.0                     # consumer on the current stream
+            torch.cuda.synchronize()
+            assert float(y.float().min()) == 6.0 and float(y.float().max()) == 6.0
+    finally:
+        comm.close()
