@@ -324,6 +324,23 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // This wave's weight row (and the gate row of a gated projection) does not depend on the input vector: its loads go out FIRST, so
+    // that their HBM latency runs under the input load + LayerNorm prologue below instead of behind it (a note is a chain of ~30 such
+    // launches and each one is latency-, not bandwidth-bound).  K <= 2048: at most 8 chunks of 4 floats per lane.
+    const int n = blockIdx.x * 4 + w;
+    const bool vec = (a.K & 3) == 0 && (a.ldw & 3) == 0;
+    const bool gated = a.glu > 0;   // glu = -1: plain activation, no gate rows
+    const float* wv_ = a.W + (long)min(n, a.N - 1) * a.ldw;
+    const float* wg_ = a.W + (long)(min(n, a.N - 1) + a.N) * a.ldw;
+    f32x4 wreg[8], greg[8];
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            wreg[c] = k < a.K ? *reinterpret_cast<const f32x4*>(wv_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            greg[c] = (gated && k < a.K) ? *reinterpret_cast<const f32x4*>(wg_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const int p = a.pos ? *a.pos : 0;
     float s = 0.f;
     if (a.att_part) {
@@ -385,29 +402,30 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
         }
     }
     __syncthreads();
-    const int n = blockIdx.x * 4 + w;
     if (n >= a.N) return;
-    const float* wv_ = a.W + (long)n * a.ldw;
-    const float* wg_ = a.W + (long)(n + a.N) * a.ldw;
     float acc = 0.f, accg = 0.f;
-    if ((a.K & 3) == 0 && (a.ldw & 3) == 0) {
-        for (int k = lane * 4; k < a.K; k += 256) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wv_ + k);
-            acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
-            if (a.glu) {
-                const f32x4 wg = *reinterpret_cast<const f32x4*>(wg_ + k);
-                accg += wg[0] * xv[0] + wg[1] * xv[1] + wg[2] * xv[2] + wg[3] * xv[3];
+    if (vec) {   // same expression order as before the preload (k ascending, four products summed left to right): bit-identical outputs
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            if (k < a.K) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
+                const f32x4 wv = wreg[c];
+                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                if (gated) {
+                    const f32x4 wg = greg[c];
+                    accg += wg[0] * xv[0] + wg[1] * xv[1] + wg[2] * xv[2] + wg[3] * xv[3];
+                }
             }
         }
     } else {
-        for (int k = lane; k < a.K; k += 64) { acc = fmaf(wv_[k], xs[k], acc); if (a.glu) accg = fmaf(wg_[k], xs[k], accg); }
+        for (int k = lane; k < a.K; k += 64) { acc = fmaf(wv_[k], xs[k], acc); if (gated) accg = fmaf(wg_[k], xs[k], accg); }
     }
     acc = wave_sum(acc);
-    if (a.glu) accg = wave_sum(accg);
+    if (gated) accg = wave_sum(accg);
     if (lane == 0) {
-        if (a.bias) { acc += a.bias[n]; if (a.glu) accg += a.bias[n + a.N]; }
-        if (a.glu) acc = acc * dec_act(accg, a.act);
+        if (a.bias) { acc += a.bias[n]; if (gated) accg += a.bias[n + a.N]; }
+        if (gated) acc = acc * dec_act(accg, a.act);
         else if (a.act >= 0 && a.glu < 0) acc = dec_act(acc, a.act);   // plain activation (glu = -1)
         if (a.residual) acc += a.residual[n];
         a.y[(long)(p + a.y_off) * a.y_ld + n] = acc;
