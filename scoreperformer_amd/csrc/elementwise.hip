@@ -350,6 +350,10 @@ extern "C" int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* 
 extern "C" int spn_colsum(const void* x, int x_dtype, long ldx, float* out, long T, int N, hipStream_t s) {
     SPN_REQUIRE(x && out && T > 0 && N > 0, "spn_colsum: bad arguments");
     int slabs = (int)((T + 1023) / 1024);
+    // short, wide inputs (the [M/128, 2I] partial rows of spn_gemm_glu_bwd): enough row slabs for >= 1024 blocks, 16+ rows each
+    const int want = (1024 + cdiv(N, 64) - 1) / cdiv(N, 64);
+    if (slabs < want) slabs = (int)(want < (T + 15) / 16 ? want : (T + 15) / 16);
+    if (slabs < 1) slabs = 1;
     if (slabs > 512) slabs = 512;
     const int rpb = (int)((T + slabs - 1) / slabs);
     dim3 grid(cdiv(N, 64), cdiv(T, rpb));
