@@ -548,8 +548,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // ==========================================================================================================
 // ALiBi band skipping.  ALiBi subtracts slope*|i - j| from the score, so for the steep heads everything far from the diagonal
 // is numerically dead: with B >= |q.k|*scale*log2e the probability of key j relative to the row's largest one is at most
-// 2^(2B - slope2*|d|) (attention_common.h, band_reach).  Tiles where that is < 2^-band_log2 (default 40: 2048 such terms sum to
-// < 2^-29 of the row normaliser, below fp32 resolution) are not visited -- in the forward AND in both backward kernels, from
+// 2^(2B - slope2*|d|) (attention_common.h, band_reach).  Tiles where that is < 2^-band_log2 (default 30: 2048 such terms sum to
+// < 2^-19 of the row normaliser, three orders of magnitude below the 2^-9 rounding of the bf16 probabilities that enter P V; 40 puts the
+// sum below fp32 resolution) are not visited -- in the forward AND in both backward kernels, from
 // the same bound, so the three stay consistent.  The bound B comes from this pre-pass: max ||q||^2 per 64-row tile and max ||k||^2
 // per (batch, kv head) (Cauchy-Schwarz).  A query tile containing a row whose own diagonal key is masked or out of range has no
 // such lower bound on its row maximum and is marked +inf = never skipped.  Learned slopes <= 0 disable skipping for that head.
@@ -637,7 +638,7 @@ int check_common(const AttnArgs& a) {
 
 // strides: 12 longs = {q_bs,q_ns,q_hs, k_bs,k_ns,k_hs, v_bs,v_ns,v_hs, o_bs,o_ns,o_hs} in elements; head dim 64.
 // probabilities below 2^-log2_threshold of their row's largest one may be skipped by the ALiBi band (0 = visit everything).
-// Default 40.  Process-wide (the "attn_band" knob of spn_set_tuning); meant for tests and ablations.
+// Default 30.  Process-wide (the "attn_band" knob of spn_set_tuning); meant for tests and ablations.
 extern "C" int spn_set_tuning(const char* name, double value);
 extern "C" void spn_attn_set_band(float log2_threshold) { spn_set_tuning("attn_band", log2_threshold < 0.f ? 0.f : log2_threshold); }
 

@@ -4,7 +4,7 @@
 #pragma once
 
 enum SpnTune {
-    SPN_TUNE_ATTN_BAND = 0,        // log2 of the smallest probability ratio still visited by the ALiBi band (0 = visit everything); 40
+    SPN_TUNE_ATTN_BAND = 0,        // log2 of the smallest probability ratio still visited by the ALiBi band (0 = visit everything); 30
     SPN_TUNE_ATTN_ORDER,           // attention block order: 1 = XCD per batch element + heaviest-first causal tiles, 0 = grid order; 1
     SPN_TUNE_GEMM_VARIANT,         // 0 = measured dispatch; 1..6 force a 128x128 variant; 9 = ping-pong wherever eligible; 0
     SPN_TUNE_GEMM_NGROUP,          // n-tiles per column group of the tile order; 8

@@ -66,10 +66,10 @@ def test_tuning_table_round_trip():
     names = [handle.spn_tuning_name(ctypes.c_int(i)).decode() for i in range(handle.spn_tuning_count())]
     assert "attn_band" in names and "gemm_variant" in names and len(set(names)) == len(names)
     out = ctypes.c_double(0)
-    assert handle.spn_get_tuning(b"attn_band", ctypes.byref(out)) == 0 and out.value == 40.0
+    assert handle.spn_get_tuning(b"attn_band", ctypes.byref(out)) == 0 and out.value == 30.0
     assert handle.spn_set_tuning(b"attn_band", ctypes.c_double(0.0)) == 0
     assert handle.spn_get_tuning(b"attn_band", ctypes.byref(out)) == 0 and out.value == 0.0
-    assert handle.spn_set_tuning(b"attn_band", ctypes.c_double(40.0)) == 0
+    assert handle.spn_set_tuning(b"attn_band", ctypes.c_double(30.0)) == 0
     assert handle.spn_set_tuning(b"no_such_knob", ctypes.c_double(1.0)) != 0
 
 

@@ -260,7 +260,7 @@ def test_attention_alibi_band_skipping_is_invisible(dev, causal, masked):
     d_o = torch.randn(b, n, h, 64, generator=g).to(dev).bfloat16()
     res = []
     try:
-        for thr in (0.0, 40.0):
+        for thr in (0.0, 40.0, 30.0):   # off / below fp32 resolution / the shipped default
             ops.attn_set_band(thr)
             o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=slopes, causal=causal)
             dqkv = torch.zeros_like(qkv)
@@ -269,13 +269,16 @@ def test_attention_alibi_band_skipping_is_invisible(dev, causal, masked):
             dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=slopes, causal=causal, want_dslope=True)
             res.append((o.float(), lse, dqkv.float(), dsl))
     finally:
-        ops.attn_set_band(40.0)
-    (o0, l0, d0, s0), (o1, l1, d1, s1) = res
+        ops.attn_set_band(30.0)
+    (o0, l0, d0, s0), (o1, l1, d1, s1), (o2, l2, d2, s2) = res
     valid = slice(None) if kmask is None else kmask   # rows at padded positions are don't-care in the model, but checked too
     assert (o0 - o1).abs().max() <= 1e-6 * o0.abs().max()
     assert (l0 - l1).abs().max() <= 1e-5
     assert (d0 - d1).abs().max() <= 1e-6 * d0.abs().max()
     assert (s0 - s1).abs().max() <= 1e-5 * s0.abs().max()
+    # the default threshold 2^-30: what is skipped sums to < 2^-19 of a row's normaliser (bf16 rounds the probabilities at 2^-9)
+    assert (o0 - o2).abs().max() <= 1e-5 * o0.abs().max() and (l0 - l2).abs().max() <= 1e-4
+    assert (d0 - d2).abs().max() <= 1e-5 * d0.abs().max() and (s0 - s2).abs().max() <= 1e-4 * s0.abs().max()
 
 
 def test_ffn_dropout_mask_is_consistent_and_unbiased(dev):

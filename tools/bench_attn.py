@@ -31,11 +31,11 @@ def main():
         tf = (time.perf_counter() - t0) / reps
         o, lse = res[0], res[1]
         bkw = {"p_drop": p_drop, "dropbits": res[2]} if p_drop > 0 else {}
-        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None, **bkw)
+        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=slopes is not None, **bkw)
+            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t0) / reps
         print(f"causal={causal}: fwd {tf*1e3:.3f} ms {fl/tf/1e12:.0f} TF/s | bwd {tb*1e3:.3f} ms {2.5*fl/tb/1e12:.0f} TF/s (5-matmul flops)")
