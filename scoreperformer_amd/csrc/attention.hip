@@ -551,8 +551,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // 2^(2B - slope2*|d|) (attention_common.h, band_reach).  Tiles where that is < 2^-band_log2 (default 30: 2048 such terms sum to
 // < 2^-19 of the row normaliser, three orders of magnitude below the 2^-9 rounding of the bf16 probabilities that enter P V; 40 puts the
 // sum below fp32 resolution) are not visited -- in the forward AND in both backward kernels, from
-// the same bound, so the three stay consistent.  The bound B comes from this pre-pass: max ||q||^2 per 64-row tile and max ||k||^2
-// per (batch, kv head) (Cauchy-Schwarz).  A query tile containing a row whose own diagonal key is masked or out of range has no
+// the same bound, so the three stay consistent.  The bound comes from this pre-pass: per 64-row query tile max ||q||^2 and the smallest
+// score of a row's OWN key (a lower bound of that row's maximum), and max ||k||^2 per (batch, kv head) (Cauchy-Schwarz for every
+// other score; band_reach, attention_common.h).  A query tile containing a row whose own key is masked or out of range has no
 // such lower bound on its row maximum and is marked +inf = never skipped.  Learned slopes <= 0 disable skipping for that head.
 // ==========================================================================================================
 __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __restrict__ band) {
@@ -562,25 +563,40 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
     if (!is_q && hi >= a.kvh) return;
     const int row = (is_q ? x : x - a.nqt64) * 64 + lane;
     const int n = is_q ? a.nq : a.nk;
-    float v = 0.f;
+    const long nq_part = (long)a.b * a.h * a.nqt64;
+    float v = 0.f, dot = __builtin_inff();   // |row|^2; query rows: q_i . k_i' with the row's own key i' = i + off
     if (row < n) {
         const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
+        const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
+        const bool own_ok = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
+        const bf16_t* pk = own_ok ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
+        float d = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
             const uint4 u = *reinterpret_cast<const uint4*>(p + ch * 8);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            const uint4 uk = *reinterpret_cast<const uint4*>(pk + ch * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w}, wk[4] = {uk.x, uk.y, uk.z, uk.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float lo = bf2f(w[e] & 0xffff), hi_ = bf2f(w[e] >> 16); v = fmaf(lo, lo, fmaf(hi_, hi_, v)); }
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf2f(w[e] & 0xffff), hi_ = bf2f(w[e] >> 16);
+                v = fmaf(lo, lo, fmaf(hi_, hi_, v));
+                d = fmaf(lo, bf2f(wk[e] & 0xffff), fmaf(hi_, bf2f(wk[e] >> 16), d));
+            }
         }
         if (is_q) {
-            const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
-            if (jd < 0 || jd >= a.nk || (a.kmask && a.kmask[(long)bi * a.nk + jd] == 0)) v = __builtin_inff();
+            if (own_ok) dot = d;
+            else v = __builtin_inff();   // no lower bound on this row's maximum: the tile is never skipped
         }
     }
     v = wave_max(v);
+    if (is_q) dot = -wave_max(-dot);   // minimum over the tile's rows (rows past nq: +inf)
     if (lane == 0) {
-        if (is_q) band[((long)(bi * a.h + hi)) * a.nqt64 + x] = v;
-        else atomicMax(reinterpret_cast<unsigned int*>(band + (long)a.b * a.h * a.nqt64 + bi * a.kvh + hi), __float_as_uint(v));   // v >= 0
+        if (is_q) {
+            band[((long)(bi * a.h + hi)) * a.nqt64 + x] = v;
+            band[nq_part + ((long)(bi * a.h + hi)) * a.nqt64 + x] = dot;
+        } else {
+            atomicMax(reinterpret_cast<unsigned int*>(band + 2 * nq_part + bi * a.kvh + hi), __float_as_uint(v));   // v >= 0
+        }
     }
 }
 
@@ -596,7 +612,7 @@ int prepare_band(AttnArgs& a, hipStream_t stream, float* own, bool reuse) {
     a.band = own;
     if (reuse) return SPN_OK;
     const size_t nq_part = (size_t)a.b * a.h * a.nqt64;
-    hipMemsetAsync(own + nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
+    (void)hipMemsetAsync(own + 2 * nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
     hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, own);
     return SPN_OK;
 }
@@ -643,7 +659,7 @@ extern "C" int spn_set_tuning(const char* name, double value);
 extern "C" void spn_attn_set_band(float log2_threshold) { spn_set_tuning("attn_band", log2_threshold < 0.f ? 0.f : log2_threshold); }
 
 // floats of a caller-owned band buffer (spn_attn_fwd fills it, spn_attn_bwd of the same problem reuses it instead of recomputing)
-extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return (long)b * h * ((nq + 63) / 64) + (long)b * kvh; }
+extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return 2l * b * h * ((nq + 63) / 64) + (long)b * kvh; }
 
 // uint16 words of the dropout keep-bit buffer for a [b, h, nq, nk] attention (1 bit per score, whole 128x128 blocks)
 extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {

@@ -34,22 +34,27 @@ struct AttnArgs {
     // i.e. exactly the forward's (and dQ's) S^T register layout.
     uint32_t thr8, thr_frac, seed; int drop_on; float inv_keep;   // p = (thr8 + thr_frac / 65536) / 256: see set_dropout (attention.hip)
     uint16_t* dropbits; int nqt16, nkt64;
-    // ALiBi band (attention.hip, "band skipping"): band[(b*h + head)*nqt64 + i/64] = max ||q_i||^2 over the 64-row tile (+inf if
-    // the tile must never be skipped), then band[b*h*nqt64 + b_*kvh + kv_head] = max ||k_j||^2.  null / band_log2 <= 0: off.
+    // ALiBi band (attention.hip, "band skipping"): per 64-row query tile max ||q_i||^2 (+inf if the tile must never be skipped) and
+    // min q_i.k_i' (the rows' own keys), then max ||k_j||^2 per (batch, kv head): layout at band_reach below.  null / band_log2 <= 0: off.
     const float* band; int nqt64; float band_log2;
     int order;   // block -> (batch, head, tile) remaps below (XCD locality, causal longest-first); SPN_ATTN_ORDER=0: plain grid order
 };
 
-// Largest |j - i - off| that can still matter for a query tile: with |q.k * scale * log2e| <= B every score obeys
-// t_ij <= B - slope2*|d| while the row maximum is at least its diagonal score >= -B, so  t_ij - m_i <= 2B - slope2*|d|.
-// Beyond D = (band_log2 + 2B) / slope2 every probability is below 2^-band_log2 of the row's largest one.
+// Largest |j - i - off| that can still matter for a query tile.  Log2-domain scores: t_ij = c1 q_i.k_j - slope2 |d|.  Every score obeys
+// t_ij <= c1 |q_i| max|k| - slope2 |d|, and the row maximum is at least the score of the row's OWN key (d = 0): m_i >= c1 q_i.k_i'.
+// So t_ij - m_i <= c1 (|q_i| max|k| - q_i.k_i') - slope2 |d|, and beyond D = (band_log2 + c1 (max|q| max|k| - min q_i.k_i')) / slope2
+// every probability of the tile's rows is below 2^-band_log2 of its row's largest one.  (Until round 2 the row maximum was bounded by
+// -c1 |q_i| max|k| instead of the actual diagonal score: 2 c1 max|q| max|k| in the numerator, a ~1.7x longer reach at initialisation.)
+// band layout: [b*h*nqt64] max |q_i|^2 per 64-row tile (+inf: never skip), [b*h*nqt64] min q_i.k_i' per tile, [b*kvh] max |k_j|^2.
 __device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, int kh, int qtile64, int ntiles, float c1, float slope2) {
     if (!a.band || !(slope2 > 0.f)) return 3.0e38f;
+    const long nq_part = (long)a.b * a.h * a.nqt64;
     const float* qt = a.band + ((long)(bi * a.h + hi)) * a.nqt64 + qtile64;
-    float qm = qt[0];
-    for (int t = 1; t < ntiles; ++t) if (qtile64 + t < a.nqt64) qm = fmaxf(qm, qt[t]);
-    const float km = a.band[(long)a.b * a.h * a.nqt64 + bi * a.kvh + kh];
-    const float D = (a.band_log2 + 2.f * c1 * sqrtf(qm * km)) / slope2;
+    float qm = qt[0], dm = qt[nq_part];
+    for (int t = 1; t < ntiles; ++t)
+        if (qtile64 + t < a.nqt64) { qm = fmaxf(qm, qt[t]); dm = fminf(dm, qt[nq_part + t]); }
+    const float km = a.band[2 * nq_part + bi * a.kvh + kh];
+    const float D = (a.band_log2 + c1 * (sqrtf(qm * km) - dm)) / slope2;
     return D < 1.0e9f ? D : 3.0e38f;   // inf / nan (never-skip tiles) -> unbounded
 }
 
