@@ -71,39 +71,32 @@ class TupleTransformer(nn.Module, Constructor):
                  style_emb_dim: Optional[int] = None, style_emb_mode: str = EmbeddingModes.CONCAT, lm_head=None,
                  regression_head=None):
         super().__init__()
-        if transformer is None:
-            transformer = TransformerConfig(_target_="default")
-        if token_embeddings is None:
-            token_embeddings = TupleTokenEmbeddingsConfig()
-        self.dim, self.max_seq_len = dim, max_seq_len
-        emb_dim = dim
-        self.context_emb_dim = context_emb_dim or 0
-        self.context_emb_mode = context_emb_mode
-        self.style_emb_dim = style_emb_dim or 0
-        self.style_emb_mode = style_emb_mode
-        self.token_emb = TupleTokenEmbeddingsRegistry.instantiate(
-            config=token_embeddings, num_tokens=num_tokens, emb_dims=token_embeddings.get("emb_dims", emb_dim),
-            project_emb_dim=emb_dim)
-        if self.context_emb_mode != EmbeddingModes.ATTENTION:
-            transformer.cross_attend = False
-        self.transformer = TransformerRegistry.instantiate(
-            transformer, dim=dim, use_adanorm=self.style_emb_mode == EmbeddingModes.ADANORM, style_emb_dim=self.style_emb_dim)
-        self.pos_emb = None
-        if use_abs_pos_emb:
-            self.pos_emb = AbsolutePositionalEmbedding(emb_dim, self.max_seq_len)
-            nn.init.kaiming_normal_(self.pos_emb.emb.weight)
-        self.emb_norm = LayerNorm(emb_dim) if emb_norm else nn.Identity()
-        self.emb_dropout = nn.Dropout(emb_dropout) if emb_dropout > 0. else nn.Identity()
         if emb_dropout > 0.:
             raise NotImplementedError("emb_dropout > 0 is not used by any shipped recipe")
-        self.project_emb = nn.Identity()
-        total_emb_dim = (emb_dim + int(context_emb_mode == EmbeddingModes.CONCAT) * self.context_emb_dim
-                         + int(style_emb_mode == EmbeddingModes.CONCAT) * self.style_emb_dim)
-        if total_emb_dim != dim:
-            self.project_emb = nn.Linear(total_emb_dim, dim)
-        self.lm_head = None
-        if lm_head is not None:
-            self.lm_head = TupleTokenHeadsRegistry.instantiate(config=lm_head, dim=dim, embeddings=self.token_emb)
+        stack_cfg = transformer if transformer is not None else TransformerConfig(_target_="default")
+        emb_cfg = token_embeddings if token_embeddings is not None else TupleTokenEmbeddingsConfig()
+        self.dim, self.max_seq_len = dim, max_seq_len
+        self.context_emb_dim, self.context_emb_mode = (context_emb_dim or 0), context_emb_mode
+        self.style_emb_dim, self.style_emb_mode = (style_emb_dim or 0), style_emb_mode
+        cat_context, cat_style = context_emb_mode == EmbeddingModes.CONCAT, style_emb_mode == EmbeddingModes.CONCAT
+
+        # sub-modules in the reference's registration order (= its state_dict order): token_emb, transformer, pos_emb, emb_norm,
+        # emb_dropout, project_emb, lm_head, regression_head
+        self.token_emb = TupleTokenEmbeddingsRegistry.instantiate(
+            config=emb_cfg, num_tokens=num_tokens, emb_dims=emb_cfg.get("emb_dims", dim), project_emb_dim=dim)
+        if context_emb_mode != EmbeddingModes.ATTENTION:
+            stack_cfg.cross_attend = False        # a context that is concatenated / summed is not cross-attended to
+        self.transformer = TransformerRegistry.instantiate(
+            stack_cfg, dim=dim, use_adanorm=style_emb_mode == EmbeddingModes.ADANORM, style_emb_dim=self.style_emb_dim)
+        self.pos_emb = AbsolutePositionalEmbedding(dim, max_seq_len) if use_abs_pos_emb else None
+        if self.pos_emb is not None:
+            nn.init.kaiming_normal_(self.pos_emb.emb.weight)
+        self.emb_norm = LayerNorm(dim) if emb_norm else nn.Identity()
+        self.emb_dropout = nn.Identity()
+        width_in = dim + (self.context_emb_dim if cat_context else 0) + (self.style_emb_dim if cat_style else 0)
+        self.project_emb = nn.Linear(width_in, dim) if width_in != dim else nn.Identity()
+        self.lm_head = (TupleTokenHeadsRegistry.instantiate(config=lm_head, dim=dim, embeddings=self.token_emb)
+                        if lm_head is not None else None)
         self.regression_head = None
         if regression_head is not None:
             assert self.token_emb.continuous, "TupleTokenRegressionHead depends on `continuous` token embeddings."

@@ -4,7 +4,6 @@ The residual stream is fp32; each sub-layer is  x <- x + f(norm(x))  with the ad
 """
 import copy
 from dataclasses import dataclass
-from functools import partial
 from typing import List, Optional, Union
 
 import torch
@@ -12,7 +11,6 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import functional as F_
-from ...utils import equals
 from ...utils.config import DictConfig
 from ..constructor import VariableModuleConfig, Constructor, Registry
 from ..layers import Residual, AdaptiveLayerNorm, LayerNorm
@@ -48,38 +46,37 @@ class TransformerConfig(VariableModuleConfig):
 
 @TransformerRegistry.register("default")
 class Transformer(nn.Module, Constructor):
+    # sub-layer pattern of one block, by (cross_attend, only_cross): self-attention 'a', cross-attention 'c', feed-forward 'f'
+    _PATTERNS = {(False, False): "af", (False, True): "af", (True, False): "acf", (True, True): "cf"}
+
     def __init__(self, dim: int = 512, depth: int = 4, heads: int = 8, attention=None, feed_forward=None, causal: bool = False,
                  cross_attend: bool = False, only_cross: bool = False, pre_norm: bool = True, use_adanorm: bool = False,
                  style_emb_dim: Optional[int] = None):
         super().__init__()
-        attention = attention if attention else AttentionConfig()
-        feed_forward = feed_forward if feed_forward else FeedForwardConfig()
-        self.dim, self.depth = dim, depth
-        self.layers = nn.ModuleList([])
-        self.pre_norm, self.ada_norm = pre_norm, use_adanorm
-        assert not use_adanorm or style_emb_dim is not None, 'condition_dim should be provided with adanorm'
-        norm_fn = partial(AdaptiveLayerNorm, dim, style_emb_dim) if use_adanorm else partial(LayerNorm, dim)
-        self.cross_attend = cross_attend
-        if cross_attend and not only_cross:
-            default_block = ('a', 'c', 'f')
-        elif cross_attend and only_cross:
-            default_block = ('c', 'f')
-        else:
-            default_block = ('a', 'f')
-        self.layer_types = default_block * depth
-        self.num_attn_layers = len(list(filter(equals('a'), self.layer_types)))
-        self.final_norm = norm_fn() if pre_norm else nn.Identity()
-        for layer_type in self.layer_types:
-            if layer_type == 'a':
-                layer = Attention.init(config=attention, dim=dim, heads=heads, causal=causal)
-            elif layer_type == 'c':
-                layer = Attention.init(config=attention, dim=dim, heads=heads)
-            elif layer_type == 'f':
-                layer = FeedForward.init(config=feed_forward, dim=dim)
-            else:
-                raise Exception(f'invalid layer type {layer_type}')
-            norms = nn.ModuleList([norm_fn() if pre_norm else None, None, norm_fn() if not pre_norm else None])
-            self.layers.append(nn.ModuleList([norms, layer, Residual(dim)]))
+        if use_adanorm and style_emb_dim is None:
+            raise AssertionError('condition_dim should be provided with adanorm')
+        attn_cfg = attention or AttentionConfig()
+        ffn_cfg = feed_forward or FeedForwardConfig()
+        self.dim, self.depth, self.pre_norm, self.ada_norm, self.cross_attend = dim, depth, pre_norm, use_adanorm, cross_attend
+
+        def new_norm():   # one normalisation module of this stack (adaptive: conditioned on the style embedding)
+            return AdaptiveLayerNorm(dim, style_emb_dim) if use_adanorm else LayerNorm(dim)
+
+        make = {   # constructors of the three sub-layer kinds
+            "a": lambda: Attention.init(config=attn_cfg, dim=dim, heads=heads, causal=causal),
+            "c": lambda: Attention.init(config=attn_cfg, dim=dim, heads=heads),
+            "f": lambda: FeedForward.init(config=ffn_cfg, dim=dim),
+        }
+        self.layer_types = tuple(self._PATTERNS[(bool(cross_attend), bool(only_cross))]) * depth
+        self.num_attn_layers = self.layer_types.count("a")
+        # registration order = state_dict order of the reference: `layers.<i>.0.<slot>` norms, `.1` the sub-layer, `.2` the residual, then
+        # `final_norm`; slot 0 is the pre-norm, slot 2 the post-norm, slot 1 stays empty
+        self.layers = nn.ModuleList()
+        self.final_norm = new_norm() if pre_norm else nn.Identity()
+        for kind in self.layer_types:
+            block = make[kind]()
+            slots = [new_norm() if pre_norm else None, None, None if pre_norm else new_norm()]
+            self.layers.append(nn.ModuleList([nn.ModuleList(slots), block, Residual(dim)]))
 
     def _norm(self, norm, x, style, out_fp32=False, fork=False):
         if self.ada_norm:
