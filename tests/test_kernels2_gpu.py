@@ -212,3 +212,12 @@ def test_feedforward_fused_glu_matches_two_kernel_path(monkeypatch):
         assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
         for a, b in zip(g1, g2):
             assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)   # bias column sums: same values, another summation order
+
+
+def test_gemm_random_shapes_full_tensor_screen():
+    """Race / edge screen of the ping-pong GEMM (peeled K loop, asm LDS DMA, pre-read fragments, split-K through a workspace): random
+    shapes in every layout, compared in full with torch's fp32 matmul of the same bf16 operands (tools/stress_gemm.py, 80 cases)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_gemm.py"), "80", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
