@@ -629,6 +629,63 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
             }
         }
     } else {
+    if constexpr (ES == 4) {
+        // fp32 output with a residual (y = residual + ...: the attention and feed-forward output projections), interior tile: the
+        // residual block of every pass (32 rows x 32 columns = 128-byte row segments) arrives by LDS DMA into this wave's 16 KiB of the
+        // dead operand ring -- whole cache lines, no registers, four passes in flight -- instead of 32-byte pieces per lane in the
+        // accumulator layout.  VM counter, oldest first (D = 4 DMA instructions, S = the 4 stores of a pass):
+        //   D0 D1 D2 D3 | pass 0: S0 D4 | pass 1: S1 D5 | pass 2: S2 D6 | pass 3: S3 D7 | S4 | S5 | S6 | S7
+        if (ring && g.residual && lead && !g.accumulate && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && (long)g.M * g.ldr * 4 < (1L << 31)) {
+            const int row = lane & 31, hl = lane >> 5;
+            float rsv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rsv[i] = g.rowmask ? (g.rowmask[cm0 + wr * 128 + 32 * i + row] ? 1.f : 0.f) : 1.f;
+            const u32x4 rsR = spn_buffer_rsrc(g.residual, 0x7fffffffu);
+            const uint32_t ring_w = spn_lds_addr(ring);
+            uint32_t vo[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+                vo[it] = (uint32_t)((r * g.ldr + c * 4) * 4);
+            }
+            auto issue_r = [&](int k) __attribute__((always_inline)) {   // pass k = (row block k >> 1, column half k & 1) -> ring slot k & 3
+                const uint32_t soff = (uint32_t)(((long)(cm0 + wr * 128 + 32 * (k >> 1)) * g.ldr + cn0 + wc * 64 + 32 * (k & 1)) * 4);
+                const uint32_t dst = ring_w + (uint32_t)((k & 3) * 4096);
+                spn_dma16x2(rsR, dst, vo[0], vo[1], soff);
+                spn_dma16x2(rsR, dst + 2048u, vo[2], vo[3], soff);
+            };
+            issue_r(0); issue_r(1); issue_r(2); issue_r(3);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = k >> 1, jh = k & 1;
+                if (k == 0 || k == 7) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (k == 1 || k == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (k == 2 || k == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                f32x4 res[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    res[q] = *reinterpret_cast<const f32x4*>(ring + (k & 3) * 4096 + row * 128 + ((((2 * q + hl) ^ row) & 7) << 4));
+                if (k + 4 < 8) {   // the slot is free once the reads above have returned
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue_r(k + 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = (f32x4{acc[i][jh][4 * q], acc[i][jh][4 * q + 1], acc[i][jh][4 * q + 2], acc[i][jh][4 * q + 3]} * g.alpha + bv[jh * 4 + q]) * rsv[i] + res[q];
+                    const int colb = (8 * q + hl * 4) * 4;
+                    *reinterpret_cast<f32x4*>(stg + row * 128 + ((((colb >> 4) ^ row) & 7) << 4)) = v;
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                    const uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ r) & 7) << 4));
+                    *reinterpret_cast<uint4*>(C + (long)(cm0 + wr * 128 + 32 * i + r) * g.ldc + cn0 + wc * 64 + jh * 32 + chunk * 4) = val;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = lane & 31;
@@ -931,7 +988,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
         extra = GLUF ? ((has_next && cm0 + PP_BM <= g.M) ? 1 : 0)
                     : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? 1 : 0);
     }
-    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, smem + wave * 16384);
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, PERSIST ? nullptr : smem + wave * 16384);
     if (!PERSIST) break;
     }
 #undef PP_SYNC_MFMA_BEGIN
@@ -1073,7 +1130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
     }
     __syncthreads();   // every wave is done with the operand ring: its first 16 KiB become the four staging slabs
     // gated backward: the four staging slabs, then 16 KiB per wave for the u blocks that arrive by LDS DMA (80 KiB in all)
-    pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096, smem + 16384 + wave * 16384);
+    pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096, GLU >= 3 ? smem + 16384 + wave * 16384 : nullptr);
 }
 
 // ---- split-K plumbing -------------------------------------------------------------------------------------
