@@ -126,6 +126,9 @@ shapes = [
     ("ada", (T, 1024, 64, False, False, True, True)),
     ("adad", (T, 64, 1024, False, True, False, False)),
     ("big", (8192, 8192, 8192, False, False, False, False)),
+    ("w1g", (4096, 512, T, True, True, True, False)),      # weight gradients (split-K)
+    ("w2g", (512, 2048, T, True, True, True, False)),
+    ("qkvg", (640, 512, T, True, True, True, False)),
 ]
 for tag, sh in shapes:
     if args.only and tag not in args.only.split(","):
