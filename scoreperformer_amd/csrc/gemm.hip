@@ -66,6 +66,22 @@ struct GemmArgs {
 #endif
 };
 
+// field-by-field copy out of the kernel-argument segment (constant address space: s_load; see the epilogue of gemm_pp_kernel)
+typedef const __attribute__((address_space(4))) GemmArgs* GemmKernargPtr;
+__device__ __forceinline__ GemmArgs kernarg_copy(GemmKernargPtr k) {
+    GemmArgs r;
+    r.A = k->A; r.B = k->B; r.C = k->C; r.bias = k->bias; r.residual = k->residual; r.rowmask = k->rowmask;
+    r.M = k->M; r.N = k->N; r.K = k->K; r.lda = k->lda; r.ldb = k->ldb; r.ldc = k->ldc; r.ldr = k->ldr;
+    r.alpha = k->alpha; r.accumulate = k->accumulate; r.batch = k->batch; r.sA = k->sA; r.sB = k->sB; r.sC = k->sC;
+    r.splitk = k->splitk; r.kt_per_split = k->kt_per_split; r.ngroup = k->ngroup; r.pp_addr_ok = k->pp_addr_ok;
+    r.slice_xcd = k->slice_xcd; r.stagger = k->stagger; r.tx = k->tx; r.ty = k->ty;
+    r.ws = k->ws; r.ws_bytes = k->ws_bytes; r.G = k->G; r.ldg = k->ldg; r.thr16 = k->thr16; r.seed = k->seed; r.keep_scale = k->keep_scale;
+#ifdef SPN_GEMM_TIMING
+    r.dbg = k->dbg;
+#endif
+    return r;
+}
+
 // ---- LDS addressing -------------------------------------------------------------------------------------
 // K-contiguous tile: [128 rows][64 k] bf16, row = 128 B = 8 chunks of 16 B, chunk index XOR (row & 7).
 template <int BK>
@@ -755,7 +771,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // slot of half-tile kind c (0 AX, 1 BX, 2 BY, 3 AY) of K tile t
 #define PP_SLOT(c_, t_) (smem + ((c_) * 2 + ((t_) & 1)) * PP_HALF)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;   // PERSIST launders it at every tile boundary (see the tile loop)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 #ifdef SPN_GEMM_TIMING
@@ -848,6 +865,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     };
     prologue();
     for (int vid = first; vid < nwg; vid += stride) {
+    // PERSIST: an opaque copy of the lane id per tile and per part (K loop / epilogue).  Without it every lane-derived LDS address of the
+    // K loop stays in a register through the epilogue and every epilogue constant through the K loop: 30-60 spilled VGPRs whose
+    // scratch reloads (a memory round trip each, on the VM counter) cost more than the workgroup launches the persistent walk saves.
+    if (PERSIST) asm volatile("" : "+v"(lane));
     f32x16 acc[4][2];   // acc[2h + i][j]: rows 64h + 32i.., columns 32j..
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -963,16 +984,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 
     // ---- epilogue: through the wave's own 4 KiB slab of the 32 KiB the ring leaves free, so that C leaves as whole 128-byte row
     //      segments (see gemm_kernel) while (PERSIST) the ring already receives the NEXT tile's first half-tiles ----
-    OutT* C = reinterpret_cast<OutT*>(g.C) + (long)zid * g.sC;
+    if (PERSIST) asm volatile("" : "+v"(lane));
+    // The epilogue reads its arguments (output pointers, strides, bias / residual / mask, dropout words) from the kernel-argument
+    // segment AGAIN, through a pointer the optimiser cannot see through: scalar loads that hit the constant cache.  Taken from `g`
+    // they are live across the K loop, which has no SGPRs to spare (buffer descriptors, ring addresses, counters): hipcc parked them
+    // in scratch memory and fetched them back with vector loads + s_waitcnt vmcnt(0) in the middle of the epilogue.
+    GemmKernargPtr gk = (GemmKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gk));
+    const GemmArgs ge = kernarg_copy(gk);   // scalar loads of the fields the epilogue uses; the rest is dead code
+    OutT* C = reinterpret_cast<OutT*>(ge.C) + (long)zid * ge.sC;
     const bool lead = !split || zid == 0;
     char* stg = smem + 8 * PP_HALF + wave * 4096;
     f32x4 bv[8];
 #pragma unroll
     for (int jq = 0; jq < 8; ++jq) {
         // GLU: bv[0..3] = bias of the value columns, bv[4..7] = bias of the gate columns (N = I is a multiple of 128: no edge)
-        const int bn = GLUF ? (jq >> 2) * g.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
-                            : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, g.N - 4);
-        bv[jq] = (g.bias && lead) ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int bn = GLUF ? (jq >> 2) * ge.N + n0 + wc * 32 + 8 * (jq & 3) + (lane >> 5) * 4
+                            : min(n0 + wc * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, ge.N - 4);
+        bv[jq] = (ge.bias && lead) ? *reinterpret_cast<const f32x4*>(ge.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();   // every wave is done with the operand ring
     const int cm0 = m0, cn0 = n0;
@@ -985,10 +1014,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             prologue();
         }
         // interior tiles issue exactly NSX store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-        extra = GLUF ? ((has_next && cm0 + PP_BM <= g.M) ? 1 : 0)
-                    : ((has_next && cm0 + PP_BM <= g.M && cn0 + PP_BN <= g.N && !g.residual && !g.accumulate && !g.rowmask) ? 1 : 0);
+        extra = GLUF ? ((has_next && cm0 + PP_BM <= ge.M) ? 1 : 0)
+                    : ((has_next && cm0 + PP_BM <= ge.M && cn0 + PP_BN <= ge.N && !ge.residual && !ge.accumulate && !ge.rowmask) ? 1 : 0);
     }
-    pp_store_tile<OutT, GLU>(g, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, PERSIST ? nullptr : smem + wave * 16384);
+    pp_store_tile<OutT, GLU>(ge, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, PERSIST ? nullptr : smem + wave * 16384);
     if (!PERSIST) break;
     }
 #undef PP_SYNC_MFMA_BEGIN
@@ -1217,11 +1246,17 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     g.tx = grid.x; g.ty = grid.y;
     // (weight gradients at C3: 4096x512x131072 609 -> 590 us, 512x2048x131072 335 -> 323 us)
     g.slice_xcd = (spn_tune_i(SPN_TUNE_GEMM_SLICE_XCD) && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
-    // one block per CU walking the tile list: the K = 512 projections gain 1-4 % per launch under HIP events, the step does not
-    // (170.8 vs 171.5 ms: the next kernel can no longer start under the last round), so it stays a tuning aid
+    // one block per CU walking the tile list (no workgroup launch between tiles, the next tile's first loads in flight during the
+    // epilogue).  A block keeps its share of tiles whatever happens to its CU, so a kernel that holds CUs while this one runs (the
+    // all-reduce of a data-parallel backward) would delay that share by a block lifetime: forward products walk by default, input
+    // gradients only when the host says nothing else runs (gemm_persist_bwd; scoreperformer_amd/parallel.py sets it for one process)
     const int persist_env = spn_tune_i(SPN_TUNE_GEMM_PERSIST);   // 0 off, else min rounds
     g.stagger = spn_tune_i(SPN_TUNE_GEMM_STAGGER) * 1024 / 32;
-    if (persist_env > 0 && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) {
+    // measured (tools/bench_gemm.py, one box): bf16 outputs with a short contraction gain 4-8 % (131072x4096x512 652 -> 618 us,
+    // 131072x640x512 124 -> 115 us, 131072x2048x512 NT 357 -> 343 us); K >= 2048 and the fp32 + residual epilogues (which stage the
+    // residual through the ring the next tile's prologue would fill) lose 3-5 %: those keep one block per tile
+    const bool persist_ok = sizeof(OutT) == 2 && nt <= 16 && !g.residual && ((!TA && !TB) || spn_tune_i(SPN_TUNE_GEMM_PERSIST_BWD) > 0);
+    if (persist_env > 0 && persist_ok && grid.z == 1 && (long)grid.x * grid.y >= 256l * persist_env) {
         static std::atomic<unsigned> optin_p{0};
         spn_lds_optin(optin_p, reinterpret_cast<const void*>(&gemm_pp_kernel<TA, TB, OutT, 0, true>), LDS_BYTES);
         hipLaunchKernelGGL((gemm_pp_kernel<TA, TB, OutT, 0, true>), dim3(256, 1, 1), dim3(512), LDS_BYTES, stream, g);
@@ -1328,9 +1363,8 @@ int launch_pp_glu(GemmArgs g, hipStream_t stream) {
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y; g.slice_xcd = 0;
     // one block per CU walking the tile list: the next tile's first DMA is in flight while this tile's (long, VALU-bound) epilogue runs
-    // (811 -> 783 us at 131072 x 2048 x 512 on an otherwise idle chip).  Off by default: with a static tile list per block, a CU that
-    // a concurrent kernel holds (the RCCL all-reduce of the data-parallel step) delays ITS whole share of tiles by one block
-    // lifetime, while the plain grid just hands those tiles to the other CUs.
+    // (764 -> 722 us at 131072 x 2048 x 512, 820 -> 763 us with dropout).  A forward kernel: nothing else holds CUs while it runs (see
+    // launch_pp for the backward side of that argument).
     const int persist_env = spn_tune_i(SPN_TUNE_GLU_PERSIST);   // 0 off, else min rounds
     g.stagger = spn_tune_i(SPN_TUNE_GEMM_STAGGER) * 1024 / 32;
     if (persist_env > 0 && (long)grid.x * grid.y >= 256l * persist_env) {

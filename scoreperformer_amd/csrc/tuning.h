@@ -10,8 +10,8 @@ enum SpnTune {
     SPN_TUNE_GEMM_NGROUP,          // n-tiles per column group of the tile order; 8
     SPN_TUNE_GEMM_SLICE_XCD,       // split-K: an XCD runs whole K slices; 1
     SPN_TUNE_GEMM_SPLIT_BLOCKS,    // split-K block target of the ping-pong kernel (0 = one full round of 256); 0
-    SPN_TUNE_GEMM_PERSIST,         // plain GEMM: 256 persistent blocks when the grid has at least this many rounds (0 = off); 0
-    SPN_TUNE_GLU_PERSIST,          // gated GEMM: the same; 0
+    SPN_TUNE_GEMM_PERSIST,         // plain GEMM, bf16 output, K <= 1024: 256 persistent blocks when the grid has at least this many rounds (0 = off); 2
+    SPN_TUNE_GLU_PERSIST,          // gated GEMM: the same; 2
     SPN_TUNE_EMBED_STATS_BLOCKS,   // 2048
     SPN_TUNE_EMBED_SCATTER_MFMA,   // 1 = one-hot MFMA scatter, 0 = LDS-atomic scatter; 1
     SPN_TUNE_EMBED_SCATTER_BLOCKS, // 256
@@ -20,6 +20,8 @@ enum SpnTune {
     SPN_TUNE_GEMM_DUO_NGROUP,      // n-tiles per column group of the duo kernel's tile order; 8
     SPN_TUNE_GEMM_STAGGER,         // persistent GEMM: start delay spread over the 32 CU slots of an XCD, in units of 1024 shader cycles (0 = off); 0
     SPN_TUNE_GLU_BWD_DUO,          // gated-backward GEMM (spn_gemm_glu_bwd): 1 = two workgroups per CU (256x128 tiles), 0 = ping-pong kernel; 1
+    SPN_TUNE_GEMM_PERSIST_BWD,     // 1 = the persistent walk also for input-gradient GEMMs (N-contiguous B).  Only safe when no other kernel holds CUs
+                                   // during the backward (a concurrent all-reduce starves the blocks that land on its CUs): the host sets it; 0
     SPN_TUNE_COUNT
 };
 

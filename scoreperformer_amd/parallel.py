@@ -7,6 +7,7 @@ backward pass, i.e. while the rest of backward is still running; the 1/world fac
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -34,6 +35,11 @@ class GradSync:
             self.native = NativeComm.from_group(group)
         elif transport not in ("torch", "spn"):
             raise ValueError(f"unknown transport {transport!r}")
+        # Input-gradient GEMMs may walk their tiles with one persistent block per CU only when no all-reduce kernel holds CUs during
+        # the backward (csrc/gemm.hip, launch_pp): this object is the one place that knows.  SPN_GEMM_PERSIST_BWD in the environment wins.
+        if torch.cuda.is_available() and not dry_run and "SPN_GEMM_PERSIST_BWD" not in os.environ:
+            from . import lib
+            lib.set_tuning("gemm_persist_bwd", 0.0 if self.active else 1.0)
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}

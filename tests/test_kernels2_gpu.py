@@ -138,10 +138,21 @@ def test_cross_entropy_forward_backward():
 
 @pytest.mark.parametrize("M,I,K,act,p", [(256, 128, 256, 0, 0.0), (1000, 256, 512, 0, 0.1), (4096, 2048, 512, 1, 0.0),
                                          (8192 + 8, 2048, 512, 0, 0.1), (131072, 2048, 512, 0, 0.1)])
-def test_gemm_glu_equals_gemm_then_activation(M, I, K, act, p):
+@pytest.mark.parametrize("persist", [2, 0])
+def test_gemm_glu_equals_gemm_then_activation(M, I, K, act, p, persist):
     """Fused GLU projection: u is the plain GEMM's output and g the stand-alone activation kernel's output on that u, bit for bit
-    (same rounding point, same dropout mask), at edge row counts and at the benchmark's FFN shape."""
-    from scoreperformer_amd import ops
+    (same rounding point, same dropout mask), at edge row counts and at the benchmark's FFN shape; as one persistent block per CU
+    (the default from two rounds of tiles on) and as one block per tile."""
+    from scoreperformer_amd import lib, ops
+    old = lib.get_tuning("glu_persist")
+    lib.set_tuning("glu_persist", persist)
+    try:
+        _glu_case(M, I, K, act, p, ops)
+    finally:
+        lib.set_tuning("glu_persist", old)
+
+
+def _glu_case(M, I, K, act, p, ops):
     gen = torch.Generator(device="cuda").manual_seed(M + I)
     x = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).bfloat16()
     w = (torch.randn(2 * I, K, device="cuda", generator=gen) * K ** -0.5).bfloat16()

@@ -479,12 +479,24 @@ def test_embedding_forward_backward_match_torch(E, V, with_ln, pad_rows):
         assert rel_err(dgamma, rg.grad) < 2e-3 and rel_err(dbeta, rb.grad) < 2e-3
 
 
+@pytest.mark.parametrize("persist", [2, 0])
 @pytest.mark.parametrize("out_f32,tb", [(False, False), (True, False), (False, True)])
-def test_gemm_persistent_tile_walk(dev, out_f32, tb):
-    """A launch of > 512 output tiles with ragged M and a bias against fp32 matmul, and written exactly once.  With SPN_GEMM_PERSIST=2 in
-    the environment this is the one-block-per-CU tile walk (next tile's loads in flight during the epilogue, store credits in the wait
-    counts, edge tiles on the stronger wait); by default it is the plain grid."""
-    from scoreperformer_amd import ops
+def test_gemm_persistent_tile_walk(dev, out_f32, tb, persist):
+    """A launch of > 512 output tiles with ragged M and a bias against fp32 matmul, and written exactly once, as the one-block-per-CU
+    tile walk (knobs gemm_persist / gemm_persist_bwd: next tile's loads in flight during the epilogue, store credits in the wait
+    counts, edge tiles on the stronger wait; bf16 outputs only, fp32 outputs always take the plain grid) and as the plain grid."""
+    from scoreperformer_amd import lib, ops
+    old = lib.get_tuning("gemm_persist"), lib.get_tuning("gemm_persist_bwd")
+    lib.set_tuning("gemm_persist", persist)
+    lib.set_tuning("gemm_persist_bwd", 1 if persist else 0)
+    try:
+        _persistent_tile_walk_case(dev, out_f32, tb, ops)
+    finally:
+        lib.set_tuning("gemm_persist", old[0])
+        lib.set_tuning("gemm_persist_bwd", old[1])
+
+
+def _persistent_tile_walk_case(dev, out_f32, tb, ops):
     g = torch.Generator().manual_seed(11)
     M, N, K = 16384 + 8, 2304, 512
     a = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
