@@ -58,6 +58,14 @@ __device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, i
     return D < 1.0e9f ? D : 3.0e38f;   // inf / nan (never-skip tiles) -> unbounded
 }
 
+// The kernel arguments again, straight from the kernel-argument segment (constant address space: scalar loads through the constant
+// cache).  A kernel that takes its arguments from the by-value struct keeps every field it ever uses in an SGPR from the first
+// instruction on -- ~90 of them here -- and hipcc parks what does not fit in VGPR lanes, to be fetched back with v_readlane (a VALU
+// slot each, in VALU-bound loops).  Code that runs once (an epilogue) or once per tile reads this copy instead, behind an opaque
+// `asm volatile("" : "+s"(ptr))` so that the loads are issued where they are used and not hoisted back to the top.
+typedef const __attribute__((address_space(4))) AttnArgs* AttnKernargPtr;
+__device__ __forceinline__ AttnKernargPtr attn_kernarg() { return (AttnKernargPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+
 // geometry of the keep-bit buffer: whole 128-query blocks and 128-key blocks, so no kernel needs bounds checks
 __host__ __device__ inline int dropbits_nqt16(int nq) { return 8 * ((nq + 127) / 128); }
 __host__ __device__ inline int dropbits_nkt64(int nk) { return 2 * ((nk + 127) / 128); }

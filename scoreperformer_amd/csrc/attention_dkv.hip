@@ -151,19 +151,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     float lreg = 0.f, dreg = 0.f;
     int n_issued = 0;   // stage of the next issue = n_issued & 1
     auto issue = [&](int it) {
+        // pointers and strides of the tile request: read from the kernel-argument segment here, once per tile (attention_common.h)
+        AttnKernargPtr ai = attn_kernarg();
+        asm volatile("" : "+s"(ai));
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
         if (DROP) {
-            const uint16_t* bp = a.dropbits + ((long)(bi * a.h + hh) * a.nqt16 + i0 / 16) * bstride + bit_lane;
+            const uint16_t* bp = ai->dropbits + ((long)(bi * ai->h + hh) * ai->nqt16 + i0 / 16) * bstride + bit_lane;
 #pragma unroll
             for (int qb = 0; qb < 4; ++qb) bwn[qb] = *reinterpret_cast<const uint2*>(bp + qb * bstride);
         }
-        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(a.q + bi * a.q_bs + hh * a.q_hs), 0,
-                                                                              (int)(((long)(a.nq - 1) * a.q_ns + 64) * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.d_o + bi * a.o_bs + hh * a.o_hs), 0,
-                                                                              (int)(((long)(a.nq - 1) * a.o_ns + 64) * 2), 0x00020000);
+        const long q_ns = ai->q_ns, o_ns = ai->o_ns;
+        const int nq = ai->nq;
+        const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(ai->q + bi * ai->q_bs + hh * ai->q_hs), 0,
+                                                                              (int)(((long)(nq - 1) * q_ns + 64) * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(ai->d_o + bi * ai->o_bs + hh * ai->o_hs), 0,
+                                                                              (int)(((long)(nq - 1) * o_ns + 64) * 2), 0x00020000);
         char* base = smem + (n_issued & 1) * 32768 + wv * 2048;
-        const uint32_t sq = (uint32_t)i0 * (uint32_t)a.q_ns * 2u, sd = (uint32_t)i0 * (uint32_t)a.o_ns * 2u;
+        const uint32_t sq = (uint32_t)i0 * (uint32_t)q_ns * 2u, sd = (uint32_t)i0 * (uint32_t)o_ns * 2u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(base + i * 1024), 16, voQa[i], sq, 0, 0);
@@ -174,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         ++n_issued;
         if (tid < 64) {
             const int i = i0 + tid;
-            const long si = ((long)bi * a.h + hh) * a.nq + i;
-            const float lse_i = i < a.nq ? a.lse[si] : NEG_FILL;
+            const long si = ((long)bi * ai->h + hh) * nq + i;
+            const float lse_i = i < nq ? ai->lse[si] : NEG_FILL;
             lreg = lse_i > -1e37f ? -lse_i * LOG2E : NEG_FILL;   // rows beyond nq / fully masked rows: p = exp2(t + NEG) = 0
-            dreg = i < a.nq ? a.delta[si] : 0.f;
+            dreg = i < nq ? ai->delta[si] : 0.f;
         }
     };
     // ALiBi band (attention.hip): a (head, query tile) whose reach ends before this block's 128 keys is not visited
@@ -226,16 +231,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         else dkv_tile<T_GEN, DROP>(q_tile, qt_tile, do_tile, dot_tile, nl2_s, dl_s, kf, vf, dk, dv, jf, key_ok, i0 + off, c1, slope2, a.causal, lane, g, bw, boff, log2_inv_keep, keep_prob);
         it = it_next;
     }
+    AttnKernargPtr ae = attn_kernarg();   // the output pointers and strides are not held in registers across the tile loop
+    asm volatile("" : "+s"(ae));
+    const float out_scale = ae->scale;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        if (jcol[kb] >= a.nk) continue;
-        bf16_t* pk_ = a.dk + bi * a.dk_bs + (long)jcol[kb] * a.dk_ns + kh * a.dk_hs;
-        bf16_t* pv_ = a.dv + bi * a.dv_bs + (long)jcol[kb] * a.dv_ns + kh * a.dv_hs;
+        if (jcol[kb] >= ae->nk) continue;
+        bf16_t* pk_ = ae->dk + bi * ae->dk_bs + (long)jcol[kb] * ae->dk_ns + kh * ae->dk_hs;
+        bf16_t* pv_ = ae->dv + bi * ae->dv_bs + (long)jcol[kb] * ae->dv_ns + kh * ae->dv_hs;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             uint2 x, y;
-            x.x = pack_bf2(dk[db][kb][0] * a.scale, dk[db][kb][1] * a.scale);
-            x.y = pack_bf2(dk[db][kb][2] * a.scale, dk[db][kb][3] * a.scale);
+            x.x = pack_bf2(dk[db][kb][0] * out_scale, dk[db][kb][1] * out_scale);
+            x.y = pack_bf2(dk[db][kb][2] * out_scale, dk[db][kb][3] * out_scale);
             y.x = pack_bf2(dv[db][kb][0], dv[db][kb][1]); y.y = pack_bf2(dv[db][kb][2], dv[db][kb][3]);
             *reinterpret_cast<uint2*>(pk_ + 16 * db + 4 * g) = x;
             *reinterpret_cast<uint2*>(pv_ + 16 * db + 4 * g) = y;
