@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 2 */
+int spn_abi_version(void); /* 3 */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -185,6 +185,14 @@ int spn_dec_embed(int nkeys, const float* const* tables, const int* E, const lon
 int spn_dec_embed_proj(int nkeys, const float* const* tables, const int* E, const long* tokens_a, const long* tokens_b, long tok_ld,
                        const int* pos, const float* gamma, const float* beta, float eps, const float* W, long ldw, const float* bias, float* y,
                        int N, spn_stream_t s);
+/* First launch of a fused step: spn_dec_embed_proj, plus the position latch (*pos_latch = *pos: every later launch of the step reads
+ * pos_latch, the LAST one -- spn_dec_head with pos_next = pos -- writes position + 1 back, so no launch reads a scalar that is written in
+ * the same launch and the one-thread spn_dec_add_pos between two notes is gone), plus an optional rider GEMV in the same launch:
+ * ry[n] = rW[n, :] . rx[(*pos + rx_off) * rx_ld ..] + rbias[n] (the stacked AdaLN condition projections of the step); rW = null: none. */
+int spn_dec_step_begin(int nkeys, const float* const* tables, const int* E, const long* tokens_a, const long* tokens_b, long tok_ld,
+                       const int* pos, int* pos_latch, const float* gamma, const float* beta, float eps, const float* W, long ldw,
+                       const float* bias, float* y, int N, const float* rW, long r_ldw, int rN, int rK, const float* rx, long rx_ld,
+                       int rx_off, const float* rbias, float* ry, spn_stream_t s);
 int spn_dec_copy_row(const float* src, long src_ld, int src_off, float* dst, long dst_ld, int dst_off, const int* pos, int D,
                      spn_stream_t s);
 int spn_dec_glu(const float* u, float* out, int I, int act, int glu, spn_stream_t s);
@@ -203,6 +211,11 @@ int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const float* x, l
 int spn_dec_attn_out(const float* W, long ldw, int N, const float* part, int h, int splits, const float* residual, float* y, spn_stream_t s);
 int spn_dec_cat(const float* x, int d, const float* gamma, const float* beta, float eps, const float* ctx, long ctx_ld, int ctx_w,
                 const float* style, long style_ld, int style_w, const int* pos, float* out, spn_stream_t s);
+/* spn_dec_cat + the projection GEMV over its output in one launch: y = W . (LN?(x[0:d]) | ctx[*pos + 1] | style[*pos + 1]) + bias, y2 = row
+ * *pos mirror (models/scoreperformer/transformer.py:160-181 for one position) */
+int spn_dec_cat_gemv(const float* W, long ldw, int N, const float* x, int d, const float* gamma, const float* beta, float eps,
+                     const float* ctx, long ctx_ld, int ctx_w, const float* style, long style_ld, int style_w, const float* bias, float* y,
+                     float* y2, long y2_ld, const int* pos, spn_stream_t s);
 int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* slopes, const int* pos, float* o, float* part, int* counter,
                   float* kmax2, int h, int kvh, float scale, int splits, spn_stream_t s);
 /* cross-attention of the decoded position over a static context (decoder layer type 'c': modules/transformer/transformer.py:201 under
@@ -211,14 +224,15 @@ int spn_dec_xattn(const float* q, const float* kctx, const float* vctx, const fl
                   float* part, int* counter, int h, int kvh, float scale, int splits, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
-                 const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs, spn_stream_t s);
+                 const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,
+                 int* pos_next /* null, or: *pos_next = *pos + 1 (see spn_dec_step_begin) */, spn_stream_t s);
 
 /* spn_dec_head with sampling instead of the arg-max (modules/sampling.py:28-59: top_k filter, temperature, one multinomial draw):
  * logits = scratch [n, ldl]; topk[n] = ids kept per key (device); seed = device scalar mixed with the position and the key. */
 int spn_dec_head_sample(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
                         const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld,
                         int mask_id, const int* pos, float* part, int* counter, int slabs, float* logits, int ldl, const int* topk,
-                        float temperature, const unsigned* seed, spn_stream_t s);
+                        float temperature, const unsigned* seed, int* pos_next, spn_stream_t s);
 
 /* batched (prefill) forms of the decode kernels: rows t0 .. t0+n-1 of a window whose tokens are known (the reference recomputes a
  * cropped window in one batched forward, inference/generators.py:184-241 -> wrappers.py:391-393); K/V rows already in the caches. */

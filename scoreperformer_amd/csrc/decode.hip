@@ -101,13 +101,59 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedDesc d, const lo
 // 0 = the tokens at row *pos, 1 = the masked copy at row *pos + 1):  y[seq * N + n] = W[n, :] . LN(concat_k table_k[token_k]) + bias[n].
 // Every block rebuilds the (<= 2048-wide) embedding in LDS -- the same gather, statistics and normalisation as dec_embed_kernel -- and
 // then runs the row products of gemv_nk_kernel, so the values equal dec_embed + gemv bit for bit (4 launches of a decode step become 1).
+// A second, independent GEMV that rides in the same launch (blocks behind the embedding blocks): y[n] = W[n, :] . x[(p + x_off) * x_ld ..] +
+// bias[n] -- the stacked AdaLN condition projections of a step, which depend on the position only.  W = null: no rider.
+struct DecRider { const float* W; long ldw; int N, K; const float* x; long x_ld; int x_off; const float* bias; float* y; };
+// latch: the FIRST launch of a step reads the position from `pos` and (block 0) republishes it in `pos_latch`, which every later
+// launch of the step reads; the LAST launch (dec_head_kernel) writes position + 1 back to `pos`.  Nobody reads a scalar in the launch
+// that writes it, so the one-thread "advance" launch between two notes is gone.  pos_latch = null: `pos` is read-only here.
 __global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, const long* __restrict__ tok_a, const long* __restrict__ tok_b,
-                                                             long tok_ld, const int* __restrict__ pos, const float* __restrict__ gamma,
+                                                             long tok_ld, const int* __restrict__ pos, int* __restrict__ pos_latch,
+                                                             const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, const float* __restrict__ W, long ldw,
-                                                             const float* __restrict__ bias, float* __restrict__ y, int N) {
+                                                             const float* __restrict__ bias, float* __restrict__ y, int N, int nbe, DecRider r) {
     __shared__ __attribute__((aligned(16))) float buf[2048];
     __shared__ float red[8];
-    const int seq = blockIdx.y;
+    if ((int)blockIdx.x >= 2 * nbe) {   // rider GEMV: one wave per output row, the arithmetic of gemv_nk_kernel
+        const int lane = threadIdx.x & 63;
+        const int n = ((int)blockIdx.x - 2 * nbe) * 4 + (threadIdx.x >> 6);
+        if (n >= r.N) return;
+        const float* w = r.W + (long)n * r.ldw;
+        const float bias_r = r.bias ? r.bias[n] : 0.f;
+        const bool vec = (r.K & 3) == 0 && (r.ldw & 3) == 0;
+        f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec && lane * 4 < r.K) w0 = *reinterpret_cast<const f32x4*>(w + lane * 4);   // first chunk before the position is known
+        const float* x = r.x + (long)(*pos + r.x_off) * r.x_ld;
+        float acc = 0.f;
+        if (vec) {
+            for (int k = lane * 4; k < r.K; k += 256) {
+                const f32x4 wv = k == lane * 4 ? w0 : *reinterpret_cast<const f32x4*>(w + k);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
+                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            }
+        } else {
+            for (int k = lane; k < r.K; k += 64) acc = fmaf(w[k], x[k], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) r.y[n] = r.bias ? acc + bias_r : acc;
+        return;
+    }
+    const int seq = (int)blockIdx.x / nbe, bx = (int)blockIdx.x % nbe;
+    if (pos_latch && blockIdx.x == 0 && threadIdx.x == 0) *pos_latch = *pos;
+    // this wave's weight row and bias do not depend on the tokens: requested first, they arrive under the position -> token -> table row
+    // -> LayerNorm chain below (three dependent trips to memory) instead of behind it
+    const int lane_ = threadIdx.x & 63, n_ = bx * 4 + (threadIdx.x >> 6);
+    const bool vec_ = (d.D & 3) == 0 && (ldw & 3) == 0;
+    const float* wrow = W + (long)min(n_, N - 1) * ldw;
+    f32x4 wreg[8];
+    if (vec_) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane_ * 4 + c * 256;
+            wreg[c] = k < d.D ? *reinterpret_cast<const f32x4*>(wrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float bias_v = bias ? bias[min(n_, N - 1)] : 0.f;
     const long* tok = (seq ? tok_b : tok_a) + (long)(*pos + seq) * tok_ld;
     float s = 0.f;
     for (int c = threadIdx.x; c < d.D; c += 256) {
@@ -132,23 +178,27 @@ __global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, con
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = bx * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const float* w = W + (long)n * ldw;
     const int K = d.D;
     float acc = 0.f;
-    if ((K & 3) == 0 && (ldw & 3) == 0) {
-        for (int k = lane * 4; k < K; k += 256) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(buf + k);
-            acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+    if (vec_) {   // same expression order as the loop it replaces (k ascending, four products summed left to right)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            if (k < K) {
+                const f32x4 wv = wreg[c];
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(buf + k);
+                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            }
         }
     } else {
         for (int k = lane; k < K; k += 64) acc = fmaf(w[k], buf[k], acc);
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-        if (bias) acc += bias[n];
+        if (bias) acc += bias_v;
         y[seq * N + n] = acc;
     }
 }
@@ -316,6 +366,9 @@ struct DecGemvArgs {
     // (running max, normaliser, 64 weighted value sums).  Every block redoes the 8 KiB merge in its prologue; the kernel boundary in
     // front of this launch orders it behind the partials, so the attention kernel needs neither fences nor a last-block tail.
     const float* att_part; int att_h, att_S;
+    // x = ( LN?(x[0 : cat_d]) | ctx[(p + 1) * ctx_ld ..][0 : ctx_w] | style[(p + 1) * style_ld ..][0 : style_w] ), K = the sum: the decoder's
+    // concatenated input of one position (transformer.py:160-176), built in the prologue instead of by dec_cat_kernel.  cat_d = 0: off.
+    int cat_d; const float* cat_ctx; long cat_ctx_ld; int cat_ctx_w; const float* cat_style; long cat_style_ld; int cat_style_w;
 };
 __device__ __forceinline__ float dec_act(float g, int act) {
     return act == 0 ? g / (1.f + __expf(-g)) : 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
@@ -341,6 +394,13 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
             greg[c] = (gated && k < a.K) ? *reinterpret_cast<const f32x4*>(wg_ + k) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // ... and so do the bias / residual of this wave's output and the position scalar.  A note is a chain of ~37 launches, each of
+    // them a chain of DEPENDENT global loads (a miss costs 1-2 us here: the previous launch's output is fresh in memory, not in this
+    // XCD's L2): everything that can be requested up front is, and the input vector is only addressed through the position when it
+    // really is a row of a [positions, K] buffer (x_ld != 0).
+    const int nn = min(n, a.N - 1);
+    const float bias_v = a.bias ? a.bias[nn] : 0.f, bias_g = (a.bias && gated) ? a.bias[nn + a.N] : 0.f;
+    const float res_v = a.residual ? a.residual[nn] : 0.f;
     const int p = a.pos ? *a.pos : 0;
     float s = 0.f;
     if (a.att_part) {
@@ -350,6 +410,28 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
             const float* ph = a.att_part + (long)(k >> 6) * a.att_S * 66;
             const int dcol = 2 + (k & 63);
             float mm = -INFINITY;
+            float num = 0.f, den = 0.f;
+            if (a.att_S <= 16) {   // the usual split: all three fields of all records requested at once (one memory latency, not two)
+                float mv[16], lv[16], nv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool in = q < a.att_S;
+                    mv[q] = in ? ph[q * 66] : -INFINITY;
+                    lv[q] = in ? ph[q * 66 + 1] : 0.f;
+                    nv[q] = in ? ph[q * 66 + dcol] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (q < a.att_S) {
+                        const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
+                        num += nv[q] * f; den += lv[q] * f;
+                    }
+                }
+                xs[k] = num / den;
+                continue;
+            }
             for (int q0 = 0; q0 < a.att_S; q0 += 16) {
                 float mv[16];
 #pragma unroll
@@ -357,7 +439,6 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
             }
-            float num = 0.f, den = 0.f;
             for (int q0 = 0; q0 < a.att_S; q0 += 16) {
                 float mv[16], lv[16], nv[16];
 #pragma unroll
@@ -377,8 +458,28 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
             }
             xs[k] = num / den;
         }
+    } else if (a.cat_d > 0) {
+        // same arithmetic as dec_cat_kernel: LayerNorm over the first cat_d entries only, the context / style rows appended as they are
+        for (int k = threadIdx.x; k < a.cat_d; k += 256) { const float v = a.x[k]; xs[k] = v; s += v; }
+        if (a.cat_ctx) for (int k = threadIdx.x; k < a.cat_ctx_w; k += 256) xs[a.cat_d + k] = a.cat_ctx[(long)(p + 1) * a.cat_ctx_ld + k];
+        if (a.cat_style)
+            for (int k = threadIdx.x; k < a.cat_style_w; k += 256)
+                xs[a.cat_d + (a.cat_ctx ? a.cat_ctx_w : 0) + k] = a.cat_style[(long)(p + 1) * a.cat_style_ld + k];
+        if (a.gamma) {
+            s = wave_sum(s);
+            if (lane == 0) red[w] = s;
+            __syncthreads();
+            const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.cat_d;
+            float q2 = 0.f;
+            for (int k = threadIdx.x; k < a.cat_d; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+            q2 = wave_sum(q2);
+            if (lane == 0) red[4 + w] = q2;
+            __syncthreads();
+            const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.cat_d + a.eps);
+            for (int k = threadIdx.x; k < a.cat_d; k += 256) xs[k] = (xs[k] - mu) * rs * a.gamma[k] + a.beta[k];
+        }
     } else {
-        const float* x = a.x + (long)(p + a.x_off) * a.x_ld;
+        const float* x = a.x_ld ? a.x + (long)(p + a.x_off) * a.x_ld : a.x;
         for (int k = threadIdx.x; k < a.K; k += 256) { const float v = x[k]; xs[k] = v; s += v; }
     }
     if (a.norm) {
@@ -424,10 +525,10 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
     acc = wave_sum(acc);
     if (gated) accg = wave_sum(accg);
     if (lane == 0) {
-        if (a.bias) { acc += a.bias[n]; if (gated) accg += a.bias[n + a.N]; }
+        if (a.bias) { acc += bias_v; if (gated) accg += bias_g; }
         if (gated) acc = acc * dec_act(accg, a.act);
         else if (a.act >= 0 && a.glu < 0) acc = dec_act(acc, a.act);   // plain activation (glu = -1)
-        if (a.residual) acc += a.residual[n];
+        if (a.residual) acc += res_v;
         a.y[(long)(p + a.y_off) * a.y_ld + n] = acc;
         if (a.y2) a.y2[(long)(p + a.y2_off) * a.y2_ld + n] = acc;
     }
@@ -499,19 +600,31 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(qkv + hi * 64 + l16 * 4) * scale;
     float m = -INFINITY, l = 0.f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = j0 + w * 4 + grp; j < j1; j += 16) {
-        const float* kr = (j == t) ? knew : kcache + j * cw + kh * 64;
-        const float* vr = (j == t) ? vnew : vcache + j * cw + kh * 64;
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + l16 * 4);
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + l16 * 4);
-        float sc = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
-        sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
-        sc -= slope * (float)(t - j);
-        const float m_new = fmaxf(m, sc);
-        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
-        l = l * alpha + pj;
-        acc = acc * alpha + v4 * pj;
-        m = m_new;
+    // the keys of a lane group, four at a time: the eight row loads of a batch are in flight together (a cache row read costs a trip to
+    // the Infinity Cache, ~0.7 us; one key per trip made this loop the longest part of a note); arithmetic in the same order as before
+    for (int jb = j0 + w * 4 + grp; jb < j1; jb += 64) {
+        f32x4 k4[4], v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(jb + 16 * u, j1 - 1);
+            const float* kr = (j == t) ? knew : kcache + j * cw + kh * 64;
+            const float* vr = (j == t) ? vnew : vcache + j * cw + kh * 64;
+            k4[u] = *reinterpret_cast<const f32x4*>(kr + l16 * 4);
+            v4[u] = *reinterpret_cast<const f32x4*>(vr + l16 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + 16 * u;
+            if (j >= j1) break;
+            float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+            sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+            sc -= slope * (float)(t - j);
+            const float m_new = fmaxf(m, sc);
+            const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
+            l = l * alpha + pj;
+            acc = acc * alpha + v4[u] * pj;
+            m = m_new;
+        }
     }
     const int gi = w * 4 + grp;
     if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
@@ -576,18 +689,30 @@ __global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict_
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + hi * 64 + l16 * 4) * scale;
     float m = -INFINITY, l = 0.f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int j = j0 + w * 4 + grp; j < j1; j += 16) {
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(kctx + j * cw + kh * 64 + l16 * 4);
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vctx + j * cw + kh * 64 + l16 * 4);
-        float sc = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
-        sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
-        sc -= slope * (float)(nk - 1 - j);
-        if (kmask && kmask[j] == 0) sc = -1.7014118e38f;
-        const float m_new = fmaxf(m, sc);
-        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
-        l = l * alpha + pj;
-        acc = acc * alpha + v4 * pj;
-        m = m_new;
+    for (int jb = j0 + w * 4 + grp; jb < j1; jb += 64) {   // four keys per lane group and trip to memory (see dec_attn2_kernel)
+        f32x4 k4[4], v4[4];
+        uint8_t km[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = min(jb + 16 * u, j1 - 1);
+            k4[u] = *reinterpret_cast<const f32x4*>(kctx + j * cw + kh * 64 + l16 * 4);
+            v4[u] = *reinterpret_cast<const f32x4*>(vctx + j * cw + kh * 64 + l16 * 4);
+            km[u] = kmask ? kmask[j] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jb + 16 * u;
+            if (j >= j1) break;
+            float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+            sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+            sc -= slope * (float)(nk - 1 - j);
+            if (km[u] == 0) sc = -1.7014118e38f;
+            const float m_new = fmaxf(m, sc);
+            const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
+            l = l * alpha + pj;
+            acc = acc * alpha + v4[u] * pj;
+            m = m_new;
+        }
     }
     const int gi = w * 4 + grp;
     if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
@@ -646,12 +771,33 @@ template <bool SAMPLE>
 __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const float* __restrict__ e, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, unsigned ban_mask,
                                                        long* __restrict__ tokens, long tok_ld, int mask_id, const int* __restrict__ pos,
-                                                       float* __restrict__ part, int* __restrict__ counter, DecSampleArgs sa) {
+                                                       float* __restrict__ part, int* __restrict__ counter, DecSampleArgs sa,
+                                                       int* __restrict__ pos_next) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float bv[4];
     __shared__ int bi[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, q = blockIdx.x;
+    // last launch of a step: the NEXT step's position (read by its first launch, spn_dec_step_begin; nobody reads pos_next here)
+    if (pos_next && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *pos_next = *pos + 1;
+    const int c0 = d.col0[q], W = d.width[q], V = d.V[q];
+    // rows of this dim are split over gridDim.y slabs (4 rows per slab step); the last slab to finish picks the winner.  A wave takes
+    // its rows four at a time and requests the NEXT four before it multiplies the current ones; the first four are requested before
+    // the LayerNorm prologue (table rows do not depend on the input): one row per trip to memory made this loop ~8 dependent latencies
+    const int nsl = gridDim.y, sl = blockIdx.y, vstep = 4 * nsl;
+    const bool batched = W <= 256;
+    const float* tab = d.table[q];
+    float rw[4][4], rn[4][4];
+    auto load_rows = [&](float (&dst)[4][4], int vb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* row = tab + (long)min(vb + u * vstep, V - 1) * W;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[u][c] = (lane + 64 * c < W) ? row[lane + 64 * c] : 0.f;
+        }
+    };
+    int vb = sl * 4 + w;
+    if (batched && vb < V) load_rows(rw, vb);
     float s = 0.f;
     for (int k = threadIdx.x; k < d.D; k += 256) { const float v = e[k]; xs[k] = v; s += v; }
     s = wave_sum(s);
@@ -664,21 +810,44 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
     if (lane == 0) red[4 + w] = q2;
     __syncthreads();
     const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
-    const int c0 = d.col0[q], W = d.width[q], V = d.V[q];
     for (int k = threadIdx.x; k < W; k += 256) xs[c0 + k] = (xs[c0 + k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
     __syncthreads();
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    // rows of this dim are split over gridDim.y slabs (4 rows per slab step); the last slab to finish picks the winner
-    const int nsl = gridDim.y, sl = blockIdx.y;
-    for (int v = sl * 4 + w; v < V; v += 4 * nsl) {
-        const float* row = d.table[q] + (long)v * W;
-        float acc = 0.f;
-        for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
+    auto take = [&](int v, float acc) {
         acc = wave_sum(acc);
         if (v < 32 && ((ban_mask >> v) & 1u)) acc = -INFINITY;
         if (SAMPLE && lane == 0) sa.logits[(long)q * sa.ldl + v] = acc;
         if (acc > best || (acc == best && v < idx)) { best = acc; idx = v; }
+    };
+    if (batched) {
+        for (; vb < V; vb += 4 * vstep) {
+            const bool more = vb + 4 * vstep < V;
+            if (more) load_rows(rn, vb + 4 * vstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = vb + u * vstep;
+                if (v >= V) break;
+                float acc = 0.f;   // k = lane, lane + 64, ...: the order of the one-row-at-a-time loop
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (lane + 64 * c < W) acc = fmaf(rw[u][c], xs[c0 + lane + 64 * c], acc);
+                take(v, acc);
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) rw[u][c] = rn[u][c];
+            }
+        }
+    } else {
+        for (int v = vb; v < V; v += vstep) {
+            const float* row = tab + (long)v * W;
+            float acc = 0.f;
+            for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
+            take(v, acc);
+        }
     }
     if (lane == 0) { bv[w] = best; bi[w] = idx; }
     __syncthreads();
@@ -791,8 +960,35 @@ extern "C" int spn_dec_embed_proj(int nkeys, const float* const* tables, const i
     for (int i = 0; i < nkeys; ++i) { d.table[i] = tables[i]; d.width[i] = E[i]; d.col0[i] = col; col += E[i]; }
     d.nkeys = nkeys; d.D = col;
     SPN_REQUIRE(col <= 2048, "spn_dec_embed_proj: total width <= 2048");
-    hipLaunchKernelGGL(dec_embed_proj_kernel, dim3(cdiv(N, 4), 2), dim3(256), 0, s, d, tokens_a, tokens_b, tok_ld, pos, gamma, beta, eps, W, ldw,
-                       bias, y, N);
+    DecRider r;
+    memset(&r, 0, sizeof(r));
+    const int nbe = cdiv(N, 4);
+    hipLaunchKernelGGL(dec_embed_proj_kernel, dim3(2 * nbe), dim3(256), 0, s, d, tokens_a, tokens_b, tok_ld, pos, (int*)nullptr, gamma, beta, eps,
+                       W, ldw, bias, y, N, nbe, r);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// First launch of a fused step: spn_dec_embed_proj + the position latch (*pos_latch = *pos, see dec_embed_proj_kernel) + an optional
+// rider GEMV ry[n] = rW[n, :] . rx[(*pos + rx_off) * rx_ld ..] + rbias[n] (rW = null: none) in the same launch.
+extern "C" int spn_dec_step_begin(int nkeys, const float* const* tables, const int* E, const long* tokens_a, const long* tokens_b, long tok_ld,
+                                  const int* pos, int* pos_latch, const float* gamma, const float* beta, float eps, const float* W, long ldw,
+                                  const float* bias, float* y, int N, const float* rW, long r_ldw, int rN, int rK, const float* rx, long rx_ld,
+                                  int rx_off, const float* rbias, float* ry, hipStream_t s) {
+    SPN_REQUIRE(nkeys > 0 && nkeys <= 16 && tokens_a && tokens_b && pos && pos_latch && W && y && N > 0, "spn_dec_step_begin: bad arguments");
+    SPN_REQUIRE(!rW || (rN > 0 && rK > 0 && rx && ry), "spn_dec_step_begin: bad rider arguments");
+    DecEmbedDesc d;
+    memset(&d, 0, sizeof(d));
+    int col = 0;
+    for (int i = 0; i < nkeys; ++i) { d.table[i] = tables[i]; d.width[i] = E[i]; d.col0[i] = col; col += E[i]; }
+    d.nkeys = nkeys; d.D = col;
+    SPN_REQUIRE(col <= 2048, "spn_dec_step_begin: total width <= 2048");
+    DecRider r;
+    memset(&r, 0, sizeof(r));
+    if (rW) { r.W = rW; r.ldw = r_ldw; r.N = rN; r.K = rK; r.x = rx; r.x_ld = rx_ld; r.x_off = rx_off; r.bias = rbias; r.y = ry; }
+    const int nbe = cdiv(N, 4);
+    hipLaunchKernelGGL(dec_embed_proj_kernel, dim3(2 * nbe + (rW ? cdiv(rN, 4) : 0)), dim3(256), 0, s, d, tokens_a, tokens_b, tok_ld, pos,
+                       pos_latch, gamma, beta, eps, W, ldw, bias, y, N, nbe, r);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -843,7 +1039,21 @@ extern "C" int spn_dec_fused_gemv(const float* W, long ldw, int N, int K, const 
     SPN_REQUIRE(W && x && y && N > 0 && K > 0 && K <= 2048, "spn_dec_fused_gemv: bad arguments (K <= 2048)");
     SPN_REQUIRE(norm >= 0 && norm <= 2 && (norm != 2 || gamma), "spn_dec_fused_gemv: bad norm mode");
     DecGemvArgs a{W, ldw, N, K, x, x_ld, x_off, norm, gamma, beta, eps, bias, residual, y, y_ld, y_off, y2, y2_ld, y2_off,
-                  xn_out, xn_ld, xn_off, glu, act, pos, nullptr, 0, 0};
+                  xn_out, xn_ld, xn_off, glu, act, pos, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, 0, 0};
+    hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// y = W . ( LN?(x[0:d]) | ctx[*pos + 1] | style[*pos + 1] ) + bias, mirrored into row *pos of y2: spn_dec_cat + spn_dec_fused_gemv in one
+// launch (the decoder's input projection over the concatenated embeddings, models/scoreperformer/transformer.py:160-181)
+extern "C" int spn_dec_cat_gemv(const float* W, long ldw, int N, const float* x, int d, const float* gamma, const float* beta, float eps,
+                                const float* ctx, long ctx_ld, int ctx_w, const float* style, long style_ld, int style_w, const float* bias,
+                                float* y, float* y2, long y2_ld, const int* pos, hipStream_t s) {
+    const int K = d + (ctx ? ctx_w : 0) + (style ? style_w : 0);
+    SPN_REQUIRE(W && x && y && pos && N > 0 && d > 0 && K <= 2048 && (!gamma || beta), "spn_dec_cat_gemv: bad arguments (K <= 2048)");
+    DecGemvArgs a{W, ldw, N, K, x, 0, 0, 0, gamma, beta, eps, bias, nullptr, y, 0, 0, y2, y2_ld, 0,
+                  nullptr, 0, 0, 0, -1, pos, nullptr, 0, 0, d, ctx, ctx_ld, ctx_w, style, style_ld, style_w};
     hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
@@ -855,7 +1065,7 @@ extern "C" int spn_dec_attn_out(const float* W, long ldw, int N, const float* pa
                                 hipStream_t s) {
     SPN_REQUIRE(W && part && y && N > 0 && h > 0 && h * 64 <= 2048 && splits > 0 && splits <= 64, "spn_dec_attn_out: bad arguments");
     DecGemvArgs a{W, ldw, N, h * 64, nullptr, 0, 0, 0, nullptr, nullptr, 0.f, nullptr, residual, y, 0, 0, nullptr, 0, 0,
-                  nullptr, 0, 0, 0, -1, nullptr, part, h, splits};
+                  nullptr, 0, 0, 0, -1, nullptr, part, h, splits, 0, nullptr, 0, 0, nullptr, 0, 0};
     hipLaunchKernelGGL(dec_fused_gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, a);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
@@ -894,7 +1104,7 @@ extern "C" int spn_dec_xattn(const float* q, const float* kctx, const float* vct
 
 extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
                             const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld,
-                            int mask_id, const int* pos, float* part, int* counter, int slabs, hipStream_t s) {
+                            int mask_id, const int* pos, float* part, int* counter, int slabs, int* pos_next, hipStream_t s) {
     SPN_REQUIRE(n > 0 && n <= 16 && tables && e && gamma && beta && tokens && pos && D > 0 && D <= 2048, "spn_dec_head: bad arguments");
     SPN_REQUIRE(part && counter && slabs > 0 && slabs <= 64, "spn_dec_head: scratch (n*slabs*2 floats, n zeroed ints) required");
     DecHeadDesc d;
@@ -902,7 +1112,7 @@ extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, con
     for (int i = 0; i < n; ++i) { d.table[i] = tables[i]; d.V[i] = V[i]; d.width[i] = width[i]; d.col0[i] = col0[i]; d.dim[i] = dim[i]; }
     d.n = n; d.D = D;
     hipLaunchKernelGGL(dec_head_kernel<false>, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
-                       counter, DecSampleArgs{});
+                       counter, DecSampleArgs{}, pos_next);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -910,7 +1120,7 @@ extern "C" int spn_dec_head(int n, const float* const* tables, const int* V, con
 extern "C" int spn_dec_head_sample(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D,
                                    const float* e, const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens,
                                    long tok_ld, int mask_id, const int* pos, float* part, int* counter, int slabs, float* logits, int ldl,
-                                   const int* topk, float temperature, const unsigned* seed, hipStream_t s) {
+                                   const int* topk, float temperature, const unsigned* seed, int* pos_next, hipStream_t s) {
     SPN_REQUIRE(n > 0 && n <= 16 && tables && e && gamma && beta && tokens && pos && D > 0 && D <= 2048, "spn_dec_head_sample: bad arguments");
     SPN_REQUIRE(part && counter && slabs > 0 && slabs <= 64 && logits && topk && seed && temperature > 0.f, "spn_dec_head_sample: bad arguments");
     DecHeadDesc d;
@@ -921,7 +1131,7 @@ extern "C" int spn_dec_head_sample(int n, const float* const* tables, const int*
     }
     d.n = n; d.D = D;
     hipLaunchKernelGGL(dec_head_kernel<true>, dim3(n, slabs), dim3(256), 0, s, d, e, gamma, beta, eps, ban_mask, tokens, tok_ld, mask_id, pos, part,
-                       counter, DecSampleArgs{logits, ldl, topk, 1.f / temperature, seed});
+                       counter, DecSampleArgs{logits, ldl, topk, 1.f / temperature, seed}, pos_next);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

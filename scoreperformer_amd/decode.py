@@ -52,7 +52,11 @@ class GreedyDecoder:
         m, dev, d = self.m, self.dev, self.dim
         te = m.token_emb
         z = lambda *s: torch.zeros(*s, device=dev, dtype=F32)
-        self.pos = torch.zeros(1, device=dev, dtype=torch.int32)
+        # position scalars: `pos` is what the launches of a step read; `pos_next` is read by the first launch of a step only
+        # (ops.dec_step_begin latches it into `pos`) and written by its last one (the head: position + 1) -- no separate "advance" launch
+        self.pos2 = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.pos, self.pos_next = self.pos2[0:1], self.pos2[1:2]
+        self.x0 = z(d)   # token embedding of the position before the (LN | context | style) projection writes the stream `x`
         self.e_cat = z(te.total_emb_dim)
         self.proj_cat = z(2 * d)
         self.tok_emb = z(L, d)
@@ -252,26 +256,41 @@ class GreedyDecoder:
         te, tr = m.token_emb, m.transformer
         has_norm = isinstance(te.norm, nn.LayerNorm)
         gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
+        head, fn = m.lm_head, tr.final_norm
+        fused_tail = isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity)
+        # A dependent launch costs >= 4 us under graph replay whatever it does (profiles/, one-thread kernel), so three of them are
+        # folded away: the position advance (latch protocol of ops.dec_step_begin; needs the fused head as the step's last launch), the
+        # AdaLN-row GEMV (position-only input: rides in the first launch), the concatenation (prologue of the projection GEMV)
+        latched = fused_tail and not self.legacy_launches
+        en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
+        cat_args = dict(gamma=en.weight.data if en is not None else None, beta=en.bias.data if en is not None else None,
+                        eps=en.eps if en is not None else 1e-5, ctx=self.ctx2d if m.context_emb_mode == "cat" else None,
+                        style=self.style2d if m.style_emb_mode == "cat" else None)
         if self.legacy_launches:
             for si, (toks, off) in enumerate(((self.seq2d, 0), (self.masked2d, 1))):
                 ops.dec_embed(self.tables, toks, pos, self.e_cat, row_off=off, gamma=gam, beta=bet, eps=eps)
                 ops.dec_gemv(te.project_emb.weight.data, self.e_cat, self.proj_cat[si * d:(si + 1) * d], bias=te.project_emb.bias.data)
+        elif latched:   # + position latch, + every AdaLN (gamma | beta) row of the step as a rider GEMV
+            rider = (self.ada_W, self.style2d, 1, self.ada_b, self.gb_all.view(-1)) if self.ada_rows else None
+            ops.dec_step_begin(self.tables, self.seq2d, self.masked2d, self.pos_next, pos, te.project_emb.weight.data, te.project_emb.bias.data,
+                               self.proj_cat, gamma=gam, beta=bet, eps=eps, rider=rider)
         else:   # both sequences' tuple embeddings and their projection: one launch (4 before)
             ops.dec_embed_proj(self.tables, self.seq2d, self.masked2d, pos, te.project_emb.weight.data, te.project_emb.bias.data, self.proj_cat,
                                gamma=gam, beta=bet, eps=eps)
-        ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x, bias=te.project_multiemb.bias.data, pos=pos,
-                           y2=self.tok_emb, y2_ld=d)
-        en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
-        ops.dec_cat(self.x, d, self.xcat, pos, gamma=en.weight.data if en is not None else None,
-                    beta=en.bias.data if en is not None else None, eps=en.eps if en is not None else 1e-5,
-                    ctx=self.ctx2d if m.context_emb_mode == "cat" else None, style=self.style2d if m.style_emb_mode == "cat" else None)
-        if self.ada_rows:   # every AdaLN (gamma | beta) row of this step: one GEMV over the stacked condition projections
+        fold_cat = isinstance(m.project_emb, nn.Linear) and not self.legacy_launches
+        ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x0 if fold_cat else self.x, bias=te.project_multiemb.bias.data,
+                           pos=pos, y2=self.tok_emb, y2_ld=d)
+        if self.ada_rows and not latched:   # every AdaLN (gamma | beta) row of this step: one GEMV over the stacked condition projections
             ops.dec_gemv(self.ada_W, self.style2d, self.gb_all.view(-1), bias=self.ada_b, pos=pos, x_ld=self.style2d.stride(0), x_off=1)
-        if isinstance(m.project_emb, nn.Linear):
-            ops.dec_fused_gemv(m.project_emb.weight.data, self.xcat, self.x, bias=m.project_emb.bias.data, pos=pos, y2=self.hid[0], y2_ld=d)
+        if fold_cat:    # (LN(x0) | context row | style row) built in the prologue of the projection (x0 -> x: not in place)
+            ops.dec_cat_gemv(m.project_emb.weight.data, self.x0, d, self.x, pos, bias=m.project_emb.bias.data, y2=self.hid[0], y2_ld=d, **cat_args)
         else:
-            ops.dec_copy_row(self.xcat, self.x, pos, d)
-            ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
+            ops.dec_cat(self.x, d, self.xcat, pos, **cat_args)
+            if isinstance(m.project_emb, nn.Linear):
+                ops.dec_fused_gemv(m.project_emb.weight.data, self.xcat, self.x, bias=m.project_emb.bias.data, pos=pos, y2=self.hid[0], y2_ld=d)
+            else:
+                ops.dec_copy_row(self.xcat, self.x, pos, d)
+                ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
         ai = ci = 0
         n_layers = len(tr.layers)
         for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
@@ -301,9 +320,7 @@ class GreedyDecoder:
                 nxt_attn = li + 1 < n_layers
                 ops.dec_fused_gemv(out.weight.data, self.g, self.x, bias=out.bias.data if out.bias is not None else None, residual=self.x,
                                    pos=pos, y2=self.hid[ai] if nxt_attn else None, y2_ld=d if nxt_attn else 0)
-        head = m.lm_head
-        fn = tr.final_norm
-        if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity):
+        if fused_tail:
             mode, g_, b_, eps_ = self._norm_args(fn)
             ops.dec_fused_gemv(self.head_Wt, self.x, self.e_head, norm=mode, gamma=g_, beta=b_, eps=eps_, pos=pos,
                                xn_out=self.hid[-1], xn_ld=d)
@@ -314,12 +331,14 @@ class GreedyDecoder:
                 ops.dec_head_sample([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
                                     head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part,
                                     self.head_counter, self.head_logits, self.sampling["topk"], self.seed_dev,
-                                    temperature=self.sampling["temperature"], slabs=self.head_slabs)
+                                    temperature=self.sampling["temperature"], slabs=self.head_slabs,
+                                    pos_next=self.pos_next if latched else None)
             else:
                 ops.dec_head([self.tables[dim] for dim in dims], [offs[dim] for dim in dims], list(dims), te.total_emb_dim, self.e_head,
                              head.norm.weight.data, head.norm.bias.data, head.norm.eps, self.seq2d, pos, self.head_part, self.head_counter,
-                             slabs=self.head_slabs)
-            ops.dec_add_pos(pos, 1)
+                             slabs=self.head_slabs, pos_next=self.pos_next if latched else None)
+            if not latched:
+                ops.dec_add_pos(pos, 1)
             return
         if self.sampling is not None:
             raise NotImplementedError("decode engine: sampling needs the fused tied LM head")
@@ -359,7 +378,7 @@ class GreedyDecoder:
             self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
         n_steps = last                              # positions t = 0 .. last-1 (predicting t+1)
         step = self._step_fused if self.fused else self._step
-        self.pos.zero_()
+        self.pos2.zero_()
         if self.use_graph and n_steps > 2:
             step(dims)                              # warm-up (also position 0), eager
             torch.cuda.synchronize()
@@ -557,7 +576,7 @@ class RenderSession(GreedyDecoder):
         if batched_prefill and c == 0 and Lin - 1 - n_new >= self.prefill_min:
             self.prefill(Lin - 1 - n_new)
             c = self.length
-        self.pos.fill_(c)
+        self.pos2.fill_(c)
         if self.sampling is not None:   # a fresh stream per call: positions repeat after a cut, (seed, position, key) must not
             self.sampling["calls"] += 1
             self.seed_dev.fill_((self.sampling["calls"] * 0x9E3779B1) & 0x7FFFFFFF)

@@ -849,6 +849,24 @@ def dec_embed_proj(tables, tokens_a, tokens_b, pos, W, bias, y, *, gamma=None, b
     return y
 
 
+def dec_step_begin(tables, tokens_a, tokens_b, pos_next, pos, W, bias, y, *, gamma=None, beta=None, eps=1e-5, rider=None):
+    """First launch of a fused decode step: `dec_embed_proj` reading the position from `pos_next`, republishing it in `pos` (the scalar
+    every later launch of the step reads; the head launch writes position + 1 back into `pos_next`), and an optional rider GEMV
+    `rider = (W_r, x2d, x_off, bias_r, y_r)`: y_r = W_r . x2d[*pos_next + x_off] + bias_r in the same launch."""
+    if tokens_a.stride(0) != tokens_b.stride(0):
+        raise SpnError("dec_step_begin: the two token arrays must share their row stride")
+    E = [t.shape[1] for t in tables]
+    if rider is not None:
+        rW, rx, rx_off, rb, ry = rider
+        rargs = (ptr(rW), c_long(rW.stride(0)), c_int(rW.shape[0]), c_int(rW.shape[1]), ptr(rx), c_long(rx.stride(0)), c_int(rx_off), ptr(rb), ptr(ry))
+    else:
+        rargs = (ptr(None), c_long(0), c_int(0), c_int(0), ptr(None), c_long(0), c_int(0), ptr(None), ptr(None))
+    call("spn_dec_step_begin", c_int(len(tables)), _ptr_array(tables), _int_array(E), ptr(tokens_a), ptr(tokens_b), c_long(tokens_a.stride(0)),
+         ptr(pos_next), ptr(pos), ptr(gamma), ptr(beta), c_float(eps), ptr(W), c_long(W.stride(0)), ptr(bias), ptr(y), c_int(W.shape[0]),
+         *rargs, stream_ptr())
+    return y
+
+
 def dec_copy_row(src, dst, pos, D, *, src_ld=0, src_off=0, dst_ld=0, dst_off=0):
     call("spn_dec_copy_row", ptr(src), c_long(src_ld), c_int(src_off), ptr(dst), c_long(dst_ld), c_int(dst_off), ptr(pos), c_int(D),
          stream_ptr())
@@ -889,6 +907,15 @@ def dec_cat(x, d, out, pos, *, gamma=None, beta=None, eps=1e-5, ctx=None, style=
     return out
 
 
+def dec_cat_gemv(W, x, d, y, pos, *, gamma=None, beta=None, eps=1e-5, ctx=None, style=None, bias=None, y2=None, y2_ld=0):
+    """y = W . (LN?(x[:d]) | ctx[*pos + 1] | style[*pos + 1]) + bias, row *pos of y2 mirrored: `dec_cat` + `dec_fused_gemv` in one launch."""
+    call("spn_dec_cat_gemv", ptr(W), c_long(W.stride(0)), c_int(W.shape[0]), ptr(x), c_int(d), ptr(gamma), ptr(beta), c_float(eps), ptr(ctx),
+         c_long(ctx.stride(0) if ctx is not None else 0), c_int(ctx.shape[1] if ctx is not None else 0), ptr(style),
+         c_long(style.stride(0) if style is not None else 0), c_int(style.shape[1] if style is not None else 0), ptr(bias), ptr(y), ptr(y2),
+         c_long(y2_ld), ptr(pos), stream_ptr())
+    return y
+
+
 def dec_attn2(qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, *, h, kvh, scale, splits):
     call("spn_dec_attn2", ptr(qkv), ptr(kcache), ptr(vcache), ptr(slopes), ptr(pos), ptr(o), ptr(part), ptr(counter), ptr(kmax2),
          c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
@@ -909,12 +936,13 @@ def dec_xattn(q, kctx, vctx, slopes, kmask, o, part, counter, *, h, kvh, scale, 
     return o
 
 
-def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1):
+def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):
+    """`pos_next`: int32 device scalar that receives position + 1 (the launch that closes a fused step, see `dec_step_begin`)."""
     V = [t.shape[0] for t in tables]
     W = [t.shape[1] for t in tables]
     call("spn_dec_head", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(W), _int_array(col0), _int_array(dims), c_int(D),
          ptr(e), ptr(gamma), ptr(beta), c_float(eps), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)), c_int(mask_id),
-         ptr(pos), ptr(part), ptr(counter), c_int(slabs), stream_ptr())
+         ptr(pos), ptr(part), ptr(counter), c_int(slabs), ptr(pos_next), stream_ptr())
 
 
 def dec_attn_rows(q, kcache, vcache, slopes, t0, o, *, h, kvh, scale):
@@ -931,7 +959,7 @@ def dec_glu_rows(u, out, I, *, act=0, glu=True):
 
 
 def dec_head_sample(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, logits, topk, seed, *, temperature=1.0,
-                    slabs=8, ban_mask=0b11, mask_id=1):
+                    slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):
     """dec_head with top-k filtering + temperature + one multinomial draw per key instead of the arg-max (logits: fp32 scratch
     [n, ld]; topk: int32 [n] on the device; seed: int32/uint32 device scalar)."""
     V = [t.shape[0] for t in tables]
@@ -939,7 +967,7 @@ def dec_head_sample(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, p
     call("spn_dec_head_sample", c_int(len(tables)), _ptr_array(tables), _int_array(V), _int_array(W), _int_array(col0), _int_array(dims),
          c_int(D), ptr(e), ptr(gamma), ptr(beta), c_float(eps), ctypes.c_uint(ban_mask), ptr(tokens2d), c_long(tokens2d.stride(0)),
          c_int(mask_id), ptr(pos), ptr(part), ptr(counter), c_int(slabs), ptr(logits), c_int(logits.stride(0)), ptr(topk),
-         c_float(temperature), ptr(seed), stream_ptr())
+         c_float(temperature), ptr(seed), ptr(pos_next), stream_ptr())
 
 
 def dec_add_pos(pos, delta=1):
