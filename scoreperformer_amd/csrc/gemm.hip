@@ -1306,10 +1306,11 @@ static bool duo_eligible(const GemmArgs& g, bool ta) {
 // (r02_gemm_ab.txt).  Two workgroups per CU overlap one tile's epilogue with the other's main loop, but a 256x128 tile moves 1.5x the
 // operand bytes per flop through the CU's 64 B/clk vector-memory path and issues 1.5x the LDS-DMA instructions per wave, so on every
 // wide projection the 256x256 ping-pong kernel stays ahead (K = 512, N = 4096: 855 vs 764 TF/s); duo wins only where a 256-wide
-// tile would be mostly padding (N <= 128: the 64-column condition gradients, 51 vs 73 us).
+// tile would be mostly padding (N <= 128: the 64-column condition gradients, 51 vs 73 us) and where the ping-pong kernel cannot go at
+// all (K < 256: the AdaLN condition projections, K = 64, 131008 x 1024 x 64: 67 vs 78-83 us on the 128x128 kernel).
 static bool duo_preferred(const GemmArgs& g, bool tb, bool f32) {
     (void)tb; (void)f32;
-    return g.N <= 128;
+    return g.N <= 128 || g.K < 4 * PP_BK;
 }
 
 template <bool TB, typename OutT, int GLU>

@@ -234,3 +234,28 @@ def test_gemm_random_shapes_full_tensor_screen():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(80, 7, verbose=False) == 0
+
+
+@pytest.mark.parametrize("K", [64, 96, 160, 224])
+@pytest.mark.parametrize("tb,f32,extras", [(False, False, True), (True, True, True), (False, True, False)])
+def test_gemm_short_contraction_on_the_duo_kernel(K, tb, f32, extras):
+    """K < 256 (below the ping-pong kernel's range: the AdaLN condition projections have K = 64) goes to the two-workgroups-per-CU
+    kernel when the launch has >= 512 tiles: two to seven K tiles of 32, ragged M, bias / residual, against fp32 matmul in full."""
+    from scoreperformer_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(K + 7 * tb + 13 * f32)
+    M, N = 256 * 70 + 8, 1024          # 71 x 8 = 568 tiles of 256 x 128
+    a = (torch.randn(M, K, device=dev, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=dev, generator=g) * K ** -0.5).bfloat16()
+    b = w.t().contiguous() if tb else w
+    bias = torch.randn(N, device=dev, generator=g) if extras else None
+    res = torch.randn(M, N, device=dev, generator=g) if (extras and f32) else None
+    out = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    ops.gemm(a, b, tb=tb, out=out, bias=bias, residual=res)
+    ref = a.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    if res is not None:
+        ref = ref + res
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (2e-5 * K ** 0.5 if f32 else 1e-2) and bool(torch.isfinite(out.float()).all()), err
