@@ -193,8 +193,22 @@ def roofline_leg(ops, step, args):
             kname = ("gemm_duo_kernel<true, unsigned short, 3>" if lib.get_tuning("glu_bwd_duo") else
                      "gemm_pp_kernel<false, true, unsigned short, 3>")
         else:
-            kname = (f"gemm_pp_kernel<{'true' if lay[0] == 'T' else 'false'}, {'true' if lay[1] == 'T' else 'false'}, "
-                     f"{'float' if dt == 'f32' else 'unsigned short'}, {1 if dt.endswith('+glu') else 0}>")
+            # the name rocprofv3 prints: the library's dispatch restated (csrc/gemm.hip: launch_pp / dispatch) -- short or narrow
+            # products run on the two-workgroups-per-CU or the 128x128 kernel, the last template argument is the persistent tile walk
+            mnk = [int(v) for v in tag.split(":")[0].split("x")]
+            ta, tb, f32, glu = lay[0] == "T", lay[1] == "T", dt.startswith("f32"), dt.endswith("+glu")
+            ctype = "float" if f32 else "unsigned short"
+            tf = lambda v: "true" if v else "false"   # noqa: E731
+            if glu:
+                kname = f"gemm_pp_kernel<false, false, unsigned short, 1, {tf(lib.get_tuning('glu_persist') > 0)}>"
+            elif not ta and (mnk[1] <= 128 or mnk[2] < 256) and lib.get_tuning("gemm_duo") > 0:
+                kname = f"gemm_duo_kernel<{tf(tb)}, {ctype}, 0>"
+            elif mnk[0] < 128 or mnk[1] < 128 or mnk[2] < 256 or mnk[2] % 64:
+                kname = f"gemm_kernel<{tf(ta)}, {tf(tb)}, {ctype}, 32, 2>"
+            else:
+                walk = (not f32 and mnk[2] <= 1024 and lib.get_tuning("gemm_persist") > 0 and mnk[0] * mnk[1] >= 2 * 256 * 65536
+                        and ((not ta and not tb) or lib.get_tuning("gemm_persist_bwd") > 0))
+                kname = f"gemm_pp_kernel<{tf(ta)}, {tf(tb)}, {ctype}, 0, {tf(walk)}>"   # (the two bf16 launches with a residual stay on the plain grid)
         a = by_inst.setdefault(kname, [0, 0.0, 0.0])
         a[0] += 1; a[1] += f; a[2] += t
     # launches whose epilogue also does the feed-forward's activation work (forward: GLU + dropout, backward: activation backward +
@@ -252,7 +266,7 @@ def roofline_leg(ops, step, args):
                             f"{tj.get('commit', 'of that round')}), not re-measured by this run: counters need their own rocprofv3 --pmc "
                             f"passes.  " + (tj.get("note") or ""))
             break
-    return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT, GLU> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
+    return {"bound": "mfma", "kernel": "gemm_pp_kernel<TA, TB, OutT, GLU, PERSIST> (256x256x64 ping-pong tiles, v_mfma_f32_32x32x16_bf16; all GEMM launches "
                                        "of a step, a split-K launch includes its reduce kernel; GLU = 1 / 3: the gated FFN projections with "
                                        "the activation (forward) / activation backward in the epilogue, counted at the GEMM's 2MNK only)",
             "achieved": flops / (ms * 1e-3) / 1e12 if ms else None, "peak": 2500.0, "unit": "TFLOP/s",
