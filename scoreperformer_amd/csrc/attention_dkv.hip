@@ -185,16 +185,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             dreg = i < nq ? ai->delta[si] : 0.f;
         }
     };
-    // ALiBi band (attention.hip): a (head, query tile) whose reach ends before this block's 128 keys is not visited
-    auto next_live = [&](int it) {
-        for (; it < n_iter; ++it) {
-            const int hh = kh * heads_per_kv + it / (nqt - t_first);
-            const int i0 = (t_first + it % (nqt - t_first)) * 64;
-            const float reach = band_reach(a, bi, hh, kh, i0 / 64, 1, c1, a.slopes ? a.slopes[hh] * LOG2E : 0.f);
-            if (!(reach < 1.0e9f)) break;
-            const float r_lo = (float)(i0 + off), r_hi = r_lo + 63.f;
-            if ((float)j0 <= r_hi + reach && (float)(j0 + 127) >= r_lo - reach) break;
+    // ALiBi band (attention.hip): a (head, query tile) whose reach ends before this block's 128 keys is not visited.  Which iterations
+    // are live is decided ONCE, by all 256 threads in parallel, into a bit mask in LDS: decided tile by tile inside the loop, the two
+    // dependent global loads of band_reach (and ~110 scalar / vector instructions around them) sat in front of every tile request.
+    constexpr int LIVE_WORDS = 16;   // up to 1024 (head, query tile) iterations; longer walks decide on the fly as before
+    __shared__ unsigned long long live_mask[LIVE_WORDS];
+    auto is_live = [&](int it) {
+        const int hh = kh * heads_per_kv + it / (nqt - t_first);
+        const int i0 = (t_first + it % (nqt - t_first)) * 64;
+        const float reach = band_reach(a, bi, hh, kh, i0 / 64, 1, c1, a.slopes ? a.slopes[hh] * LOG2E : 0.f);
+        if (!(reach < 1.0e9f)) return true;
+        const float r_lo = (float)(i0 + off), r_hi = r_lo + 63.f;
+        return (float)j0 <= r_hi + reach && (float)(j0 + 127) >= r_lo - reach;
+    };
+    const bool masked_walk = n_iter <= 64 * LIVE_WORDS;
+    if (masked_walk) {
+        for (int base = 0; base < n_iter; base += 256) {
+            const int it = base + tid;
+            const unsigned long long m = __ballot(it < n_iter && is_live(it));
+            if (lane == 0) live_mask[(base >> 6) + w] = m;
         }
+        __syncthreads();
+    }
+    auto next_live = [&](int it) {
+        if (masked_walk) {
+            while (it < n_iter) {
+                const unsigned long long word = live_mask[it >> 6] >> (it & 63);
+                if (word) { it += __builtin_ctzll(word); break; }
+                it = (it | 63) + 1;
+            }
+            return min(it, n_iter);
+        }
+        for (; it < n_iter; ++it)
+            if (is_live(it)) break;
         return it;
     };
     int it = next_live(0);
