@@ -557,22 +557,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // such lower bound on its row maximum and is marked +inf = never skipped.  Learned slopes <= 0 disable skipping for that head.
 // ==========================================================================================================
 __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __restrict__ band) {
+    // One wave per 64-row tile; EIGHT LANES per row (one 16-byte chunk each: a wave load covers 8 whole 128-byte rows), eight passes.
+    // (One lane per row made every wave load touch 64 cache lines for 16 useful bytes each.)
     const int lane = threadIdx.x, bi = blockIdx.z, hi = blockIdx.y, x = blockIdx.x;
     const int off = a.nk - a.nq;
     const bool is_q = x < a.nqt64;
     if (!is_q && hi >= a.kvh) return;
-    const int row = (is_q ? x : x - a.nqt64) * 64 + lane;
     const int n = is_q ? a.nq : a.nk;
     const long nq_part = (long)a.b * a.h * a.nqt64;
-    float v = 0.f, dot = __builtin_inff();   // |row|^2; query rows: q_i . k_i' with the row's own key i' = i + off
-    if (row < n) {
-        const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
-        const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
-        const bool own_ok = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
-        const bf16_t* pk = own_ok ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
-        float d = 0.f;
+    const int ch = lane & 7;
+    float vmax = 0.f, dmin = __builtin_inff();   // max |row|^2; query rows: min q_i . k_i' with the row's own key i' = i + off
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = (is_q ? x : x - a.nqt64) * 64 + pass * 8 + (lane >> 3);
+        float v = 0.f, d = 0.f;
+        bool own_ok = false;
+        if (row < n) {
+            const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
+            const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
+            own_ok = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
+            const bf16_t* pk = own_ok ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
             const uint4 u = *reinterpret_cast<const uint4*>(p + ch * 8);
             const uint4 uk = *reinterpret_cast<const uint4*>(pk + ch * 8);
             const uint32_t w[4] = {u.x, u.y, u.z, u.w}, wk[4] = {uk.x, uk.y, uk.z, uk.w};
@@ -583,13 +587,17 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
                 d = fmaf(lo, bf2f(wk[e] & 0xffff), fmaf(hi_, bf2f(wk[e] >> 16), d));
             }
         }
-        if (is_q) {
-            if (own_ok) dot = d;
-            else v = __builtin_inff();   // no lower bound on this row's maximum: the tile is never skipped
+        // the row's eight partial sums (lanes 8r .. 8r + 7)
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (row < n) {
+            if (is_q && !own_ok) v = __builtin_inff();   // no lower bound on this row's maximum: the tile is never skipped
+            vmax = fmaxf(vmax, v);
+            if (own_ok) dmin = fminf(dmin, d);
         }
     }
-    v = wave_max(v);
-    if (is_q) dot = -wave_max(-dot);   // minimum over the tile's rows (rows past nq: +inf)
+    const float v = wave_max(vmax);
+    const float dot = is_q ? -wave_max(-dmin) : 0.f;   // minimum over the tile's rows (rows past nq: +inf)
     if (lane == 0) {
         if (is_q) {
             band[((long)(bi * a.h + hi)) * a.nqt64 + x] = v;
