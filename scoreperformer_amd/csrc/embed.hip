@@ -195,6 +195,84 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(GatherDesc d, const long
     }
 }
 
+// The same with EIGHT columns per lane (all key widths multiples of 8): the output leaves as 16-byte pieces.  With 8-byte stores the
+// kernel is bound by store ISSUE, not by bandwidth (402 MB of bf16 rows at C3 through 8-byte-per-lane instructions: 172 us).
+template <int NW>
+__global__ __launch_bounds__(256) void embed_fwd_wide_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             bf16_t* __restrict__ y, long ldy, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int T, float eps) {
+    constexpr int RPW = 2;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= T) return;
+    f32x4 v[RPW][NW][2];
+    int tok_l[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = min(row0 + r, T - 1);
+        tok_l[r] = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int col = (lane + 64 * i) * 8;
+        int kk = 0;
+        for (int q = 1; q < d.nkeys; ++q) if (col >= d.col0[q]) kk = q;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const long tok = __shfl(tok_l[r], kk, 64);
+            const float* src = d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]);
+            v[r][i][0] = col < d.D ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[r][i][1] = col < d.D ? *reinterpret_cast<const f32x4*>(src + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        if (row >= T) break;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) sum += v[r][i][h][0] + v[r][i][h][1] + v[r][i][h][2] + v[r][i][h][3];
+        float mu = 0.f, rs = 1.f;
+        if (gamma) {
+            mu = wave_sum(sum) / (float)d.D;
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                if ((lane + 64 * i) * 8 < d.D) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float t = v[r][i][h][e] - mu; sq += t * t; }
+                }
+            }
+            rs = rsqrtf(wave_sum(sq) / (float)d.D + eps);
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int col = (lane + 64 * i) * 8;
+            if (col >= d.D) continue;
+            uint4 pk;
+            uint32_t* pw = reinterpret_cast<uint32_t*>(&pk);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 o = v[r][i][h];
+                if (gamma) {
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + col + 4 * h);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + col + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (v[r][i][h][e] - mu) * rs * ga[e] + be[e];
+                }
+                pw[2 * h] = pack_bf2(o[0], o[1]); pw[2 * h + 1] = pack_bf2(o[2], o[3]);
+            }
+            *reinterpret_cast<uint4*>(y + (long)row * ldy + col) = pk;
+        }
+    }
+}
+
 // backward pass 1: per-row LN-backward sums s1 = mean(g), s2 = mean(g*xhat) with g = dy*gamma, and dgamma/dbeta.
 template <int NV>
 __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, const long* __restrict__ tokens, long tok_bs, long tok_ts, int t_len,
@@ -555,6 +633,16 @@ extern "C" int spn_embed_fwd(int nkeys, const float* const* tables, const int* V
     SPN_REQUIRE(!gamma || (mean && rstd && beta), "spn_embed_fwd: mean/rstd/beta required with gamma");
     const int nv = round_nv((D + 255) / 256);
     dim3 grid(cdiv(T, 8));   // 4 waves x 2 rows
+    bool wide = D % 8 == 0 && ldy % 8 == 0 && D <= 2048 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    for (int i = 0; i < nkeys; ++i) wide = wide && E[i] % 8 == 0;
+    if (wide) {   // 16-byte output pieces: 8 columns per lane, (D + 511) / 512 chunks
+        const int nw = (D + 511) / 512;
+#define CASEW(NW_) case NW_: hipLaunchKernelGGL((embed_fwd_wide_kernel<NW_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, gamma, beta, (bf16_t*)y, ldy, mean, rstd, T, eps); break;
+        switch (nw) { CASEW(1) CASEW(2) CASEW(3) CASEW(4) default: return SPN_ERR_ARG; }
+#undef CASEW
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
 #define CASE(NV_) case NV_: hipLaunchKernelGGL((embed_fwd_kernel<NV_>), grid, dim3(256), 0, stream, d, tokens, tok_bs, tok_ts, t_len, gamma, beta, (bf16_t*)y, ldy, mean, rstd, T, eps); break;
     switch (nv) { CASE(1) CASE(2) CASE(4) CASE(6) CASE(8) default: return SPN_ERR_ARG; }
 #undef CASE
