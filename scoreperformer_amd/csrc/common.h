@@ -82,16 +82,41 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return cdf + x * pdf;
 }
 
+// 64-lane reductions through DPP (data-parallel primitives: a lane permutation folded into the VALU instruction), result in every lane.
+// __shfl_xor compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar per step, six dependent ones per reduction (~700
+// cycles); the DPP ladder (two quad permutes, row_half_mirror, row_mirror, row_bcast:15, row_bcast:31, one v_readlane) is ~40.
+// Same association order for every lane, so the result is wave-uniform by construction.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float spn_dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += spn_dpp<0xB1, 0xf>(v, v);     // quad_perm [1,0,3,2]
+    v += spn_dpp<0x4E, 0xf>(v, v);     // quad_perm [2,3,0,1]
+    v += spn_dpp<0x141, 0xf>(v, v);    // row_half_mirror
+    v += spn_dpp<0x140, 0xf>(v, v);    // row_mirror: every lane holds its 16-lane row's sum
+    v += spn_dpp<0x142, 0xa>(0.f, v);  // row_bcast:15 into rows 1 and 3
+    v += spn_dpp<0x143, 0xc>(0.f, v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over each aligned group of 16 lanes (one DPP row), result in all 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+    v += spn_dpp<0xB1, 0xf>(v, v);
+    v += spn_dpp<0x4E, 0xf>(v, v);
+    v += spn_dpp<0x141, 0xf>(v, v);
+    return v + spn_dpp<0x140, 0xf>(v, v);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float ninf = -__builtin_inff();
+    v = fmaxf(v, spn_dpp<0xB1, 0xf>(v, v));
+    v = fmaxf(v, spn_dpp<0x4E, 0xf>(v, v));
+    v = fmaxf(v, spn_dpp<0x141, 0xf>(v, v));
+    v = fmaxf(v, spn_dpp<0x140, 0xf>(v, v));
+    v = fmaxf(v, spn_dpp<0x142, 0xa>(ninf, v));
+    v = fmaxf(v, spn_dpp<0x143, 0xc>(ninf, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- LDS DMA through inline asm ----------------------------------------------------------------------------------------------

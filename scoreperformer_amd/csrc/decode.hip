@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
             const int j = jb + 16 * u;
             if (j >= j1) break;
             float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-            sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+            sc = row16_sum(sc);   // the 16 lanes of a key: one DPP row (four ds_bpermute round trips per key before)
             sc -= slope * (float)(t - j);
             const float m_new = fmaxf(m, sc);
             const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict_
             const int j = jb + 16 * u;
             if (j >= j1) break;
             float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-            sc += __shfl_xor(sc, 8, 64); sc += __shfl_xor(sc, 4, 64); sc += __shfl_xor(sc, 2, 64); sc += __shfl_xor(sc, 1, 64);
+            sc = row16_sum(sc);   // the 16 lanes of a key: one DPP row (four ds_bpermute round trips per key before)
             sc -= slope * (float)(nk - 1 - j);
             if (km[u] == 0) sc = -1.7014118e38f;
             const float m_new = fmaxf(m, sc);
