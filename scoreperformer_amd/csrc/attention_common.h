@@ -209,7 +209,9 @@ __device__ __forceinline__ bool xcd_batch_coords(const AttnArgs& a, int& bi, int
     const int L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), xcd = L & 7, idx = L >> 3;
     tile = idx % nx;
     const int rest = idx / nx;
-    hi = rest % ny;
+    // heads from the LAST one down: ALiBi slopes fall with the head index, so the last heads have the widest band and the longest
+    // blocks (32 key tiles against 3-5 for the steepest head at n = 2048); started last, they were the tail of every launch
+    hi = ny - 1 - rest % ny;
     bi = (rest / ny) * 8 + xcd;
     return true;
 }
