@@ -31,8 +31,9 @@ def parse():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the bucketed RCCL all-reduce path on a one-rank group")
-    ap.add_argument("--dp-transport", choices=("torch", "spn"), default=os.environ.get("SPN_DP_TRANSPORT", "torch"),
-                    help="gradient all-reduce through torch.distributed (default) or libspn.so's own RCCL wrapper (spn_comm_allreduce)")
+    ap.add_argument("--dp-transport", choices=("auto", "torch", "spn"), default=os.environ.get("SPN_DP_TRANSPORT", "auto"),
+                    help="gradient all-reduce through libspn.so's own RCCL wrapper (spn_comm_allreduce) or torch.distributed; auto = spn, "
+                         "checked against torch.distributed on a small buffer at start-up, torch when that check fails on any rank")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048)
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -72,7 +73,7 @@ def main():
         spn_build.build()
     if dist is not None:
         dist.barrier()
-    from scoreperformer_amd import ops
+    from scoreperformer_amd import ops, lib as lib_mod
     from scoreperformer_amd.arena import ParamArena, FusedAdamW
     from scoreperformer_amd.models import ScorePerformer
     from scoreperformer_amd.parallel import GradSync
@@ -86,7 +87,10 @@ def main():
     model.train()
     model.sync_free = True
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
-    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp, transport=args.dp_transport)
+    transport, transport_note = pick_transport(args, dist, dev)
+    # the persistent tile walk of the input-gradient GEMMs is only safe while no all-reduce kernel holds CUs during the backward
+    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp, transport=transport,
+                    persistent_backward=(dist is None) if "SPN_GEMM_PERSIST_BWD" not in os.environ else None)
     batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
     # segment-slot counts are known to the (host-side) input pipeline: pass them as python ints, no device read-back
     model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in
@@ -130,6 +134,8 @@ def main():
                                f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss,
+                   "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
+                   "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
                    "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},
     }
 
@@ -158,6 +164,34 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+
+
+def pick_transport(args, dist, dev):
+    """Which all-reduce carries the gradient buckets.  `auto`: libspn.so's own RCCL wrapper (spn_comm_*, include/spn.h) after a
+    start-up check -- a small buffer reduced through it must equal the same buffer reduced by torch.distributed on EVERY rank;
+    otherwise (init error, wrong sum) all ranks agree on torch.distributed.  Nothing is re-executed; the process group exists already."""
+    if dist is None:
+        return "torch", "single process: no all-reduce"
+    if args.dp_transport != "auto":
+        return args.dp_transport, "as requested"
+    ok, why = 1, "spn_comm_allreduce == dist.all_reduce on a 1 Mi-element probe on every rank"
+    try:
+        from scoreperformer_amd.comm import NativeComm
+        comm = NativeComm.from_group(dist.group.WORLD)
+        probe = torch.arange(1 << 20, device=dev, dtype=torch.float32) * (1.0 + dist.get_rank())
+        want = probe.clone()
+        comm.all_reduce_(probe)
+        comm.wait()
+        dist.all_reduce(want)
+        torch.cuda.synchronize()
+        if not torch.equal(probe, want):
+            ok, why = 0, "probe mismatch"
+        comm.close()
+    except Exception as exc:  # noqa: BLE001 -- any failure of the native path selects the torch path, on all ranks
+        ok, why = 0, repr(exc)
+    flag = torch.tensor([ok], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return ("spn", why) if int(flag) == 1 else ("torch", "native transport check failed on some rank (" + why + "): torch.distributed")
 
 
 def _collect(ops, step, n=2):
@@ -234,10 +268,14 @@ def roofline_leg(ops, step, args):
     layers = max(1, attn_on["launches_per_step"] // 2)
     attention = {"bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s",
                  "band_log2": band_default, "with_band": attn_on, "band_off": attn_off,
-                 "achieved": attn_on["tflops_dense_counted"], "frac": (attn_on["tflops_dense_counted"] or 0.0) / 2500.0,
-                 "achieved_executed_only": attn_off["tflops_dense_counted"], "frac_executed_only": (attn_off["tflops_dense_counted"] or 0.0) / 2500.0,
+                 "achieved": attn_off["tflops_dense_counted"], "frac": (attn_off["tflops_dense_counted"] or 0.0) / 2500.0,
+                 "achieved_dense_counted": attn_on["tflops_dense_counted"], "frac_dense_counted": (attn_on["tflops_dense_counted"] or 0.0) / 2500.0,
+                 "frac_executed_only": (attn_off["tflops_dense_counted"] or 0.0) / 2500.0,
                  "floor_us_per_layer_fwd": {"bidirectional": 220, "causal": 110},
-                 "note": "dense-counted flops / time; `band_off` visits every unmasked tile, so its figure is executed flops / time; "
+                 "note": "`achieved` / `frac` = EXECUTED flops / time: measured with the ALiBi band switched off (`band_off`: every unmasked "
+                         "tile is visited, so dense-counted flops are the executed ones).  `achieved_dense_counted` / `frac_dense_counted` = "
+                         "dense-counted flops / time of the shipped configuration (`with_band`), which credits tiles the band never visits; "
+                         "`frac_executed_only` repeats `frac` under its round-2 name.  "
                          f"{layers} attention layers per step (fwd + bwd launches each)"}
 
     # ---- element-wise tail: HBM-bound kernels, algorithmic bytes (every operand once) / time against 8 TB/s
@@ -256,7 +294,7 @@ def roofline_leg(ops, step, args):
 
     traffic, traffic_note = None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fname in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+    for fname in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
         tpath = os.path.join(here, "profiles", fname)
         if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
             with open(tpath) as fh:
@@ -365,7 +403,7 @@ def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
         model.perf_encoder._z_override, model.perf_encoder.segment_bounds = None, bounds
         model.load_state_dict(sd_now)
         model.train()
-    return {"value": args.cpu_batch * n / dt, "unit": "note-tokens/s", "cores": threads, "kind": "port", "parity": parity,
+    return {"value": args.cpu_batch * n / dt, "unit": "note-tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port", "parity": parity,
             "sample": f"{args.cpu_batch} sequences x {n} notes of the same C3 model, forward+backward (no optimizer), fp32, torch "
                       f"{torch.__version__} CPU with {threads} threads (host has {os.cpu_count()} cores), {dt:.1f} s wall",
             "cpu_loss": float(out["loss"].detach())}

@@ -66,11 +66,13 @@ int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
 long spn_attn_dropbits_elems(int b, int h, int nq, int nk);
 /* ALiBi band skipping: key tiles whose probabilities are provably below 2^-log2_threshold of the row maximum (Cauchy-Schwarz
- * bound on q.k plus the linear distance penalty) are not visited, forward and backward alike.  Default 40; 0 = visit all. */
+ * bound on q.k plus the linear distance penalty) are not visited, forward and backward alike.  Default 30 (the "attn_band" knob of
+ * spn_set_tuning); 0 = visit all.  This is an APPROXIMATION, on by default whenever a band buffer is passed: at 30 every skipped
+ * probability is < 2^-30 of its row's largest one, so the skipped mass of a row of 2048 keys is < 2^-19 of the softmax normaliser --
+ * far below the 2^-9 rounding of the bf16 probabilities that enter P V, but above fp32 resolution (40 puts it below). */
 void spn_attn_set_band(float log2_threshold);
 /* `band` (spn_attn_band_elems floats): caller-owned buffer of the band bounds; spn_attn_fwd fills it and spn_attn_bwd of the same
- * q / k / mask reads it back.  null (or no slopes): every tile is visited -- skipped tiles contribute below fp32 resolution, so the
- * result does not depend on it. */
+ * q / k / mask reads it back.  null (or no slopes, or slopes <= 0, or a row whose own key is masked): every tile is visited. */
 long spn_attn_band_elems(int b, int h, int kvh, int nq);
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
                  void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
@@ -262,7 +264,9 @@ int spn_collate_pad_tokens(const int32_t* flat, const int32_t* off, int b, int K
  *      id128: 128 bytes made by spn_comm_unique_id on one rank and handed to every rank out of band.  spn_comm_init is collective.
  *      spn_comm_allreduce: in-place sum of buf[0 .. count) (dtype 0 fp32, 1 bf16) ordered behind everything enqueued on
  *      producer_stream so far; returns at once.  spn_comm_wait: consumer_stream waits for every all-reduce enqueued so far.
- *      No host synchronisation; streams / events are created in init and released in destroy. */
+ *      No host synchronisation in allreduce / wait; streams / events are created in init (on the device current at that call, which
+ *      every later entry point re-selects for the duration of the call; a buffer on another device is rejected) and released in
+ *      destroy, which -- the one exception in this library -- first waits for the communication stream to drain. */
 int spn_comm_unique_id(void* id128, const char* rccl_path);
 int spn_comm_init(void** comm, int nranks, int rank, const void* id128, const char* rccl_path);
 int spn_comm_allreduce(void* comm, void* buf, size_t count, int dtype, spn_stream_t producer_stream);

@@ -1,11 +1,16 @@
-"""A checkpoint file written by the REFERENCE (run in the authoring container only):
+"""A checkpoint file written by the REFERENCE'S OWN Trainer (run in the authoring container only):
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.refimport.make_golden_checkpoint
 
-Builds the reference's ScorePerformer at a micro size, takes two AdamW steps with the reference's `Optimizer` wrapper's inner
-torch.optim.AdamW on a seeded batch, and saves the dict of `Trainer._save_checkpoint` (trainer.py:296-314) with torch.save to
-tests/golden/micro_checkpoint.pt, plus the loss of a third forward (tests/golden/micro_checkpoint_probe.npz) so a loader can
-prove it restored a working model.  Data only (tensors, config dict, JSON strings).
+Builds the reference's ScorePerformer at a micro size and the reference's real `Trainer` around it (experiments/trainer.py:43-200:
+CPU device, no dashboard logger, a two-item list as the "dataset"), whose `build_optimizer` makes the reference's `Optimizer` wrapper
+(experiments/optimizers.py:123-150: torch.optim.AdamW + ExponentialLR from an `OptimizerConfig`).  Two steps through
+`Optimizer.step(loss)` (optimizers.py:151-169: backward, clip, AdamW, zero_grad), one `anneal_on_epoch_end`, then the reference's
+`Trainer._save_checkpoint(path)` (trainer.py:296-314) itself writes tests/golden/micro_checkpoint.pt: envelope, JSON strings, config
+container, state_dict and optimizer state are all the reference's own.  The loss of a third forward goes to
+tests/golden/micro_checkpoint_probe.npz so that a loader can prove it restored a working model.  Data only (tensors, config dict, JSON
+strings).  Import shims: oracle/refimport/stubs.py plus a placeholder `torch.utils.tensorboard.SummaryWriter` (tensorboard is not
+installed; `dashboard_logger=None` keeps the callback from ever being built).
 """
 import json
 import os
@@ -20,7 +25,16 @@ from oracle.refimport import stubs  # noqa: E402
 
 stubs.install()
 warnings.filterwarnings("ignore")
+import types  # noqa: E402
+
+_tb = types.ModuleType("torch.utils.tensorboard")
+_tb.SummaryWriter = type("SummaryWriter", (), {})            # never instantiated (dashboard_logger=None)
+sys.modules.setdefault("torch.utils.tensorboard", _tb)
 from scoreperformer.models import ScorePerformer  # noqa: E402  (the reference)
+from scoreperformer.experiments.components import ExperimentConfig  # noqa: E402
+from scoreperformer.experiments.optimizers import OptimizerConfig  # noqa: E402
+from scoreperformer.experiments.trainer import Trainer  # noqa: E402
+from scoreperformer.experiments.trainer_config import TrainerConfig  # noqa: E402
 
 from oracle.refimport.make_golden import SMALL_VOCAB, RandnRecorder  # noqa: E402
 from oracle.weights import filled_state_dict  # noqa: E402
@@ -35,24 +49,24 @@ def main():
     model = ScorePerformer.init(model_config(**MICRO))
     model.load_state_dict(filled_state_dict(model, seed=21), strict=True)
     model.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
-    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.99)
     batch = synthetic_batch(2, 24, seed=31, ragged=True, num_tokens=SMALL_VOCAB)
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="spn_ref_trainer_")
+    tcfg = TrainerConfig(output_dir=os.path.join(tmp, "results"), log_dir=os.path.join(tmp, "logs"), device="cpu", dashboard_logger=None,
+                         disable_tqdm=True, num_workers=0, batch_size=2, epochs=1, seed=0,
+                         optimization=OptimizerConfig(lr=1e-3, optimizer="AdamW", optimizer_params={"weight_decay": 1e-2},
+                                                      lr_scheduler="exponential", lr_scheduler_params={"gamma": 0.99}, grad_clip=None))
+    from omegaconf import OmegaConf
+    exp = ExperimentConfig(data=OmegaConf.create({"dataset": "synthetic"}), model=cfg, trainer=tcfg)
+    trainer = Trainer(model, exp, train_dataset=[0, 1], collator=lambda items: batch)     # the reference's Trainer, unmodified
     for _ in range(2):
         torch.manual_seed(7)
-        opt.zero_grad()
-        model(**batch).loss.backward()
-        opt.step()
-    sched.step()
-    plain = json.loads(json.dumps(cfg, default=lambda o: dict(o)))
-    checkpoint = {
-        "experiment": {"config": json.dumps({"model": plain}), "trainer": json.dumps({"output_dir": "results"}),
-                       "state": json.dumps({"epoch": 1, "global_step": 2})},
-        "model": {"config": plain, "state_dict": model.state_dict()},
-        "optimizer": {"optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict()},
-    }
+        trainer.optimizer.step(trainer.model(**batch).loss)                               # optimizers.py:151-169
+        trainer.state.global_step += 1
+    trainer.optimizer.anneal_on_epoch_end()
+    trainer.state.epoch = 1
     path = os.path.join(OUT, "micro_checkpoint.pt")
-    torch.save(checkpoint, path)
+    trainer._save_checkpoint(path)                                                        # trainer.py:296-314
     model.eval()
     with RandnRecorder() as rec, torch.no_grad():
         torch.manual_seed(9)

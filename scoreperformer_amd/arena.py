@@ -46,8 +46,10 @@ class ParamArena:
         self.exp_avg_sq = torch.zeros(total, device=device, dtype=F32)
         self.shadow = torch.zeros(total, device=device, dtype=BF16)
         self._normsq = torch.zeros(1, device=device, dtype=F32)
-        self.step_count = 0
-        self._mask_key, self._slot_mask = None, None   # which parameters the last optimizer step updated, and its device mask
+        # torch.optim.AdamW keeps ONE STEP COUNTER PER PARAMETER (bias corrections 1 - beta^own_step): a parameter that is frozen for a
+        # while, or unused in some batches (an LM-head key without valid labels), falls behind the others
+        self.steps: List[int] = [0] * len(params)
+        self._masks: Dict[tuple, torch.Tensor] = {}    # device slot masks by selection (a handful: they change on freeze / unfreeze)
         with torch.no_grad():
             for p, off in zip(params, offsets):
                 n = p.numel()
@@ -131,41 +133,59 @@ class ParamArena:
             touched = [True] * len(touched)
         return [bool(p.requires_grad and t) for p, t in zip(self.param_list, touched)]
 
+    @property
+    def step_count(self) -> int:
+        """Steps taken by the most-stepped parameter (every parameter's own count: `steps`)."""
+        return max(self.steps) if self.steps else 0
+
+    @property
+    def updated(self) -> List[bool]:
+        return [s > 0 for s in self.steps]
+
     def _mask_for(self, active: List[bool]) -> Optional[torch.Tensor]:
         if all(active):
             return None
         key = tuple(active)
-        if key != self._mask_key:   # rebuilt only when the set changes (freeze / unfreeze), not every step
-            m = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
+        m = self._masks.get(key)
+        if m is None:   # built only when a selection is new (freeze / unfreeze, a key without labels), not every step
+            host = torch.zeros(self.total // ALIGN, dtype=torch.uint8)
             bounds = self.offsets[1:] + [self.total]
             for on, s, e in zip(active, self.offsets, bounds):
                 if on:
-                    m[s // ALIGN:e // ALIGN] = 1
-            self._mask_key, self._slot_mask = key, m.to(self.device)
-        return self._slot_mask
+                    host[s // ALIGN:e // ALIGN] = 1
+            if len(self._masks) >= 16:
+                self._masks.pop(next(iter(self._masks)))
+            m = self._masks[key] = host.to(self.device)
+        return m
 
     def step(self, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
              max_norm: Optional[float] = None, grad_scale: float = 1.0) -> torch.Tensor:
         """clip_grad_norm_(max_norm) + AdamW over the arena; returns the (unclipped) grad norm as a device scalar.
-        Parameters without a gradient this step (see `active_params`) are left untouched, as torch.optim.AdamW leaves them."""
-        self.step_count += 1
+        Parameters without a gradient this step (see `active_params`) are left untouched, as torch.optim.AdamW leaves them, and every
+        parameter is bias-corrected with ITS OWN step count: one launch when all updated parameters share it (always, unless parameters
+        were frozen or unused for some steps), else one launch per distinct count over that count's slots."""
         active = self.active_params()
-        self.updated = [a or u for a, u in zip(active, getattr(self, "updated", [False] * len(active)))]
+        for i, on in enumerate(active):
+            if on:
+                self.steps[i] += 1
         normsq = self.grad_norm_sq()
-        ops.adamw_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, normsq,
-                       max_norm=max_norm or 0.0, grad_scale=grad_scale, lr=lr, betas=betas, eps=eps,
-                       weight_decay=weight_decay, step=self.step_count, slot_mask=self._mask_for(active))
+        for sv in sorted({s for s, on in zip(self.steps, active) if on}):
+            sel = [on and s == sv for s, on in zip(self.steps, active)]
+            ops.adamw_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.shadow, normsq,
+                           max_norm=max_norm or 0.0, grad_scale=grad_scale, lr=lr, betas=betas, eps=eps,
+                           weight_decay=weight_decay, step=sv, slot_mask=self._mask_for(sel))
         for p in self.param_list:
             p._spn_touched = False
         return normsq.sqrt() * grad_scale
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": torch.tensor(self.step_count)}
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": torch.tensor(self.step_count),
+                "steps": torch.tensor(self.steps, dtype=torch.int64)}
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.step_count = int(sd["step"])
+        self.steps = [int(v) for v in sd["steps"]] if "steps" in sd else [int(sd["step"])] * len(self.param_list)
 
 
 class FusedAdamW:
@@ -189,12 +209,11 @@ class FusedAdamW:
         a = self.arena
         state = {}
         if a.step_count > 0:
-            updated = getattr(a, "updated", None)
             for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
-                if updated is not None and not updated[i]:
+                if a.steps[i] == 0:
                     continue   # torch.optim.AdamW holds no state for a parameter it never stepped (frozen / unused)
                 n = p.numel()
-                state[i] = {"step": torch.tensor(float(a.step_count)),
+                state[i] = {"step": torch.tensor(float(a.steps[i])),
                             "exp_avg": a.exp_avg[off:off + n].view(p.shape).clone(),
                             "exp_avg_sq": a.exp_avg_sq[off:off + n].view(p.shape).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
@@ -211,7 +230,7 @@ class FusedAdamW:
         g = groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
         a.exp_avg.zero_(); a.exp_avg_sq.zero_()
-        steps = set()
+        steps = [0] * len(a.param_list)
         for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
             st = sd["state"].get(g["params"][i])
             if st is None:
@@ -221,8 +240,5 @@ class FusedAdamW:
                 raise ValueError(f"optimizer state of parameter {a.names[i]} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
             a.exp_avg[off:off + n].view(p.shape).copy_(st["exp_avg"])
             a.exp_avg_sq[off:off + n].view(p.shape).copy_(st["exp_avg_sq"])
-            steps.add(int(st["step"]))
-        if len(steps) > 1:
-            raise ValueError("per-parameter step counts differ; the fused update keeps one step counter")
-        a.step_count = steps.pop() if steps else 0
-        a.updated = [sd["state"].get(g["params"][i]) is not None for i in range(len(a.param_list))]
+            steps[i] = int(st["step"])   # per parameter, as torch.optim.AdamW keeps them (they differ after a freeze / unfreeze)
+        a.steps = steps

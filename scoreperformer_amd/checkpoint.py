@@ -55,8 +55,10 @@ def _adamw_state_on_host(optimizer):
     if a.step_count > 0:                                                   # two bulk copies instead of 2 per parameter
         m, v = a.exp_avg.cpu(), a.exp_avg_sq.cpu()
         for i, (p, off) in enumerate(zip(a.param_list, a.offsets)):
+            if i not in sd["state"]:
+                continue                                                   # never stepped: torch.optim.AdamW holds no state for it
             n = p.numel()
-            sd["state"][i] = {"step": torch.tensor(float(a.step_count)), "exp_avg": m[off:off + n].view(p.shape).clone(),
+            sd["state"][i] = {"step": torch.tensor(float(a.steps[i])), "exp_avg": m[off:off + n].view(p.shape).clone(),
                               "exp_avg_sq": v[off:off + n].view(p.shape).clone()}
     return sd
 

@@ -60,7 +60,11 @@ class NativeComm:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        # at interpreter exit the library (or ctypes itself) may already be torn down: never raise from here, and skip the call
+        # when the binding is gone rather than jump into an unloaded library
         try:
-            self.close()
-        except Exception:
+            from . import lib as _lib
+            if _lib is not None and getattr(_lib, "_lib", None) is not None and self._h:
+                self.close()
+        except BaseException:   # noqa: BLE001
             pass

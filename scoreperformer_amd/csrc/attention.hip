@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
 
 // fills a.band for this problem.  The band buffer is the CALLER's (spn_attn_band_elems floats): the forward fills it (`reuse` = false),
 // the backward of the same q / k / mask reads it back (`reuse` = true).  Without a buffer (or without ALiBi slopes, or with the knob
-// at 0) every tile is visited -- the skipped tiles contribute below fp32 resolution, so results do not depend on it.  Nothing is
+// at 0) every tile is visited; with it, skipped tiles contribute < 2^-19 of a row's normaliser at the default threshold (include/spn.h).  Nothing is
 // allocated or synchronised here.
 int prepare_band(AttnArgs& a, hipStream_t stream, float* own, bool reuse) {
     const float band_log2 = (float)spn_tune(SPN_TUNE_ATTN_BAND);

@@ -88,6 +88,18 @@ struct SpnComm {
     hipEvent_t produced;   // producer stream -> communication stream
     hipEvent_t reduced;    // communication stream -> consumer stream
     int nranks, rank;
+    int device;            // the device that was current in spn_comm_init: stream, events and the RCCL communicator live on it
+};
+
+// Every entry point runs with the communicator's device current (streams / events of another device are invalid handles): a caller
+// on a different device is switched over for the duration of the call and switched back.
+struct DeviceGuard {
+    int prev = -1; bool switched = false, ok = true;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != want) { ok = hipSetDevice(want) == hipSuccess; switched = ok; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
 }  // namespace
@@ -109,6 +121,7 @@ extern "C" int spn_comm_init(void** comm_out, int nranks, int rank, const void* 
     if (int rc = bind_rccl(rccl_path)) return rc;
     SpnComm* c = new SpnComm();
     c->nranks = nranks; c->rank = rank;
+    if (hipGetDevice(&c->device) != hipSuccess) { delete c; spn_set_error("spn_comm_init: hipGetDevice failed"); return SPN_ERR_HIP; }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     int rc = g_rccl.comm_init_rank(&c->comm, nranks, id, rank);
@@ -129,6 +142,12 @@ extern "C" int spn_comm_init(void** comm_out, int nranks, int rank, const void* 
 extern "C" int spn_comm_allreduce(void* comm, void* buf, size_t count, int dtype, hipStream_t producer_stream) {
     SpnComm* c = (SpnComm*)comm;
     if (!c || !buf || count == 0 || (dtype != 0 && dtype != 1)) { spn_set_error("spn_comm_allreduce: bad arguments"); return SPN_ERR_ARG; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { spn_set_error("spn_comm_allreduce: cannot select the communicator's device"); return SPN_ERR_HIP; }
+    int buf_dev = c->device;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, buf) == hipSuccess) buf_dev = attr.device;
+    if (buf_dev != c->device) { spn_set_error("spn_comm_allreduce: the buffer lives on another device than the communicator"); return SPN_ERR_ARG; }
     if (hipEventRecord(c->produced, producer_stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->produced, 0) != hipSuccess) {
         spn_set_error("spn_comm_allreduce: cannot fence the communication stream behind the producer stream");
         return SPN_ERR_HIP;
@@ -143,6 +162,8 @@ extern "C" int spn_comm_allreduce(void* comm, void* buf, size_t count, int dtype
 extern "C" int spn_comm_wait(void* comm, hipStream_t consumer_stream) {
     SpnComm* c = (SpnComm*)comm;
     if (!c) { spn_set_error("spn_comm_wait: null communicator"); return SPN_ERR_ARG; }
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { spn_set_error("spn_comm_wait: cannot select the communicator's device"); return SPN_ERR_HIP; }
     if (hipStreamWaitEvent(consumer_stream, c->reduced, 0) != hipSuccess) { spn_set_error("spn_comm_wait: hipStreamWaitEvent failed"); return SPN_ERR_HIP; }
     return SPN_OK;
 }
@@ -150,7 +171,9 @@ extern "C" int spn_comm_wait(void* comm, hipStream_t consumer_stream) {
 extern "C" int spn_comm_destroy(void* comm) {
     SpnComm* c = (SpnComm*)comm;
     if (!c) return SPN_OK;
-    const int rc = g_rccl.comm_destroy ? g_rccl.comm_destroy(c->comm) : kNcclSuccess;   // RCCL drains its own stream use
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);   // teardown only: nothing of ours is left in flight when stream and events go, whatever RCCL returns
+    const int rc = g_rccl.comm_destroy ? g_rccl.comm_destroy(c->comm) : kNcclSuccess;
     (void)hipEventDestroy(c->produced);
     (void)hipEventDestroy(c->reduced);
     (void)hipStreamDestroy(c->stream);

@@ -578,7 +578,8 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                 }
             }
         }
-        if (g.ws) {
+        // the partial buffer has ceil(M / 128) rows: a wave slab that starts at or beyond M (last row tile, 0 < M % 256 <= 128) owns none
+        if (g.ws && cm0 + wr * 128 < g.M) {
             float* P = reinterpret_cast<float*>(g.ws) + (long)(cm0 / 128 + wr) * (2 * I);
 #pragma unroll
             for (int part = 0; part < 2; ++part) {

@@ -7,7 +7,6 @@ backward pass, i.e. while the rest of backward is still running; the 1/world fac
 """
 from __future__ import annotations
 
-import os
 from typing import List, Optional
 
 import torch
@@ -16,30 +15,39 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, arena, group=None, bucket_mb: float = 32.0, force: bool = False, grad_dtype: torch.dtype = torch.float32,
-                 dry_run: bool = False, transport: str = "torch"):
+                 dry_run: bool = False, transport: str = "torch", persistent_backward: Optional[bool] = None):
         """`force=True` keeps the bucketed all-reduce path active on a one-rank group (single-GPU tests of the RCCL path).
         `grad_dtype=torch.bfloat16` sends every bucket as bf16 (half the bytes over xGMI: 144 MB instead of 288 MB per step at C3;
         the sum over ranks is then formed in bf16 -- about 3 significant digits per element -- so fp32 stays the default).
         `dry_run=True` runs the whole readiness protocol without a process group: buckets are "launched" into `self.events`
         (tools/record_grad_events.py records the real model's pending / ready order that way).
         `transport="spn"`: buckets go through libspn.so's own RCCL wrapper (`spn_comm_allreduce`: ncclAllReduce on a dedicated
-        communication stream, event-fenced; comm.NativeComm, created collectively over `group`) instead of `dist.all_reduce`."""
+        communication stream, event-fenced; comm.NativeComm, created collectively over `group`) instead of `dist.all_reduce`;
+        it needs a process group and raises without one (no silent fall-back to the torch path).
+        `persistent_backward`: the process-wide `gemm_persist_bwd` knob (csrc/tuning.h) -- input-gradient GEMMs walk their tiles with
+        one persistent block per CU, which is only safe when NO other kernel holds CUs during the backward (a concurrent all-reduce
+        starves the blocks that land on its CUs).  None (default) leaves the knob alone; True asks for the walk and is honoured only
+        when this object reduces nothing itself (`active` is False) -- the caller vouches that nobody else reduces during backward
+        either; False switches it off.  `close()` restores the value found at construction."""
+        if transport not in ("torch", "spn"):
+            raise ValueError(f"unknown transport {transport!r}")
         self.arena, self.group = arena, group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.dry_run = dry_run
         self.active = dry_run or self.world > 1 or (force and group is not None)
         self.grad_dtype = grad_dtype
         self.native = None
-        if transport == "spn" and not dry_run and group is not None and (self.world > 1 or force):
-            from .comm import NativeComm
-            self.native = NativeComm.from_group(group)
-        elif transport not in ("torch", "spn"):
-            raise ValueError(f"unknown transport {transport!r}")
-        # Input-gradient GEMMs may walk their tiles with one persistent block per CU only when no all-reduce kernel holds CUs during
-        # the backward (csrc/gemm.hip, launch_pp): this object is the one place that knows.  SPN_GEMM_PERSIST_BWD in the environment wins.
-        if torch.cuda.is_available() and not dry_run and "SPN_GEMM_PERSIST_BWD" not in os.environ:
+        if transport == "spn" and not dry_run:
+            if group is None:
+                raise ValueError("GradSync(transport='spn') needs a process group (the RCCL id travels over it)")
+            if self.world > 1 or force:
+                from .comm import NativeComm
+                self.native = NativeComm.from_group(group)
+        self._knob_before = None
+        if persistent_backward is not None and not dry_run:
             from . import lib
-            lib.set_tuning("gemm_persist_bwd", 0.0 if self.active else 1.0)
+            self._knob_before = lib.get_tuning("gemm_persist_bwd")
+            lib.set_tuning("gemm_persist_bwd", 1.0 if (persistent_backward and not self.active) else 0.0)
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
@@ -149,6 +157,16 @@ class GradSync:
         if b not in bufs:
             bufs[b] = torch.empty(n, dtype=self.grad_dtype, device=device)
         return bufs[b]
+
+    def close(self):
+        """Restore the `gemm_persist_bwd` knob this object changed (if it did) and drop the native communicator."""
+        if self._knob_before is not None:
+            from . import lib
+            lib.set_tuning("gemm_persist_bwd", self._knob_before)
+            self._knob_before = None
+        if self.native is not None:
+            self.native.close()
+            self.native = None
 
     def begin_step(self):
         if not self.active:

@@ -53,6 +53,10 @@ def test_library_owns_no_memory_and_reads_no_environment():
     for f in sorted(os.listdir(csrc)):
         if f.endswith((".hip", ".cpp", ".h")):
             text = open(os.path.join(csrc, f)).read()
+            if f == "comm.cpp":   # the one sanctioned wait: spn_comm_destroy drains ITS OWN communication stream before teardown
+                head, sep, tail = text.partition('extern "C" int spn_comm_destroy')
+                assert sep and tail.count("hipStreamSynchronize") == 1 and "hipStreamSynchronize" not in head
+                text = head + tail.replace("hipStreamSynchronize", "", 1)
             for word in banned:
                 assert word not in text, f"{f} uses {word}"
 

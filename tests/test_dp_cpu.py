@@ -153,3 +153,78 @@ def test_gradsync_replays_the_real_models_event_order(variant, grad_dtype):
         p.join(180)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+# ---- C4: the hierarchical MMD-VAE path under data parallelism -----------------------------------------------------------------------
+# BASELINE config 4 (style-encoder VAE with the MMD loss, DP).  The MMD term is a kernel mean over the rank's own latents and its own
+# N(0, I) samples (mmd_transformer.py:505-534): it is NOT additive over a batch split, so the data-parallel step is DEFINED as every rank's
+# own loss (token losses + its per-rank MMD estimates) on its half, gradients summed by the all-reduce, 1/world in the optimizer
+# (SURVEY.md §8(e)).  Two gloo ranks run the fp32 CPU oracle of the tiny model on their halves with the MMD weight ON, send the
+# gradients through GradSync's buckets, and rank 0 checks the reduced arena against the two-half computation done in one process.
+
+def _oracle_half(rank, world):
+    from oracle import ref_cpu
+    from oracle.weights import canonical, filled_state_dict
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    torch.set_num_threads(1)
+    cfg = model_config("tiny", dropout=0.0)
+    assert float(cfg["perf_encoder"]["loss_weight"]) == 1.0          # the MMD path is on
+    sd = filled_state_dict(ScorePerformer.init(model_config("tiny", dropout=0.0)), seed=5)
+    batch = synthetic_batch(2 * world, 64, seed=17)
+    half = {k: v[rank * 2:(rank + 1) * 2] for k, v in batch.items()}
+    z = [torch.randn(256, d, generator=torch.Generator().manual_seed(1000 * rank + i)) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
+    leaves, sdg = {}, {}
+    for k, v in sd.items():
+        leaf = v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v
+        sdg[k] = leaves.setdefault(canonical(k), leaf)
+    out = ref_cpu.score_performer_forward(sdg, cfg, half, z, training=True)
+    out["loss"].backward()
+    names = sorted(k for k, v in leaves.items() if v.requires_grad and v.grad is not None)
+    return names, [leaves[k].grad.detach().clone() for k in names], {k: float(v.detach()) for k, v in out["losses"].items()}
+
+
+def _c4_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scoreperformer_amd.parallel import GradSync
+    names, grads, losses = _oracle_half(rank, world)
+    mmd = {k: v for k, v in losses.items() if k.startswith("MMD/")}
+    assert len(mmd) == 4 and all(v > 0 for v in mmd.values()), losses
+    arena = FakeArena([g.numel() for g in grads])
+    sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05)
+    assert len(sync.buckets) >= 4
+    sync.begin_step()
+    for p in arena.param_list:
+        p._spn_grad_pending()
+    for p, g in reversed(list(zip(arena.param_list, grads))):
+        p.grad += g.view(p.shape)
+        p._spn_grad_ready()
+    sync.finish()
+    # every rank's MMD estimate is its own: gather them and make sure they differ (different halves, different samples)
+    box = [None] * world
+    dist.all_gather_object(box, mmd)
+    assert box[0] != box[1]
+    if rank == 0:
+        other_names, other, other_losses = _oracle_half(1, world)
+        assert other_names == names and {k: v for k, v in other_losses.items() if k.startswith("MMD/")} == box[1]
+        for p, g0, g1, k in zip(arena.param_list, grads, other, names):
+            want = (g0 + g1).view(p.shape)
+            assert torch.equal(p.grad, want), (k, float((p.grad - want).abs().max()))
+        # the MMD gradient is really in there: the latent heads get gradient from nothing else but MMD + the decoder's style path
+        assert any("vae_head" in k or "latent" in k for k in names)
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_c4_mmd_path_under_two_rank_data_parallelism():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c4_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]

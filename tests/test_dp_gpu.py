@@ -110,6 +110,65 @@ def test_two_rank_data_parallel_step_equals_the_global_batch_step(dev):
     assert float(dp.max()) <= 2.5e-3 and float((dp > 2e-4).float().mean()) < 0.05, (float(dp.max()), float((dp > 2e-4).float().mean()))
 
 
+def test_two_rank_step_with_the_mmd_path_on_matches_the_two_half_oracle(dev):
+    """C4 (hierarchical MMD-VAE path + data parallelism) as a combination: with the MMD weight ON every rank's loss contains ITS OWN
+    kernel-mean estimates (its half of the batch against its own N(0, I) samples; mmd_transformer.py:505-534), and the data-parallel
+    gradient is the SUM of the ranks' gradients.  The HIP path runs the two halves (one after the other on this GPU, arenas summed as the
+    all-reduce sums them); the fp32 CPU oracle runs the same two halves with the same samples: per-rank MMD entries within 1e-3, per-rank
+    losses within 1e-3, the summed gradient within 5 % relative L2 as one vector (bf16 GEMM operands)."""
+    from oracle import ref_cpu
+    from oracle.weights import canonical, filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    world = 2
+    cfg = model_config("tiny", dropout=0.0)
+    assert float(cfg["perf_encoder"]["loss_weight"]) == 1.0
+    model = ScorePerformer.init(model_config("tiny", dropout=0.0))
+    model.load_state_dict(filled_state_dict(model, seed=5))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    arena = ParamArena(model, dev)
+    model.train()
+    batch = synthetic_batch(2 * world, 64, seed=17, ragged=True)
+    zs = [[torch.randn(256, d, generator=torch.Generator().manual_seed(1000 * r + i)) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
+          for r in range(world)]
+    total = torch.zeros_like(arena.grads)
+    got = []
+    for r in range(world):
+        half = {k: v[r * 2:(r + 1) * 2].to(dev) for k, v in batch.items()}
+        model.perf_encoder._z_override = [t.to(dev) for t in zs[r]]
+        arena.zero_grad()
+        out = model(**half)
+        out.loss.backward()
+        total += arena.grads
+        got.append({k: float(v) for k, v in out.losses.items()} | {"loss": float(out.loss)})
+    torch.cuda.synchronize()
+    leaves, sdg = {}, {}
+    for k, v in sd.items():
+        leaf = v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v
+        sdg[k] = leaves.setdefault(canonical(k), leaf)
+    for r in range(world):
+        half = {k: v[r * 2:(r + 1) * 2] for k, v in batch.items()}
+        ref = ref_cpu.score_performer_forward(sdg, cfg, half, zs[r], training=True)
+        ref["loss"].backward()                      # accumulates over the two halves: the all-reduce's sum
+        assert abs(got[r]["loss"] - float(ref["loss"].detach())) <= 1e-3
+        mmd_keys = [k for k in ref["losses"] if k.startswith("MMD/")]
+        assert len(mmd_keys) == 4
+        for k in mmd_keys:
+            assert abs(got[r][k] - float(ref["losses"][k].detach())) <= 1e-3, (r, k)
+    assert any(abs(got[0][k] - got[1][k]) > 1e-6 for k in got[0] if k.startswith("MMD/"))   # per-rank estimates, not one shared value
+    err2 = ref2 = 0.0
+    seen = set()
+    for (k, p), off in zip(zip(arena.names, arena.param_list), arena.offsets):
+        g_ref = sdg[k].grad
+        if g_ref is None or id(p) in seen:
+            continue
+        seen.add(id(p))
+        g = total[off:off + p.numel()].view(p.shape).float().cpu()
+        err2 += float((g - g_ref).double().pow(2).sum()); ref2 += float(g_ref.double().pow(2).sum())
+    assert len(seen) > 100 and err2 ** 0.5 <= 0.05 * ref2 ** 0.5, (err2 ** 0.5, ref2 ** 0.5)
+
+
 def test_native_comm_allreduce_is_stream_ordered(dev):
     """spn_comm_*: one-rank communicator bound to the RCCL copy PyTorch loaded; the all-reduce (identity on one rank, fp32 and bf16)
     runs on the library's own stream, ordered behind the producer kernel and ahead of the consumer through events only."""

@@ -192,6 +192,37 @@ def test_gemm_glu_bwd_equals_gemm_then_activation_backward(M, I, K, act, p):
     assert torch.equal(du2.view(torch.int16), du.view(torch.int16))
 
 
+@pytest.mark.parametrize("duo", [0, 1])
+@pytest.mark.parametrize("M", [8200, 9000, 256 + 128, 256 + 8, 512 - 8])
+def test_gemm_glu_bwd_partial_rows_stay_inside_the_buffer(M, duo):
+    """The column-sum partial buffer is [ceil(M / 128), 2I] (include/spn.h).  With 0 < M % 256 <= 128 the last 256-row tile's second
+    128-row wave slab starts at or beyond M and owns no partial row: a canary row behind the buffer must survive (both tile kernels)."""
+    import ctypes
+    from ctypes import c_float, c_int
+    from scoreperformer_amd import lib, ops
+    I, K = 256, 256
+    gen = torch.Generator(device="cuda").manual_seed(M)
+    dy = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).bfloat16()
+    w2 = (torch.randn(K, I, device="cuda", generator=gen) * K ** -0.5).bfloat16()
+    u = torch.randn(M, 2 * I, device="cuda", generator=gen).bfloat16()
+    rows = (M + 127) // 128
+    part = torch.full((rows + 1, 2 * I), 12345.0, device="cuda")
+    du = torch.empty(M, 2 * I, device="cuda", dtype=torch.bfloat16)
+    old = lib.get_tuning("glu_bwd_duo")
+    lib.set_tuning("glu_bwd_duo", duo)
+    try:
+        ops.call("spn_gemm_glu_bwd", ops.ptr(dy), ops.ptr(w2), ops.ptr(u), ops.ptr(du), ops.ptr(part), c_int(M), c_int(I), c_int(K),
+                 c_int(K), c_int(I), c_int(2 * I), c_int(2 * I), c_int(0), c_float(0.0), ctypes.c_uint(0), ops.stream_ptr())
+    finally:
+        lib.set_tuning("glu_bwd_duo", old)
+    torch.cuda.synchronize()
+    assert bool((part[rows] == 12345.0).all()), "partial row past ceil(M / 128) was written"
+    ref = ops.act_bwd(u, ops.gemm(dy, w2, tb=True, out_dtype=torch.bfloat16), act=0, glu=True)
+    assert torch.equal(du.view(torch.int16), ref.view(torch.int16))
+    exact = ref.float().sum(0)
+    assert float((part[:rows].sum(0) - exact).abs().max()) < 1e-3 * float(ref.float().abs().sum(0).max()) + 1e-3
+
+
 def test_gemm_glu_rejects_unsupported_shapes():
     from scoreperformer_amd import ops
     assert not ops.gemm_glu_ok(64, 128, 256) and not ops.gemm_glu_ok(256, 192, 256) and not ops.gemm_glu_ok(256, 128, 200)

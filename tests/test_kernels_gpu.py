@@ -281,6 +281,56 @@ def test_attention_alibi_band_skipping_is_invisible(dev, causal, masked):
     assert (d0 - d2).abs().max() <= 1e-5 * d0.abs().max() and (s0 - s2).abs().max() <= 1e-4 * s0.abs().max()
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_alibi_band_is_safe_on_trained_like_inputs(dev, causal):
+    """The band is an approximation that ships switched on (threshold 2^-30, csrc/tuning.h): it must stay invisible on inputs unlike the
+    random-normal ones above -- queries and keys that share a strong common direction (scores q.k * scale of 40 and more, the regime of a
+    trained model's sharp heads), learned slopes from 0.5 down to 2^-10, one head with slope 0 and one with a NEGATIVE slope (both must
+    disable skipping for that head), ragged key masks (rows whose own key is masked have no lower bound on their maximum and are never
+    skipped).  Same bounds as test_attention_alibi_band_skipping_is_invisible."""
+    from scoreperformer_amd import ops
+    b, n, h = 2, 1024, 8
+    g = torch.Generator().manual_seed(23)
+    common = torch.randn(1, 1, 64, generator=g) * 2.0
+    qh = torch.randn(b, n, h, 64, generator=g) * 2.5 + common[:, :, None, :]
+    kh = torch.randn(b, n, 1, 64, generator=g) * 2.5 + common[:, :, None, :]
+    # a few outlier keys / queries with 3x the norm, as attention sinks have
+    kh[:, ::97] *= 3.0
+    qh[:, ::131] *= 3.0
+    vh = torch.randn(b, n, 1, 64, generator=g)
+    qkv = torch.cat([qh.flatten(2), kh.flatten(2), vh.flatten(2)], -1).to(dev).bfloat16()
+    q, k, v = (qkv[..., :h * 64].unflatten(-1, (h, 64)), qkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)),
+               qkv[..., (h + 1) * 64:].unflatten(-1, (1, 64)))
+    scale = 64 ** -0.5
+    smax = float((torch.einsum("bihd,bjd->bhij", q.float()[:1, :256], k.float()[:1, :, 0]) * scale).abs().max())
+    assert smax >= 40.0, smax
+    slopes = torch.tensor([0.5, 0.25, 2.0 ** -4, 2.0 ** -6, 2.0 ** -8, 2.0 ** -10, 0.0, -0.01], device=dev)
+    kmask = torch.ones(b, n, dtype=torch.bool, device=dev)
+    kmask[0, 900:] = False
+    kmask[1, 417:] = False
+    kmask[1, 100:130] = False   # a hole: rows 100..129 have their own key masked
+    d_o = torch.randn(b, n, h, 64, generator=g).to(dev).bfloat16()
+    res = []
+    try:
+        for thr in (0.0, 30.0):
+            ops.attn_set_band(thr)
+            o, lse = ops.attn_fwd(q, k, v, kmask=kmask, slopes=slopes, causal=causal, scale=scale)
+            dqkv = torch.zeros_like(qkv)
+            dq, dk, dv = (dqkv[..., :h * 64].unflatten(-1, (h, 64)), dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)),
+                          dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64)))
+            dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=slopes, causal=causal, scale=scale,
+                               want_dslope=True)
+            res.append((o.float(), lse, dqkv.float(), dsl))
+    finally:
+        ops.attn_set_band(30.0)
+    (o0, l0, d0, s0), (o2, l2, d2, s2) = res
+    assert torch.isfinite(o0).all() and torch.isfinite(d0).all() and torch.isfinite(s0).all()
+    assert (o0 - o2).abs().max() <= 1e-5 * o0.abs().max() and (l0 - l2).abs().max() <= 1e-4
+    assert (d0 - d2).abs().max() <= 1e-5 * d0.abs().max() and (s0 - s2).abs().max() <= 1e-4 * s0.abs().max()
+    # heads with slope <= 0 are never skipped: bit-identical with the band on
+    assert torch.equal(o0[:, :, 6:], o2[:, :, 6:])
+
+
 def test_ffn_dropout_mask_is_consistent_and_unbiased(dev):
     from scoreperformer_amd import ops
     g = torch.Generator().manual_seed(5)

@@ -102,6 +102,46 @@ def test_optimizer_step_matches_torch_adamw(dev):
     assert (p0._spn_shadow.float() - p0.detach()).abs().max().item() <= 2 ** -8 * p0.abs().max().item()
 
 
+def test_optimizer_keeps_a_step_count_per_parameter_like_torch_adamw(dev):
+    """A parameter that is frozen for some steps (Model.freeze, models/base.py:95-102) or simply gets no gradient falls behind: torch.optim.AdamW
+    bias-corrects it with ITS OWN step count and stores that count per parameter.  Five steps with a changing set of gradient-less
+    parameters follow torch's trajectory, the state dict carries torch's per-parameter steps, and a torch optimizer state with differing
+    steps loads back."""
+    from scoreperformer_amd.arena import FusedAdamW, ParamArena
+    model, arena, sd = build("tiny_mixlm", dev)
+    g = torch.Generator().manual_seed(1)
+    ref_params = [p.detach().cpu().clone().requires_grad_(True) for p in arena.param_list]
+    opt_ref = torch.optim.AdamW(ref_params, lr=1e-2, weight_decay=1e-2)
+    opt = FusedAdamW(arena, lr=1e-2, weight_decay=1e-2, grad_clip=None)
+    n = len(ref_params)
+    for step in range(5):
+        off = {i for i in range(n) if (i + step) % 3 == 0 and step in (1, 2, 4)} | ({0, 1, 2} if step < 3 else set())
+        for i, (p, rp) in enumerate(zip(arena.param_list, ref_params)):
+            if i in off:
+                rp.grad = None
+                p._spn_touched = False
+                continue
+            gr = torch.randn(p.shape, generator=g) * 0.3
+            p.grad.copy_(gr.to(dev))
+            p._spn_touched = True
+            rp.grad = gr.clone()
+        opt_ref.step()
+        opt.step()
+    assert len(set(arena.steps)) > 2 and arena.steps[0] == 2
+    for i, (p, rp) in enumerate(zip(arena.param_list, ref_params)):
+        assert (p.detach().cpu() - rp.detach()).abs().max().item() <= 1e-6 + 2e-5 * rp.abs().max().item(), (i, arena.steps[i])
+    ours, theirs = opt.state_dict(), opt_ref.state_dict()
+    assert sorted(ours["state"]) == sorted(theirs["state"])
+    for i, st in theirs["state"].items():
+        assert int(ours["state"][i]["step"]) == int(st["step"]) == arena.steps[i]
+        assert (ours["state"][i]["exp_avg"].cpu() - st["exp_avg"]).abs().max().item() <= 1e-6
+    # a torch state with differing steps loads (a reference optimizer checkpoint taken after a freeze / unfreeze)
+    model2, arena2, _ = build("tiny_mixlm", dev)
+    opt2 = FusedAdamW(arena2, lr=1.0)
+    opt2.load_state_dict(theirs)
+    assert arena2.steps == arena.steps and opt2.lr == 1e-2
+
+
 def test_greedy_render_matches_reference_tokens(dev):
     """Cached greedy `unmask_tokens` on the GPU reproduces the reference's tokens bit-exactly (north_star: bit-exact token
     argmax at greedy decode); fixture: 39 notes x 4 predicted dims from the reference's own cached decode."""

@@ -42,19 +42,19 @@ NAMED = [
 GRAD_BOUNDS = {k: REL for k in NAMED}
 
 
-def run_c2(dev, threads=32):
+def run_c2(dev, threads=32, preset="c2", seq=1024, seed=21):
     from oracle import ref_cpu
     from oracle.weights import canonical
     from scoreperformer_amd.arena import ParamArena
     from scoreperformer_amd.models import ScorePerformer
     from scoreperformer_amd.synthetic import model_config, synthetic_batch
-    cfg = model_config("c2")
+    cfg = model_config(preset)
     torch.manual_seed(1234)
-    model = ScorePerformer.init(model_config("c2"))      # the model's own initialisation (what a training run starts from)
+    model = ScorePerformer.init(model_config(preset))    # the model's own initialisation (what a training run starts from)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     arena = ParamArena(model, dev)
     model.train()
-    batch = synthetic_batch(2, 1024, seed=21, ragged=True, deadpan_p=0.25)
+    batch = synthetic_batch(2, seq, seed=seed, ragged=True, deadpan_p=0.25)
     z = [torch.randn(256, d, generator=torch.Generator().manual_seed(100 + i)) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
     model.perf_encoder._z_override = [t.to(dev) for t in z]
     out = model(**{k: v.to(dev) for k, v in batch.items()})
@@ -101,6 +101,27 @@ def test_c2_loss_and_gradients_match_the_cpu_oracle(dev):
     bad = [(k, e * n, n) for k, e, n in rows if not e * n <= REL * n + FLOOR]   # (tensor, absolute L2 error, reference norm)
     assert not bad, ([b for b in bad if b[0] in NAMED], bad[:10])
     # and the gradient as one vector: relative L2 error <= 5 %, norm within 1 %
+    err2 = sum((e * n) ** 2 for _, e, n in rows) ** 0.5
+    ref2 = sum(n ** 2 for _, _, n in rows) ** 0.5
+    assert err2 <= 0.05 * ref2, (err2, ref2)
+    named = dict(model.named_parameters())
+    got2 = sum(float(named[k].grad.double().pow(2).sum()) for k in names) ** 0.5
+    assert abs(got2 - ref2) <= 1e-2 * ref2, (got2, ref2)
+
+
+def test_c3_step_matches_oracle(dev):
+    """BASELINE config 3's workload as a test (the bench line's parity leg, moved into pytest): the C3 model (max_seq_len 2048),
+    2 sequences x 2048 notes, one ragged, training mode, dropout 0, forward + backward through the HIP path against the fp32 CPU oracle
+    on identical inputs, weights and N(0, I) samples.  |loss_HIP - loss_CPU| <= 1e-3 (north_star), every loss-dict entry within 1e-3,
+    the whole gradient as one vector within 5 % relative L2 and 1 % in norm (per-tensor bounds: the C2 test above)."""
+    model, out, ref, sdg = run_c2(dev, preset="c3", seq=2048, seed=33)
+    got, want = float(out.loss.detach()), float(ref["loss"].detach())
+    assert abs(got - want) <= 1e-3, (got, want)
+    for k, v in ref["losses"].items():
+        assert abs(float(out.losses[k]) - float(v.detach())) <= 1e-3, (k, float(out.losses[k]), float(v.detach()))
+    names = all_grad_names(model, sdg)
+    assert len(names) >= 300
+    rows = grad_errors(model, sdg, names)
     err2 = sum((e * n) ** 2 for _, e, n in rows) ** 0.5
     ref2 = sum(n ** 2 for _, _, n in rows) ** 0.5
     assert err2 <= 0.05 * ref2, (err2, ref2)

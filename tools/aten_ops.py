@@ -33,7 +33,7 @@ def main():
     model.train()
     model.sync_free = True
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
-    sync = GradSync(arena, None)
+    sync = GradSync(arena, None, persistent_backward=True)
     batch = synthetic_batch(args.batch, args.seq, seed=1234, device=dev)
     model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in
                                          (("bar_mean", "bars"), ("beat_mean", "beats"), ("onset_mean", "onsets"))}
