@@ -17,6 +17,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libspn.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# per-source additions.  attention*: no SLP vectorisation -- it packs neighbouring fp32 multiplies / adds into v_pk_*_f32, which cost
+# ~1.9 VALU issue slots for two results (tools/issue_probe.hip) and surround them with v_mov shuffles, in kernels bound by VALU issue
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"], "attention_dkv.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -26,7 +29,7 @@ def _sources():
 def _digest(src):
     """Content hash of everything an object depends on: compiler flags, the source and every header of csrc/ (a stale object --
     older flags, a reverted header with an older mtime -- is rebuilt, not reused)."""
-    h = hashlib.sha256(" ".join([HIPCC] + FLAGS).encode())
+    h = hashlib.sha256(" ".join([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])).encode())
     for path in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")):
         with open(path, "rb") as fh:
             h.update(path.encode() + b"\0" + fh.read())
@@ -45,7 +48,7 @@ def _compile(name):
     src = os.path.join(CSRC, name)
     obj = os.path.join(OBJ, name.rsplit(".", 1)[0] + ".o")
     if _stale(src, obj):
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if name.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(name, []) + (["-x", "hip"] if name.endswith(".cpp") else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {name}:\n{r.stderr[-4000:]}")

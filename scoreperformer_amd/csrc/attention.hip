@@ -297,33 +297,52 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 // ==========================================================================================================
 // dQ (+ d slope): same decomposition as the forward
 // ==========================================================================================================
+// The kernel is bound by VALU ISSUE, not by the matrix pipe (tools/issue_probe.hip: a SIMD issues one VALU instruction per ~3.5
+// cycles at two waves, v_exp_f32 costs two such slots, and the MFMAs of a key tile hide completely under ~450 VALU instructions).
+// So everything that can ride on an MFMA does:
+//   * linear tiles (all keys on one side of the wave's 32 rows: |d| = sigma (i - j), sigma = +-1): the key part of the ALiBi term,
+//     sigma slope2 (4g + r) / c1, is the C INPUT of the score MFMA (a loop-invariant register quad, re-signed when the walk crosses
+//     the diagonal), the row part sigma slope2 (j0 + 16 kb - i) - lse_i one scalar per (row block, key block) and tile: a score costs
+//     ONE fma before its exp (was: add + fma + sub);
+//   * -delta_i (times the keep probability under dropout) is the C input of the dP MFMA, so dS = P' * select(keep, dP - delta', -delta')
+//     is one v_bfi_b32 + one multiply (was: and + fma + multiply); 1 / keep_prob rides on the row term of the exponent;
+//   * d slope_h = sum_ij dS_ij (-|d_ij|) needs the row sums sum_j dS_ij, sum_j dS_ij |d_ij| and sum_j P_ij |d_ij|: with |d| linear in
+//     the key index they are three more ROWS of the dQ^T = K^T dS^T product -- an A fragment holding (sigma, sigma * jrel, 1) against the
+//     bf16 dS^T (and P^T) B fragments that exist anyway: two MFMAs per 512 scores instead of three accumulations per score; the
+//     per-tile results are folded into per-row accumulators with the tile's distance (i - j0) once per tile.
+// Tiles with a masked key, the causal diagonal or the sequence end take the general per-score path (T_GEN) as before.
+//
 // d slope_h = sum_ij dS_ij * (-|j - i - off|).  delta is computed from the bf16-rounded O, so each row's dS carries a
 // common error -P_ij * eps_i; since sum_j dS_ij must be 0, the measured row sum r_i = -eps_i gives the exact
 // correction  + r_i * sum_j P_ij |d_ij|  (otherwise the error is amplified by the mean attended distance).
-template <int MODE, bool SLOPE_GRAD, bool DROP>
-__device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (&dp)[2][2], const float (&l2)[2], const float (&dl)[2],
-                                          const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
-                                          bool causal, float (&acc_d)[2], float (&acc_r)[2], float (&acc_p)[2],
-                                          const uint32_t (&kw)[2], float inv_keep) {
-    uint32_t mbits[2] = {0, 0};
-    if (MODE == T_GEN) {
+__device__ __forceinline__ float sel_bits(int m, float a, float b) {   // m all-ones: a, m zero: b  -> one v_bfi_b32
+    // The mask is laundered through an EMPTY asm statement: knowing that it is a sign-extended bit, hipcc rewrites (b & ~m) as shift +
+    // compare + cndmask and the whole select as four VALU instructions.  (The instruction itself must NOT be written as asm: `a` comes
+    // straight out of an MFMA, and hipcc inserts the MFMA-write -> VALU-read wait states only for instructions it schedules itself.)
+    asm("" : "+v"(m));
+    return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m));
+}
+
+// general tile: per-score masks and |d| (diagonal / masked / ragged tiles)
+template <bool SLOPE_GRAD, bool DROP>
+__device__ __forceinline__ void dq_scores_gen(int u, f32x4 (&s)[2][2], const f32x4 (&dp)[2][2], const float (&l2)[2], const float (&dl)[2],
+                                              const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
+                                              bool causal, float (&acc_d)[2], float (&acc_r)[2], float (&acc_p)[2],
+                                              const uint32_t (&kw)[2], float inv_keep) {
+    uint32_t mbits[2];
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) mbits[k2] = *reinterpret_cast<const uint32_t*>(m_tile + 16 * (2 * u + k2) + 4 * g);
-    }
-    const float sj0 = slope2 * (j0f + (float)(4 * g));
+    for (int k2 = 0; k2 < 2; ++k2) mbits[k2] = *reinterpret_cast<const uint32_t*>(m_tile + 16 * (2 * u + k2) + 4 * g);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-        const float uo = MODE == T_LEFT ? -slope2 * i_f[qb] : (MODE == T_RIGHT ? slope2 * i_f[qb] : 0.f);
-        const float mm = l2[qb] - uo;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float jc = (float)(16 * (2 * u + k2) + r);
-                const float jf = j0f + (float)(4 * g) + jc;
-                const bool ok = MODE != T_GEN || ((((mbits[k2] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
-                const float t = score<MODE>(s[k2][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
-                const float p = fast_exp2(t - mm);
+                const float jf = j0f + (float)(4 * g) + (float)(16 * (2 * u + k2) + r);
+                const bool ok = (((mbits[k2] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]);
+                const float ad = fabsf(jf - i_f[qb]);
+                const float t = ok ? fmaf(-slope2, ad, s[k2][qb][r] * c1) : NEG_FILL;
+                const float p = fast_exp2(t - l2[qb]);
                 float ds;
                 if (DROP) {   // keep bit 4*kb + r of the forward's word -> all-ones / zero mask
                     const int keepm = __builtin_amdgcn_sbfe((int)kw[qb], 4 * (2 * u + k2) + r, 1);
@@ -332,17 +351,14 @@ __device__ __forceinline__ void dq_scores(int u, f32x4 (&s)[2][2], const f32x4 (
                 } else {
                     ds = p * (dp[k2][qb][r] - dl[qb]);
                 }
-                if (SLOPE_GRAD) {
-                    const float ad = fabsf(jf - i_f[qb]);
-                    acc_d[qb] = fmaf(ds, ad, acc_d[qb]); acc_r[qb] += ds; acc_p[qb] = fmaf(p, ad, acc_p[qb]);
-                }
+                if (SLOPE_GRAD) { acc_d[qb] = fmaf(ds, ad, acc_d[qb]); acc_r[qb] += ds; acc_p[qb] = fmaf(p, ad, acc_p[qb]); }
                 s[k2][qb][r] = ds;
             }
         }
     }
 }
 
-template <bool DROP>
+template <bool DROP, bool SLOPE_GRAD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     // three images per key tile -- K "a" (A operand of S^T), K "t" (K^T, A operand of dQ^T), V "a" (A operand of dP^T = V dO^T) -- by LDS
     // DMA into two alternating stages, one barrier per tile (see attn_fwd_kernel); K is fetched twice (it comes from the L2)
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const uint8_t* mp = a.kmask ? a.kmask + (long)bi * a.nk : nullptr;
     const float slope2 = a.slopes ? a.slopes[hi] * LOG2E : 0.f;
     const float c1 = a.scale * LOG2E;
-    const bool slope_grad = a.dslope != nullptr;
+    const float keep_prob = DROP ? 1.f / a.inv_keep : 1.f;
 
     bf16x8 qf[2][2], dof[2][2];
     float l2[2], dl[2], i_f[2];
@@ -399,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         dl[qb] = group_sum(dsum);
         if (g == 0 && i < a.nq) const_cast<float*>(a.delta)[si] = dl[qb];
     }
-    const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
+    const int wv = __builtin_amdgcn_readfirstlane(w);       // the wave index as a scalar: tile classes must be wave-uniform FOR THE COMPILER
+    const int i_lo = q0 + 32 * wv + off, i_hi = i_lo + 31;
     const long bstride = (long)a.nkt64 * 64;
     const uint16_t* bitbase = DROP ? a.dropbits + ((long)(bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * bstride + lane : nullptr;
     uint32_t kw[2] = {0, 0}, kwn[2] = {0, 0};   // keep-bit words of the current / next key tile
@@ -409,6 +426,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) dq[db][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     float acc_d[2] = {0.f, 0.f}, acc_r[2] = {0.f, 0.f}, acc_p[2] = {0.f, 0.f};
+
+    // ---- loop-invariant operands of the linear tiles (see the header of this section)
+    const float sc = slope2 / c1;
+    float sigma = 1.f;                                       // the walk starts left of the diagonal (or stays there: causal)
+    f32x4 kq0;                                               // C input of the score MFMAs: sigma * sc * (4g + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) kq0[r] = sc * (float)(4 * g + r);
+    f32x4 ndl[2];                                            // C input of the dP MFMAs: -delta' (delta' = delta * keep_prob)
+    float l2x[2];                                            // lse in log2 units minus log2(1 / keep_prob): exp2 gives P / keep_prob
+    const float log2_inv = DROP ? __builtin_log2f(a.inv_keep) : 0.f;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float nd = -dl[qb] * keep_prob;
+        ndl[qb] = f32x4{nd, nd, nd, nd};
+        l2x[qb] = l2[qb] - log2_inv;
+    }
+    // A fragment of the three extra product rows: row 0 = sigma, row 1 = sigma * jrel, row 2 = 1; element e of lane (p, g) multiplies
+    // key 32u + 16(e >> 2) + 4g + (e & 3) of the tile -- the enumeration of the dS^T / P^T B fragments (pack8 of two 16-key blocks)
+    bf16x8 wfr[2];
+    uint32_t wflip = 0u;                                     // sign bits of the rows that carry sigma
+    if (SLOPE_GRAD) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float jrel = (float)(32 * u + 16 * (e >> 2) + 4 * g + (e & 3));
+                wfr[u][e] = (__bf16)(c == 0 ? 1.f : (c == 1 ? jrel : (c == 2 ? 1.f : 0.f)));
+            }
+        wflip = c < 2 ? 0x80008000u : 0u;
+    }
 
     int nt = (a.nk + 63) / 64, t_lo = 0;
     if (a.causal) {
@@ -423,7 +470,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
         }
     }
-    const int wv = __builtin_amdgcn_readfirstlane(w);
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
     uint32_t voKa[2], voKt[2], voV[2];
@@ -471,12 +517,71 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             if (DROP) { kwn[0] = bitbase[(t + 1) * 64]; kwn[1] = bitbase[bstride + (t + 1) * 64]; }
         }
         // rows beyond nq hold zero fragments and are never written; the last q block may straddle nq: use the general path
-        const bool rows_ok = q0 + 32 * w + 31 < a.nq;
-        int cls = classify(j0, i_lo, i_hi, *full_flag != 0, a.causal != 0);
+        const bool rows_ok = q0 + 32 * wv + 31 < a.nq;
+        // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
+        int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
         if (cls == T_SKIP) continue;
-        if (!rows_ok && slope_grad) cls = T_GEN;
-
+        if (!rows_ok && SLOPE_GRAD) cls = T_GEN;
         const float j0f = (float)j0;
+
+        if (cls == T_GEN) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 s[2][2], dp[2][2];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int kb = 2 * u + k2;
+                    bf16x8 kf0 = frag_rows(k_tile, 16 * kb, 0, lane), kf1 = frag_rows(k_tile, 16 * kb, 1, lane);
+                    bf16x8 vf0 = frag_rows(v_tile, 16 * kb, 0, lane), vf1 = frag_rows(v_tile, 16 * kb, 1, lane);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
+                        s[k2][qb] = acc;
+                        f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, dof[qb][0], acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, dof[qb][1], acc2, 0, 0, 0);
+                        dp[k2][qb] = acc2;
+                    }
+                }
+                dq_scores_gen<SLOPE_GRAD, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
+                bf16x8 dsf[2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) dsf[qb] = pack8(s[0][qb], s[1][qb]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    bf16x8 ktf = frag_cols_t(kt_tile, 16 * db, u, lane);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+                        dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb], dq[db][qb], 0, 0, 0);
+                }
+            }
+            continue;
+        }
+
+        // ---- linear tile
+        const float sg = cls == T_LEFT ? 1.f : -1.f;
+        if (sg != sigma) {   // the walk crossed the diagonal (once per block): re-sign the key part and the weight rows
+            sigma = sg;
+            kq0 = -kq0;
+            if (SLOPE_GRAD) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    uint4 x = __builtin_bit_cast(uint4, wfr[u]);
+                    x.x ^= wflip; x.y ^= wflip; x.z ^= wflip; x.w ^= wflip;
+                    wfr[u] = __builtin_bit_cast(bf16x8, x);
+                }
+            }
+        }
+        float rowck[2][4];   // sigma slope2 (j0 + 16 kb - i) - lse2_i  (+ log2 keep_prob^-1)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float rc = fmaf(sg * slope2, j0f - i_f[qb], -l2x[qb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) rowck[qb][kb] = rc + sg * slope2 * (float)(16 * kb);
+        }
+        f32x4 ws[2], wp[2];   // rows 0..2 of (weights x dS^T) and (weights x P^T) of this tile, per row block
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 s[2][2], dp[2][2];
@@ -487,25 +592,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 bf16x8 vf0 = frag_rows(v_tile, 16 * kb, 0, lane), vf1 = frag_rows(v_tile, 16 * kb, 1, lane);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
-                    s[k2][qb] = acc;
-                    f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, dof[qb][0], acc2, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, dof[qb][1], acc2, 0, 0, 0);
-                    dp[k2][qb] = acc2;
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], kq0, 0, 0, 0);
+                    s[k2][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
+                    f32x4 acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf0, dof[qb][0], ndl[qb], 0, 0, 0);
+                    dp[k2][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf1, dof[qb][1], acc2, 0, 0, 0);
                 }
             }
-            if (slope_grad) {
-                if (cls == T_LEFT) dq_scores<T_LEFT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-                else dq_scores<T_GEN, true, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-            } else {
-                if (cls == T_LEFT) dq_scores<T_LEFT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-                else if (cls == T_RIGHT) dq_scores<T_RIGHT, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-                else dq_scores<T_GEN, false, DROP>(u, s, dp, l2, dl, i_f, c1, slope2, j0f, g, m_tile, a.causal, acc_d, acc_r, acc_p, kw, a.inv_keep);
-            }
+            f32x4 pr[2][2];   // P / keep_prob
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = fast_exp2(fmaf(s[k2][qb][r], c1, rowck[qb][2 * u + k2]));
+                        float y = dp[k2][qb][r];                                  // dP - delta'
+                        if (DROP) y = sel_bits(__builtin_amdgcn_sbfe((int)kw[qb], 4 * (2 * u + k2) + r, 1), y, ndl[qb][0]);
+                        s[k2][qb][r] = p * y;
+                        if (SLOPE_GRAD) pr[k2][qb][r] = p;
+                    }
             bf16x8 dsf[2];
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) dsf[qb] = pack8(s[0][qb], s[1][qb]);
@@ -515,6 +620,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb)
                     dq[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qb], dq[db][qb], 0, 0, 0);
+            }
+            if (SLOPE_GRAD) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const bf16x8 pf = pack8(pr[0][qb], pr[1][qb]);
+                    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+                    ws[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[u], dsf[qb], u == 0 ? z : ws[qb], 0, 0, 0);
+                    wp[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[u], pf, u == 0 ? z : wp[qb], 0, 0, 0);
+                }
+            }
+        }
+        if (SLOPE_GRAD) {
+            // lanes of group 0 hold rows 0..2 of this lane's query column: sigma sum dS, sigma sum dS jrel, sum dS (and the same of P');
+            // |d| = sigma (i - j0 - jrel).  The other lane groups hold all-zero rows and add nothing.
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float dist = i_f[qb] - j0f;
+                acc_d[qb] += fmaf(dist, ws[qb][0], -ws[qb][1]);
+                acc_r[qb] += ws[qb][2];
+                acc_p[qb] = fmaf(keep_prob, fmaf(dist, wp[qb][0], -wp[qb][1]), acc_p[qb]);
             }
         }
     }
@@ -532,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             }
         }
     }
-    if (slope_grad) {
+    if (SLOPE_GRAD) {
         float dslope = 0.f;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -731,8 +856,11 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     rc = prepare_band(a, stream, const_cast<float*>(band), true);   // the bounds the forward computed for this q / k / mask (null: visit all)
     if (rc) return rc;
     // dQ first: it computes delta = rowsum(O * dO) in its prologue and stores it for dK/dV
-    if (a.drop_on) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(cdiv(nq, 128), h, b), dim3(256), 0, stream, a);
+    const dim3 gq(cdiv(nq, 128), h, b);
+    if (a.drop_on && dslope) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, true>), gq, dim3(256), 0, stream, a);
+    else if (a.drop_on) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, dim3(256), 0, stream, a);
+    else if (dslope) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, dim3(256), 0, stream, a);
     launch_attn_dkv(a, stream);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
