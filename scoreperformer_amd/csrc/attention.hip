@@ -33,63 +33,42 @@ using namespace spn_attn;
 // ==========================================================================================================
 // forward: grid (ceil(nq/128), h, b), 256 threads; wave w owns query rows q0 + 32w .. +31
 // ==========================================================================================================
-template <int MODE, bool DROP>
-__device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], float (&m_run)[2], float (&l_run)[2],
-                                            const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
-                                            bool causal, const uint32_t (&rowc)[2], int i_odd, int j0, uint32_t thr8,
-                                            uint16_t* bitp, long bstride) {
-    uint32_t mbits[4] = {0, 0, 0, 0};
-    if (MODE == T_GEN) {
+// Dropout of one probability with NO mask register: `word` holds the keep bits of the scores still to come, the next one in bit 31.
+// v_add_co_u32 shifts the word left by one and leaves the bit that falls out, for all 64 lanes, in VCC; v_cndmask_b32 applies it.  Two
+// VALU slots per score like v_bfe_i32 + v_and_b32, but no live mask per score (hipcc hoists all 32 extractions of a tile to its top:
+// +16 registers, which costs this kernel its third wave per SIMD), and no v_and + v_cmp + v_cndmask (what hipcc makes of a bit test).
+// Both instructions sit in one asm statement, the add first: p comes out of v_exp_f32 and a transcendental result may not be read by the
+// very next VALU instruction -- hipcc pads nothing in front of an asm statement, the add (which does not read p) is that padding.
+__device__ __forceinline__ float drop_next(float p, uint32_t& word) {
+    float r;
+    asm("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=v"(r), "+v"(word) : "v"(p) : "vcc");
+    return r;
+}
+
+// general tile (diagonal / masked / ragged): per-score masks and |d|
+template <bool DROP>
+__device__ __forceinline__ void fwd_softmax_gen(f32x4 (&s)[4][2], f32x4 (&o)[4][2], float (&m_run)[2], float (&l_run)[2],
+                                                const float (&i_f)[2], float c1, float slope2, float j0f, int g, const uint8_t* m_tile,
+                                                bool causal, uint32_t keep32, uint16_t* bitp, long bstride) {
+    uint32_t mbits[4];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) mbits[kb] = *reinterpret_cast<const uint32_t*>(m_tile + 16 * kb + 4 * g);
-    }
-    const float sj0 = slope2 * (j0f + (float)(4 * g));
-    // linear-bias tiles: the per-key bias of this lane's 16 keys, as pairs for the packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32:
-    // two scores per VALU slot -- the kernel is VALU-bound at head dim 64).  Shared by both query blocks.
-    f32x2 kbias[4][2];
-    if (MODE != T_GEN) {
-        const float sg = MODE == T_LEFT ? 1.f : -1.f;
+    for (int kb = 0; kb < 4; ++kb) mbits[kb] = *reinterpret_cast<const uint32_t*>(m_tile + 16 * kb + 4 * g);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float tmax = NEG_FILL;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x2 jc = f32x2{(float)(16 * kb + 2 * hh), (float)(16 * kb + 2 * hh + 1)};
-                kbias[kb][hh] = (jc * slope2 + sj0) * sg;
+            for (int r = 0; r < 4; ++r) {
+                const float jf = j0f + (float)(4 * g) + (float)(16 * kb + r);
+                const bool ok = ((((mbits[kb] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
+                const float t = ok ? fmaf(-slope2, fabsf(jf - i_f[qb]), s[kb][qb][r] * c1) : NEG_FILL;
+                s[kb][qb][r] = t;
+                tmax = fmaxf(tmax, t);
             }
-    }
-    // one counter per (row c of the block, key tile, lane group g): rowc[0] is the row's constant, the tile index comes in here
-    const uint32_t keep32 = DROP ? drop_keep32(rowc[0] + __umul24((uint32_t)((j0 >> 4) + g), 0xEBCA77u), thr8) : 0xffffffffu;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const float u = MODE == T_LEFT ? -slope2 * i_f[qb] : (MODE == T_RIGHT ? slope2 * i_f[qb] : 0.f);
-        float tmax = NEG_FILL;
-        if (MODE != T_GEN) {
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const f32x2 sv = f32x2{s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]};
-                    const f32x2 t = sv * c1 + kbias[kb][hh];
-                    s[kb][qb][2 * hh] = t.x; s[kb][qb][2 * hh + 1] = t.y;
-                    tmax = fmaxf(fmaxf(tmax, t.x), t.y);
-                }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float jc = (float)(16 * kb + r);
-                    const float jf = j0f + (float)(4 * g) + jc;
-                    const bool ok = ((((mbits[kb] >> (8 * r)) & 0xff) != 0) && (!causal || jf <= i_f[qb]));
-                    const float t = score<MODE>(s[kb][qb][r], c1, slope2, sj0 + slope2 * jc, jf, i_f[qb], ok);
-                    s[kb][qb][r] = t;
-                    tmax = fmaxf(tmax, t);
-                }
-        }
         // The running maximum only has to be the SAME for the 4 lanes of a row and within 2^RESCALE_THR of the true one.  So the test uses
         // each lane's OWN maximum (no cross-lane traffic); the two swizzles of the row reduction -- LDS-crossbar round trips in the
         // middle of the dependency chain max -> exp -> P V -- run only in the rare iteration that actually raises a maximum.
-        tmax += u;
         if (__any(tmax > m_run[qb] + RESCALE_THR)) {   // wave-uniform: rescale only when some row's max really grew
             tmax = group_max(tmax);
             const float m_new = fmaxf(m_run[qb], tmax);
@@ -99,34 +78,74 @@ __device__ __forceinline__ void fwd_softmax(f32x4 (&s)[4][2], f32x4 (&o)[4][2], 
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
         }
-        const float mm = m_run[qb] - u;
-        f32x2 psum2 = f32x2{0.f, 0.f};
+        const float mm = m_run[qb];
+        float psum = 0.f;
+        uint32_t word = qb == 1 ? keep32 : keep32 << 16;   // bit 16 qb + 4 kb + r: taken from the top, so (kb, r) run downwards
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 3; kb >= 0; --kb)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const f32x2 a = f32x2{s[kb][qb][2 * hh], s[kb][qb][2 * hh + 1]} - mm;
-                const f32x2 p = f32x2{fast_exp2(a.x), fast_exp2(a.y)};
-                s[kb][qb][2 * hh] = p.x; s[kb][qb][2 * hh + 1] = p.y;
-                psum2 += p;
+            for (int r = 3; r >= 0; --r) {
+                const float p = fast_exp2(s[kb][qb][r] - mm);
+                psum += p;   // the softmax normaliser is that of the un-dropped probabilities
+                s[kb][qb][r] = DROP ? drop_next(p, word) : p;
             }
-        l_run[qb] += psum2.x + psum2.y;   // the softmax normaliser is that of the un-dropped probabilities
-        if (DROP) {
-            const uint32_t kw = (keep32 >> (16 * qb)) & 0xffffu;   // keep bits of this lane's 16 scores of row block qb, bit 4*kb + r
+        l_run[qb] += psum;
+        if (DROP) bitp[qb * bstride] = (uint16_t)((keep32 >> (16 * qb)) & 0xffffu);
+    }
+}
+
+// linear tile (all keys on one side of the wave's rows: |d| = sigma (i - j)).  The scores arrive from the MFMA with the key part of the
+// ALiBi term already in them (C input kq0 = sigma slope2 (4g + r) / c1, attn_fwd_kernel) and are taken RELATIVE TO THE RUNNING MAXIMUM
+// by the row term rowck = sigma slope2 (j0 + 16 kb - i) - m_base: one fma per score in front of its exp (was: packed fma + subtract).
+// m_base is the running maximum, or 0 while the row has none yet (a row term of 1.7e38 would swallow the score).
+template <bool DROP>
+__device__ __forceinline__ void fwd_softmax_lin(f32x4 (&s)[4][2], f32x4 (&o)[4][2], float (&m_run)[2], float (&l_run)[2],
+                                                const float (&i_f)[2], float c1, float sg_slope2, float j0f, uint32_t keep32,
+                                                uint16_t* bitp, long bstride) {
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+    for (int qb = 0; qb < 2; ++qb) {
+        const float m_base = m_run[qb] > -1e37f ? m_run[qb] : 0.f;
+        const float rc = fmaf(sg_slope2, j0f - i_f[qb], -m_base);
+        float tmax = NEG_FILL;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = __builtin_amdgcn_sbfe(keep32, 16 * qb + 4 * kb + r, 1);   // all-ones when kept
-                    s[kb][qb][r] = __int_as_float(__float_as_int(s[kb][qb][r]) & m);
-                }
-            bitp[qb * bstride] = (uint16_t)kw;
+        for (int kb = 0; kb < 4; ++kb) {
+            const float rck = rc + sg_slope2 * (float)(16 * kb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = fmaf(s[kb][qb][r], c1, rck);
+                s[kb][qb][r] = t;
+                tmax = fmaxf(tmax, t);
+            }
         }
+        if (__any(tmax > (m_run[qb] - m_base) + RESCALE_THR)) {   // see fwd_softmax_gen; everything here is relative to m_base
+            tmax = group_max(tmax);
+            const float m_new = fmaxf(m_run[qb], m_base + tmax);
+            const float alpha = fast_exp2(m_run[qb] - m_new);
+            const float shift = m_new - m_base;
+            m_run[qb] = m_new;
+            l_run[qb] *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db][qb] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[kb][qb] -= shift;
+        }
+        float psum = 0.f;
+        uint32_t word = qb == 1 ? keep32 : keep32 << 16;   // bit 16 qb + 4 kb + r: taken from the top, so (kb, r) run downwards
+#pragma unroll
+        for (int kb = 3; kb >= 0; --kb)
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                const float p = fast_exp2(s[kb][qb][r]);
+                psum += p;
+                s[kb][qb][r] = DROP ? drop_next(p, word) : p;
+            }
+        l_run[qb] += psum;
+        if (DROP) bitp[qb * bstride] = (uint16_t)((keep32 >> (16 * qb)) & 0xffffu);
     }
 }
 
 template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
     // K / V tiles arrive by LDS DMA (buffer_load ... lds: no VGPR round trip, no ds_write, no address arithmetic in the loop) into
     // two alternating stages, so ONE barrier per key tile both publishes tile t and proves that the stage tile t+1 is about to
     // overwrite is no longer read.  The DMA writes LDS linearly (wave base + lane * 16): the XOR swizzles of the "a" / "t" layouts sit
@@ -158,9 +177,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = load_row_frag(qp, a.q_ns, q0 + 32 * w + 16 * qb + c, a.nq, ks, lane);
     }
-    const int i_lo = q0 + 32 * w + off, i_hi = i_lo + 31;
+    const int wv = __builtin_amdgcn_readfirstlane(w);   // the wave index as a scalar: tile classes must be wave-uniform FOR THE COMPILER
+    const int i_lo = q0 + 32 * wv + off, i_hi = i_lo + 31;
     uint32_t rowc[2] = {0, 0};
-    const int i_odd = c & 1;   // (q0 + 32w + 16qb + c) & 1
     if (DROP) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 
     const long bstride = (long)a.nkt64 * 64;   // keep-bit words between consecutive 16-query tiles
-    uint16_t* bitbase = DROP ? a.dropbits + ((long)(bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * bstride + lane : nullptr;
+    uint16_t* bitbase = DROP ? a.dropbits + ((long)(bi * a.h + hi) * a.nqt16 + (q0 + 32 * wv) / 16) * bstride + lane : nullptr;
 
     f32x4 o[4][2];
 #pragma unroll
@@ -191,24 +210,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         }
     }
 
-    const int wv = __builtin_amdgcn_readfirstlane(w);
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
-    uint32_t voK[2], voV[2];   // this wave's two 1 KiB pieces of a tile: LDS chunk L = piece * 64 + lane <- source chunk (inverse swizzle)
+    // C input of the score MFMAs on linear tiles: the key part of the ALiBi term, sigma slope2 (4g + r) / c1 (re-signed when the walk
+    // crosses the diagonal, once per block)
+    float sigma = 1.f;
+    f32x4 kq0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int L = (wv * 2 + i) * 64 + lane, row = L >> 3, ch = L & 7;
-        voK[i] = (uint32_t)(((long)row * a.k_ns + ((ch ^ (row & 7)) << 3)) * 2);
-        voV[i] = (uint32_t)(((long)row * a.v_ns + ((ch ^ (((row >> 1) & 3) << 1)) << 3)) * 2);
+    for (int r = 0; r < 4; ++r) kq0[r] = (slope2 / c1) * (float)(4 * g + r);
+    // this wave's two 1 KiB pieces of a tile: LDS chunk L = piece * 64 + lane <- source chunk (inverse swizzle).  The second piece lies 8
+    // rows further down with the same swizzle (both keys repeat every 8 rows): same lane offset, 8 rows on the SCALAR offset
+    uint32_t voK, voV;
+    {
+        const int L = wv * 128 + lane, row = L >> 3, ch = L & 7;
+        voK = (uint32_t)(((long)row * a.k_ns + ((ch ^ (row & 7)) << 3)) * 2);
+        voV = (uint32_t)(((long)row * a.v_ns + ((ch ^ (((row >> 1) & 3) << 1)) << 3)) * 2);
     }
     auto issue_tile = [&](int t) {
         char* kd = k_stage + (t & 1) * 8192 + wv * 2048;
         char* vd = v_stage + (t & 1) * 8192 + wv * 2048;
-        const uint32_t sk = (uint32_t)(t * 64) * (uint32_t)a.k_ns * 2u, sv = (uint32_t)(t * 64) * (uint32_t)a.v_ns * 2u;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(kd + i * 1024), 16, voK[i], sk, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(vd + i * 1024), 16, voV[i], sv, 0, 0);
+            const uint32_t sk = (uint32_t)(t * 64 + 8 * i) * (uint32_t)a.k_ns * 2u, sv = (uint32_t)(t * 64 + 8 * i) * (uint32_t)a.v_ns * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(kd + i * 1024), 16, voK, sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(vd + i * 1024), 16, voV, sv, 0, 0);
         }
     };
     uint8_t mreg = 1;
@@ -233,31 +258,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             issue_tile(t + 1);
             if (tid < 64) { const int j = j0 + 64 + tid; mreg = (j < a.nk) ? (mp ? mp[j] : 1) : 0; }
         }
-        const int cls = classify(j0, i_lo, i_hi, *full_flag != 0, a.causal != 0);
+        // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
+        const int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
         if (cls == T_SKIP) continue;
-
-        // S^T = K Q^T
-        f32x4 s[4][2];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            bf16x8 kf0 = frag_rows(k_tile, 16 * kb, 0, lane), kf1 = frag_rows(k_tile, 16 * kb, 1, lane);
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
-                s[kb][qb] = acc;
-            }
-        }
         const float j0f = (float)j0;
         uint32_t thr_t = a.thr8;
         if (DROP && a.thr_frac) {   // this block's threshold: thr8 + Bernoulli(frac16 / 65536), all-scalar (set_dropout)
-            const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((bi * a.h + hi) * a.nqt16 + (q0 + 32 * w) / 16) * a.nkt64 + t));
+            const uint32_t blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((bi * a.h + hi) * a.nqt16 + (q0 + 32 * wv) / 16) * a.nkt64 + t));
             thr_t += ((block_mix(blk ^ a.seed) & 0xffffu) < a.thr_frac) ? 1u : 0u;
         }
-        if (cls == T_LEFT) fwd_softmax<T_LEFT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
-        else if (cls == T_RIGHT) fwd_softmax<T_RIGHT, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
-        else fwd_softmax<T_GEN, DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, rowc, i_odd, j0, thr_t, bitbase + t * 64, bstride);
+        // one counter per (row c of the block, key tile, lane group g): rowc[0] is the row's constant, the tile index comes in here
+        const uint32_t keep32 = DROP ? drop_keep32(rowc[0] + __umul24((uint32_t)((j0 >> 4) + g), 0xEBCA77u), thr_t) : 0xffffffffu;
+
+        // S^T = K Q^T
+        f32x4 s[4][2];
+        if (cls == T_GEN) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                bf16x8 kf0 = frag_rows(k_tile, 16 * kb, 0, lane), kf1 = frag_rows(k_tile, 16 * kb, 1, lane);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], acc, 0, 0, 0);
+                    s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
+                }
+            }
+            fwd_softmax_gen<DROP>(s, o, m_run, l_run, i_f, c1, slope2, j0f, g, m_tile, a.causal, keep32, bitbase + t * 64, bstride);
+        } else {
+            const float sg = cls == T_LEFT ? 1.f : -1.f;
+            if (sg != sigma) { sigma = sg; kq0 = -kq0; }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                bf16x8 kf0 = frag_rows(k_tile, 16 * kb, 0, lane), kf1 = frag_rows(k_tile, 16 * kb, 1, lane);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[qb][0], kq0, 0, 0, 0);
+                    s[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[qb][1], acc, 0, 0, 0);
+                }
+            }
+            fwd_softmax_lin<DROP>(s, o, m_run, l_run, i_f, c1, sg * slope2, j0f, keep32, bitbase + t * 64, bstride);
+        }
 
         // O^T += V^T P^T
 #pragma unroll
