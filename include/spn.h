@@ -94,6 +94,15 @@ int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy,
                            const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx,
                            void* dx16, long lddx16, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
 
+/* AdaptiveLayerNorm FORWARD with the condition projection INSIDE the kernel (modules/layers.py:31-47: gamma | beta = Linear(condition),
+ * never materialised as [T, 2D] rows by a K = 64 GEMM).  spn_adaln_ok: 1 when the fused kernel takes the shape (D = 512, C = 64);
+ * otherwise project with spn_gemm_bf16 and use spn_layernorm_fwd_gb16.  x fp32 [T, D]; cond bf16 [T, C]; W bf16 [2D, C] contiguous
+ * (gamma rows, then beta rows); bias fp32 [2D]; y bf16 [T, D]; mean / rstd [T]; gamma_out: optional bf16 [T, D] (ldg), the gamma rows
+ * the backward needs -- spn_layernorm_bwd_gb16(gb16 = gamma_out, ldgb = ldg) reads only the gamma half of a (gamma | beta) row. */
+int spn_adaln_ok(int D, int C);
+int spn_adaln_fwd(const float* x, long ldx, const void* cond, long ldc, const void* W, const float* bias, void* y, long ldy,
+                  void* gamma_out, long ldg, float* mean, float* rstd, int T, int D, int C, float eps, spn_stream_t s);
+
 /* ---- gated feed-forward input projection, activation fused into the GEMM epilogue (feedforward.py:13-21 GLU.forward and the
  * nn.Dropout of feedforward.py:57-60):  u[M,2I] = x W^T + bias (bf16, value | gate, kept for the backward);
  * g[M,I] = dropout(u[:, :I] * act(u[:, I:])) with the mask of spn_act_fwd(seed): spn_act_bwd(u, dg, ...) is its backward.

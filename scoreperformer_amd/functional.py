@@ -304,6 +304,9 @@ def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5, fork=False):
 # restores the fp32 rows.
 import os as _os
 ADALN_GB_DTYPE = F32 if _os.environ.get("SPN_ADALN_GB", "bf16") == "fp32" else BF16
+# D = 512, C = 64: the forward computes the projection on the matrix cores inside the LayerNorm kernel (fp32 gamma / beta in registers,
+# nothing but the bf16 gamma rows for the backward is written); SPN_ADALN_FUSED=0 restores GEMM + LayerNorm
+ADALN_FUSED = _os.environ.get("SPN_ADALN_FUSED", "1") != "0" and ADALN_GB_DTYPE == BF16
 
 
 class AdaLayerNormFn(Function):
@@ -322,8 +325,13 @@ class AdaLayerNormFn(Function):
             except Exception:
                 pass
         c2 = cb.reshape(-1, cb.shape[-1])
-        gb = ops.gemm(c2, bf16_weight(weight), out_dtype=ADALN_GB_DTYPE, bias=bias.detach())   # [T, 2D] (gamma | beta)
-        y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
+        if (ADALN_FUSED and not out_fp32 and x.dtype == F32 and ops.adaln_ok(D, c2.shape[1]) and x.is_contiguous()
+                and c2.stride(-1) == 1 and bias.dtype == F32):
+            # the projection runs inside the LayerNorm kernel (csrc/adaln.hip): no [T, 2D] rows; the backward gets the gamma half
+            y, mean, rstd, gb = ops.adaln_fwd(x, c2, bf16_weight(weight), bias.detach(), eps=eps)
+        else:
+            gb = ops.gemm(c2, bf16_weight(weight), out_dtype=ADALN_GB_DTYPE, bias=bias.detach())   # [T, 2D] (gamma | beta)
+            y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
         ctx.save_for_backward(x, c2, gb, mean, rstd)
         ctx.weight_ref, ctx.bias_ref, ctx.cond_shape, ctx.cond_dtype = weight, bias, cond.shape, cond.dtype
         _pend(weight); _pend(bias)

@@ -191,6 +191,28 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tenso
 # attention core
 # ---------------------------------------------------------------------------------------------------------
 
+def adaln_ok(D: int, C: int) -> bool:
+    return bool(load().spn_adaln_ok(c_int(D), c_int(C)))
+
+
+def adaln_fwd(x: torch.Tensor, cond: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, want_gamma: bool = True):
+    """y (bf16) = (W_gamma cond + b_gamma) * LN(x) + (W_beta cond + b_beta) with the projection inside the kernel; returns y, mean, rstd and
+    the bf16 gamma rows [T, D] (what the backward needs of the projection; None without `want_gamma`)."""
+    require_gpu(x, cond, w, bias)
+    x2, c2 = _rows2d(x), _rows2d(cond)
+    T, D = x2.shape
+    C = c2.shape[1]
+    assert x2.dtype == F32 and c2.dtype == BF16 and w.dtype == BF16 and bias.dtype == F32 and w.shape == (2 * D, C) and w.is_contiguous()
+    assert x2.stride(1) == 1 and c2.stride(1) == 1 and c2.shape[0] == T
+    y = torch.empty((T, D), device=x.device, dtype=BF16)
+    gam = torch.empty((T, D), device=x.device, dtype=BF16) if want_gamma else None
+    mean = torch.empty(T, device=x.device, dtype=F32)
+    rstd = torch.empty(T, device=x.device, dtype=F32)
+    call("spn_adaln_fwd", ptr(x2), c_long(x2.stride(0)), ptr(c2), c_long(c2.stride(0)), ptr(w), ptr(bias), ptr(y), c_long(D), ptr(gam), c_long(D),
+         ptr(mean), ptr(rstd), c_int(T), c_int(D), c_int(C), c_float(eps), stream_ptr())
+    return y, mean, rstd, gam
+
+
 def _bnhd_strides(t: torch.Tensor) -> Tuple[int, int, int]:
     """(batch, seq, head) element strides of a [b, n, h, 64] view with unit inner stride."""
     if t.ndim != 4 or t.shape[-1] != 64 or t.stride(-1) != 1:
@@ -793,6 +815,17 @@ def layernorm_fwd(x, gamma, beta, gb=None, out_dtype=BF16, eps=1e-5, out=None): 
     by = n * (x.element_size() + ysz) + (2 * n * gb.element_size() if gb is not None else 0)
     return PROFILE.wrap("ln_fwd", float(by), f"T{n // x.shape[-1]} D{x.shape[-1]} {'ada' if gb is not None else 'ln'}",
                         lambda: _ln_fwd_raw(x, gamma, beta, gb, out_dtype, eps, out))
+
+
+_adaln_fwd_raw = adaln_fwd
+
+
+def adaln_fwd(x, cond, w, bias, eps=1e-5, want_gamma=True):  # noqa: F811
+    if not PROFILE.enabled:
+        return _adaln_fwd_raw(x, cond, w, bias, eps, want_gamma)
+    n = x.numel()
+    by = n * (4 + 2 + (2 if want_gamma else 0)) + cond.numel() * 2
+    return PROFILE.wrap("ln_fwd", float(by), f"T{n // x.shape[-1]} D{x.shape[-1]} ada-fused", lambda: _adaln_fwd_raw(x, cond, w, bias, eps, want_gamma))
 
 
 def layernorm_bwd(x, dy, gamma, gb, mean, rstd, *, dres=None, dx_dtype=F32, dgamma=None, dbeta=None, want_dgb=False, want_dx16=False):  # noqa: F811

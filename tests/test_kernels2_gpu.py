@@ -290,3 +290,39 @@ def test_gemm_short_contraction_on_the_duo_kernel(K, tb, f32, extras):
         ref = ref + res
     err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
     assert err < (2e-5 * K ** 0.5 if f32 else 1e-2) and bool(torch.isfinite(out.float()).all()), err
+
+
+@pytest.mark.parametrize("T", [77, 1024, 8200])
+def test_adaln_forward_with_the_projection_inside_the_kernel(T):
+    """AdaptiveLayerNorm (modules/layers.py:31-47) with gamma | beta = Linear(condition) computed on the matrix cores inside the LayerNorm
+    forward (D = 512, C = 64): y, mean, rstd and the bf16 gamma rows against fp32 torch, at ragged token counts; the gamma rows are what
+    spn_layernorm_bwd_gb16 reads in the backward, checked through the autograd function against the unfused path."""
+    from scoreperformer_amd import ops
+    import scoreperformer_amd.functional as F_
+    D, C = 512, 64
+    assert ops.adaln_ok(D, C) and not ops.adaln_ok(128, 32)
+    g = torch.Generator(device="cuda").manual_seed(T)
+    x = torch.randn(T, D, device="cuda", generator=g) * 2 + 0.3
+    cond = torch.randn(T, C, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(2 * D, C, device="cuda", generator=g) * 0.1)
+    bias = torch.cat([torch.ones(D), torch.zeros(D)]).cuda() + 0.05 * torch.randn(2 * D, device="cuda", generator=g)
+    y, mean, rstd, gam = ops.adaln_fwd(x, cond, w.bfloat16(), bias)
+    gb = cond.float() @ w.bfloat16().float().t() + bias
+    ref = gb[:, :D] * F.layer_norm(x, (D,)) + gb[:, D:]
+    assert rel_err(y, ref) < 6e-3 and rel_err(gam, gb[:, :D]) < 5e-3        # bf16 outputs of fp32 values
+    assert rel_err(mean, x.mean(1)) < 1e-5 and rel_err(rstd, (x.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    # through autograd: fused forward + wave-per-row backward on the gamma rows == GEMM + LayerNorm path
+    dy = torch.randn(T, D, device="cuda", generator=g)
+    outs = []
+    for fused in (True, False):
+        F_.ADALN_FUSED = fused
+        try:
+            xs, cs = x.clone().requires_grad_(True), cond.float().requires_grad_(True)
+            ws, bs = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+            yy = F_.ada_layer_norm(xs.view(1, T, D), cs.view(1, T, C), ws, bs)
+            yy.float().backward(dy.view(1, T, D))
+            outs.append((yy.detach().float(), xs.grad, cs.grad, ws.grad, bs.grad))
+        finally:
+            F_.ADALN_FUSED = True
+    for a, b_ in zip(*outs):
+        assert rel_err(a, b_) < 1e-2
