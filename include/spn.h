@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 3 */
+int spn_abi_version(void); /* 4: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -233,6 +233,11 @@ int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, const float* s
  * the cache protocol :159-181; ALiBi distance from the END of the context as attention.py:193-197 gives it for a single query) */
 int spn_dec_xattn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask, int nk, float* o,
                   float* part, int* counter, int h, int kvh, float scale, int splits, spn_stream_t s);
+/* the same with the number of context rows read from device memory at run time (render sessions: the context grows under one graph) */
+int spn_dec_xattn_dyn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask, const int* nk_dev,
+                      float* o, float* part, int* counter, int h, int kvh, float scale, int splits, spn_stream_t s);
+/* out[0] = tab[*pos] */
+int spn_dec_lookup(const int* tab, const int* pos, int* out, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,

@@ -674,8 +674,10 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
 // the reference's fill value (attend.py:102-108).  Same split-key scheme as dec_attn2_kernel; nothing is appended.
 __global__ __launch_bounds__(256) void dec_xattn_kernel(const float* __restrict__ q, const float* __restrict__ kctx, const float* __restrict__ vctx,
                                                         const float* __restrict__ slopes, const uint8_t* __restrict__ kmask, int nk,
+                                                        const int* __restrict__ nk_dev,
                                                         float* __restrict__ o, float* __restrict__ part, int* __restrict__ counter,
                                                         int h, int kvh, float scale, int merge) {
+    if (nk_dev) nk = *nk_dev;   // render sessions: the context grows from call to call under ONE captured graph (buffers sized for the window)
     __shared__ float sm[16], sl[16];
     __shared__ __attribute__((aligned(16))) float so[16][64];
     __shared__ int is_last;
@@ -1097,7 +1099,29 @@ extern "C" int spn_dec_xattn(const float* q, const float* kctx, const float* vct
                              float* part, int* counter, int h, int kvh, float scale, int splits, hipStream_t s) {
     SPN_REQUIRE(q && kctx && vctx && part && counter && nk > 0 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
                 "spn_dec_xattn: bad arguments");
-    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, nk, o, part, counter, h, kvh, scale, o ? 1 : 0);
+    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, nk, (const int*)nullptr, o, part, counter, h,
+                       kvh, scale, o ? 1 : 0);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// the same with the number of context rows read from DEVICE memory at run time (*nk_dev, 1 <= *nk_dev <= rows of kctx / vctx / kmask)
+extern "C" int spn_dec_xattn_dyn(const float* q, const float* kctx, const float* vctx, const float* slopes, const uint8_t* kmask,
+                                 const int* nk_dev, float* o, float* part, int* counter, int h, int kvh, float scale, int splits, hipStream_t s) {
+    SPN_REQUIRE(q && kctx && vctx && part && counter && nk_dev && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
+                "spn_dec_xattn_dyn: bad arguments");
+    hipLaunchKernelGGL(dec_xattn_kernel, dim3(h, splits), dim3(256), 0, s, q, kctx, vctx, slopes, kmask, 1, nk_dev, o, part, counter, h, kvh, scale,
+                       o ? 1 : 0);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+namespace { __global__ void dec_lookup_kernel(const int* __restrict__ tab, const int* __restrict__ pos, int* __restrict__ out) { out[0] = tab[pos[0]]; } }
+// out[0] = tab[*pos]: a device-side row index that is a table function of the position (the reference-compatible head row of
+// cross-attending decoders, decode.py)
+extern "C" int spn_dec_lookup(const int* tab, const int* pos, int* out, hipStream_t s) {
+    SPN_REQUIRE(tab && pos && out, "spn_dec_lookup: bad arguments");
+    hipLaunchKernelGGL(dec_lookup_kernel, dim3(1), dim3(1), 0, s, tab, pos, out);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -23,10 +23,17 @@ F32 = torch.float32
 
 
 class GreedyDecoder:
-    def __init__(self, decoder, max_len: int, use_graph: bool = True, fused: bool = True, attn_splits: int = 16):
+    def __init__(self, decoder, max_len: int, use_graph: bool = True, fused: bool = True, attn_splits: int = 16,
+                 reference_compat: bool = False):
         """decoder: the TupleTransformer wrapped by the MixedLM wrapper (`model.perf_decoder.model`).
         fused: ~40 fused launches per note (LayerNorm inside the GEMVs, GLU epilogue, split-key attention, one LM-head launch)
-        instead of ~110 small ones; same arithmetic, same tokens."""
+        instead of ~110 small ones; same arithmetic, same tokens.
+        reference_compat (cross-attending decoders only; no effect otherwise): reproduce the reference's cached decode TOKEN FOR TOKEN,
+        including its defect in this mode -- under the cache protocol a cross-attention block returns one row per prefix position
+        (modules/transformer/transformer.py:201, attention.py:216-218), the rows pile up in the cached final hiddens and
+        `hidden_state[:, idx - 1]` (wrappers.py:364) reads the hidden of a STALE position from the third decoded note on: decoded note
+        number s (1-based) is predicted from the hidden of position first - 1 + (t - 1), t the smallest integer with t (t + 1) / 2 >= s.
+        Default False: the evident intent, row idx - 1."""
         self.m = m = decoder
         import os
         attn_splits = int(os.environ.get("SPN_DEC_SPLITS", attn_splits))   # tuning aid
@@ -44,6 +51,9 @@ class GreedyDecoder:
         self.dev = next(m.parameters()).device
         self.dim = m.dim
         self.ada = tr.ada_norm
+        self.reference_compat = bool(reference_compat) and self.cross
+        self.stale_tab = None      # reference_compat: int32 [max_len] device table, position -> row of the final hiddens the head reads
+        self.nk_dev = None         # render sessions with a cross-attending decoder: int32 device scalar, valid context rows
         self.graph = None
         self.sampling = None       # None = arg-max; dict(topk=int32 device tensor [n dims], temperature=float) = top-k sampling
 
@@ -56,6 +66,7 @@ class GreedyDecoder:
         # (ops.dec_step_begin latches it into `pos`) and written by its last one (the head: position + 1) -- no separate "advance" launch
         self.pos2 = torch.zeros(2, device=dev, dtype=torch.int32)
         self.pos, self.pos_next = self.pos2[0:1], self.pos2[1:2]
+        self.pos_stale = torch.zeros(1, device=dev, dtype=torch.int32)
         self.x0 = z(d)   # token embedding of the position before the (LN | context | style) projection writes the stream `x`
         self.e_cat = z(te.total_emb_dim)
         self.proj_cat = z(2 * d)
@@ -138,7 +149,7 @@ class GreedyDecoder:
             ops.dec_gemv(block.to_q.weight.data, self.h, self.q_only)
         slopes = self._slopes(block)
         ops.dec_xattn(self.q_only, self.xk[ci], self.xv[ci], slopes, self.xmask, None if fused else self.o, self.att_part, self.att_counter,
-                      h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits)
+                      h=self.heads, kvh=self.kvh, scale=block.scale, splits=self.attn_splits, nk_dev=self.nk_dev)
         if fused:   # the output projection merges the split-key partials in its prologue: no fences / last-block tail in the attention kernel
             ops.dec_attn_out(block.to_out.weight.data, self.att_part, self.x, h=self.heads, splits=self.attn_splits, residual=self.x)
         else:
@@ -219,6 +230,9 @@ class GreedyDecoder:
         # LM head on this position for the candidate dims, arg-max written where the next position holds MASK
         head = m.lm_head
         keys = list(te.embs.keys())
+        if self.reference_compat:   # the head reads the cached final hidden of the (stale) row the reference reads: see __init__
+            ops.dec_lookup(self.stale_tab, pos, self.pos_stale)
+            ops.dec_copy_row(self.hid[-1], self.h, self.pos_stale, self.dim, src_ld=self.dim, src_off=0)
         if isinstance(head, TupleTokenTiedLMHead):
             if head.reuse_projection:
                 ops.dec_gemv(head.project_emb.weight.data, self.h, self.e_head, kn_layout=True)
@@ -257,7 +271,8 @@ class GreedyDecoder:
         has_norm = isinstance(te.norm, nn.LayerNorm)
         gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
         head, fn = m.lm_head, tr.final_norm
-        fused_tail = isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity)
+        fused_tail = (isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity)
+                      and not self.reference_compat)
         # A dependent launch costs >= 4 us under graph replay whatever it does (profiles/, one-thread kernel), so three of them are
         # folded away: the position advance (latch protocol of ops.dec_step_begin; needs the fused head as the step's last launch), the
         # AdaLN-row GEMV (position-only input: rides in the first launch), the concatenation (prologue of the projection GEMV)
@@ -377,6 +392,15 @@ class GreedyDecoder:
         with torch.no_grad():
             self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
         n_steps = last                              # positions t = 0 .. last-1 (predicting t+1)
+        if self.reference_compat:
+            first = int(rows.min())                 # the first position that holds MASK: the reference's first (cache-free) call
+            tab = list(range(L))
+            for p_ in range(first - 1, L):          # position p_ predicts idx = p_ + 1, decoded note number s = idx - first + 1
+                s_, t_ = p_ + 2 - first, 1
+                while t_ * (t_ + 1) // 2 < s_:
+                    t_ += 1
+                tab[p_] = first - 1 + (t_ - 1)
+            self.stale_tab = torch.tensor(tab, device=self.dev, dtype=torch.int32)
         step = self._step_fused if self.fused else self._step
         self.pos2.zero_()
         if self.use_graph and n_steps > 2:
@@ -406,7 +430,8 @@ class GreedyDecoder:
                 att.append(AttentionIntermediates(keys=view(self.kc[ai], n), values=view(self.vc[ai], n)))
                 ai += 1
             elif lt == 'c':
-                att.append(AttentionIntermediates(keys=view(self.xk[ci], self.xk[ci].shape[0]), values=view(self.xv[ci], self.xv[ci].shape[0])))
+                nctx = getattr(self, "ctx_rows", None) or self.xk[ci].shape[0]
+                att.append(AttentionIntermediates(keys=view(self.xk[ci], nctx), values=view(self.xv[ci], nctx)))
                 ci += 1
         return TupleTransformerCaches(token_emb=self.tok_emb[None, :n],
                                       transformer=TransformerIntermediates(hiddens=[h[None, :n] for h in self.hid], attention=att))
@@ -423,14 +448,26 @@ class RenderSession(GreedyDecoder):
 
     def __init__(self, decoder, max_len: int, dims: List[int], mask_token_id: int = 1, **kw):
         super().__init__(decoder, max_len, **kw)
-        if self.cross:
-            raise NotImplementedError("render session: cross-attending decoders render through GreedyDecoder / the module path")
+        if self.reference_compat:
+            raise NotImplementedError("render session: reference_compat exists for the single-call decode only (GreedyDecoder.run)")
         m, dev = self.m, self.dev
         self._alloc(max_len)
+        if self.cross:
+            # context_emb_mode 'attention' (inference/generators.py:230-240 with modules/transformer/transformer.py:92-93,201): the decoder
+            # attends the score embeddings of the WINDOW, which grows by the new notes at every call -- projected keys / values live in
+            # static [max_len, .] buffers, rows are appended as the window grows (a projection is row-wise), and the captured step reads the
+            # number of valid rows from device memory (spn_dec_xattn_dyn).  ALiBi distances count from the end of the context, as the
+            # reference's cache protocol gives them.
+            n_cross = sum(1 for t in m.transformer.layer_types if t == 'c')
+            self.xk = [torch.zeros(max_len, self.kvh * 64, device=dev, dtype=F32) for _ in range(n_cross)]
+            self.xv = [torch.zeros(max_len, self.kvh * 64, device=dev, dtype=F32) for _ in range(n_cross)]
+            self.nk_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.ctx_rows = 0
         K = len(m.token_emb.embs)
         self.seq2d = torch.zeros(max_len, K, device=dev, dtype=torch.int64)
         self.masked2d = torch.zeros(max_len, K, device=dev, dtype=torch.int64)
-        self.ctx2d = torch.zeros(max_len, m.context_emb_dim, device=dev, dtype=F32) if getattr(m, "context_emb_dim", 0) else None
+        self.ctx2d = (torch.zeros(max_len, m.context_emb_dim, device=dev, dtype=F32)
+                      if (getattr(m, "context_emb_dim", 0) and not self.cross) else None)
         self.style2d = torch.zeros(max_len, m.style_emb_dim, device=dev, dtype=F32) if getattr(m, "style_emb_dim", 0) else None
         with torch.no_grad():
             self.tables = [t.detach().float().contiguous() for t in build_tables(list(m.token_emb.embs.values()))]
@@ -468,8 +505,22 @@ class RenderSession(GreedyDecoder):
 
     def reset(self):
         self.length, self.tag = 0, None
+        self.ctx_rows = 0
         for k in self.kmax2:
             k.zero_()
+
+    def _extend_context(self, context: torch.Tensor, n: int):
+        """Cross-attending decoders: keys / values of context rows ctx_rows .. n-1 (the rows of the new notes), then *nk_dev = n."""
+        if n > self.ctx_rows:
+            rows = context[self.ctx_rows:n].float().contiguous()
+            ci = 0
+            for lt, (_n, block, _r) in zip(self.m.transformer.layer_types, self.m.transformer.layers):
+                if lt == 'c':
+                    ops.gemm_f32(rows, block.to_k.weight.data, out=self.xk[ci][self.ctx_rows:n])
+                    ops.gemm_f32(rows, block.to_v.weight.data, out=self.xv[ci][self.ctx_rows:n])
+                    ci += 1
+            self.ctx_rows = n
+        self.nk_dev.fill_(n)
 
     def truncate(self, length: int):
         self.length = max(0, min(self.length, int(length)))
@@ -480,6 +531,8 @@ class RenderSession(GreedyDecoder):
         n = caches.token_emb.shape[1]
         if n > self.max_len:
             raise ValueError("caches longer than the session")
+        if self.cross:
+            raise NotImplementedError("render session: module caches of a cross-attending decoder are not adopted (re-prime note by note)")
         self.reset()
         self.tok_emb[:n].copy_(caches.token_emb[0])
         for dst, h in zip(self.hid, caches.transformer.hiddens):
@@ -569,6 +622,11 @@ class RenderSession(GreedyDecoder):
             raise ValueError("cache longer than the input window: truncate() or reset() first")
         self.seq2d[c:Lin].copy_(tokens[c:Lin], non_blocking=True)
         self.masked2d[c:Lin].copy_(masked[c:Lin], non_blocking=True)
+        if self.cross:
+            if context is None or context.shape[0] < Lin:
+                raise ValueError("render session: a cross-attending decoder needs the context rows of the whole window")
+            self._extend_context(context, Lin)
+            batched_prefill = False   # the batched re-priming pass has no cross-attention: a cropped window is re-primed note by note
         if self.ctx2d is not None:
             self.ctx2d[c:Lin].copy_(context[c:Lin])
         if self.style2d is not None:

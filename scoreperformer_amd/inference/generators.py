@@ -257,7 +257,7 @@ class ScorePerformerGenerator:
                 if caches is None:
                     session.reset()
                     have = last - 1 - n_new                                      # rows every new note can take from the caches
-                    if self.prefill == "modules" and have >= self.prefill_min:
+                    if self.prefill == "modules" and have >= self.prefill_min and not session.cross:
                         session.load_caches(self._prefill_modules(model_in[:have + 1], doubled[:have + 1], score_embs, perf_embs))
                 else:
                     session.truncate(caches.length)
@@ -329,13 +329,21 @@ class ScorePerformerGenerator:
             if seq.shape[0] - 1 - n_new != caches.token_emb.shape[1] or caches.token_emb.shape[1] == 0 \
                     or len(caches.transformer.attention) == 0:
                 caches = None
-        with torch.inference_mode():
-            out, caches = self.model.perf_decoder.unmask_tokens(
-                seq, torch.from_numpy(doubled).to(self.device),
-                context=score_embs.unsqueeze(0) if score_embs is not None else None,
-                style_embeddings=perf_embs.unsqueeze(0) if perf_embs is not None else None,
-                caches=caches if not disable_caches else None, return_caches=True, filter_logits_fn=filter_logits_fn,
-                filter_kwargs=filter_kwargs, disable_tqdm=disable_tqdm)
+        dec = self.model.perf_decoder
+        engine_flag = getattr(dec, "use_decode_engine", True)
+        # this IS the module path: a first call (caches=None) through the engine would hand engine-built caches to the module forward of
+        # the next call, which cannot continue from them
+        dec.use_decode_engine = False
+        try:
+            with torch.inference_mode():
+                out, caches = dec.unmask_tokens(
+                    seq, torch.from_numpy(doubled).to(self.device),
+                    context=score_embs.unsqueeze(0) if score_embs is not None else None,
+                    style_embeddings=perf_embs.unsqueeze(0) if perf_embs is not None else None,
+                    caches=caches if not disable_caches else None, return_caches=True, filter_logits_fn=filter_logits_fn,
+                    filter_kwargs=filter_kwargs, disable_tqdm=disable_tqdm)
+        finally:
+            dec.use_decode_engine = engine_flag
         return out[-n_new:].cpu().numpy(), caches
 
     def predict_number_of_notes(self, start_time: float = 0., time_window: float = 0.2, max_notes: int = 32):

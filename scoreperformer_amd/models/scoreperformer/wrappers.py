@@ -293,7 +293,9 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
             return None
         try:
             from ...decode import GreedyDecoder
-            return GreedyDecoder(self.model, filled.shape[1])
+            # `reference_compat` (attribute, default False): cross-attending decoders reproduce the reference's stale-hidden-row behaviour
+            # token for token (decode.GreedyDecoder; wrappers.py:364 with modules/transformer/transformer.py:201)
+            return GreedyDecoder(self.model, filled.shape[1], reference_compat=bool(getattr(self, "reference_compat", False)))
         except NotImplementedError:
             return None
 

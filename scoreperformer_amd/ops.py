@@ -962,11 +962,20 @@ def dec_attn_out(W, part, y, *, h, splits, residual=None):
     return y
 
 
-def dec_xattn(q, kctx, vctx, slopes, kmask, o, part, counter, *, h, kvh, scale, splits):
-    """Single-query cross-attention over the projected context rows (see spn_dec_xattn); kmask: uint8 [nk] or None."""
+def dec_xattn(q, kctx, vctx, slopes, kmask, o, part, counter, *, h, kvh, scale, splits, nk_dev=None):
+    """Single-query cross-attention over the projected context rows (see spn_dec_xattn); kmask: uint8 [nk] or None.
+    nk_dev: int32 device scalar with the number of valid context rows (kctx / vctx are then buffers of at least that many rows)."""
+    if nk_dev is not None:
+        call("spn_dec_xattn_dyn", ptr(q), ptr(kctx), ptr(vctx), ptr(slopes), ptr(kmask), ptr(nk_dev), ptr(o), ptr(part), ptr(counter),
+             c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
+        return o
     call("spn_dec_xattn", ptr(q), ptr(kctx), ptr(vctx), ptr(slopes), ptr(kmask), c_int(kctx.shape[0]), ptr(o), ptr(part), ptr(counter),
          c_int(h), c_int(kvh), c_float(scale), c_int(splits), stream_ptr())
     return o
+
+
+def dec_lookup(tab, pos, out):
+    call("spn_dec_lookup", ptr(tab), ptr(pos), ptr(out), stream_ptr())
 
 
 def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):

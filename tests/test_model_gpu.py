@@ -385,3 +385,78 @@ def test_decode_with_cross_attending_decoder_matches_the_oracle(dev):
     dec.use_decode_engine = False
     out_m, _ = dec.unmask_tokens(tokens.to(dev), masked.to(dev), **args)
     assert (out_m.cpu().numpy() == want).mean() > 0.97                # bf16 GEMMs: only near-ties of the top-2 logits may flip
+
+
+def _xattn_model(dev):
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    kw = dict(preset="tiny", context_emb_mode="attention", num_tokens=SMALL_VOCAB)
+    model = ScorePerformer.init(model_config(**kw))
+    sd = filled_state_dict(model, seed=4)
+    model.load_state_dict(sd)
+    ParamArena(model, dev)
+    model.eval()
+    return model, sd, model_config(**kw)
+
+
+def test_reference_compat_reproduces_the_references_cross_attention_decode_token_for_token(dev):
+    """`reference_compat=True`: the decode engine of a cross-attending decoder reads the final hidden of the row the REFERENCE reads
+    (wrappers.py:364 after the per-prefix rows of modules/transformer/transformer.py:201 have piled up in its caches) and so reproduces the
+    reference's own cached decode of tests/golden/tiny_greedy_xattn.npz -- all 39 notes x 4 predicted dims, not only the first three notes
+    that precede the defect.  (Default False: the intended row, test_decode_with_cross_attending_decoder_matches_the_oracle.)"""
+    from scoreperformer_amd.modules.sampling import top_k
+    fix = dict(np.load(os.path.join(GOLD, "tiny_greedy_xattn.npz"), allow_pickle=False))
+    model, sd, cfg = _xattn_model(dev)
+    dec = model.perf_decoder
+    tokens, masked = torch.from_numpy(fix["in/tokens"]).to(dev), torch.from_numpy(fix["in/masked_perf"]).to(dev)
+    args = dict(context=torch.from_numpy(fix["out/score_embeddings"]).to(dev), context_mask=torch.from_numpy(fix["in/score_mask"]).to(dev),
+                style_embeddings=torch.from_numpy(fix["out/perf_embeddings"]).to(dev), filter_logits_fn=top_k, filter_kwargs={"k": 1},
+                disable_tqdm=True)
+    dec.reference_compat = True
+    try:
+        out = dec.unmask_tokens(tokens, masked, **args)
+    finally:
+        dec.reference_compat = False
+    assert np.array_equal(out.cpu().numpy(), fix["out/tokens"])
+    plain = dec.unmask_tokens(tokens, masked, **args)
+    assert not np.array_equal(plain.cpu().numpy(), fix["out/tokens"])     # the default keeps the intended row
+
+
+def test_render_session_serves_cross_attending_decoders(dev):
+    """`decode.RenderSession` with context_emb_mode='attention' (inference/generators.py:230-240): the window's score embeddings are the
+    attended context and grow with every call; keys / values are appended to static buffers and the captured step reads the context
+    length from device memory.  Teacher-forced on the fixture's tokens, two notes per call, the session's predictions equal those of the
+    module path called the reference's way (`unmask_tokens` with caches cut to the known prefix and the window's context) except at
+    near-ties of the bf16 module path."""
+    from scoreperformer_amd.decode import RenderSession
+    from scoreperformer_amd.inference import ScorePerformerGenerator
+    from scoreperformer_amd.modules.sampling import top_k
+    fix = dict(np.load(os.path.join(GOLD, "tiny_greedy_xattn.npz"), allow_pickle=False))
+    model, sd, cfg = _xattn_model(dev)
+    dec = model.perf_decoder
+    dims = [3, 5, 10, 11]
+    truth = torch.from_numpy(fix["out/tokens"][0]).to(dev)                 # [40, 12]
+    masked = torch.from_numpy(fix["in/masked_perf"][0]).to(dev)
+    ctx = torch.from_numpy(fix["out/score_embeddings"][0]).to(dev)
+    sty = torch.from_numpy(fix["out/perf_embeddings"][0]).to(dev)
+    sess = RenderSession(dec.model, 64, dims)
+    assert sess.cross
+    dec.use_decode_engine = False    # the module path proper on the reference side (caches=None would otherwise go through the engine)
+    caches, agree, total, g = None, 0, 0, 2
+    for k in range(4, 38, g):
+        Lin = k + g
+        model_in = truth[:Lin].clone()
+        model_in[k:Lin, dims] = 1
+        doubled = masked[:Lin]
+        sess.truncate(k - 1)
+        got = sess.decode(model_in, doubled, ctx[:Lin], sty[:Lin], g).cpu().numpy()
+        if caches is not None:
+            caches = ScorePerformerGenerator.cut_caches(caches, right_idx=k - 1)
+        want, caches = dec.unmask_tokens(model_in, doubled, context=ctx[:Lin].unsqueeze(0), style_embeddings=sty[:Lin].unsqueeze(0),
+                                         caches=caches, return_caches=True, filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        want = want[-g:].cpu().numpy()
+        assert (got[:, [d for d in range(12) if d not in dims]] == want[:, [d for d in range(12) if d not in dims]]).all()
+        agree += int((got[:, dims] == want[:, dims]).sum()); total += g * len(dims)
+    assert sess.steps_run > 30 and agree >= 0.95 * total, (agree, total)
