@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 4: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup */
+int spn_abi_version(void); /* 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -238,6 +238,35 @@ int spn_dec_xattn_dyn(const float* q, const float* kctx, const float* vctx, cons
                       float* o, float* part, int* counter, int h, int kvh, float scale, int splits, spn_stream_t s);
 /* out[0] = tab[*pos] */
 int spn_dec_lookup(const int* tab, const int* pos, int* out, spn_stream_t s);
+
+/* One pre-norm decoder layer pair -- self-attention block + gated feed-forward block of a cached decode step
+ * (modules/transformer/transformer.py:159-221, attention.py:107-222, feedforward.py:13-64) -- as ONE persistent launch of spn_dec_pair_groups() workgroups
+ * whose five phases hand their vectors over inside the launch (8-byte {epoch, value} granules, agent-scope stores and polls:
+ * csrc/decode_layer.hip).  Same arithmetic and association order as spn_dec_fused_gemv + spn_dec_attn2 + spn_dec_attn_out +
+ * spn_dec_fused_gemv(glu) + spn_dec_fused_gemv: x leaves bit-identical.  The granule buffers must be zeroed once per render; `tick`
+ * (device int, advanced by the launch with bump = 1: the LAST pair of a note) makes the epochs unique; *err != 0 after a launch means a
+ * hand-off timed out (the launch never hangs; results are then garbage). */
+typedef struct spn_dec_pair_args {
+    const float* Wqkv; long ld_qkv;            /* [(h + 2 kvh) * 64, d]: q | k | v rows */
+    const float* Wo; long ld_o;                /* [d, h * 64] */
+    const float* W1; long ld_1; const float* b1;   /* [2 * inner, d]: value rows, then gate rows; bias [2 * inner] or null */
+    const float* W2; long ld_2; const float* b2;   /* [d, inner]; bias [d] or null */
+    const float* slopes;                       /* [h] ALiBi slopes or null */
+    float* kcache; float* vcache; float* kmax2;    /* [L, kvh * 64] x 2, running max |k|^2 [kvh] */
+    int norm1; const float* gam1; const float* bet1; float eps1;   /* 1 = LayerNorm(gamma, beta; null = plain), 2 = adaptive row (gamma | beta) */
+    int norm2; const float* gam2; const float* bet2; float eps2;
+    float* x;                                  /* [d] residual stream, in and out */
+    float* y2; long y2_ld;                     /* null, or the hidden-cache mirror: y2[*pos * y2_ld + n] = x[n] */
+    int d, h, kvh, inner, S, act;              /* S = key splits (<= 16), act 0 = SiLU, 1 = GELU */
+    float scale;
+    const int* pos; int* tick; int layer, bump;
+    unsigned long long* gq; unsigned long long* gp; unsigned long long* go; unsigned long long* gx; unsigned long long* gg;
+                                               /* granules: (h + 2 kvh) * 64, h * S * 66, h * 64, d, inner */
+    int* err;
+    long long* stamps;                         /* null, or [groups][8] constant-clock (100 MHz) time stamps after each phase: tuning aid */
+} spn_dec_pair_args;
+int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S); /* workgroups of the launch for this shape; 0 = not supported */
+int spn_dec_pair(const spn_dec_pair_args* args, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,

@@ -30,7 +30,9 @@ def _digest(src):
     """Content hash of everything an object depends on: compiler flags, the source and every header of csrc/ (a stale object --
     older flags, a reverted header with an older mtime -- is rebuilt, not reused)."""
     h = hashlib.sha256(" ".join([HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])).encode())
-    for path in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")):
+    inc = os.path.join(HERE, "..", "include")   # include/spn.h: csrc/decode_layer.hip takes its argument struct from the C-ABI header
+    for path in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
+            sorted(os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")):
         with open(path, "rb") as fh:
             h.update(path.encode() + b"\0" + fh.read())
     return h.hexdigest()

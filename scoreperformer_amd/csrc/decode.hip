@@ -13,6 +13,11 @@
 // exact near-ties.
 #include "common.h"
 
+// No floating-point contraction in this file: whether `a * b + c` becomes one fused operation or two is otherwise the optimiser's choice per
+// call site (packed multiplies + adds in one loop, fused multiply-adds in its twin), and the persistent layer launch
+// (decode_layer.hip, same pragma) must reproduce these kernels' residual stream BIT FOR BIT.  The step is latency-bound: no cost.
+#pragma clang fp contract(off)
+
 namespace {
 
 // y[n] = act( sum_k W[n*ldw + k] * x[k] + bias[n] ) + residual[n];  one wave per output row, 4 rows per block

@@ -1,0 +1,455 @@
+// One decoder layer pair (self-attention block + feed-forward block) of a cached decode step as ONE persistent launch.
+//
+// The graph engine (decode.hip, decode.py::_step_fused) runs such a pair as five dependent launches: LayerNorm + q|k|v GEMV, split-key
+// attention, output projection (+ merge of the split partials, + residual), LayerNorm + gated input projection, output projection
+// (+ residual).  Every one of them is a chain "kernel boundary -> input vector from memory -> a few hundred bytes of arithmetic per lane
+// -> store": ~6 us each at batch 1, whatever the arithmetic.  Here the five phases live in one launch of G workgroups (512 threads,
+// one per CU) and hand their vectors over INSIDE the launch:
+//   * the data is the flag: every value travels as one naturally aligned 8-byte granule {tag = epoch, fp32 bits}, written by ONE
+//     agent-scope (write-through, `sc1`) store and polled with agent-scope loads until every tag a workgroup needs carries the epoch of
+//     this phase of this note -- no fences, no counters, no barrier (cdna_hip_programming.md Guideline 16, form R2);
+//   * weight rows do not depend on the hand-off: every wave requests the rows of its NEXT phase before it starts polling, so the
+//     weight stream runs under the hop instead of behind it;
+//   * epoch = tick * 256 + 8 * layer + phase + 1 with `tick` a device counter that the last pair launch of a note advances: tags never
+//     repeat within a render (the host zeroes the granule buffers when a render starts), also when a session re-decodes a position.
+// Arithmetic, association order and rounding are those of the five kernels it replaces (one wave per output row, lanes own
+// k = 4 lane + 256 c; LayerNorm partial sums per thread of the first four waves; the split-key online softmax of dec_attn2_kernel with
+// 16 lane groups per split; the 16-record merge of dec_fused_gemv_kernel's prologue): the residual stream leaves bit-identical.
+// Every poll loop is bounded: a workgroup that never sees its tags sets *err and stops polling (the launch completes with garbage and
+// the host raises), it never hangs the device.
+//
+// Replaces (per note) the layer body of `ScorePerformerMixedLMWrapper.unmask_tokens` (wrappers.py:325-407 ->
+// modules/transformer/transformer.py:159-221, attention.py:107-222, feedforward.py:13-64) for pre-norm ('a', 'f') decoders.
+#include "common.h"
+#include "../../include/spn.h"   // spn_dec_pair_args
+
+#pragma clang fp contract(off)   // as decode.hip: the same source expression must round the same way in both files
+
+namespace {
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int NT = 512, NW = 8;                 // threads / waves per workgroup
+constexpr unsigned SPIN_LIMIT = 1u << 18;        // polls per hand-off before giving up (~0.3 s)
+
+__device__ __forceinline__ gu64* as_global(unsigned long long* p) { return (gu64*)(uintptr_t)p; }
+
+__device__ __forceinline__ void put(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store(as_global(g), ((unsigned long long)epoch << 32) | __float_as_uint(v), RLX_AGENT);
+}
+
+// Hand-off read: thread tid polls the granules idx = tid + 512 k < n (k < 4) until each carries `epoch`, then leaves the values in
+// xs[idx].  One load per lane and pass at n <= 512: measured against one polling wave per workgroup with 8 loads per lane (fewer
+// pollers on the hot lines, but every pass is 8 serial sc1 loads long: the hops were 1-2 us SLOWER).
+__device__ __forceinline__ void gather(unsigned long long* g, int n, unsigned epoch, float* xs, int tid, int* err) {
+    unsigned v[4] = {0u, 0u, 0u, 0u};
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + NT * k;
+            if (idx < n) {
+                const unsigned long long x = __hip_atomic_load(as_global(g + idx), RLX_AGENT);
+                v[k] = (unsigned)x;
+                ok &= (unsigned)(x >> 32) == epoch;
+            }
+        }
+        if (ok) break;
+        if (++spins > SPIN_LIMIT) { *err = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + NT * k;
+        if (idx < n) xs[idx] = __uint_as_float(v[k]);
+    }
+}
+
+// Hand-off write of a workgroup's 16 consecutive outputs (two per wave, staged in outv by lane 0 of every wave): ONE store instruction,
+// 16 lanes x 8 bytes = one whole 128-byte line.  (One 8-byte store per wave made 16 partial writes of every line: the fabric serialises
+// them, and the hop behind 512 such stores took 4.5 us instead of ~1.5.)
+__device__ __forceinline__ void publish16(unsigned long long* g, int n0, int n, unsigned epoch, const float* outv, int tid) {
+    __syncthreads();
+    if (tid < 16 && n0 + tid < n) put(g + n0 + tid, epoch, outv[tid]);
+}
+
+__device__ __forceinline__ float pair_act(float g, int act) {
+    return act == 0 ? g / (1.f + __expf(-g)) : 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+}
+
+// the affine parameters of a pre-norm for this thread's entries k = tid, tid + 256 (K <= 512), requested when the launch starts: read
+// behind the statistics they were a dependent trip to memory (1.5-2 us: the adaptive (gamma | beta) row is written earlier in the same note)
+struct NormRegs { float g[2], b[2]; };
+__device__ __forceinline__ NormRegs norm_regs(int K, int mode, const float* gam, const float* bet, int tid) {
+    NormRegs r;
+    const float* be = mode == 2 ? gam + K : bet;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int k = tid + 256 * i;
+        const bool in = tid < 256 && k < K && gam != nullptr;
+        r.g[i] = in ? gam[k] : 1.f;
+        r.b[i] = in ? be[k] : 0.f;
+    }
+    return r;
+}
+
+// LayerNorm of xs[0 .. K) in place, the arithmetic of dec_fused_gemv_kernel (256 threads own k = tid, tid + 256)
+__device__ __forceinline__ void block_norm(float* xs, float* red, int K, bool affine, const NormRegs& nr, float eps, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    float s = 0.f;
+    if (tid < 256) for (int k = tid; k < K; k += 256) s += xs[k];
+    s = wave_sum(s);
+    if (tid < 256 && lane == 0) red[w] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+    float q2 = 0.f;
+    if (tid < 256) for (int k = tid; k < K; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+    q2 = wave_sum(q2);
+    if (tid < 256 && lane == 0) red[4 + w] = q2;
+    __syncthreads();
+    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)K + eps);
+    if (tid < 256) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = tid + 256 * i;
+            if (k < K) {
+                float v = (xs[k] - mu) * rs;
+                if (affine) v = v * nr.g[i] + nr.b[i];
+                xs[k] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// one weight row in registers: lane owns k = 4 lane + 256 c
+template <int C>
+__device__ __forceinline__ void load_row(f32x4 (&r)[C], const float* w, int K, int lane) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int k = lane * 4 + c * 256;
+        r[c] = k < K ? *reinterpret_cast<const f32x4*>(w + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// R rows against the vector in LDS: the vector's chunks are read ONCE for all rows and every step is branch-free (a row-by-row loop with
+// an exec-masked branch per chunk cost ~190 ns per row: 3.1 us for the 16 products of a feed-forward wave).  Per row the expression is the
+// one of dec_fused_gemv_kernel: chunks ascending, ((p0 + p1) + p2) + p3 added to the running sum, then the DPP ladder of wave_sum.
+template <int C, int R>
+__device__ __forceinline__ void dot_rows(const f32x4 (&r)[R][C], const float* xs, int K, int lane, float (&out)[R]) {
+    f32x4 xv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int k = lane * 4 + c * 256;
+        xv[c] = *reinterpret_cast<const f32x4*>(xs + min(k, 2044));
+    }
+    float acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        acc[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int k = lane * 4 + c * 256;
+            const float t = r[i][c][0] * xv[c][0] + r[i][c][1] * xv[c][1] + r[i][c][2] * xv[c][2] + r[i][c][3] * xv[c][3];
+            acc[i] = k < K ? acc[i] + t : acc[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) out[i] = wave_sum(acc[i]);
+}
+
+// Roles.  Workgroups 0 .. h S - 1 ("A") own the phases every one of which is wide: q|k|v rows (the first ceil(N1 / 16) of them), one
+// (head, split) of the attention each, and 16 gated feed-forward rows each.  Workgroups h S .. h S + ceil(d / 16) - 1 ("B") own the
+// d-row phases: the merge of a head's partials (the first h of them), the attention output projection and the feed-forward output
+// projection, 16 rows each.  The last ceil(inner / 32) workgroups ("C") own the gated feed-forward rows, 32 each.  Every weight row a workgroup will ever need is requested when the launch STARTS, in the order of use: loads
+// return in order, so a request in front of a poll would hold every pass of that poll back by a trip to HBM -- with the roles split this
+// way no workgroup has anything in flight when it polls, and its weights have landed long before its inputs do.
+__global__ __launch_bounds__(NT) void dec_pair_kernel(spn_dec_pair_args a) {
+    __shared__ __attribute__((aligned(16))) float xs[2048];
+    __shared__ float red[8];
+    __shared__ float sm[16], sl[16];
+    __shared__ __attribute__((aligned(16))) float so[16][64];
+    __shared__ __attribute__((aligned(16))) float qs[192];
+    __shared__ float outv[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int d = a.d, h = a.h, kvh = a.kvh, S = a.S, inner = a.inner;
+    // (position, tick and error word are requested here and first USED behind the weight requests of the role: read up front, the error
+    // check alone held every workgroup's first weight load back by a trip to memory)
+    const int err_in = *a.err;
+#define STAMP(k_) do { if (a.stamps && tid == 0) a.stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    STAMP(0);
+    const int t = *a.pos;
+    const unsigned e0 = (unsigned)(*a.tick) * 256u + 8u * (unsigned)a.layer + 1u;   // layer < 32
+    const int N1 = (h + 2 * kvh) * 64;
+    const int nA = h * S;
+
+    if (b < nA) {
+        // ================================================ A: q|k|v rows, attention split, gated rows ===================================
+        const int r0 = b * 16 + 2 * w;                      // this wave's rows of a phase: r0, r0 + 1
+        const bool own1 = b * 16 < N1;
+        f32x4 wq[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wq[i][0] = wq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + i < N1) load_row<2>(wq[i], a.Wqkv + (long)(r0 + i) * a.ld_qkv, d, lane);
+        }
+        if (own1) for (int k = tid; k < d; k += NT) xs[k] = a.x[k];
+        const NormRegs n1 = norm_regs(d, a.norm1, a.gam1, a.bet1, tid);
+        if (err_in) return;   // an earlier launch of this render timed out: do not wait again
+        // ---- phase 1: q | k | v = Wqkv . LN(x) ----------------------------------------------------------------------------------------
+        if (own1) {
+            __syncthreads();
+            block_norm(xs, red, d, a.gam1 != nullptr, n1, a.eps1, tid);
+            float y[2];
+            dot_rows<2, 2>(wq, xs, d, lane, y);
+            if (lane == 0) { outv[2 * w] = y[0]; outv[2 * w + 1] = y[1]; }
+            publish16(a.gq, b * 16, N1, e0, outv, tid);
+        }
+        STAMP(1);
+        // ---- phase 2: split-key attention of (head hi, split sp) --------------------------------------------------------------------------
+        const int hi = b / S, sp = b - hi * S;
+        const int kh = kvh == 1 ? 0 : hi;
+        const long cw = (long)kvh * 64;
+        __syncthreads();
+        if (tid < 192) {   // q of the head, new key, new value: 3 x 64 granules
+            const int part = tid >> 6;
+            const int idx = (part == 0 ? hi * 64 : (part == 1 ? h * 64 + kh * 64 : h * 64 + kvh * 64 + kh * 64)) + lane;
+            unsigned v = 0, spins = 0;
+            for (;;) {
+                const unsigned long long x = __hip_atomic_load(as_global(a.gq + idx), RLX_AGENT);
+                v = (unsigned)x;
+                if ((unsigned)(x >> 32) == e0) break;
+                if (++spins > SPIN_LIMIT) { *a.err = 2; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            qs[tid] = __uint_as_float(v);
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int grp = lane >> 4, l16 = lane & 15;
+            const float* knew = qs + 64;
+            const float* vnew = qs + 128;
+            float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
+            kn2 = wave_sum(kn2); qn2 = wave_sum(qn2);
+            if (sp == 0 && w == 0) {
+                a.kcache[t * cw + kh * 64 + lane] = knew[lane];
+                a.vcache[t * cw + kh * 64 + lane] = vnew[lane];
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.kmax2 + kh), __float_as_uint(kn2));
+            }
+            const float slope = a.slopes ? a.slopes[hi] : 0.f;
+            int j_lo = 0;
+            if (slope > 0.f) {
+                const float km = fmaxf(a.kmax2[kh], kn2);
+                const float reach = (104.f + 2.f * a.scale * sqrtf(qn2 * km)) / slope;
+                if (reach < (float)t) j_lo = t - (int)reach - 1;
+            }
+            const int total = t + 1 - j_lo;
+            const int chunk = (total + S - 1) / S;
+            const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + l16 * 4) * a.scale;
+            float m = -INFINITY, l = 0.f;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the rows of up to 16 keys per lane group (= 256 keys per workgroup: the whole split at L <= 4096) are requested TOGETHER: one trip
+            // to the Infinity Cache instead of four; the arithmetic runs in the order of dec_attn2_kernel's loop (jb ascending, then u)
+            for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
+                f32x4 k4[16], v4[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = min(jb0 + 16 * u, j1 - 1);
+                    if (j == t) {
+                        k4[u] = *reinterpret_cast<const f32x4*>(knew + l16 * 4);
+                        v4[u] = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
+                    } else {
+                        k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + j * cw + kh * 64 + l16 * 4);
+                        v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + j * cw + kh * 64 + l16 * 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int j = jb0 + 16 * u;
+                    if (j < j1) {
+                        float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+                        sc = row16_sum(sc);
+                        sc -= slope * (float)(t - j);
+                        const float m_new = fmaxf(m, sc);
+                        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
+                        l = l * alpha + pj;
+                        acc = acc * alpha + v4[u] * pj;
+                        m = m_new;
+                    }
+                }
+            }
+            const int gi = w * 4 + grp;
+            if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
+            *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+        }
+        __syncthreads();
+        if (tid < 66) {
+            float mm = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
+            float num = 0.f, den = 0.f;
+            const int col = min(tid, 63);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
+                num += so[q][col] * f; den += sl[q] * f;
+            }
+            // record (max, normaliser, 64 weighted value sums): lanes 0-63 of wave 0 store the sums, lanes 0-1 of wave 1 the two scalars
+            unsigned long long* mine = a.gp + ((long)hi * S + sp) * 66;
+            put(mine + (tid < 64 ? 2 + tid : tid - 64), e0 + 1, tid < 64 ? num : (tid == 64 ? mm : den));
+        }
+        STAMP(2);
+        return;
+    }
+    const int nB = (d + 15) / 16;
+    if (b >= nA + nB) {
+        // ================================================ C: gated feed-forward rows =======================================================
+        // 32 rows per workgroup (4 per wave: value + gate rows, requested at the start), so that only ceil(inner / 32) workgroups poll the
+        // x1 lines: with all h S attention workgroups polling them this hop took 3.4-4.5 us, with 32-64 pollers ~1 us.  (64 rows per
+        // workgroup: 16 wave reductions per wave, 2.5 us of issue time on the critical path.)
+        const int bc = b - nA - nB;
+        const int r0 = bc * 32 + 4 * w;
+        f32x4 w1v[4][2], w1g[4][2];
+        float b1v[4], b1g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w1v[i][0] = w1v[i][1] = w1g[i][0] = w1g[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            b1v[i] = b1g[i] = 0.f;
+            if (r0 + i < inner) {
+                load_row<2>(w1v[i], a.W1 + (long)(r0 + i) * a.ld_1, d, lane);
+                load_row<2>(w1g[i], a.W1 + (long)(r0 + i + inner) * a.ld_1, d, lane);
+                if (a.b1) { b1v[i] = a.b1[r0 + i]; b1g[i] = a.b1[r0 + i + inner]; }
+            }
+        }
+        const NormRegs n2 = norm_regs(d, a.norm2, a.gam2, a.bet2, tid);
+        if (err_in) return;
+        STAMP(1);
+        gather(a.gx, d, e0 + 3, xs, tid, a.err);
+        __syncthreads();
+        STAMP(2);
+        block_norm(xs, red, d, a.gam2 != nullptr, n2, a.eps2, tid);
+        STAMP(3);
+        float* outc = &so[0][0];   // 32 results of the workgroup
+        float accv[4], accg[4];
+        dot_rows<2, 4>(w1v, xs, d, lane, accv);
+        dot_rows<2, 4>(w1g, xs, d, lane, accg);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = accv[i], ag = accg[i];
+            if (a.b1) { acc += b1v[i]; ag += b1g[i]; }
+            if (lane == 0) outc[4 * w + i] = acc * pair_act(ag, a.act);
+        }
+        STAMP(4);
+        __syncthreads();
+        if (tid < 32 && bc * 32 + tid < inner) put(a.gg + bc * 32 + tid, e0 + 4, outc[tid]);   // one store instruction: 2 whole lines
+        STAMP(5);
+        return;
+    }
+    // ==================================================== B: merge, output projections ====================================================
+    const int bb = b - nA;
+    const int r0 = bb * 16 + 2 * w;
+    f32x4 wo[2][2], w2[2][8];
+    float res0[2] = {0.f, 0.f}, b2v[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        wo[i][0] = wo[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r0 + i < d) { load_row<2>(wo[i], a.Wo + (long)(r0 + i) * a.ld_o, h * 64, lane); res0[i] = a.x[r0 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w2[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r0 + i < d) { load_row<8>(w2[i], a.W2 + (long)(r0 + i) * a.ld_2, inner, lane); if (a.b2) b2v[i] = a.b2[r0 + i]; }
+    }
+    if (err_in) return;
+    // ---- phase 2b: the first h of these workgroups merge the S partials of head bb -------------------------------------------------------
+    if (bb < h) {
+        gather(a.gp + (long)bb * S * 66, S * 66, e0 + 1, xs, tid, a.err);     // S <= 16: 1056 granules
+        __syncthreads();
+        if (tid < 64) {
+            const int dcol = 2 + tid;
+            float mv[16], lv[16], nv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool in = q < S;
+                mv[q] = in ? xs[q * 66] : -INFINITY;
+                lv[q] = in ? xs[q * 66 + 1] : 0.f;
+                nv[q] = in ? xs[q * 66 + dcol] : 0.f;
+            }
+            float mm = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < S) {
+                    const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
+                    num += nv[q] * f; den += lv[q] * f;
+                }
+            }
+            put(a.go + bb * 64 + tid, e0 + 2, num / den);
+        }
+        __syncthreads();
+    }
+    STAMP(3);
+    // ---- phase 3: x1 = x + Wo . o ----------------------------------------------------------------------------------------------------------
+    float x1[2];
+    gather(a.go, h * 64, e0 + 2, xs, tid, a.err);
+    __syncthreads();
+    dot_rows<2, 2>(wo, xs, h * 64, lane, x1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        x1[i] = x1[i] + res0[i];
+        if (lane == 0) outv[2 * w + i] = x1[i];
+    }
+    publish16(a.gx, bb * 16, d, e0 + 3, outv, tid);
+    STAMP(4);
+    // ---- phase 5: x = x1 + W2 . g + b2 -------------------------------------------------------------------------------------------------------
+    __syncthreads();
+    gather(a.gg, inner, e0 + 4, xs, tid, a.err);
+    __syncthreads();
+    float y5[2];
+    dot_rows<8, 2>(w2, xs, inner, lane, y5);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float acc = y5[i];
+        if (lane == 0 && r0 + i < d) {
+            if (a.b2) acc += b2v[i];
+            acc += x1[i];
+            a.x[r0 + i] = acc;
+            if (a.y2) a.y2[(long)t * a.y2_ld + r0 + i] = acc;
+        }
+    }
+    STAMP(6);
+    // Everybody has read the tick by now: this workgroup's inputs needed every A workgroup's gated rows, those needed every B workgroup's
+    // x1 rows, and every workgroup reads the tick before its first phase.
+    if (a.bump && bb == 0 && tid == 0) *a.tick = *a.tick + 1;
+}
+
+}  // namespace
+
+// number of workgroups the launch uses for this shape (h S attention + ceil(d / 16) projection + ceil(inner / 32) feed-forward
+// workgroups: all resident at once, one per CU), 0 = shape not supported
+extern "C" int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S) {
+    if (!(d % 4 == 0 && d >= 64 && d <= 512 && h >= 1 && h * 64 <= 512 && inner % 4 == 0 && inner >= 16 && inner <= 2048 && S >= 1 && S <= 16 &&
+          (kvh == 1 || kvh == h)))
+        return 0;
+    const int nA = h * S, nB = (d + 15) / 16, nC = (inner + 31) / 32, N1 = (h + 2 * kvh) * 64;
+    if ((N1 + 15) / 16 > nA || h > nB || nA + nB + nC > 256) return 0;
+    return nA + nB + nC;
+}
+
+extern "C" int spn_dec_pair(const spn_dec_pair_args* args, hipStream_t s) {
+    SPN_REQUIRE(args, "spn_dec_pair: null argument");
+    const spn_dec_pair_args& a = *args;
+    const int G = spn_dec_pair_groups(a.d, a.h, a.kvh, a.inner, a.S);
+    SPN_REQUIRE(G > 0, "spn_dec_pair: shape not supported (spn_dec_pair_groups)");
+    SPN_REQUIRE(a.Wqkv && a.Wo && a.W1 && a.W2 && a.x && a.kcache && a.vcache && a.kmax2 && a.pos && a.tick && a.err && a.gq && a.gp && a.go &&
+                a.gx && a.gg, "spn_dec_pair: null operand");
+    SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pair: weight rows must be 16-byte aligned");
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, a);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}

@@ -40,6 +40,9 @@ class GreedyDecoder:
         self.head_slabs = int(os.environ.get("SPN_DEC_HEAD_SLABS", 8))
         self.legacy_launches = os.environ.get("SPN_DEC_LEGACY", "0") == "1"   # A/B aid: round-1 launch list (separate embed / merge kernels)
         self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
+        # one persistent launch per ('a', 'f') layer pair instead of five (csrc/decode_layer.hip)
+        self.use_pair = os.environ.get("SPN_DEC_PAIR", "1") != "0"
+        self.pair_groups = 0       # workgroups of that launch (0: shape not supported, the five launches run)
         tr = m.transformer
         types = tuple(tr.layer_types)
         self.cross = 'c' in types
@@ -59,6 +62,7 @@ class GreedyDecoder:
 
     # -- buffers -------------------------------------------------------------------------------------------
     def _alloc(self, L):
+        import os
         m, dev, d = self.m, self.dev, self.dim
         te = m.token_emb
         z = lambda *s: torch.zeros(*s, device=dev, dtype=F32)
@@ -102,6 +106,15 @@ class GreedyDecoder:
         self.head_logits = z(16, 1024)
         self.seed_dev = torch.zeros(1, device=dev, dtype=torch.int32)
         self.kmax2 = [z(self.kvh) for _ in range(n_self)]
+        if self.use_pair:
+            self.pair_groups = ops.dec_pair_groups(d, self.heads, self.kvh, self.g.numel(), S)
+        if self.pair_groups:   # hand-off granules of the persistent layer-pair launch ({epoch, value} words: zero = no epoch)
+            zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
+            self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()))
+            self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
+            self.pair_stamps = ([torch.zeros(self.pair_groups * 8, device=dev, dtype=torch.int64) for _ in range(n_self)]
+                                if os.environ.get("SPN_DEC_PAIR_STAMPS", "0") == "1" else None)   # tuning aid (tools/bench_dec_pair.py)
         tr = m.transformer
         self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
         self.ada_rows = {}
@@ -308,8 +321,31 @@ class GreedyDecoder:
                 ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
         ai = ci = 0
         n_layers = len(tr.layers)
+        pairs = self._pair_plan() if self.pair_groups else {}
+        skip = False
         for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
+            if skip:
+                skip = False
+                continue
             mode, g_, b_, eps_ = self._norm_args(norms[0])
+            if li in pairs:
+                fnorms, ff, _ = tr.layers[li + 1]
+                m2, g2, b2_, e2 = self._norm_args(fnorms[0])
+                lin, out = ff.ff[0].proj, ff.ff[3]
+                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
+                nxt_attn = li + 2 < n_layers
+                ops.dec_pair(Wqkv=wqkv, ld_qkv=wqkv.stride(0), Wo=block.to_out.weight.data, ld_o=block.to_out.weight.stride(0),
+                             W1=lin.weight.data, ld_1=lin.weight.stride(0), b1=lin.bias.data if lin.bias is not None else None,
+                             W2=out.weight.data, ld_2=out.weight.stride(0), b2=out.bias.data if out.bias is not None else None,
+                             slopes=self._slopes(block), kcache=self.kc[ai], vcache=self.vc[ai], kmax2=self.kmax2[ai],
+                             norm1=mode, gam1=g_, bet1=b_, eps1=eps_, norm2=m2, gam2=g2, bet2=b2_, eps2=e2, x=self.x,
+                             y2=self.hid[ai + 1] if nxt_attn else None, y2_ld=d if nxt_attn else 0, d=d, h=self.heads, kvh=self.kvh,
+                             inner=self.g.numel(), S=self.attn_splits, act=ff.act_code, scale=block.scale, pos=pos, tick=self.pair_tick,
+                             layer=pairs[li][0], bump=pairs[li][1], err=self.pair_err,
+                             stamps=self.pair_stamps[ai] if self.pair_stamps is not None else None, **self.pair_g)
+                ai += 1
+                skip = True
+                continue
             if lt == 'c':
                 self._cross_layer(ci, norms[0], block, True)
                 ci += 1
@@ -365,6 +401,27 @@ class GreedyDecoder:
         ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
         self._head_tail(dims)
 
+    def _pair_plan(self):
+        """{index of an 'a' layer that runs with the following 'f' layer as one persistent launch: (pair number, last pair of the note)}"""
+        tr = self.m.transformer
+        types, plan = list(tr.layer_types), {}
+        for li in range(len(types) - 1):
+            if types[li] != 'a' or types[li + 1] != 'f':
+                continue
+            ff = tr.layers[li + 1][1]
+            if not ff.glu or isinstance(ff.ff[1], nn.LayerNorm) or ff.act_code not in (0, 1):
+                continue
+            if len(plan) >= 32:
+                continue
+            plan[li] = [len(plan), 0]
+        if plan:
+            plan[max(plan)][1] = 1
+        return plan
+
+    def _pair_check(self):
+        if self.pair_groups and int(self.pair_err.item()):
+            raise RuntimeError(f"decode engine: a hand-off of the persistent layer launch timed out (code {int(self.pair_err.item())})")
+
     # -- public ----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, tokens: torch.Tensor, tokens_masked: torch.Tensor, context: Optional[torch.Tensor],
@@ -406,6 +463,7 @@ class GreedyDecoder:
         if self.use_graph and n_steps > 2:
             step(dims)                              # warm-up (also position 0), eager
             torch.cuda.synchronize()
+            self._pair_check()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 step(dims)                          # recorded, not executed; every replay reads *pos on the device
@@ -416,6 +474,7 @@ class GreedyDecoder:
             for _ in range(n_steps):
                 step(dims)
         self.n_steps = n_steps
+        self._pair_check()
         return self.seq2d[None], n_steps
 
     def caches(self):

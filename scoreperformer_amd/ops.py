@@ -978,6 +978,36 @@ def dec_lookup(tab, pos, out):
     call("spn_dec_lookup", ptr(tab), ptr(pos), ptr(out), stream_ptr())
 
 
+class DecPairArgs(ctypes.Structure):
+    """include/spn.h: spn_dec_pair_args (field for field)."""
+    _P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+    _fields_ = [("Wqkv", _P), ("ld_qkv", _L), ("Wo", _P), ("ld_o", _L), ("W1", _P), ("ld_1", _L), ("b1", _P), ("W2", _P), ("ld_2", _L), ("b2", _P),
+                ("slopes", _P), ("kcache", _P), ("vcache", _P), ("kmax2", _P),
+                ("norm1", _I), ("gam1", _P), ("bet1", _P), ("eps1", _F), ("norm2", _I), ("gam2", _P), ("bet2", _P), ("eps2", _F),
+                ("x", _P), ("y2", _P), ("y2_ld", _L), ("d", _I), ("h", _I), ("kvh", _I), ("inner", _I), ("S", _I), ("act", _I), ("scale", _F),
+                ("pos", _P), ("tick", _P), ("layer", _I), ("bump", _I), ("gq", _P), ("gp", _P), ("go", _P), ("gx", _P), ("gg", _P), ("err", _P), ("stamps", _P)]
+
+
+def dec_pair_groups(d, h, kvh, inner, S) -> int:
+    """Workgroups of the persistent layer-pair launch for this shape; 0 = the shape is not supported (run the five launches)."""
+    return int(load().spn_dec_pair_groups(int(d), int(h), int(kvh), int(inner), int(S)))
+
+
+def dec_pair(**kw):
+    """One decoder layer pair (attention block + gated feed-forward) as one persistent launch: spn_dec_pair.  Keyword arguments = the
+    fields of spn_dec_pair_args; tensors are passed as tensors (None = null)."""
+    a = DecPairArgs()
+    for name, ctype in DecPairArgs._fields_:
+        v = kw.pop(name, None)
+        if ctype is ctypes.c_void_p:
+            setattr(a, name, None if v is None else v.data_ptr())
+        else:
+            setattr(a, name, v if v is not None else 0)
+    if kw:
+        raise SpnError(f"dec_pair: unknown fields {sorted(kw)}")
+    call("spn_dec_pair", ctypes.byref(a), stream_ptr())
+
+
 def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):
     """`pos_next`: int32 device scalar that receives position + 1 (the launch that closes a fused step, see `dec_step_begin`)."""
     V = [t.shape[0] for t in tables]

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(handle, s)]
     assert not missing, missing
-    assert handle.spn_abi_version() == 4
+    assert handle.spn_abi_version() == 5
 
 
 def test_python_bindings_call_only_declared_symbols():
@@ -88,3 +88,16 @@ def test_gemm_workspace_query_is_pure():
     need = q(4096, 512, 131072, 1 | 2 | 4 | 8)
     assert need > 0 and need % (4096 * 512 * 4) == 0
     assert q(512, 2048, 131072, 1 | 2 | 4) > 0
+
+
+def test_dec_pair_groups_is_a_host_function():
+    """spn_dec_pair_groups (include/spn.h): workgroups of the persistent decoder layer-pair launch -- h * S attention + ceil(d / 16)
+    projection + ceil(inner / 32) feed-forward workgroups, all resident at once (<= 256 CUs); 0 for shapes the launch does not take."""
+    from scoreperformer_amd import build, lib
+    build.build()
+    handle = ctypes.CDLL(lib.LIB_PATH)
+    assert handle.spn_dec_pair_groups(512, 8, 1, 2048, 16) == 128 + 32 + 64     # C5 decoder
+    assert handle.spn_dec_pair_groups(512, 8, 8, 2048, 16) == 224               # multi-head keys / values
+    assert handle.spn_dec_pair_groups(128, 2, 1, 512, 16) == 32 + 8 + 16
+    assert handle.spn_dec_pair_groups(1024, 16, 1, 4096, 16) == 0               # wider than the kernel's register plan
+    assert handle.spn_dec_pair_groups(512, 8, 1, 2048, 32) == 0                 # more splits than the merge holds

@@ -1,0 +1,89 @@
+"""GPU: the persistent layer-pair launch of the decode engine (csrc/decode_layer.hip: one launch per pre-norm ('a', 'f') decoder layer pair,
+five phases handed over inside the launch through {epoch, value} granules) against the five launches it replaces.
+
+Same arithmetic, association order and rounding by construction (both files compile without floating-point contraction), so the
+comparison is EXACT: greedy tokens, every cached hidden row, every cached key / value row.  The five-launch engine itself is pinned to
+the reference's tokens and to the CPU oracle elsewhere (tests/test_model_gpu.py, tests/test_c5_decode_gpu.py: those tests run the pair
+launch, which is the default).  Reference path: models/scoreperformer/wrappers.py:325-407 -> modules/transformer/transformer.py:159-221.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(dev, preset, L, monkeypatch, **cfg_kw):
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import GreedyDecoder
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    torch.manual_seed(3)
+    model = ScorePerformer.init(model_config(preset, max_seq_len=L, **cfg_kw))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=11, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    tokens = batch["masked_perf"].clone()
+    tokens[:, 0] = batch["perf"][:, 0]
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPN_DEC_PAIR", flag)
+        eng = GreedyDecoder(model.perf_decoder.model, L)
+        toks, n = eng.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
+        torch.cuda.synchronize()
+        out.append((eng, toks.clone(), n))
+    return out
+
+
+@pytest.mark.parametrize("preset,L,kw", [("tiny", 200, {}), ("tiny", 96, {"one_kv_head": False}), ("c5", 700, {})])
+def test_pair_launch_equals_the_five_launches_bit_for_bit(dev, monkeypatch, preset, L, kw):
+    (e0, t0, n0), (e1, t1, n1) = _engines(dev, preset, L, monkeypatch, **kw)
+    assert e0.pair_groups == 0 and e1.pair_groups > 0, (e0.pair_groups, e1.pair_groups)
+    assert len(e1._pair_plan()) == len(e1.kc)                      # every layer pair runs as one launch
+    assert n0 == n1 == L - 1 and int(e1.pair_err.item()) == 0
+    assert torch.equal(t0, t1)
+    for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
+        assert torch.equal(a[:n1], b[:n1])
+    assert int(e1.pair_tick.item()) == n1                          # one epoch per decoded note
+
+
+def test_pair_launch_serves_a_render_session_that_revisits_positions(dev, monkeypatch):
+    """A RenderSession truncates and re-decodes positions (the generator's sliding window): the epoch counter keeps counting, so the tags of
+    a re-decoded position never equal those left by its first visit.  Tokens equal the five-launch session's."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import RenderSession
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import PREDICTED_DIMS, model_config, synthetic_batch
+    L = 120
+    torch.manual_seed(5)
+    model = ScorePerformer.init(model_config("tiny", max_seq_len=L))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=13, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    truth, masked = batch["perf"][0], batch["masked_perf"][0]
+    ctx, sty = enc.score_embeddings[0], enc.perf_embeddings[0]
+    dims = list(PREDICTED_DIMS)
+    got = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPN_DEC_PAIR", flag)
+        sess = RenderSession(model.perf_decoder.model, L, dims)
+        rows = []
+        for k in (20, 36, 28, 60, 44, 90):          # windows end here; going back re-decodes positions already visited
+            g = 8
+            win = truth[:k + g].clone()
+            win[k:k + g, dims] = 1
+            sess.truncate(min(sess.length, k - 1))
+            rows.append(sess.decode(win, masked[:k + g], ctx[:k + g], sty[:k + g], g).clone())
+        torch.cuda.synchronize()
+        assert (sess.pair_groups > 0) == (flag == "1")
+        got.append(torch.cat(rows))
+    assert torch.equal(got[0], got[1])
