@@ -256,17 +256,20 @@ typedef struct spn_dec_pair_args {
     int norm1; const float* gam1; const float* bet1; float eps1;   /* 1 = LayerNorm(gamma, beta; null = plain), 2 = adaptive row (gamma | beta) */
     int norm2; const float* gam2; const float* bet2; float eps2;
     float* x;                                  /* [d] residual stream, in and out */
-    float* y2; long y2_ld;                     /* null, or the hidden-cache mirror: y2[*pos * y2_ld + n] = x[n] */
+    float* y2; long y2_ld;                     /* null, or the hidden-cache mirror of the pair's output: y2[*pos * y2_ld + n] */
     int d, h, kvh, inner, S, act;              /* S = key splits (<= 16), act 0 = SiLU, 1 = GELU */
     float scale;
     const int* pos; int* tick; int layer, bump;
     unsigned long long* gq; unsigned long long* gp; unsigned long long* go; unsigned long long* gx; unsigned long long* gg;
-                                               /* granules: (h + 2 kvh) * 64, h * S * 66, h * 64, d, inner */
+    unsigned long long* gxo;                   /* granules: (h + 2 kvh) * 64, h * S * 66, h * 64, d, inner, d (gxo: the stream to the next pair of a chain) */
     int* err;
     long long* stamps;                         /* null, or [groups][8] constant-clock (100 MHz) time stamps after each phase: tuning aid */
 } spn_dec_pair_args;
 int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S); /* workgroups of the launch for this shape; 0 = not supported */
-int spn_dec_pair(const spn_dec_pair_args* args, spn_stream_t s);
+/* A chain of n consecutive pairs (1 <= n <= 32, one shape, ascending `layer`) in ONE launch: the residual stream goes from pair to pair
+ * inside the launch (gxo).  `host` = the n records (validated here), `dev` = the same records in device memory (read by the launch).  x
+ * of the first record is read, x of the last one written; every pair writes its y2 mirror. */
+int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,

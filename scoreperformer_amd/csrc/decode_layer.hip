@@ -38,21 +38,23 @@ __device__ __forceinline__ void put(unsigned long long* g, unsigned epoch, float
     __hip_atomic_store(as_global(g), ((unsigned long long)epoch << 32) | __float_as_uint(v), RLX_AGENT);
 }
 
-// Hand-off read: thread tid polls the granules idx = tid + 512 k < n (k < 4) until each carries `epoch`, then leaves the values in
-// xs[idx].  One load per lane and pass at n <= 512: measured against one polling wave per workgroup with 8 loads per lane (fewer
-// pollers on the hot lines, but every pass is 8 serial sc1 loads long: the hops were 1-2 us SLOWER).
+// Hand-off read: thread tid polls the granule PAIRS p = tid + 512 k (granules 2p, 2p + 1; k < 2, n even and <= 2048) with one 16-byte
+// agent-scope load each until both tags carry `epoch`, then leaves the values in xs.  One load per lane and pass at n <= 1024.  Measured
+// against one polling wave per workgroup with 8 loads per lane (fewer pollers on the hot lines, but every pass is 8 serial loads long):
+// the hops were 1-2 us SLOWER that way.
+typedef unsigned int pair_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void gather(unsigned long long* g, int n, unsigned epoch, float* xs, int tid, int* err) {
-    unsigned v[4] = {0u, 0u, 0u, 0u};
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, n * 8, 0x00020000);
+    pair_u32x4 v[2] = {pair_u32x4{0u, 0u, 0u, 0u}, pair_u32x4{0u, 0u, 0u, 0u}};
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = tid + NT * k;
-            if (idx < n) {
-                const unsigned long long x = __hip_atomic_load(as_global(g + idx), RLX_AGENT);
-                v[k] = (unsigned)x;
-                ok &= (unsigned)(x >> 32) == epoch;
+        for (int k = 0; k < 2; ++k) {
+            const int p = tid + NT * k;
+            if (2 * p < n) {
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, p * 16, 0, 16);   // aux 16 = sc1: served past the L1, at agent scope
+                ok &= v[k][1] == epoch && v[k][3] == epoch;
             }
         }
         if (ok) break;
@@ -60,9 +62,9 @@ __device__ __forceinline__ void gather(unsigned long long* g, int n, unsigned ep
         __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + NT * k;
-        if (idx < n) xs[idx] = __uint_as_float(v[k]);
+    for (int k = 0; k < 2; ++k) {
+        const int p = tid + NT * k;
+        if (2 * p < n) { xs[2 * p] = __uint_as_float(v[k][0]); xs[2 * p + 1] = __uint_as_float(v[k][2]); }
     }
 }
 
@@ -158,13 +160,18 @@ __device__ __forceinline__ void dot_rows(const f32x4 (&r)[R][C], const float* xs
     for (int i = 0; i < R; ++i) out[i] = wave_sum(acc[i]);
 }
 
-// Roles.  Workgroups 0 .. h S - 1 ("A") own the phases every one of which is wide: q|k|v rows (the first ceil(N1 / 16) of them), one
-// (head, split) of the attention each, and 16 gated feed-forward rows each.  Workgroups h S .. h S + ceil(d / 16) - 1 ("B") own the
-// d-row phases: the merge of a head's partials (the first h of them), the attention output projection and the feed-forward output
-// projection, 16 rows each.  The last ceil(inner / 32) workgroups ("C") own the gated feed-forward rows, 32 each.  Every weight row a workgroup will ever need is requested when the launch STARTS, in the order of use: loads
-// return in order, so a request in front of a poll would hold every pass of that poll back by a trip to HBM -- with the roles split this
-// way no workgroup has anything in flight when it polls, and its weights have landed long before its inputs do.
-__global__ __launch_bounds__(NT) void dec_pair_kernel(spn_dec_pair_args a) {
+// Roles.  Workgroups 0 .. h S - 1 ("A") own the q|k|v rows (the first ceil(N1 / 16) of them, 16 rows each) and one (head, split) of the
+// attention each.  Workgroups h S .. h S + ceil(d / 16) - 1 ("B") own the d-row phases: the merge of a head's partials (the first h of
+// them), the attention output projection and the feed-forward output projection, 16 rows each.  The last ceil(inner / 32) workgroups
+// ("C") own the gated feed-forward rows, 32 each.  Every weight row a workgroup needs for a layer is requested as soon as it has
+// published its last result of the PREVIOUS layer (at the start of the launch for the first one), in the order of use: loads return in
+// order, so a request in front of a poll whose data is about to land would hold every pass of that poll back by a trip to HBM -- with the
+// roles split this way a workgroup's next inputs are always several hand-offs away when it requests weights.
+//
+// A CHAIN of n consecutive layer pairs runs in one launch (`layers`: device array): the residual stream goes from a pair's last phase to
+// the next pair's first one as granules too (gxo; the projection workgroups keep their own rows as the next residual in registers), so
+// the ~1.6 us between two launches and the first weight trip of every pair but the first leave the critical path.
+__global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers, int n_layers) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float sm[16], sl[16];
@@ -173,178 +180,202 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(spn_dec_pair_args a) {
     __shared__ float outv[16];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    const int d = a.d, h = a.h, kvh = a.kvh, S = a.S, inner = a.inner;
+    const spn_dec_pair_args& a0 = layers[0];
+    const int d = a0.d, h = a0.h, kvh = a0.kvh, S = a0.S, inner = a0.inner;   // the same in every pair of a chain (checked by the host)
     // (position, tick and error word are requested here and first USED behind the weight requests of the role: read up front, the error
     // check alone held every workgroup's first weight load back by a trip to memory)
-    const int err_in = *a.err;
+    const int err_in = *a0.err;
+    int* const err = a0.err;
 #define STAMP(k_) do { if (a.stamps && tid == 0) a.stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-    STAMP(0);
-    const int t = *a.pos;
-    const unsigned e0 = (unsigned)(*a.tick) * 256u + 8u * (unsigned)a.layer + 1u;   // layer < 32
+    const int t = *a0.pos;
+    const unsigned ebase = (unsigned)(*a0.tick) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
-    const int nA = h * S;
+    const int nA = h * S, nB = (d + 15) / 16;
 
     if (b < nA) {
-        // ================================================ A: q|k|v rows, attention split, gated rows ===================================
-        const int r0 = b * 16 + 2 * w;                      // this wave's rows of a phase: r0, r0 + 1
+        // ================================================ A: q|k|v rows, attention split ==================================================
+        const int r0 = b * 16 + 2 * w;                      // this wave's rows of phase 1: r0, r0 + 1
         const bool own1 = b * 16 < N1;
-        f32x4 wq[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            wq[i][0] = wq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (r0 + i < N1) load_row<2>(wq[i], a.Wqkv + (long)(r0 + i) * a.ld_qkv, d, lane);
-        }
-        if (own1) for (int k = tid; k < d; k += NT) xs[k] = a.x[k];
-        const NormRegs n1 = norm_regs(d, a.norm1, a.gam1, a.bet1, tid);
-        if (err_in) return;   // an earlier launch of this render timed out: do not wait again
-        // ---- phase 1: q | k | v = Wqkv . LN(x) ----------------------------------------------------------------------------------------
-        if (own1) {
-            __syncthreads();
-            block_norm(xs, red, d, a.gam1 != nullptr, n1, a.eps1, tid);
-            float y[2];
-            dot_rows<2, 2>(wq, xs, d, lane, y);
-            if (lane == 0) { outv[2 * w] = y[0]; outv[2 * w + 1] = y[1]; }
-            publish16(a.gq, b * 16, N1, e0, outv, tid);
-        }
-        STAMP(1);
-        // ---- phase 2: split-key attention of (head hi, split sp) --------------------------------------------------------------------------
         const int hi = b / S, sp = b - hi * S;
         const int kh = kvh == 1 ? 0 : hi;
         const long cw = (long)kvh * 64;
-        __syncthreads();
-        if (tid < 192) {   // q of the head, new key, new value: 3 x 64 granules
-            const int part = tid >> 6;
-            const int idx = (part == 0 ? hi * 64 : (part == 1 ? h * 64 + kh * 64 : h * 64 + kvh * 64 + kh * 64)) + lane;
-            unsigned v = 0, spins = 0;
-            for (;;) {
-                const unsigned long long x = __hip_atomic_load(as_global(a.gq + idx), RLX_AGENT);
-                v = (unsigned)x;
-                if ((unsigned)(x >> 32) == e0) break;
-                if (++spins > SPIN_LIMIT) { *a.err = 2; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            qs[tid] = __uint_as_float(v);
-        }
-        __syncthreads();
-        if (tid < 256) {
-            const int grp = lane >> 4, l16 = lane & 15;
-            const float* knew = qs + 64;
-            const float* vnew = qs + 128;
-            float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
-            kn2 = wave_sum(kn2); qn2 = wave_sum(qn2);
-            if (sp == 0 && w == 0) {
-                a.kcache[t * cw + kh * 64 + lane] = knew[lane];
-                a.vcache[t * cw + kh * 64 + lane] = vnew[lane];
-                if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.kmax2 + kh), __float_as_uint(kn2));
-            }
-            const float slope = a.slopes ? a.slopes[hi] : 0.f;
-            int j_lo = 0;
-            if (slope > 0.f) {
-                const float km = fmaxf(a.kmax2[kh], kn2);
-                const float reach = (104.f + 2.f * a.scale * sqrtf(qn2 * km)) / slope;
-                if (reach < (float)t) j_lo = t - (int)reach - 1;
-            }
-            const int total = t + 1 - j_lo;
-            const int chunk = (total + S - 1) / S;
-            const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);
-            const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + l16 * 4) * a.scale;
-            float m = -INFINITY, l = 0.f;
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            // the rows of up to 16 keys per lane group (= 256 keys per workgroup: the whole split at L <= 4096) are requested TOGETHER: one trip
-            // to the Infinity Cache instead of four; the arithmetic runs in the order of dec_attn2_kernel's loop (jb ascending, then u)
-            for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
-                f32x4 k4[16], v4[16];
+        f32x4 wq[2][2];
+        NormRegs n1;
+        auto request = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int j = min(jb0 + 16 * u, j1 - 1);
-                    if (j == t) {
-                        k4[u] = *reinterpret_cast<const f32x4*>(knew + l16 * 4);
-                        v4[u] = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
-                    } else {
-                        k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + j * cw + kh * 64 + l16 * 4);
-                        v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + j * cw + kh * 64 + l16 * 4);
+            for (int i = 0; i < 2; ++i) {
+                wq[i][0] = wq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r0 + i < N1) load_row<2>(wq[i], a.Wqkv + (long)(r0 + i) * a.ld_qkv, d, lane);
+            }
+            n1 = norm_regs(d, a.norm1, a.gam1, a.bet1, tid);
+        };
+        request(a0);
+        if (own1) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
+        if (err_in) return;   // an earlier launch of this render timed out: do not wait again
+        for (int l = 0; l < n_layers; ++l) {
+            const spn_dec_pair_args& a = layers[l];
+            const unsigned e0 = ebase + 8u * (unsigned)a.layer;   // layer < 32
+            STAMP(0);
+            // ---- phase 1: q | k | v = Wqkv . LN(x) ------------------------------------------------------------------------------------
+            if (own1) {
+                if (l > 0) gather(layers[l - 1].gxo, d, ebase + 8u * (unsigned)layers[l - 1].layer + 5u, xs, tid, err);
+                __syncthreads();
+                block_norm(xs, red, d, a.gam1 != nullptr, n1, a.eps1, tid);
+                float y[2];
+                dot_rows<2, 2>(wq, xs, d, lane, y);
+                if (lane == 0) { outv[2 * w] = y[0]; outv[2 * w + 1] = y[1]; }
+                publish16(a.gq, b * 16, N1, e0, outv, tid);
+            }
+            STAMP(1);
+            // ---- phase 2: split-key attention of (head hi, split sp) ----------------------------------------------------------------------
+            __syncthreads();
+            if (tid < 192) {   // q of the head, new key, new value: 3 x 64 granules
+                const int part = tid >> 6;
+                const int idx = (part == 0 ? hi * 64 : (part == 1 ? h * 64 + kh * 64 : h * 64 + kvh * 64 + kh * 64)) + lane;
+                unsigned v = 0, spins = 0;
+                for (;;) {
+                    const unsigned long long x = __hip_atomic_load(as_global(a.gq + idx), RLX_AGENT);
+                    v = (unsigned)x;
+                    if ((unsigned)(x >> 32) == e0) break;
+                    if (++spins > SPIN_LIMIT) { *err = 2; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                qs[tid] = __uint_as_float(v);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                const int grp = lane >> 4, l16 = lane & 15;
+                const float* knew = qs + 64;
+                const float* vnew = qs + 128;
+                float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
+                kn2 = wave_sum(kn2); qn2 = wave_sum(qn2);
+                if (sp == 0 && w == 0) {
+                    a.kcache[t * cw + kh * 64 + lane] = knew[lane];
+                    a.vcache[t * cw + kh * 64 + lane] = vnew[lane];
+                    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.kmax2 + kh), __float_as_uint(kn2));
+                }
+                const float slope = a.slopes ? a.slopes[hi] : 0.f;
+                int j_lo = 0;
+                if (slope > 0.f) {
+                    const float km = fmaxf(a.kmax2[kh], kn2);
+                    const float reach = (104.f + 2.f * a.scale * sqrtf(qn2 * km)) / slope;
+                    if (reach < (float)t) j_lo = t - (int)reach - 1;
+                }
+                const int total = t + 1 - j_lo;
+                const int chunk = (total + S - 1) / S;
+                const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + l16 * 4) * a.scale;
+                float m = -INFINITY, lsum = 0.f;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                // the rows of up to 16 keys per lane group (= 256 keys per workgroup: the whole split at L <= 4096) are requested TOGETHER: one
+                // trip to the Infinity Cache instead of four; the arithmetic runs in the order of dec_attn2_kernel's loop (jb ascending, then u)
+                for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
+                    f32x4 k4[16], v4[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = min(jb0 + 16 * u, j1 - 1);
+                        if (j == t) {
+                            k4[u] = *reinterpret_cast<const f32x4*>(knew + l16 * 4);
+                            v4[u] = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
+                        } else {
+                            k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + j * cw + kh * 64 + l16 * 4);
+                            v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + j * cw + kh * 64 + l16 * 4);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = jb0 + 16 * u;
+                        if (j < j1) {
+                            float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
+                            sc = row16_sum(sc);
+                            sc -= slope * (float)(t - j);
+                            const float m_new = fmaxf(m, sc);
+                            // exp(m - m_new) and exp(sc - m_new): one of the two arguments is 0 and the other -|sc - m| -- one exponential
+                            const float e = __expf(-fabsf(sc - m));
+                            const float alpha = sc > m ? e : 1.f, pj = sc > m ? 1.f : e;
+                            lsum = lsum * alpha + pj;
+                            acc = acc * alpha + v4[u] * pj;
+                            m = m_new;
+                        }
                     }
                 }
+                const int gi = w * 4 + grp;
+                if (l16 == 0) { sm[gi] = m; sl[gi] = lsum; }
+                *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+            }
+            __syncthreads();
+            if (tid < 66) {
+                float mm = -INFINITY;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int j = jb0 + 16 * u;
-                    if (j < j1) {
-                        float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-                        sc = row16_sum(sc);
-                        sc -= slope * (float)(t - j);
-                        const float m_new = fmaxf(m, sc);
-                        const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
-                        l = l * alpha + pj;
-                        acc = acc * alpha + v4[u] * pj;
-                        m = m_new;
-                    }
+                for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
+                float num = 0.f, den = 0.f;
+                const int col = min(tid, 63);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
+                    num += so[q][col] * f; den += sl[q] * f;
                 }
+                // record (max, normaliser, 64 weighted value sums): lanes 0-63 of wave 0 store the sums, lanes 0-1 of wave 1 the two scalars
+                unsigned long long* mine = a.gp + ((long)hi * S + sp) * 66;
+                put(mine + (tid < 64 ? 2 + tid : tid - 64), e0 + 1, tid < 64 ? num : (tid == 64 ? mm : den));
             }
-            const int gi = w * 4 + grp;
-            if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
-            *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+            STAMP(2);
+            if (l + 1 < n_layers) request(layers[l + 1]);
         }
-        __syncthreads();
-        if (tid < 66) {
-            float mm = -INFINITY;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
-            float num = 0.f, den = 0.f;
-            const int col = min(tid, 63);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
-                num += so[q][col] * f; den += sl[q] * f;
-            }
-            // record (max, normaliser, 64 weighted value sums): lanes 0-63 of wave 0 store the sums, lanes 0-1 of wave 1 the two scalars
-            unsigned long long* mine = a.gp + ((long)hi * S + sp) * 66;
-            put(mine + (tid < 64 ? 2 + tid : tid - 64), e0 + 1, tid < 64 ? num : (tid == 64 ? mm : den));
-        }
-        STAMP(2);
         return;
     }
-    const int nB = (d + 15) / 16;
     if (b >= nA + nB) {
         // ================================================ C: gated feed-forward rows =======================================================
-        // 32 rows per workgroup (4 per wave: value + gate rows, requested at the start), so that only ceil(inner / 32) workgroups poll the
-        // x1 lines: with all h S attention workgroups polling them this hop took 3.4-4.5 us, with 32-64 pollers ~1 us.  (64 rows per
-        // workgroup: 16 wave reductions per wave, 2.5 us of issue time on the critical path.)
+        // 32 rows per workgroup (4 per wave: value + gate rows), so that only ceil(inner / 32) workgroups poll the x1 lines: with all h S
+        // attention workgroups polling them this hop took 3.4-4.5 us, with 32-64 pollers ~1 us.  (64 rows per workgroup: 16 wave
+        // reductions per wave, 2.5 us of issue time on the critical path.)
         const int bc = b - nA - nB;
         const int r0 = bc * 32 + 4 * w;
         f32x4 w1v[4][2], w1g[4][2];
         float b1v[4], b1g[4];
+        NormRegs n2;
+        auto request = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            w1v[i][0] = w1v[i][1] = w1g[i][0] = w1g[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            b1v[i] = b1g[i] = 0.f;
-            if (r0 + i < inner) {
-                load_row<2>(w1v[i], a.W1 + (long)(r0 + i) * a.ld_1, d, lane);
-                load_row<2>(w1g[i], a.W1 + (long)(r0 + i + inner) * a.ld_1, d, lane);
-                if (a.b1) { b1v[i] = a.b1[r0 + i]; b1g[i] = a.b1[r0 + i + inner]; }
+            for (int i = 0; i < 4; ++i) {
+                w1v[i][0] = w1v[i][1] = w1g[i][0] = w1g[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                b1v[i] = b1g[i] = 0.f;
+                if (r0 + i < inner) {
+                    load_row<2>(w1v[i], a.W1 + (long)(r0 + i) * a.ld_1, d, lane);
+                    load_row<2>(w1g[i], a.W1 + (long)(r0 + i + inner) * a.ld_1, d, lane);
+                    if (a.b1) { b1v[i] = a.b1[r0 + i]; b1g[i] = a.b1[r0 + i + inner]; }
+                }
             }
-        }
-        const NormRegs n2 = norm_regs(d, a.norm2, a.gam2, a.bet2, tid);
+            n2 = norm_regs(d, a.norm2, a.gam2, a.bet2, tid);
+        };
+        request(a0);
         if (err_in) return;
-        STAMP(1);
-        gather(a.gx, d, e0 + 3, xs, tid, a.err);
-        __syncthreads();
-        STAMP(2);
-        block_norm(xs, red, d, a.gam2 != nullptr, n2, a.eps2, tid);
-        STAMP(3);
-        float* outc = &so[0][0];   // 32 results of the workgroup
-        float accv[4], accg[4];
-        dot_rows<2, 4>(w1v, xs, d, lane, accv);
-        dot_rows<2, 4>(w1g, xs, d, lane, accg);
+        for (int l = 0; l < n_layers; ++l) {
+            const spn_dec_pair_args& a = layers[l];
+            const unsigned e0 = ebase + 8u * (unsigned)a.layer;
+            STAMP(0);
+            STAMP(1);
+            __syncthreads();
+            gather(a.gx, d, e0 + 3, xs, tid, err);
+            __syncthreads();
+            STAMP(2);
+            block_norm(xs, red, d, a.gam2 != nullptr, n2, a.eps2, tid);
+            STAMP(3);
+            float* outc = &so[0][0];   // 32 results of the workgroup
+            float accv[4], accg[4];
+            dot_rows<2, 4>(w1v, xs, d, lane, accv);
+            dot_rows<2, 4>(w1g, xs, d, lane, accg);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float acc = accv[i], ag = accg[i];
-            if (a.b1) { acc += b1v[i]; ag += b1g[i]; }
-            if (lane == 0) outc[4 * w + i] = acc * pair_act(ag, a.act);
+            for (int i = 0; i < 4; ++i) {
+                float acc = accv[i], ag = accg[i];
+                if (a.b1) { acc += b1v[i]; ag += b1g[i]; }
+                if (lane == 0) outc[4 * w + i] = acc * pair_act(ag, a.act);
+            }
+            STAMP(4);
+            __syncthreads();
+            if (tid < 32 && bc * 32 + tid < inner) put(a.gg + bc * 32 + tid, e0 + 4, outc[tid]);   // one store instruction: 2 whole lines
+            STAMP(5);
+            if (l + 1 < n_layers) request(layers[l + 1]);
         }
-        STAMP(4);
-        __syncthreads();
-        if (tid < 32 && bc * 32 + tid < inner) put(a.gg + bc * 32 + tid, e0 + 4, outc[tid]);   // one store instruction: 2 whole lines
-        STAMP(5);
         return;
     }
     // ==================================================== B: merge, output projections ====================================================
@@ -352,80 +383,101 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(spn_dec_pair_args a) {
     const int r0 = bb * 16 + 2 * w;
     f32x4 wo[2][2], w2[2][8];
     float res0[2] = {0.f, 0.f}, b2v[2] = {0.f, 0.f};
+    auto request = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        wo[i][0] = wo[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r0 + i < d) { load_row<2>(wo[i], a.Wo + (long)(r0 + i) * a.ld_o, h * 64, lane); res0[i] = a.x[r0 + i]; }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) w2[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (r0 + i < d) { load_row<8>(w2[i], a.W2 + (long)(r0 + i) * a.ld_2, inner, lane); if (a.b2) b2v[i] = a.b2[r0 + i]; }
-    }
-    if (err_in) return;
-    // ---- phase 2b: the first h of these workgroups merge the S partials of head bb -------------------------------------------------------
-    if (bb < h) {
-        gather(a.gp + (long)bb * S * 66, S * 66, e0 + 1, xs, tid, a.err);     // S <= 16: 1056 granules
-        __syncthreads();
-        if (tid < 64) {
-            const int dcol = 2 + tid;
-            float mv[16], lv[16], nv[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool in = q < S;
-                mv[q] = in ? xs[q * 66] : -INFINITY;
-                lv[q] = in ? xs[q * 66 + 1] : 0.f;
-                nv[q] = in ? xs[q * 66 + dcol] : 0.f;
-            }
-            float mm = -INFINITY;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
-            float num = 0.f, den = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (q < S) {
-                    const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
-                    num += nv[q] * f; den += lv[q] * f;
-                }
-            }
-            put(a.go + bb * 64 + tid, e0 + 2, num / den);
+        for (int i = 0; i < 2; ++i) {
+            wo[i][0] = wo[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + i < d) load_row<2>(wo[i], a.Wo + (long)(r0 + i) * a.ld_o, h * 64, lane);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) w2[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            b2v[i] = 0.f;
+            if (r0 + i < d) { load_row<8>(w2[i], a.W2 + (long)(r0 + i) * a.ld_2, inner, lane); if (a.b2) b2v[i] = a.b2[r0 + i]; }
+        }
+    };
+    request(a0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) if (r0 + i < d) res0[i] = a0.x[r0 + i];
+    if (err_in) return;
+    for (int l = 0; l < n_layers; ++l) {
+        const spn_dec_pair_args& a = layers[l];
+        const unsigned e0 = ebase + 8u * (unsigned)a.layer;
+        STAMP(0);
+        // ---- phase 2b: the first h of these workgroups merge the S partials of head bb ---------------------------------------------------
+        if (bb < h) {
+            __syncthreads();
+            gather(a.gp + (long)bb * S * 66, S * 66, e0 + 1, xs, tid, err);     // S <= 16: 1056 granules
+            __syncthreads();
+            if (tid < 64) {
+                const int dcol = 2 + tid;
+                float mv[16], lv[16], nv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const bool in = q < S;
+                    mv[q] = in ? xs[q * 66] : -INFINITY;
+                    lv[q] = in ? xs[q * 66 + 1] : 0.f;
+                    nv[q] = in ? xs[q * 66 + dcol] : 0.f;
+                }
+                float mm = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (q < S) {
+                        const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
+                        num += nv[q] * f; den += lv[q] * f;
+                    }
+                }
+                put(a.go + bb * 64 + tid, e0 + 2, num / den);
+            }
+        }
+        STAMP(3);
+        // ---- phase 3: x1 = x + Wo . o ------------------------------------------------------------------------------------------------------
+        float x1[2];
         __syncthreads();
-    }
-    STAMP(3);
-    // ---- phase 3: x1 = x + Wo . o ----------------------------------------------------------------------------------------------------------
-    float x1[2];
-    gather(a.go, h * 64, e0 + 2, xs, tid, a.err);
-    __syncthreads();
-    dot_rows<2, 2>(wo, xs, h * 64, lane, x1);
+        gather(a.go, h * 64, e0 + 2, xs, tid, err);
+        __syncthreads();
+        dot_rows<2, 2>(wo, xs, h * 64, lane, x1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        x1[i] = x1[i] + res0[i];
-        if (lane == 0) outv[2 * w + i] = x1[i];
-    }
-    publish16(a.gx, bb * 16, d, e0 + 3, outv, tid);
-    STAMP(4);
-    // ---- phase 5: x = x1 + W2 . g + b2 -------------------------------------------------------------------------------------------------------
-    __syncthreads();
-    gather(a.gg, inner, e0 + 4, xs, tid, a.err);
-    __syncthreads();
-    float y5[2];
-    dot_rows<8, 2>(w2, xs, inner, lane, y5);
+        for (int i = 0; i < 2; ++i) {
+            x1[i] = x1[i] + res0[i];
+            if (lane == 0) outv[2 * w + i] = x1[i];
+        }
+        publish16(a.gx, bb * 16, d, e0 + 3, outv, tid);
+        STAMP(4);
+        // ---- phase 5: x = x1 + W2 . g + b2 ---------------------------------------------------------------------------------------------------
+        __syncthreads();
+        gather(a.gg, inner, e0 + 4, xs, tid, err);
+        __syncthreads();
+        float y5[2];
+        dot_rows<8, 2>(w2, xs, inner, lane, y5);
+        const bool last = l + 1 == n_layers;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float acc = y5[i];
-        if (lane == 0 && r0 + i < d) {
+        for (int i = 0; i < 2; ++i) {
+            float acc = y5[i];
             if (a.b2) acc += b2v[i];
             acc += x1[i];
-            a.x[r0 + i] = acc;
-            if (a.y2) a.y2[(long)t * a.y2_ld + r0 + i] = acc;
+            res0[i] = acc;                                   // this wave's rows of the stream: the next pair's residual
+            if (lane == 0) outv[2 * w + i] = acc;
+            if (lane == 0 && r0 + i < d) {
+                if (last) a.x[r0 + i] = acc;
+                if (a.y2) a.y2[(long)t * a.y2_ld + r0 + i] = acc;
+            }
+        }
+        if (!last) {
+            publish16(a.gxo, bb * 16, d, e0 + 5, outv, tid);
+            STAMP(6);
+            request(layers[l + 1]);
+        } else {
+            STAMP(6);
+            // Everybody has read the tick by now: this workgroup's inputs needed every C workgroup's gated rows, those needed every B
+            // workgroup's x1 rows, those every A workgroup's partials, and every workgroup reads the tick before its first phase.
+            if (a.bump && bb == 0 && tid == 0) *a.tick = *a.tick + 1;
         }
     }
-    STAMP(6);
-    // Everybody has read the tick by now: this workgroup's inputs needed every A workgroup's gated rows, those needed every B workgroup's
-    // x1 rows, and every workgroup reads the tick before its first phase.
-    if (a.bump && bb == 0 && tid == 0) *a.tick = *a.tick + 1;
 }
 
 }  // namespace
@@ -441,15 +493,25 @@ extern "C" int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S) {
     return nA + nB + nC;
 }
 
-extern "C" int spn_dec_pair(const spn_dec_pair_args* args, hipStream_t s) {
-    SPN_REQUIRE(args, "spn_dec_pair: null argument");
-    const spn_dec_pair_args& a = *args;
-    const int G = spn_dec_pair_groups(a.d, a.h, a.kvh, a.inner, a.S);
-    SPN_REQUIRE(G > 0, "spn_dec_pair: shape not supported (spn_dec_pair_groups)");
-    SPN_REQUIRE(a.Wqkv && a.Wo && a.W1 && a.W2 && a.x && a.kcache && a.vcache && a.kmax2 && a.pos && a.tick && a.err && a.gq && a.gp && a.go &&
-                a.gx && a.gg, "spn_dec_pair: null operand");
-    SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pair: weight rows must be 16-byte aligned");
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, a);
+// `host`: the n argument records (validated here); `dev`: the same n records in DEVICE memory (the launch reads them there: a chain of
+// pairs does not fit the kernel-argument segment).  The caller keeps both alive and identical; nothing is copied or allocated here.
+extern "C" int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, hipStream_t s) {
+    SPN_REQUIRE(host && dev && n >= 1 && n <= 32, "spn_dec_pairs: 1 to 32 argument records, on the host and on the device");
+    const spn_dec_pair_args& f = host[0];
+    const int G = spn_dec_pair_groups(f.d, f.h, f.kvh, f.inner, f.S);
+    SPN_REQUIRE(G > 0, "spn_dec_pairs: shape not supported (spn_dec_pair_groups)");
+    for (int l = 0; l < n; ++l) {
+        const spn_dec_pair_args& a = host[l];
+        SPN_REQUIRE(a.d == f.d && a.h == f.h && a.kvh == f.kvh && a.inner == f.inner && a.S == f.S, "spn_dec_pairs: the pairs of a chain must have one shape");
+        SPN_REQUIRE(a.pos == f.pos && a.tick == f.tick && a.err == f.err, "spn_dec_pairs: one position, tick and error word per chain");
+        SPN_REQUIRE(a.layer >= 0 && a.layer < 32 && (l == 0 || a.layer > host[l - 1].layer), "spn_dec_pairs: layer numbers must ascend below 32");
+        SPN_REQUIRE(a.bump == 0 || l == n - 1, "spn_dec_pairs: only the last pair of a chain may advance the tick");
+        SPN_REQUIRE(a.Wqkv && a.Wo && a.W1 && a.W2 && a.x && a.kcache && a.vcache && a.kmax2 && a.pos && a.tick && a.err && a.gq && a.gp && a.go &&
+                    a.gx && a.gg && (a.gxo || l == n - 1), "spn_dec_pairs: null operand");
+        SPN_REQUIRE(a.x == f.x, "spn_dec_pairs: one residual stream per chain");
+        SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs: weight rows must be 16-byte aligned");
+    }
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -110,7 +110,9 @@ class GreedyDecoder:
             self.pair_groups = ops.dec_pair_groups(d, self.heads, self.kvh, self.g.numel(), S)
         if self.pair_groups:   # hand-off granules of the persistent layer-pair launch ({epoch, value} words: zero = no epoch)
             zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
-            self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()))
+            self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
+                               gxo=zg(d))
+            self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_stamps = ([torch.zeros(self.pair_groups * 8, device=dev, dtype=torch.int64) for _ in range(n_self)]
@@ -321,30 +323,17 @@ class GreedyDecoder:
                 ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
         ai = ci = 0
         n_layers = len(tr.layers)
-        pairs = self._pair_plan() if self.pair_groups else {}
-        skip = False
+        chains = self._pair_chains() if self.pair_groups else {}
+        skip = 0
         for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
             if skip:
-                skip = False
+                skip -= 1
                 continue
             mode, g_, b_, eps_ = self._norm_args(norms[0])
-            if li in pairs:
-                fnorms, ff, _ = tr.layers[li + 1]
-                m2, g2, b2_, e2 = self._norm_args(fnorms[0])
-                lin, out = ff.ff[0].proj, ff.ff[3]
-                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
-                nxt_attn = li + 2 < n_layers
-                ops.dec_pair(Wqkv=wqkv, ld_qkv=wqkv.stride(0), Wo=block.to_out.weight.data, ld_o=block.to_out.weight.stride(0),
-                             W1=lin.weight.data, ld_1=lin.weight.stride(0), b1=lin.bias.data if lin.bias is not None else None,
-                             W2=out.weight.data, ld_2=out.weight.stride(0), b2=out.bias.data if out.bias is not None else None,
-                             slopes=self._slopes(block), kcache=self.kc[ai], vcache=self.vc[ai], kmax2=self.kmax2[ai],
-                             norm1=mode, gam1=g_, bet1=b_, eps1=eps_, norm2=m2, gam2=g2, bet2=b2_, eps2=e2, x=self.x,
-                             y2=self.hid[ai + 1] if nxt_attn else None, y2_ld=d if nxt_attn else 0, d=d, h=self.heads, kvh=self.kvh,
-                             inner=self.g.numel(), S=self.attn_splits, act=ff.act_code, scale=block.scale, pos=pos, tick=self.pair_tick,
-                             layer=pairs[li][0], bump=pairs[li][1], err=self.pair_err,
-                             stamps=self.pair_stamps[ai] if self.pair_stamps is not None else None, **self.pair_g)
-                ai += 1
-                skip = True
+            if li in chains:      # a chain of ('a', 'f') pairs: ONE persistent launch (csrc/decode_layer.hip)
+                chains[li].launch()
+                ai += chains[li].n
+                skip = 2 * chains[li].n - 1
                 continue
             if lt == 'c':
                 self._cross_layer(ci, norms[0], block, True)
@@ -401,22 +390,57 @@ class GreedyDecoder:
         ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
         self._head_tail(dims)
 
-    def _pair_plan(self):
-        """{index of an 'a' layer that runs with the following 'f' layer as one persistent launch: (pair number, last pair of the note)}"""
-        tr = self.m.transformer
-        types, plan = list(tr.layer_types), {}
-        for li in range(len(types) - 1):
-            if types[li] != 'a' or types[li + 1] != 'f':
-                continue
+    def _pair_chains(self):
+        """{index of the first layer of a chain of ('a', 'f') pairs: ops.DecPairChain}: consecutive pairs the persistent launch can take
+        run as ONE launch.  Built on first use (the eager warm-up step), then reused (hipGraph capture included)."""
+        if self.pair_chains:
+            return self.pair_chains
+        tr, d = self.m.transformer, self.dim
+        types, n_layers = list(tr.layer_types), len(tr.layers)
+
+        def eligible(li):
+            if li + 1 >= n_layers or types[li] != 'a' or types[li + 1] != 'f':
+                return False
             ff = tr.layers[li + 1][1]
-            if not ff.glu or isinstance(ff.ff[1], nn.LayerNorm) or ff.act_code not in (0, 1):
+            return bool(ff.glu) and not isinstance(ff.ff[1], nn.LayerNorm) and ff.act_code in (0, 1)
+
+        n_pairs, li, ai_of = 0, 0, {}
+        ai = 0
+        for k, t_ in enumerate(types):
+            if t_ == 'a':
+                ai_of[k] = ai
+                ai += 1
+        while li < n_layers:
+            if not eligible(li) or n_pairs >= 32:
+                li += 1
                 continue
-            if len(plan) >= 32:
-                continue
-            plan[li] = [len(plan), 0]
-        if plan:
-            plan[max(plan)][1] = 1
-        return plan
+            start, records = li, []
+            while eligible(li) and n_pairs < 32:
+                (norms, block, _), (fnorms, ff, _) = tr.layers[li], tr.layers[li + 1]
+                mode, g_, b_, eps_ = self._norm_args(norms[0])
+                m2, g2, b2_, e2 = self._norm_args(fnorms[0])
+                lin, out = ff.ff[0].proj, ff.ff[3]
+                wqkv = block._fused("_w_qkv", (block.to_q.weight, block.to_k.weight, block.to_v.weight)).data
+                a_i = ai_of[li]
+                nxt_attn = li + 2 < n_layers
+                records.append(dict(
+                    Wqkv=wqkv, ld_qkv=wqkv.stride(0), Wo=block.to_out.weight.data, ld_o=block.to_out.weight.stride(0),
+                    W1=lin.weight.data, ld_1=lin.weight.stride(0), b1=lin.bias.data if lin.bias is not None else None,
+                    W2=out.weight.data, ld_2=out.weight.stride(0), b2=out.bias.data if out.bias is not None else None,
+                    slopes=self._slopes(block), kcache=self.kc[a_i], vcache=self.vc[a_i], kmax2=self.kmax2[a_i],
+                    norm1=mode, gam1=g_, bet1=b_, eps1=eps_, norm2=m2, gam2=g2, bet2=b2_, eps2=e2, x=self.x,
+                    y2=self.hid[a_i + 1] if nxt_attn else None, y2_ld=d if nxt_attn else 0, d=d, h=self.heads, kvh=self.kvh,
+                    inner=self.g.numel(), S=self.attn_splits, act=ff.act_code, scale=block.scale, pos=self.pos, tick=self.pair_tick,
+                    layer=n_pairs, bump=0, err=self.pair_err,
+                    stamps=self.pair_stamps[a_i] if self.pair_stamps is not None else None, **self.pair_g))
+                n_pairs += 1
+                li += 2
+            self.pair_chains[start] = records
+        if self.pair_chains:
+            last = max(self.pair_chains)
+            self.pair_chains[last][-1]["bump"] = 1          # the last pair of the note advances the epoch counter
+            self.pair_chains = {k: ops.DecPairChain(v, self.dev) for k, v in self.pair_chains.items()}
+        return self.pair_chains
 
     def _pair_check(self):
         if self.pair_groups and int(self.pair_err.item()):

@@ -985,7 +985,7 @@ class DecPairArgs(ctypes.Structure):
                 ("slopes", _P), ("kcache", _P), ("vcache", _P), ("kmax2", _P),
                 ("norm1", _I), ("gam1", _P), ("bet1", _P), ("eps1", _F), ("norm2", _I), ("gam2", _P), ("bet2", _P), ("eps2", _F),
                 ("x", _P), ("y2", _P), ("y2_ld", _L), ("d", _I), ("h", _I), ("kvh", _I), ("inner", _I), ("S", _I), ("act", _I), ("scale", _F),
-                ("pos", _P), ("tick", _P), ("layer", _I), ("bump", _I), ("gq", _P), ("gp", _P), ("go", _P), ("gx", _P), ("gg", _P), ("err", _P), ("stamps", _P)]
+                ("pos", _P), ("tick", _P), ("layer", _I), ("bump", _I), ("gq", _P), ("gp", _P), ("go", _P), ("gx", _P), ("gg", _P), ("gxo", _P), ("err", _P), ("stamps", _P)]
 
 
 def dec_pair_groups(d, h, kvh, inner, S) -> int:
@@ -993,19 +993,31 @@ def dec_pair_groups(d, h, kvh, inner, S) -> int:
     return int(load().spn_dec_pair_groups(int(d), int(h), int(kvh), int(inner), int(S)))
 
 
-def dec_pair(**kw):
-    """One decoder layer pair (attention block + gated feed-forward) as one persistent launch: spn_dec_pair.  Keyword arguments = the
-    fields of spn_dec_pair_args; tensors are passed as tensors (None = null)."""
-    a = DecPairArgs()
-    for name, ctype in DecPairArgs._fields_:
-        v = kw.pop(name, None)
-        if ctype is ctypes.c_void_p:
-            setattr(a, name, None if v is None else v.data_ptr())
-        else:
-            setattr(a, name, v if v is not None else 0)
-    if kw:
-        raise SpnError(f"dec_pair: unknown fields {sorted(kw)}")
-    call("spn_dec_pair", ctypes.byref(a), stream_ptr())
+class DecPairChain:
+    """The argument records of a chain of decoder layer pairs (spn_dec_pairs): a host array and its device copy, built once per engine.
+    `records`: one dict per pair with the fields of spn_dec_pair_args (tensors as tensors, None = null)."""
+
+    def __init__(self, records, device):
+        self.n = len(records)
+        self.host = (DecPairArgs * self.n)()
+        self.keep = []                                   # the tensors behind the raw pointers
+        for a, kw in zip(self.host, records):
+            kw = dict(kw)
+            for name, ctype in DecPairArgs._fields_:
+                v = kw.pop(name, None)
+                if ctype is ctypes.c_void_p:
+                    setattr(a, name, None if v is None else v.data_ptr())
+                    if v is not None:
+                        self.keep.append(v)
+                else:
+                    setattr(a, name, v if v is not None else 0)
+            if kw:
+                raise SpnError(f"dec_pairs: unknown fields {sorted(kw)}")
+        raw = bytes(self.host)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+    def launch(self):
+        call("spn_dec_pairs", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), stream_ptr())
 
 
 def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):

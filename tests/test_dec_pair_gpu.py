@@ -1,5 +1,5 @@
-"""GPU: the persistent layer-pair launch of the decode engine (csrc/decode_layer.hip: one launch per pre-norm ('a', 'f') decoder layer pair,
-five phases handed over inside the launch through {epoch, value} granules) against the five launches it replaces.
+"""GPU: the persistent layer-pair launch of the decode engine (csrc/decode_layer.hip: one launch for the whole chain of pre-norm
+('a', 'f') decoder layer pairs of a note, every phase handed over inside the launch through {epoch, value} granules) against the five launches it replaces.
 
 Same arithmetic, association order and rounding by construction (both files compile without floating-point contraction), so the
 comparison is EXACT: greedy tokens, every cached hidden row, every cached key / value row.  The five-launch engine itself is pinned to
@@ -44,7 +44,8 @@ def _engines(dev, preset, L, monkeypatch, **cfg_kw):
 def test_pair_launch_equals_the_five_launches_bit_for_bit(dev, monkeypatch, preset, L, kw):
     (e0, t0, n0), (e1, t1, n1) = _engines(dev, preset, L, monkeypatch, **kw)
     assert e0.pair_groups == 0 and e1.pair_groups > 0, (e0.pair_groups, e1.pair_groups)
-    assert len(e1._pair_plan()) == len(e1.kc)                      # every layer pair runs as one launch
+    chains = e1._pair_chains()
+    assert len(chains) == 1 and sum(c.n for c in chains.values()) == len(e1.kc)   # ALL layer pairs of a note run as one launch
     assert n0 == n1 == L - 1 and int(e1.pair_err.item()) == 0
     assert torch.equal(t0, t1)
     for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
