@@ -253,6 +253,8 @@ typedef struct spn_dec_pair_args {
     const float* W2; long ld_2; const float* b2;   /* [d, inner]; bias [d] or null */
     const float* slopes;                       /* [h] ALiBi slopes or null */
     float* kcache; float* vcache; float* kmax2;    /* [L, kvh * 64] x 2, running max |k|^2 [kvh] */
+    int* jlo;                                  /* null, or [h] (zeroed once): first key inside the ALiBi reach at the previous note -- the guess
+                                                  behind the early key / value requests */
     int norm1; const float* gam1; const float* bet1; float eps1;   /* 1 = LayerNorm(gamma, beta; null = plain), 2 = adaptive row (gamma | beta) */
     int norm2; const float* gam2; const float* bet2; float eps2;
     float* x;                                  /* [d] residual stream, in and out */

@@ -12,6 +12,7 @@
 // latency and ~100 MB of weight reads, not by math, and fp32 keeps the arg-max identical to the fp32 reference except at
 // exact near-ties.
 #include "common.h"
+#include "decode_attn.h"
 
 // No floating-point contraction in this file: whether `a * b + c` becomes one fused operation or two is otherwise the optimiser's choice per
 // call site (packed multiplies + adds in one loop, fused multiply-adds in its twin), and the persistent layer launch
@@ -597,7 +598,9 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
     if (slope > 0.f) {
         const float km = fmaxf(kmax2[kh], kn2);
         const float reach = (104.f + 2.f * scale * sqrtf(qn2 * km)) / slope;
-        if (reach < (float)t) j_lo = t - (int)reach - 1;
+        // rounded DOWN to a multiple of 256 (a few more keys than necessary, never fewer): the first key then moves once in 256 notes, which
+        // is what lets the persistent layer launch (decode_layer.hip, same expression) request the rows of a split before q exists
+        if (reach < (float)t) j_lo = (t - (int)reach - 1) & ~255;
     }
     const int total = t + 1 - j_lo;
     const int chunk = (total + S - 1) / S;
@@ -605,31 +608,18 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(qkv + hi * 64 + l16 * 4) * scale;
     float m = -INFINITY, l = 0.f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the keys of a lane group, four at a time: the eight row loads of a batch are in flight together (a cache row read costs a trip to
-    // the Infinity Cache, ~0.7 us; one key per trip made this loop the longest part of a note); arithmetic in the same order as before
-    for (int jb = j0 + w * 4 + grp; jb < j1; jb += 64) {
-        f32x4 k4[4], v4[4];
+    // the keys of a lane group, sixteen at a time (256 keys per block: the whole split at L <= 4096): all row loads of a batch are in flight
+    // together (a cache row read costs a trip to the Infinity Cache; one key per trip made this loop the longest part of a note)
+    const f32x4 knew4 = *reinterpret_cast<const f32x4*>(knew + l16 * 4), vnew4 = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
+    for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
+        f32x4 k4[16], v4[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = min(jb + 16 * u, j1 - 1);
-            const float* kr = (j == t) ? knew : kcache + j * cw + kh * 64;
-            const float* vr = (j == t) ? vnew : vcache + j * cw + kh * 64;
-            k4[u] = *reinterpret_cast<const f32x4*>(kr + l16 * 4);
-            v4[u] = *reinterpret_cast<const f32x4*>(vr + l16 * 4);
+        for (int u = 0; u < 16; ++u) {
+            const int j = max(min(min(jb0 + 16 * u, j1 - 1), t - 1), 0);   // row t is knew / vnew
+            k4[u] = *reinterpret_cast<const f32x4*>(kcache + (long)j * cw + kh * 64 + l16 * 4);
+            v4[u] = *reinterpret_cast<const f32x4*>(vcache + (long)j * cw + kh * 64 + l16 * 4);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = jb + 16 * u;
-            if (j >= j1) break;
-            float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-            sc = row16_sum(sc);   // the 16 lanes of a key: one DPP row (four ds_bpermute round trips per key before)
-            sc -= slope * (float)(t - j);
-            const float m_new = fmaxf(m, sc);
-            const float alpha = __expf(m - m_new), pj = __expf(sc - m_new);
-            l = l * alpha + pj;
-            acc = acc * alpha + v4[u] * pj;
-            m = m_new;
-        }
+        dec_attn_batch16(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, l, acc);
     }
     const int gi = w * 4 + grp;
     if (l16 == 0) { sm[gi] = m; sl[gi] = l; }

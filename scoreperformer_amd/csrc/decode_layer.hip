@@ -21,6 +21,7 @@
 // Replaces (per note) the layer body of `ScorePerformerMixedLMWrapper.unmask_tokens` (wrappers.py:325-407 ->
 // modules/transformer/transformer.py:159-221, attention.py:107-222, feedforward.py:13-64) for pre-norm ('a', 'f') decoders.
 #include "common.h"
+#include "decode_attn.h"
 #include "../../include/spn.h"   // spn_dec_pair_args
 
 #pragma clang fp contract(off)   // as decode.hip: the same source expression must round the same way in both files
@@ -209,6 +210,32 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             }
             n1 = norm_regs(d, a.norm1, a.gam1, a.bet1, tid);
         };
+        // Key / value rows of this workgroup's split, requested BEFORE the query exists: the split's key range depends on the query only
+        // through the first key inside the ALiBi reach (j_lo), which is rounded down to a multiple of 256 (more keys than necessary, never
+        // fewer) and therefore almost always equals the previous note's (jlo[head], written below).  The rows are then in registers when
+        // q arrives (one trip to the Infinity Cache, ~1.5-2 us, off the critical path); a wrong guess falls back to the loads behind q.
+        const int grp = lane >> 4, l16 = lane & 15;
+        f32x4 k4[16], v4[16];
+        bool pre = false;
+        int jlo_guess = 0;
+        auto prefetch = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
+            pre = false;
+            if (tid < 256 && a.jlo) {
+                jlo_guess = min(a.jlo[hi], t);
+                const int chunk = (t + 1 - jlo_guess + S - 1) / S;
+                const int j0 = jlo_guess + sp * chunk, j1 = min(t + 1, j0 + chunk);
+                const int jb0 = j0 + w * 4 + grp;
+                pre = true;
+                if (jb0 < j1) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int j = min(min(jb0 + 16 * u, j1 - 1), t - 1);   // row t does not exist yet: patched from q|k|v below
+                        k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
+                        v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
+                    }
+                }
+            }
+        };
         request(a0);
         if (own1) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
         if (err_in) return;   // an earlier launch of this render timed out: do not wait again
@@ -216,6 +243,14 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             const spn_dec_pair_args& a = layers[l];
             const unsigned e0 = ebase + 8u * (unsigned)a.layer;   // layer < 32
             STAMP(0);
+            // (first pair, workgroups with q|k|v rows: their x and weight loads were just issued and phase 1 waits for them -- loads return in
+            // order, so the key / value requests go out behind phase 1 there)
+            const bool late = l == 0 && own1;
+            if (!late) prefetch(a);
+            // slope and running max |k|^2 do not depend on this note's q either (the other workgroups' atomicMax below only folds in
+            // |k_new|^2, which is folded in here anyway): read behind q they were one more trip to memory on the critical path
+            const float slope = a.slopes ? a.slopes[hi] : 0.f;
+            const float kmax_old = a.kmax2[kh];
             // ---- phase 1: q | k | v = Wqkv . LN(x) ------------------------------------------------------------------------------------
             if (own1) {
                 if (l > 0) gather(layers[l - 1].gxo, d, ebase + 8u * (unsigned)layers[l - 1].layer + 5u, xs, tid, err);
@@ -226,6 +261,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 if (lane == 0) { outv[2 * w] = y[0]; outv[2 * w + 1] = y[1]; }
                 publish16(a.gq, b * 16, N1, e0, outv, tid);
             }
+            if (late) prefetch(a);
             STAMP(1);
             // ---- phase 2: split-key attention of (head hi, split sp) ----------------------------------------------------------------------
             __syncthreads();
@@ -243,8 +279,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 qs[tid] = __uint_as_float(v);
             }
             __syncthreads();
+            STAMP(3);
             if (tid < 256) {
-                const int grp = lane >> 4, l16 = lane & 15;
                 const float* knew = qs + 64;
                 const float* vnew = qs + 128;
                 float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
@@ -254,51 +290,36 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     a.vcache[t * cw + kh * 64 + lane] = vnew[lane];
                     if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.kmax2 + kh), __float_as_uint(kn2));
                 }
-                const float slope = a.slopes ? a.slopes[hi] : 0.f;
                 int j_lo = 0;
                 if (slope > 0.f) {
-                    const float km = fmaxf(a.kmax2[kh], kn2);
+                    const float km = fmaxf(kmax_old, kn2);
                     const float reach = (104.f + 2.f * a.scale * sqrtf(qn2 * km)) / slope;
-                    if (reach < (float)t) j_lo = t - (int)reach - 1;
+                    if (reach < (float)t) j_lo = (t - (int)reach - 1) & ~255;   // as dec_attn2_kernel
                 }
+                if (sp == 0 && w == 0 && lane == 0 && a.jlo) a.jlo[hi] = j_lo;   // the next note's guess
                 const int total = t + 1 - j_lo;
                 const int chunk = (total + S - 1) / S;
                 const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(qs + l16 * 4) * a.scale;
                 float m = -INFINITY, lsum = 0.f;
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                // the rows of up to 16 keys per lane group (= 256 keys per workgroup: the whole split at L <= 4096) are requested TOGETHER: one
-                // trip to the Infinity Cache instead of four; the arithmetic runs in the order of dec_attn2_kernel's loop (jb ascending, then u)
+                const bool hit = pre && j_lo == jlo_guess;   // the rows requested before q are the rows of this range (first 256 keys of it)
+                // up to 16 keys per lane group and batch (= 256 keys per workgroup: the whole split at L <= 4096): decode_attn.h
+                bool first = true;
+                const f32x4 knew4 = *reinterpret_cast<const f32x4*>(knew + l16 * 4), vnew4 = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
                 for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
-                    f32x4 k4[16], v4[16];
+                    if (!(hit && first)) {
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int j = min(jb0 + 16 * u, j1 - 1);
-                        if (j == t) {
-                            k4[u] = *reinterpret_cast<const f32x4*>(knew + l16 * 4);
-                            v4[u] = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
-                        } else {
-                            k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + j * cw + kh * 64 + l16 * 4);
-                            v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + j * cw + kh * 64 + l16 * 4);
+                        for (int u = 0; u < 16; ++u) {
+                            const int j = min(min(jb0 + 16 * u, j1 - 1), t - 1);
+                            k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
+                            v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int j = jb0 + 16 * u;
-                        if (j < j1) {
-                            float sc = q4[0] * k4[u][0] + q4[1] * k4[u][1] + q4[2] * k4[u][2] + q4[3] * k4[u][3];
-                            sc = row16_sum(sc);
-                            sc -= slope * (float)(t - j);
-                            const float m_new = fmaxf(m, sc);
-                            // exp(m - m_new) and exp(sc - m_new): one of the two arguments is 0 and the other -|sc - m| -- one exponential
-                            const float e = __expf(-fabsf(sc - m));
-                            const float alpha = sc > m ? e : 1.f, pj = sc > m ? 1.f : e;
-                            lsum = lsum * alpha + pj;
-                            acc = acc * alpha + v4[u] * pj;
-                            m = m_new;
-                        }
-                    }
+                    first = false;
+                    dec_attn_batch16(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, lsum, acc);
                 }
+                STAMP(4);
                 const int gi = w * 4 + grp;
                 if (l16 == 0) { sm[gi] = m; sl[gi] = lsum; }
                 *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;

@@ -8,6 +8,7 @@ fp32 kernels over preallocated [L, .] caches, and tokens stay on the device unti
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -112,6 +113,7 @@ class GreedyDecoder:
             zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
+            self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -427,7 +429,7 @@ class GreedyDecoder:
                     Wqkv=wqkv, ld_qkv=wqkv.stride(0), Wo=block.to_out.weight.data, ld_o=block.to_out.weight.stride(0),
                     W1=lin.weight.data, ld_1=lin.weight.stride(0), b1=lin.bias.data if lin.bias is not None else None,
                     W2=out.weight.data, ld_2=out.weight.stride(0), b2=out.bias.data if out.bias is not None else None,
-                    slopes=self._slopes(block), kcache=self.kc[a_i], vcache=self.vc[a_i], kmax2=self.kmax2[a_i],
+                    slopes=self._slopes(block), kcache=self.kc[a_i], vcache=self.vc[a_i], kmax2=self.kmax2[a_i], jlo=self.pair_jlo[a_i] if os.environ.get("SPN_DEC_PAIR_JLO", "1") != "0" else None,
                     norm1=mode, gam1=g_, bet1=b_, eps1=eps_, norm2=m2, gam2=g2, bet2=b2_, eps2=e2, x=self.x,
                     y2=self.hid[a_i + 1] if nxt_attn else None, y2_ld=d if nxt_attn else 0, d=d, h=self.heads, kvh=self.kvh,
                     inner=self.g.numel(), S=self.attn_splits, act=ff.act_code, scale=block.scale, pos=self.pos, tick=self.pair_tick,

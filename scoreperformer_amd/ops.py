@@ -982,7 +982,7 @@ class DecPairArgs(ctypes.Structure):
     """include/spn.h: spn_dec_pair_args (field for field)."""
     _P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
     _fields_ = [("Wqkv", _P), ("ld_qkv", _L), ("Wo", _P), ("ld_o", _L), ("W1", _P), ("ld_1", _L), ("b1", _P), ("W2", _P), ("ld_2", _L), ("b2", _P),
-                ("slopes", _P), ("kcache", _P), ("vcache", _P), ("kmax2", _P),
+                ("slopes", _P), ("kcache", _P), ("vcache", _P), ("kmax2", _P), ("jlo", _P),
                 ("norm1", _I), ("gam1", _P), ("bet1", _P), ("eps1", _F), ("norm2", _I), ("gam2", _P), ("bet2", _P), ("eps2", _F),
                 ("x", _P), ("y2", _P), ("y2_ld", _L), ("d", _I), ("h", _I), ("kvh", _I), ("inner", _I), ("S", _I), ("act", _I), ("scale", _F),
                 ("pos", _P), ("tick", _P), ("layer", _I), ("bump", _I), ("gq", _P), ("gp", _P), ("go", _P), ("gx", _P), ("gg", _P), ("gxo", _P), ("err", _P), ("stamps", _P)]

@@ -41,7 +41,7 @@ def timeline(L, groups, dev, model, batch, enc):
     groups = eng.pair_groups
     nA = eng.heads * eng.attn_splits
     nB = (eng.dim + 15) // 16
-    roles = {"A (q|k|v rows, attention)": (slice(0, nA), {1: "qkv out", 2: "partials out"}),
+    roles = {"A (q|k|v rows, attention)": (slice(0, nA), {1: "qkv out", 3: "q gathered", 4: "keys done", 2: "partials out"}),
              "B (merge, projections)": (slice(nA, nA + nB), {3: "merged o out", 4: "x1 out", 6: "x out"}),
              "C (gated rows)": (slice(nA + nB, groups), {1: "weights requested", 2: "x1 gathered", 3: "norm done", 4: "rows done", 5: "g out"})}
     t_prev_end = None
