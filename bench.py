@@ -368,7 +368,7 @@ def decode_leg(args, dev):
             "notes": notes, "us_per_note": best / notes * 1e6, "notes_per_s": notes / best, "masks_left": int((out == 1).sum()),
             "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": per_note / (best / notes) / 1e9,
                          "frac": per_note / (best / notes) / 1e9 / 8000.0, "algorithmic_bytes_per_note": per_note,
-                         "note": "decoder weights (fp32) + mean K/V cache bytes per note; launch-latency bound today (DESIGN.md)"}}
+                         "note": "decoder weights (fp32) + mean K/V cache bytes per note; bound by the dependent hand-offs inside the persistent layer launch today (DESIGN.md §3 decode_layer.hip)"}}
 
 
 def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
