@@ -272,6 +272,26 @@ int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S); /* workgroups 
  * inside the launch (gxo).  `host` = the n records (validated here), `dev` = the same records in device memory (read by the launch).  x
  * of the first record is read, x of the last one written; every pair writes its y2 mirror. */
 int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, spn_stream_t s);
+/* Phases around the chain, in the same launch (either part may be absent: Wm = null / Wh = null):
+ *   front (in front of the first pair; its result replaces x as the chain's input):
+ *       x0 = Wm . xin + bm                                                   (spn_dec_fused_gemv of the multi-sequence projection)
+ *       x  = Wp . (LN?(x0) | ctx[*pos + 1] | style[*pos + 1]) + bp           (spn_dec_cat_gemv)
+ *   tail (behind the last pair):  e_out = Wh . LN(x), the normalised x mirrored  (spn_dec_fused_gemv of the LM head's input projection)
+ * Same arithmetic as those launches. */
+typedef struct spn_dec_chain_ext {
+    const float* Wm; long ld_m; const float* bm; const float* xin; int Km;          /* [d, Km], Km <= 1024 */
+    float* y2m; long y2m_ld;                                                         /* null, or mirror of x0: y2m[*pos * ld + n] */
+    const float* Wp; long ld_p; const float* bp;                                     /* [d, d + ctx_w + style_w] (<= 2048 columns) */
+    const float* cat_gamma; const float* cat_beta; float cat_eps;                    /* LayerNorm of x0 (null gamma: none) */
+    const float* ctx; long ctx_ld; int ctx_w; const float* style; long style_ld; int style_w;
+    float* y2p; long y2p_ld;                                                         /* null, or mirror of x */
+    unsigned long long* gf; unsigned long long* gxf;                                 /* granules [d] each (zeroed once per render) */
+    const float* Wh; long ld_h; int Nh;                                              /* [Nh, d], Nh <= 16 h S */
+    int normh; const float* gamh; const float* beth; float epsh;                     /* as norm1 of a pair */
+    float* e_out; float* xn_out; long xn_ld;                                         /* [Nh]; null, or xn_out[*pos * ld + k] = LN(x)[k] */
+} spn_dec_chain_ext;
+int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                      const spn_dec_chain_ext* ext_dev, spn_stream_t s);
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,

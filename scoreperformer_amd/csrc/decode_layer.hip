@@ -172,7 +172,8 @@ __device__ __forceinline__ void dot_rows(const f32x4 (&r)[R][C], const float* xs
 // A CHAIN of n consecutive layer pairs runs in one launch (`layers`: device array): the residual stream goes from a pair's last phase to
 // the next pair's first one as granules too (gxo; the projection workgroups keep their own rows as the next residual in registers), so
 // the ~1.6 us between two launches and the first weight trip of every pair but the first leave the critical path.
-__global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers, int n_layers) {
+__global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers, int n_layers,
+                                                      const spn_dec_chain_ext* __restrict__ ext) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float sm[16], sl[16];
@@ -192,6 +193,11 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const unsigned ebase = (unsigned)(*a0.tick) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
     const int nA = h * S, nB = (d + 15) / 16;
+    // Optional phases around the chain (spn_dec_chain_ext): in FRONT of the first pair the two input projections of the note (B
+    // workgroups: x0 = Wm . xin + bm, then x = Wp . (LN?(x0) | context row | style row) + bp), BEHIND the last pair the LM head's input
+    // projection e = Wh . LN(x) (A workgroups).  Their epochs use pair number 31.
+    const bool front = ext && ext->Wm, tail = ext && ext->Wh;
+    const unsigned efront = ebase + 8u * 31u;
 
     if (b < nA) {
         // ================================================ A: q|k|v rows, attention split ==================================================
@@ -237,11 +243,11 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             }
         };
         request(a0);
-        if (own1) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
+        if (own1 && !front) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
         if (err_in) return;   // an earlier launch of this render timed out: do not wait again
         for (int l = 0; l < n_layers; ++l) {
             const spn_dec_pair_args& a = layers[l];
-            const unsigned e0 = ebase + 8u * (unsigned)a.layer;   // layer < 32
+            const unsigned e0 = ebase + 8u * (unsigned)a.layer;   // layer < 31
             STAMP(0);
             // (first pair, workgroups with q|k|v rows: their x and weight loads were just issued and phase 1 waits for them -- loads return in
             // order, so the key / value requests go out behind phase 1 there)
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             // ---- phase 1: q | k | v = Wqkv . LN(x) ------------------------------------------------------------------------------------
             if (own1) {
                 if (l > 0) gather(layers[l - 1].gxo, d, ebase + 8u * (unsigned)layers[l - 1].layer + 5u, xs, tid, err);
+                else if (front) gather(ext->gxf, d, efront + 1u, xs, tid, err);
                 __syncthreads();
                 block_norm(xs, red, d, a.gam1 != nullptr, n1, a.eps1, tid);
                 float y[2];
@@ -343,6 +350,31 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             STAMP(2);
             if (l + 1 < n_layers) request(layers[l + 1]);
         }
+        if (tail) {
+            // ---- tail: e = Wh . LN(x) (the LM head's input projection: rows 16 b + 2 w, + 1), the normalised x mirrored by workgroup 0 ----
+            const spn_dec_pair_args& al = layers[n_layers - 1];
+            const int Nh = ext->Nh;
+            f32x4 wh[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                wh[i][0] = wh[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r0 + i < Nh) load_row<2>(wh[i], ext->Wh + (long)(r0 + i) * ext->ld_h, d, lane);
+            }
+            const NormRegs nh = norm_regs(d, ext->normh, ext->gamh, ext->beth, tid);
+            if (b * 16 < Nh) {
+                __syncthreads();
+                gather(al.gxo, d, ebase + 8u * (unsigned)al.layer + 5u, xs, tid, err);
+                __syncthreads();
+                block_norm(xs, red, d, ext->gamh != nullptr, nh, ext->epsh, tid);
+                if (b == 0 && ext->xn_out) for (int k = tid; k < d; k += NT) ext->xn_out[(long)t * ext->xn_ld + k] = xs[k];
+                float y[2];
+                dot_rows<2, 2>(wh, xs, d, lane, y);
+                if (lane == 0) {
+                    if (r0 < Nh) ext->e_out[r0] = y[0];
+                    if (r0 + 1 < Nh) ext->e_out[r0 + 1] = y[1];
+                }
+            }
+        }
         return;
     }
     if (b >= nA + nB) {
@@ -418,10 +450,72 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (r0 + i < d) { load_row<8>(w2[i], a.W2 + (long)(r0 + i) * a.ld_2, inner, lane); if (a.b2) b2v[i] = a.b2[r0 + i]; }
         }
     };
-    request(a0);
+    if (front) {
+        // ---- front: x0 = Wm . xin + bm (K = Km <= 1024), then x = Wp . (LN?(x0) | ctx[t + 1] | style[t + 1]) + bp (K <= 2048) ----
+        const int Km = ext->Km, cw_ = ext->ctx ? ext->ctx_w : 0, sw_ = ext->style ? ext->style_w : 0, Kc = d + cw_ + sw_;
+        f32x4 wm[2][4], wp[2][8];
+        float bmv[2] = {0.f, 0.f}, bpv[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 2; ++i) if (r0 + i < d) res0[i] = a0.x[r0 + i];
-    if (err_in) return;
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wm[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wp[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r0 + i < d) {
+                load_row<4>(wm[i], ext->Wm + (long)(r0 + i) * ext->ld_m, Km, lane);
+                if (ext->bm) bmv[i] = ext->bm[r0 + i];
+            }
+        }
+        for (int k = tid; k < Km; k += NT) xs[k] = ext->xin[k];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (r0 + i < d) { load_row<8>(wp[i], ext->Wp + (long)(r0 + i) * ext->ld_p, Kc, lane); if (ext->bp) bpv[i] = ext->bp[r0 + i]; }
+        // context / style rows of the position: independent of everything computed here (up to 4 + 4 entries per thread)
+        float cx[4] = {0.f, 0.f, 0.f, 0.f}, sx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + NT * q;
+            if (k < cw_) cx[q] = ext->ctx[(long)(t + 1) * ext->ctx_ld + k];
+            if (k < sw_) sx[q] = ext->style[(long)(t + 1) * ext->style_ld + k];
+        }
+        const NormRegs nc = norm_regs(d, 1, ext->cat_gamma, ext->cat_beta, tid);
+        request(a0);
+        if (err_in) return;
+        __syncthreads();
+        float y[2];
+        dot_rows<4, 2>(wm, xs, Km, lane, y);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (ext->bm) y[i] += bmv[i];
+            if (lane == 0) outv[2 * w + i] = y[i];
+            if (lane == 0 && r0 + i < d && ext->y2m) ext->y2m[(long)t * ext->y2m_ld + r0 + i] = y[i];
+        }
+        publish16(ext->gf, bb * 16, d, efront, outv, tid);
+        __syncthreads();
+        gather(ext->gf, d, efront, xs, tid, err);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + NT * q;
+            if (k < cw_) xs[d + k] = cx[q];
+            if (k < sw_) xs[d + cw_ + k] = sx[q];
+        }
+        __syncthreads();
+        if (ext->cat_gamma) block_norm(xs, red, d, true, nc, ext->cat_eps, tid);
+        dot_rows<8, 2>(wp, xs, Kc, lane, y);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (ext->bp) y[i] += bpv[i];
+            res0[i] = y[i];
+            if (lane == 0) outv[2 * w + i] = y[i];
+            if (lane == 0 && r0 + i < d && ext->y2p) ext->y2p[(long)t * ext->y2p_ld + r0 + i] = y[i];
+        }
+        publish16(ext->gxf, bb * 16, d, efront + 1u, outv, tid);
+    } else {
+        request(a0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) if (r0 + i < d) res0[i] = a0.x[r0 + i];
+        if (err_in) return;
+    }
     for (int l = 0; l < n_layers; ++l) {
         const spn_dec_pair_args& a = layers[l];
         const unsigned e0 = ebase + 8u * (unsigned)a.layer;
@@ -493,6 +587,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             STAMP(6);
             request(layers[l + 1]);
         } else {
+            if (tail) publish16(a.gxo, bb * 16, d, e0 + 5, outv, tid);
             STAMP(6);
             // Everybody has read the tick by now: this workgroup's inputs needed every C workgroup's gated rows, those needed every B
             // workgroup's x1 rows, those every A workgroup's partials, and every workgroup reads the tick before its first phase.
@@ -532,7 +627,38 @@ extern "C" int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_a
         SPN_REQUIRE(a.x == f.x, "spn_dec_pairs: one residual stream per chain");
         SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs: weight rows must be 16-byte aligned");
     }
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n);
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, (const spn_dec_chain_ext*)nullptr);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// The same with the note's input projections in front of the first pair and / or the LM head's input projection behind the last one
+// (spn_dec_chain_ext: either part may be absent).  ext_host / ext_dev: the record on the host (validated) and in device memory.
+extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                                 const spn_dec_chain_ext* ext_dev, hipStream_t s) {
+    SPN_REQUIRE(host && dev && ext_host && ext_dev && n >= 1 && n <= 31, "spn_dec_pairs_ext: 1 to 31 argument records and the extension record, on the host and on the device");
+    const spn_dec_pair_args& f = host[0];
+    const spn_dec_chain_ext& e = *ext_host;
+    const int G = spn_dec_pair_groups(f.d, f.h, f.kvh, f.inner, f.S);
+    SPN_REQUIRE(G > 0, "spn_dec_pairs_ext: shape not supported (spn_dec_pair_groups)");
+    for (int l = 0; l < n; ++l) {
+        const spn_dec_pair_args& a = host[l];
+        SPN_REQUIRE(a.d == f.d && a.h == f.h && a.kvh == f.kvh && a.inner == f.inner && a.S == f.S, "spn_dec_pairs_ext: the pairs of a chain must have one shape");
+        SPN_REQUIRE(a.pos == f.pos && a.tick == f.tick && a.err == f.err && a.x == f.x, "spn_dec_pairs_ext: one position, tick, error word and stream per chain");
+        SPN_REQUIRE(a.layer >= 0 && a.layer < 31 && (l == 0 || a.layer > host[l - 1].layer), "spn_dec_pairs_ext: layer numbers must ascend below 31");
+        SPN_REQUIRE(a.bump == 0 || l == n - 1, "spn_dec_pairs_ext: only the last pair of a chain may advance the tick");
+        SPN_REQUIRE(a.Wqkv && a.Wo && a.W1 && a.W2 && a.x && a.kcache && a.vcache && a.kmax2 && a.gq && a.gp && a.go && a.gx && a.gg &&
+                    (a.gxo || (l == n - 1 && !e.Wh)), "spn_dec_pairs_ext: null operand");
+        SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs_ext: weight rows must be 16-byte aligned");
+    }
+    if (e.Wm) {
+        const int Kc = f.d + (e.ctx ? e.ctx_w : 0) + (e.style ? e.style_w : 0);
+        SPN_REQUIRE(e.Wp && e.xin && e.gf && e.gxf && e.Km >= 4 && e.Km <= 1024 && e.Km % 4 == 0 && Kc <= 2048 && Kc % 4 == 0 &&
+                    (e.ld_m % 4) == 0 && (e.ld_p % 4) == 0 && (!e.ctx || e.ctx_w <= 2048) && (!e.style || e.style_w <= 2048),
+                    "spn_dec_pairs_ext: front projections: Km <= 1024, d + context + style <= 2048, 16-byte aligned rows");
+    }
+    if (e.Wh) SPN_REQUIRE(e.e_out && e.Nh >= 1 && e.Nh <= 16 * f.h * f.S && (e.ld_h % 4) == 0, "spn_dec_pairs_ext: tail projection: at most 16 h S rows");
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

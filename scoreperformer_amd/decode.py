@@ -44,6 +44,7 @@ class GreedyDecoder:
         # one persistent launch per ('a', 'f') layer pair instead of five (csrc/decode_layer.hip)
         self.use_pair = os.environ.get("SPN_DEC_PAIR", "1") != "0"
         self.pair_groups = 0       # workgroups of that launch (0: shape not supported, the five launches run)
+        self.pair_front = self.pair_tail = False   # the note's input projections / the LM head's input projection ride in that launch
         tr = m.transformer
         types = tuple(tr.layer_types)
         self.cross = 'c' in types
@@ -114,6 +115,8 @@ class GreedyDecoder:
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
             self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
+            self.pair_g2 = dict(gf=zg(d), gxf=zg(d))
+            self.pair_front = self.pair_tail = False
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -310,11 +313,15 @@ class GreedyDecoder:
             ops.dec_embed_proj(self.tables, self.seq2d, self.masked2d, pos, te.project_emb.weight.data, te.project_emb.bias.data, self.proj_cat,
                                gamma=gam, beta=bet, eps=eps)
         fold_cat = isinstance(m.project_emb, nn.Linear) and not self.legacy_launches
-        ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x0 if fold_cat else self.x, bias=te.project_multiemb.bias.data,
-                           pos=pos, y2=self.tok_emb, y2_ld=d)
+        chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail) if self.pair_groups else {}
+        if not self.pair_front:   # (else: first phase of the persistent launch)
+            ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x0 if fold_cat else self.x, bias=te.project_multiemb.bias.data,
+                               pos=pos, y2=self.tok_emb, y2_ld=d)
         if self.ada_rows and not latched:   # every AdaLN (gamma | beta) row of this step: one GEMV over the stacked condition projections
             ops.dec_gemv(self.ada_W, self.style2d, self.gb_all.view(-1), bias=self.ada_b, pos=pos, x_ld=self.style2d.stride(0), x_off=1)
-        if fold_cat:    # (LN(x0) | context row | style row) built in the prologue of the projection (x0 -> x: not in place)
+        if self.pair_front:
+            pass                  # second phase of the persistent launch
+        elif fold_cat:    # (LN(x0) | context row | style row) built in the prologue of the projection (x0 -> x: not in place)
             ops.dec_cat_gemv(m.project_emb.weight.data, self.x0, d, self.x, pos, bias=m.project_emb.bias.data, y2=self.hid[0], y2_ld=d, **cat_args)
         else:
             ops.dec_cat(self.x, d, self.xcat, pos, **cat_args)
@@ -325,7 +332,6 @@ class GreedyDecoder:
                 ops.dec_copy_row(self.x, self.hid[0], pos, d, dst_ld=d)
         ai = ci = 0
         n_layers = len(tr.layers)
-        chains = self._pair_chains() if self.pair_groups else {}
         skip = 0
         for li, (lt, (norms, block, _res)) in enumerate(zip(tr.layer_types, tr.layers)):
             if skip:
@@ -364,8 +370,9 @@ class GreedyDecoder:
                                    pos=pos, y2=self.hid[ai] if nxt_attn else None, y2_ld=d if nxt_attn else 0)
         if fused_tail:
             mode, g_, b_, eps_ = self._norm_args(fn)
-            ops.dec_fused_gemv(self.head_Wt, self.x, self.e_head, norm=mode, gamma=g_, beta=b_, eps=eps_, pos=pos,
-                               xn_out=self.hid[-1], xn_ld=d)
+            if not self.pair_tail:   # (else: last phase of the persistent launch)
+                ops.dec_fused_gemv(self.head_Wt, self.x, self.e_head, norm=mode, gamma=g_, beta=b_, eps=eps_, pos=pos,
+                                   xn_out=self.hid[-1], xn_ld=d)
             offs = [0]
             for w in head.split_dims:
                 offs.append(offs[-1] + w)
@@ -392,9 +399,11 @@ class GreedyDecoder:
         ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
         self._head_tail(dims)
 
-    def _pair_chains(self):
+    def _pair_chains(self, front_ok: bool = False, tail_ok: bool = False):
         """{index of the first layer of a chain of ('a', 'f') pairs: ops.DecPairChain}: consecutive pairs the persistent launch can take
-        run as ONE launch.  Built on first use (the eager warm-up step), then reused (hipGraph capture included)."""
+        run as ONE launch.  Built on first use (the eager warm-up step), then reused (hipGraph capture included).  When one chain covers
+        the whole decoder, the note's two input projections (front_ok) and the LM head's input projection (tail_ok) become phases of the
+        same launch (spn_dec_chain_ext): self.pair_front / self.pair_tail."""
         if self.pair_chains:
             return self.pair_chains
         tr, d = self.m.transformer, self.dim
@@ -441,7 +450,30 @@ class GreedyDecoder:
         if self.pair_chains:
             last = max(self.pair_chains)
             self.pair_chains[last][-1]["bump"] = 1          # the last pair of the note advances the epoch counter
-            self.pair_chains = {k: ops.DecPairChain(v, self.dev) for k, v in self.pair_chains.items()}
+            ext = {}
+            m, te = self.m, self.m.token_emb
+            whole = len(self.pair_chains) == 1 and 0 in self.pair_chains and 2 * len(self.pair_chains[0]) == n_layers and n_pairs <= 30
+            if whole and os.environ.get("SPN_DEC_PAIR_EXT", "1") != "0":
+                cw = m.context_emb_dim if (m.context_emb_mode == "cat" and self.ctx2d is not None) else 0
+                sw = m.style_emb_dim if (m.style_emb_mode == "cat" and self.style2d is not None) else 0
+                Wm = te.project_multiemb.weight.data
+                if front_ok and Wm.shape[1] <= 1024 and Wm.shape[1] % 4 == 0 and (d + cw + sw) <= 2048 and (d + cw + sw) % 4 == 0:
+                    en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
+                    Wp = m.project_emb.weight.data
+                    ext.update(Wm=Wm, ld_m=Wm.stride(0), bm=te.project_multiemb.bias.data, xin=self.proj_cat, Km=Wm.shape[1],
+                               y2m=self.tok_emb, y2m_ld=d, Wp=Wp, ld_p=Wp.stride(0), bp=m.project_emb.bias.data,
+                               cat_gamma=en.weight.data if en is not None else None, cat_beta=en.bias.data if en is not None else None,
+                               cat_eps=en.eps if en is not None else 1e-5,
+                               ctx=self.ctx2d if cw else None, ctx_ld=self.ctx2d.stride(0) if cw else 0, ctx_w=cw,
+                               style=self.style2d if sw else None, style_ld=self.style2d.stride(0) if sw else 0, style_w=sw,
+                               y2p=self.hid[0], y2p_ld=d, gf=self.pair_g2["gf"], gxf=self.pair_g2["gxf"])
+                    self.pair_front = True
+                if tail_ok and self.head_Wt.shape[0] <= 16 * self.heads * self.attn_splits:
+                    mode, g_, b_, eps_ = self._norm_args(tr.final_norm)
+                    ext.update(Wh=self.head_Wt, ld_h=self.head_Wt.stride(0), Nh=self.head_Wt.shape[0], normh=mode, gamh=g_, beth=b_, epsh=eps_,
+                               e_out=self.e_head, xn_out=self.hid[-1], xn_ld=d)
+                    self.pair_tail = True
+            self.pair_chains = {k: ops.DecPairChain(v, self.dev, ext if (ext and k == 0) else None) for k, v in self.pair_chains.items()}
         return self.pair_chains
 
     def _pair_check(self):

@@ -993,31 +993,53 @@ def dec_pair_groups(d, h, kvh, inner, S) -> int:
     return int(load().spn_dec_pair_groups(int(d), int(h), int(kvh), int(inner), int(S)))
 
 
+class DecChainExt(ctypes.Structure):
+    """include/spn.h: spn_dec_chain_ext (field for field)."""
+    _P, _L, _I, _F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+    _fields_ = [("Wm", _P), ("ld_m", _L), ("bm", _P), ("xin", _P), ("Km", _I), ("y2m", _P), ("y2m_ld", _L),
+                ("Wp", _P), ("ld_p", _L), ("bp", _P), ("cat_gamma", _P), ("cat_beta", _P), ("cat_eps", _F),
+                ("ctx", _P), ("ctx_ld", _L), ("ctx_w", _I), ("style", _P), ("style_ld", _L), ("style_w", _I), ("y2p", _P), ("y2p_ld", _L),
+                ("gf", _P), ("gxf", _P), ("Wh", _P), ("ld_h", _L), ("Nh", _I), ("normh", _I), ("gamh", _P), ("beth", _P), ("epsh", _F),
+                ("e_out", _P), ("xn_out", _P), ("xn_ld", _L)]
+
+
+def _fill_struct(a, kw, keep, what):
+    kw = dict(kw)
+    for name, ctype in a._fields_:
+        v = kw.pop(name, None)
+        if ctype is ctypes.c_void_p:
+            setattr(a, name, None if v is None else v.data_ptr())
+            if v is not None:
+                keep.append(v)
+        else:
+            setattr(a, name, v if v is not None else 0)
+    if kw:
+        raise SpnError(f"{what}: unknown fields {sorted(kw)}")
+
+
 class DecPairChain:
     """The argument records of a chain of decoder layer pairs (spn_dec_pairs): a host array and its device copy, built once per engine.
     `records`: one dict per pair with the fields of spn_dec_pair_args (tensors as tensors, None = null)."""
 
-    def __init__(self, records, device):
+    def __init__(self, records, device, ext=None):
         self.n = len(records)
         self.host = (DecPairArgs * self.n)()
         self.keep = []                                   # the tensors behind the raw pointers
         for a, kw in zip(self.host, records):
-            kw = dict(kw)
-            for name, ctype in DecPairArgs._fields_:
-                v = kw.pop(name, None)
-                if ctype is ctypes.c_void_p:
-                    setattr(a, name, None if v is None else v.data_ptr())
-                    if v is not None:
-                        self.keep.append(v)
-                else:
-                    setattr(a, name, v if v is not None else 0)
-            if kw:
-                raise SpnError(f"dec_pairs: unknown fields {sorted(kw)}")
-        raw = bytes(self.host)
-        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            _fill_struct(a, kw, self.keep, "dec_pairs")
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
+        self.ext = self.ext_dev = None
+        if ext:                                          # front / tail phases of the same launch: spn_dec_chain_ext
+            self.ext = DecChainExt()
+            _fill_struct(self.ext, ext, self.keep, "dec_pairs_ext")
+            self.ext_dev = torch.frombuffer(bytearray(bytes(self.ext)), dtype=torch.uint8).to(device)
 
     def launch(self):
-        call("spn_dec_pairs", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), stream_ptr())
+        if self.ext is not None:
+            call("spn_dec_pairs_ext", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), ctypes.byref(self.ext),
+                 ctypes.c_void_p(self.ext_dev.data_ptr()), stream_ptr())
+        else:
+            call("spn_dec_pairs", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), stream_ptr())
 
 
 def dec_head(tables, col0, dims, D, e, gamma, beta, eps, tokens2d, pos, part, counter, *, slabs=8, ban_mask=0b11, mask_id=1, pos_next=None):

@@ -47,6 +47,7 @@ def test_pair_launch_equals_the_five_launches_bit_for_bit(dev, monkeypatch, pres
     chains = e1._pair_chains()
     assert len(chains) == 1 and sum(c.n for c in chains.values()) == len(e1.kc)   # ALL layer pairs of a note run as one launch
     assert n0 == n1 == L - 1 and int(e1.pair_err.item()) == 0
+    assert e1.pair_front and e1.pair_tail      # the note's input projections and the LM head's input projection ride in the same launch
     assert torch.equal(t0, t1)
     for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
         assert torch.equal(a[:n1], b[:n1])
