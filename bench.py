@@ -73,7 +73,7 @@ def main():
         spn_build.build()
     if dist is not None:
         dist.barrier()
-    from scoreperformer_amd import ops, lib as lib_mod
+    from scoreperformer_amd import ops, lib as lib_mod, functional as F_
     from scoreperformer_amd.arena import ParamArena, FusedAdamW
     from scoreperformer_amd.models import ScorePerformer
     from scoreperformer_amd.parallel import GradSync
@@ -136,6 +136,9 @@ def main():
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss,
                    "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
                    "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
+                   # the two default approximations inside the 1e-3 parity budget (tests/test_parity_c2_gpu.py holds both settings to it)
+                   "numerics": {"adaln_rows": "bf16" if F_.ADALN_GB_DTYPE == torch.bfloat16 else "fp32", "adaln_fused_forward": bool(F_.ADALN_FUSED),
+                                "alibi_band_log2": float(lib_mod.get_tuning("attn_band")), "ffn_fused_epilogues": bool(F_.FFN_FUSE and F_.GLU_FUSE)},
                    "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},
     }
 
