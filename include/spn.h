@@ -245,7 +245,10 @@ int spn_dec_lookup(const int* tab, const int* pos, int* out, spn_stream_t s);
  * csrc/decode_layer.hip).  Same arithmetic and association order as spn_dec_fused_gemv + spn_dec_attn2 + spn_dec_attn_out +
  * spn_dec_fused_gemv(glu) + spn_dec_fused_gemv: x leaves bit-identical.  The granule buffers must be zeroed once per render; `tick`
  * (device int, advanced by the launch with bump = 1: the LAST pair of a note) makes the epochs unique; *err != 0 after a launch means a
- * hand-off timed out (the launch never hangs; results are then garbage). */
+ * hand-off timed out (the launch never hangs; results are then garbage).
+ * RESIDENCY: every workgroup polls results of the others, so all spn_dec_pair_groups() workgroups (one per CU) must run at once: the
+ * call refuses a device with fewer CUs, and nothing else may occupy CUs of the device while the launch runs (another stream's or another
+ * process's kernel that holds CUs long enough makes the hand-offs time out: *err, never a hang). */
 typedef struct spn_dec_pair_args {
     const float* Wqkv; long ld_qkv;            /* [(h + 2 kvh) * 64, d]: q | k | v rows */
     const float* Wo; long ld_o;                /* [d, h * 64] */

@@ -611,11 +611,20 @@ extern "C" int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S) {
 
 // `host`: the n argument records (validated here); `dev`: the same n records in DEVICE memory (the launch reads them there: a chain of
 // pairs does not fit the kernel-argument segment).  The caller keeps both alive and identical; nothing is copied or allocated here.
+// every workgroup of the launch polls results of the others: all of them must be resident at once, one per CU
+static bool device_holds(int groups) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return cus >= groups;
+}
+
 extern "C" int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, hipStream_t s) {
     SPN_REQUIRE(host && dev && n >= 1 && n <= 32, "spn_dec_pairs: 1 to 32 argument records, on the host and on the device");
     const spn_dec_pair_args& f = host[0];
     const int G = spn_dec_pair_groups(f.d, f.h, f.kvh, f.inner, f.S);
     SPN_REQUIRE(G > 0, "spn_dec_pairs: shape not supported (spn_dec_pair_groups)");
+    SPN_REQUIRE(device_holds(G), "spn_dec_pairs: the device has fewer compute units than the launch has workgroups (all must be resident at once)");
     for (int l = 0; l < n; ++l) {
         const spn_dec_pair_args& a = host[l];
         SPN_REQUIRE(a.d == f.d && a.h == f.h && a.kvh == f.kvh && a.inner == f.inner && a.S == f.S, "spn_dec_pairs: the pairs of a chain must have one shape");
@@ -641,6 +650,7 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
     const spn_dec_chain_ext& e = *ext_host;
     const int G = spn_dec_pair_groups(f.d, f.h, f.kvh, f.inner, f.S);
     SPN_REQUIRE(G > 0, "spn_dec_pairs_ext: shape not supported (spn_dec_pair_groups)");
+    SPN_REQUIRE(device_holds(G), "spn_dec_pairs_ext: the device has fewer compute units than the launch has workgroups (all must be resident at once)");
     for (int l = 0; l < n; ++l) {
         const spn_dec_pair_args& a = host[l];
         SPN_REQUIRE(a.d == f.d && a.h == f.h && a.kvh == f.kvh && a.inner == f.inner && a.S == f.S, "spn_dec_pairs_ext: the pairs of a chain must have one shape");

@@ -110,6 +110,8 @@ class GreedyDecoder:
         self.kmax2 = [z(self.kvh) for _ in range(n_self)]
         if self.use_pair:
             self.pair_groups = ops.dec_pair_groups(d, self.heads, self.kvh, self.g.numel(), S)
+            if self.pair_groups > torch.cuda.get_device_properties(dev).multi_processor_count:
+                self.pair_groups = 0   # every workgroup of that launch must be resident at once, one per CU
         if self.pair_groups:   # hand-off granules of the persistent layer-pair launch ({epoch, value} words: zero = no epoch)
             zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),

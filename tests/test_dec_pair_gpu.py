@@ -89,3 +89,39 @@ def test_pair_launch_serves_a_render_session_that_revisits_positions(dev, monkey
         assert (sess.pair_groups > 0) == (flag == "1")
         got.append(torch.cat(rows))
     assert torch.equal(got[0], got[1])
+
+
+def test_a_poisoned_render_raises_instead_of_hanging(dev, monkeypatch):
+    """`*err` != 0 (a hand-off of an earlier launch of the render timed out: every poll loop of the persistent launch is bounded) makes
+    every later launch return at once and `run` raise: a broken hand-off costs a fraction of a second, never the device."""
+    import time
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import GreedyDecoder
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    L = 64
+    torch.manual_seed(3)
+    model = ScorePerformer.init(model_config("tiny", max_seq_len=L))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=11, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    tokens = batch["masked_perf"].clone()
+    tokens[:, 0] = batch["perf"][:, 0]
+    monkeypatch.setenv("SPN_DEC_PAIR", "1")
+    eng = GreedyDecoder(model.perf_decoder.model, L)
+    alloc = eng._alloc
+
+    def poisoned_alloc(n):
+        alloc(n)
+        eng.pair_err.fill_(7)
+
+    eng._alloc = poisoned_alloc
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="timed out"):
+        eng.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 30.0
