@@ -40,7 +40,8 @@ def _engines(dev, preset, L, monkeypatch, **cfg_kw):
     return out
 
 
-@pytest.mark.parametrize("preset,L,kw", [("tiny", 200, {}), ("tiny", 96, {"one_kv_head": False}), ("c5", 700, {})])
+@pytest.mark.parametrize("preset,L,kw", [("tiny", 200, {}), ("tiny", 96, {"one_kv_head": False}), ("tiny", 96, {"style_emb_mode": "cat"}),
+                                          ("tiny", 96, {"alibi_learned": False}), ("c5", 700, {})])
 def test_pair_launch_equals_the_five_launches_bit_for_bit(dev, monkeypatch, preset, L, kw):
     (e0, t0, n0), (e1, t1, n1) = _engines(dev, preset, L, monkeypatch, **kw)
     assert e0.pair_groups == 0 and e1.pair_groups > 0, (e0.pair_groups, e1.pair_groups)
