@@ -42,7 +42,7 @@ class GreedyDecoder:
         self.legacy_launches = os.environ.get("SPN_DEC_LEGACY", "0") == "1"   # A/B aid: round-1 launch list (separate embed / merge kernels)
         self.max_len, self.use_graph, self.fused, self.attn_splits = max_len, use_graph, fused, attn_splits
         # one persistent launch per ('a', 'f') layer pair instead of five (csrc/decode_layer.hip)
-        self.use_pair = os.environ.get("SPN_DEC_PAIR", "1") != "0"
+        self.use_pair = os.environ.get("SPN_DEC_PAIR", "1") != "0" and not self.legacy_launches
         self.pair_groups = 0       # workgroups of that launch (0: shape not supported, the five launches run)
         self.pair_front = self.pair_tail = False   # the note's input projections / the LM head's input projection ride in that launch
         tr = m.transformer
