@@ -177,6 +177,18 @@ def pick_transport(args, dist, dev):
         return "torch", "single process: no all-reduce"
     if args.dp_transport != "auto":
         return args.dp_transport, "as requested"
+    # stage 1, NO collective inside: can every rank reach RCCL through the library at all (symbols resolve, an id can be made)?  A rank that
+    # failed here while the others entered the communicator's collective init would leave them waiting for it.
+    pre, why = 1, ""
+    try:
+        from scoreperformer_amd.comm import unique_id
+        unique_id()
+    except Exception as exc:  # noqa: BLE001
+        pre, why = 0, repr(exc)
+    flag = torch.tensor([pre], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag) == 0:
+        return "torch", "native transport unavailable on some rank (" + (why or "another rank") + "): torch.distributed"
     ok, why = 1, "spn_comm_allreduce == dist.all_reduce on a 1 Mi-element probe on every rank"
     try:
         from scoreperformer_amd.comm import NativeComm
