@@ -36,9 +36,15 @@ def parse():
                          "checked against torch.distributed on a small buffer at start-up, torch when that check fails on any rank")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seq", type=int, default=2048)
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1, help="sequences of the CPU baseline sample (BASELINE.md section 4: b=1 at seq 2048)")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time one CPU step with one thread per core the process may run on "
+                    "(off by default: 256 threads on the GPU box took 679 s for one step, profiles/r04_bench_a.json)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline after one warm-up (median reported)")
     ap.add_argument("--dropout", type=float, default=0.1, help="attention / FFN dropout (recipes/scoreperformer/base.yaml:167,176)")
+    ap.add_argument("--latent-dropout", type=float, nargs="*", default=[0.0, 0.1, 0.2, 0.4],
+                    help="per-level latent dropout of the style encoder, inclusive across levels (recipes/scoreperformer/base.yaml:121,124)")
+    ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the child command and exit")
     ap.add_argument("--no-decode", action="store_true", help="skip the C5 decode object (N = 1 only)")
     ap.add_argument("--decode-seq", type=int, default=4096)
     return ap.parse_args()
@@ -50,14 +56,43 @@ def flops_per_token_fwd(seq, d=512, h=8, dh=64, layers=18, inner=2048):
     return layers * per_layer + 8.1e6 + 1.7e6 + 1.9e6
 
 
+def launch_command(argv, gpus, port=None):
+    """The command `python bench.py --gpus N` turns into when no launcher started it: one rank per GPU under torch.distributed.run on
+    this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process -- which has made no GPU call
+    and makes none -- starts the N ranks as a CHILD process (never an exec: a process that has touched the GPU must not be replaced, and
+    the rule is kept simple by never replacing any), lets the child write to the inherited stdout / stderr (rank 0's JSON line is the last
+    line on stdout) and returns the child's exit code."""
+    import subprocess
+    cmd = launch_command(argv, args.gpus)
+    if args.dry_launch:
+        print(" ".join(cmd))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -80,7 +115,8 @@ def main():
     from scoreperformer_amd.synthetic import model_config, synthetic_batch
 
     torch.manual_seed(1234)  # identical initial replicas on every rank
-    cfg = model_config(args.preset, max_seq_len=max(args.seq, 256), dropout=args.dropout)
+    cfg = model_config(args.preset, max_seq_len=max(args.seq, 256), dropout=args.dropout,
+                       latent_dropout=(list(args.latent_dropout) + [0.0] * 4)[:4])
     model = ScorePerformer.init(cfg)
     cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     arena = ParamArena(model, dev)
@@ -131,13 +167,15 @@ def main():
         "unit": "note-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"C3 ScorePerformer train step: 6/6/6 layers d=512 h=8 MQA GLU-SiLUx4, MMD-VAE style encoder, "
-                               f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel)",
+                               f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel), "
+                               f"latent dropout {list(cfg.perf_encoder.latent_dropout)} inclusive (recipes/scoreperformer/base.yaml:119-126)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss,
                    "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
                    "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
                    # the two default approximations inside the 1e-3 parity budget (tests/test_parity_c2_gpu.py holds both settings to it)
-                   "numerics": {"adaln_rows": "bf16" if F_.ADALN_GB_DTYPE == torch.bfloat16 else "fp32", "adaln_fused_forward": bool(F_.ADALN_FUSED),
+                   "numerics": {"latent_dropout": list(cfg.perf_encoder.latent_dropout), "inclusive_latent_dropout": bool(cfg.perf_encoder.inclusive_latent_dropout),
+                                "adaln_rows": "bf16" if F_.ADALN_GB_DTYPE == torch.bfloat16 else "fp32", "adaln_fused_forward": bool(F_.ADALN_FUSED),
                                 "alibi_band_log2": float(lib_mod.get_tuning("attn_band")), "ffn_fused_epilogues": bool(F_.FFN_FUSE and F_.GLU_FUSE)},
                    "model_tflops_per_s_per_gpu": 3 * flops_per_token_fwd(args.seq) * value / world / 1e12},
     }
@@ -155,6 +193,7 @@ def main():
             result["decode_c5"] = decode_leg(args, dev)
         except Exception as exc:  # noqa: BLE001 -- the headline line must not depend on the secondary object
             result["decode_c5"] = {"error": repr(exc)}
+    sync.close()               # restores the process-wide gemm_persist_bwd knob, releases the native communicator
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -181,8 +220,8 @@ def pick_transport(args, dist, dev):
     # failed here while the others entered the communicator's collective init would leave them waiting for it.
     pre, why = 1, ""
     try:
-        from scoreperformer_amd.comm import unique_id
-        unique_id()
+        from scoreperformer_amd.comm import available
+        available()            # binds RCCL's entry points only: no id, no bootstrap thread (rank 0 alone makes the id, in from_group)
     except Exception as exc:  # noqa: BLE001
         pre, why = 0, repr(exc)
     flag = torch.tensor([pre], device=dev)
@@ -190,14 +229,15 @@ def pick_transport(args, dist, dev):
     if int(flag) == 0:
         return "torch", "native transport unavailable on some rank (" + (why or "another rank") + "): torch.distributed"
     ok, why = 1, "spn_comm_allreduce == dist.all_reduce on a 1 Mi-element probe on every rank"
+    # small integers: every partial sum stays below 2^24, so the result is exact in fp32 whatever reduction order either communicator picks
+    probe = (torch.arange(1 << 20, device=dev) % 1024).float() * (1.0 + dist.get_rank())
+    want = probe.clone()
+    dist.all_reduce(want)      # OUTSIDE the try block: every rank issues the same torch.distributed collectives in the same order whatever fails below
     try:
         from scoreperformer_amd.comm import NativeComm
         comm = NativeComm.from_group(dist.group.WORLD)
-        probe = torch.arange(1 << 20, device=dev, dtype=torch.float32) * (1.0 + dist.get_rank())
-        want = probe.clone()
         comm.all_reduce_(probe)
         comm.wait()
-        dist.all_reduce(want)
         torch.cuda.synchronize()
         if not torch.equal(probe, want):
             ok, why = 0, "probe mismatch"
@@ -386,22 +426,68 @@ def decode_leg(args, dev):
                          "note": "decoder weights (fp32) + mean K/V cache bytes per note; bound by the dependent hand-offs inside the persistent layer launch today (DESIGN.md §3 decode_layer.hip)"}}
 
 
-def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
-    """The CPU oracle (parity-pinned port of the reference, oracle/ref_cpu.py) timed on this host's cores: forward+backward
-    of ONE sequence of `cpu_seq` notes of the same model (bounded sample), fp32."""
-    from oracle import ref_cpu
-    from scoreperformer_amd.synthetic import synthetic_batch
-    n = args.cpu_seq
-    threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))   # more threads only add oversubscription on these op sizes
+def _cpu_full_step(ref_cpu, cfg, cpu_state, batch, z, threads):
+    """One fp32 CPU train step of the oracle on fresh weights: (seconds forward, forward+backward, full step incl. clip + AdamW, loss)."""
     torch.set_num_threads(threads)
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v)
           for k, v in cpu_state.items()}
-    batch = synthetic_batch(args.cpu_batch, n, seed=99)
-    z = [torch.randn(256, d) for d in cfg["perf_encoder"]["latent_dim"]]
     t0 = time.perf_counter()
     out = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True)
+    t1 = time.perf_counter()
     out["loss"].backward()
-    dt = time.perf_counter() - t0
+    t2 = time.perf_counter()
+    seen, params = set(), []
+    for v in sd.values():      # tied tensors appear under several keys
+        if torch.is_tensor(v) and v.requires_grad and v.grad is not None and id(v) not in seen:
+            seen.add(id(v)); params.append(v)
+    with torch.no_grad():
+        ref_cpu.clip_adamw_step([p_ for p_ in params], [p_.grad for p_ in params], [torch.zeros_like(p_) for p_ in params],
+                                [torch.zeros_like(p_) for p_ in params], 1, lr=2e-4, weight_decay=1e-6, max_norm=2.0)
+    t3 = time.perf_counter()
+    return t1 - t0, t2 - t0, t3 - t0, out
+
+
+def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
+    """The CPU oracle (parity-pinned port of the reference, oracle/ref_cpu.py) timed on this host's cores the way BASELINE.md section 4
+    lays out: the same model and sequence length as the GPU run, batch reduced (b = 1 at seq 2048), fp32, one warm-up step, then the
+    MEDIAN of `cpu_reps` steps, three sections each (forward, forward+backward, full step = + global-norm clip + AdamW), normalised to
+    note-tokens/s; `value` is the full step at `cores` threads, a second figure gives one step with every host core.  Bounded sample,
+    outside the timed region."""
+    from oracle import ref_cpu
+    from scoreperformer_amd.synthetic import synthetic_batch
+    import copy
+    import statistics
+    n = args.cpu_seq
+    host = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
+    threads = max(1, min(usable, args.cpu_threads))
+    # the oracle has no latent-dropout draws of its own (masks are injected in the tests): the baseline runs the recipe without it
+    cfg_cpu = copy.deepcopy(cfg)
+    batch = synthetic_batch(args.cpu_batch, n, seed=99)
+    z = [torch.randn(256, d) for d in cfg["perf_encoder"]["latent_dim"]]
+    toks = args.cpu_batch * n
+    t_all = time.perf_counter()
+    _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, threads)            # warm-up (allocator, thread pool, first-touch)
+    runs = [_cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, threads) for _ in range(max(1, args.cpu_reps))]
+    med = [statistics.median(r[i] for r in runs) for i in range(3)]
+    out = runs[-1][3]
+    sections = {"forward": {"s": med[0], "note_tokens_per_s": toks / med[0]},
+                "forward_backward": {"s": med[1], "note_tokens_per_s": toks / med[1]},
+                "full_step": {"s": med[2], "note_tokens_per_s": toks / med[2]}}
+    all_cores = None
+    if getattr(args, "cpu_all_cores", False) and usable > threads:
+        _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, usable)
+        a = _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, usable)
+        all_cores = {"cores": usable, "full_step_s": a[2], "note_tokens_per_s": toks / a[2], "forward_backward_note_tokens_per_s": toks / a[1],
+                     "sample": "one warm-up + one timed step"}
+        torch.set_num_threads(threads)
+    wall = time.perf_counter() - t_all
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
     parity = None
     if model is not None:   # same batch, same initial weights, same MMD samples through the HIP path (dropout off): loss parity
         sd_now = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -418,9 +504,16 @@ def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
         model.perf_encoder._z_override, model.perf_encoder.segment_bounds = None, bounds
         model.load_state_dict(sd_now)
         model.train()
-    return {"value": args.cpu_batch * n / dt, "unit": "note-tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port", "parity": parity,
-            "sample": f"{args.cpu_batch} sequences x {n} notes of the same C3 model, forward+backward (no optimizer), fp32, torch "
-                      f"{torch.__version__} CPU with {threads} threads (host has {os.cpu_count()} cores), {dt:.1f} s wall",
+    if all_cores is None:
+        all_cores = {"cores": 256, "full_step_s": 679.5, "note_tokens_per_s": 3.01, "forward_backward_note_tokens_per_s": 4.41,
+                     "sample": "STORED measurement (profiles/r04_bench_a.json, one warm-up + one timed step of the same sample with 256 torch "
+                               "threads on a 256-core GPU box): two orders of magnitude SLOWER than 32 threads -- these operator sizes do "
+                               "not feed 256 threads -- and 11 minutes of wall time, so it is not re-run by default (--cpu-all-cores)"}
+    return {"value": toks / med[2], "unit": "note-tokens/s", "cores": threads, "host_cores": host, "usable_cores": usable, "cpu_model": cpu_model,
+            "kind": "port", "sections": sections, "all_host_cores": all_cores, "parity": parity,
+            "sample": f"{args.cpu_batch} sequence(s) x {n} notes of the same C3 model, fp32, torch {torch.__version__} CPU: 1 warm-up + median of "
+                      f"{len(runs)} full train steps (forward, backward, global-norm clip + AdamW through oracle.ref_cpu) with {threads} threads; "
+                      f"`value` = the full step; host has {host} cores ({cpu_model}); {wall:.0f} s wall for the whole leg",
             "cpu_loss": float(out["loss"].detach())}
 
 

@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -338,6 +338,7 @@ int spn_collate_pad_tokens(const int32_t* flat, const int32_t* off, int b, int K
  *      No host synchronisation in allreduce / wait; streams / events are created in init (on the device current at that call, which
  *      every later entry point re-selects for the duration of the call; a buffer on another device is rejected) and released in
  *      destroy, which -- the one exception in this library -- first waits for the communication stream to drain. */
+int spn_comm_available(const char* rccl_path); /* SPN_OK when RCCL can be bound in this process; not collective, makes no id */
 int spn_comm_unique_id(void* id128, const char* rccl_path);
 int spn_comm_init(void** comm, int nranks, int rank, const void* id128, const char* rccl_path);
 int spn_comm_allreduce(void* comm, void* buf, size_t count, int dtype, spn_stream_t producer_stream);

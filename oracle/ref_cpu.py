@@ -468,13 +468,13 @@ def mmd_heads(
             if torch.any(dl):
                 losses[f"MMD/{mode}/deadpan"] = F.mse_loss(dl, torch.zeros_like(dl))
     embeddings = torch.cat(embs, dim=-1) * m3
-    full = embeddings
-    if training:
+    full, dm = embeddings, None
+    if training:                                                       # mmd_transformer.py:284-291
         dm = torch.cat(drops, dim=-1) * m3 * (~deadpan_mask[:, None, None])
         embeddings = embeddings * (~dm)
     loss = sum(losses.values())
     losses["MMD"] = loss
-    return dict(latents=latents, embeddings=embeddings, full_embeddings=full, loss=loss, losses=losses)
+    return dict(latents=latents, embeddings=embeddings, full_embeddings=full, dropout_mask=dm, loss=loss, losses=losses)
 
 
 # --------------------------------------------------------------------------------------
@@ -528,7 +528,8 @@ def score_performer_forward(
     loss = ce + enc["loss"]
     losses = dict(losses, **enc["losses"])
     return dict(loss=loss, losses=losses, logits=logits, hidden_state=out, perf_embeddings=enc["embeddings"],
-                score_embeddings=score_emb, latents=enc["latents"])
+                score_embeddings=score_emb, latents=enc["latents"], perf_full_embeddings=enc["full_embeddings"],
+                perf_dropout_mask=enc["dropout_mask"])
 
 
 # --------------------------------------------------------------------------------------

@@ -12,13 +12,18 @@ from typing import Optional
 
 import torch
 
-from .lib import call, load, ptr, stream_ptr, c_int
+from .lib import SpnError, call, load, ptr, stream_ptr, c_int
 
 
 def rccl_path() -> Optional[bytes]:
     """The RCCL copy PyTorch ships (so that libspn.so binds to the runtime that is already in the process)."""
     cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
     return cand.encode() if os.path.exists(cand) else None
+
+
+def available() -> None:
+    """Raises SpnError when this process cannot bind RCCL through libspn.so; no collective, no id, no bootstrap thread."""
+    call("spn_comm_available", rccl_path())
 
 
 def unique_id() -> bytes:
@@ -40,9 +45,16 @@ class NativeComm:
         """Collective over an initialised torch.distributed group: rank 0 makes the id, everybody receives it."""
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [unique_id() if rank == 0 else None]
+        box, err = [None], None
+        if rank == 0:
+            try:
+                box = [unique_id()]
+            except Exception as exc:  # noqa: BLE001 -- the broadcast below must still happen: the other ranks are waiting in it
+                err = exc
         if world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None:
+            raise SpnError(f"rank 0 could not make an RCCL id: {err!r}" if rank == 0 else "rank 0 could not make an RCCL id")
         return cls(world, rank, box[0])
 
     def all_reduce_(self, t: torch.Tensor) -> None:

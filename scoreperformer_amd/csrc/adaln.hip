@@ -21,6 +21,10 @@
 
 namespace {
 
+// wave-private LDS slab exchange: order cross-lane writes before reads for the compiler (no instruction is emitted)
+#define SLAB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 constexpr int AD = 512, AC = 64, NBLK = AD / 16;
 constexpr int W_BYTES = 2 * AD * AC * 2;          // 131072
 constexpr int STG_ROW = 144;                       // staging row stride: 128 data bytes + 16 (keeps 16-byte alignment, spreads banks)
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(512, 2) void adaln_fwd_kernel(const float* __restri
                 *reinterpret_cast<uint2*>(stg + c * STG_ROW + (16 * j + 4 * g) * 2) = pk;
                 gpk[j].x = pack_bf2(ga[0], ga[1]); gpk[j].y = pack_bf2(ga[2], ga[3]);
             }
-            // the slab holds [16 tokens][64 features] bf16: 4 lanes per token take 32 bytes each = one whole 128-byte line per token
+            // the slab holds [16 tokens][64 features] bf16: 4 lanes per token take 32 bytes each = one whole 128-byte line per token.
+            // Lane (c, g) wrote row c, lane (row, pc) reads row `row`: a cross-lane exchange inside ONE wave -- the wave-level fence + wave
+            // barrier order the slab writes before the reads (and the reads before the next rewrite) in the compiler's eyes; the hardware
+            // executes a wave's LDS instructions in order, so they cost no instruction.
             const int row = lane >> 2, pc = lane & 3;
+            SLAB_SYNC();
             const uint4 v0 = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + pc * 32);
             const uint4 v1 = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + pc * 32 + 16);
             if (t0 + row < T) {
@@ -105,9 +113,11 @@ __global__ __launch_bounds__(512, 2) void adaln_fwd_kernel(const float* __restri
                 *reinterpret_cast<uint4*>(yp) = v0;
                 *reinterpret_cast<uint4*>(yp + 8) = v1;
             }
+            SLAB_SYNC();
             if (gamma_out) {   // the gamma rows for the backward (bf16 [T, D]): dx needs gamma_t, nothing needs beta_t
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *reinterpret_cast<uint2*>(stg + c * STG_ROW + (16 * j + 4 * g) * 2) = gpk[j];
+                SLAB_SYNC();
                 const uint4 g0 = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + pc * 32);
                 const uint4 g1 = *reinterpret_cast<const uint4*>(stg + row * STG_ROW + pc * 32 + 16);
                 if (t0 + row < T) {
@@ -115,6 +125,7 @@ __global__ __launch_bounds__(512, 2) void adaln_fwd_kernel(const float* __restri
                     *reinterpret_cast<uint4*>(gp) = g0;
                     *reinterpret_cast<uint4*>(gp + 8) = g1;
                 }
+                SLAB_SYNC();
             }
         }
     }

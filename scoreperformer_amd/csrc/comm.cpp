@@ -104,6 +104,10 @@ struct DeviceGuard {
 
 }  // namespace
 
+// No collective, no bootstrap thread, no device call: can this process reach RCCL through the library at all (the shared object loads and
+// carries the four entry points)?  A data-parallel launcher asks every rank BEFORE any rank enters spn_comm_init's collective.
+extern "C" int spn_comm_available(const char* rccl_path) { return bind_rccl(rccl_path); }
+
 extern "C" int spn_comm_unique_id(void* id128, const char* rccl_path) {
     if (!id128) { spn_set_error("spn_comm_unique_id: null output"); return SPN_ERR_ARG; }
     if (int rc = bind_rccl(rccl_path)) return rc;

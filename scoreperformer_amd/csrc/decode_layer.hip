@@ -54,13 +54,16 @@ __device__ __forceinline__ void gather(unsigned long long* g, int n, unsigned ep
         for (int k = 0; k < 2; ++k) {
             const int p = tid + NT * k;
             if (2 * p < n) {
-                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, p * 16, 0, 16);   // aux 16 = sc1: served past the L1, at agent scope
+                // aux 16 = sc1: served past the L1, at agent scope; bit 31 = volatile: the load is re-issued in every pass (the intrinsic
+                // is read-only and s_sleep touches no memory, so nothing else tells the optimiser that the granules change under it)
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, p * 16, 0, (int)(16u | 0x80000000u));
                 ok &= v[k][1] == epoch && v[k][3] == epoch;
             }
         }
         if (ok) break;
         if (++spins > SPIN_LIMIT) { *err = 1; break; }
         __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");   // belt and braces: a compiler barrier between two polling passes
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -227,7 +230,12 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         auto prefetch = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
             pre = false;
             if (tid < 256 && a.jlo) {
-                jlo_guess = min(a.jlo[hi], t);
+                // jlo[] and kmax2[] are read and written by different workgroups of the SAME launch without ordering (relaxed agent-scope
+                // accesses, no hand-off): benign by construction -- jlo is only a GUESS of which rows to request early (a stale or a fresh
+                // value both work: a wrong guess reloads behind q, see `hit` below), and kmax2 is a running maximum into which every reader
+                // folds this note's |k_new|^2 itself, so it sees an upper bound of the reach whether or not another workgroup's atomicMax
+                // has landed yet; both decode paths round j_lo down to a multiple of 256, so the summation ranges do not depend on it either.
+                jlo_guess = min(__hip_atomic_load(a.jlo + hi, RLX_AGENT), t);
                 const int chunk = (t + 1 - jlo_guess + S - 1) / S;
                 const int j0 = jlo_guess + sp * chunk, j1 = min(t + 1, j0 + chunk);
                 const int jb0 = j0 + w * 4 + grp;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             // slope and running max |k|^2 do not depend on this note's q either (the other workgroups' atomicMax below only folds in
             // |k_new|^2, which is folded in here anyway): read behind q they were one more trip to memory on the critical path
             const float slope = a.slopes ? a.slopes[hi] : 0.f;
-            const float kmax_old = a.kmax2[kh];
+            const float kmax_old = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned int*>(a.kmax2 + kh), RLX_AGENT));
             // ---- phase 1: q | k | v = Wqkv . LN(x) ------------------------------------------------------------------------------------
             if (own1) {
                 if (l > 0) gather(layers[l - 1].gxo, d, ebase + 8u * (unsigned)layers[l - 1].layer + 5u, xs, tid, err);
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     const float reach = (104.f + 2.f * a.scale * sqrtf(qn2 * km)) / slope;
                     if (reach < (float)t) j_lo = (t - (int)reach - 1) & ~255;   // as dec_attn2_kernel
                 }
-                if (sp == 0 && w == 0 && lane == 0 && a.jlo) a.jlo[hi] = j_lo;   // the next note's guess
+                if (sp == 0 && w == 0 && lane == 0 && a.jlo) __hip_atomic_store(a.jlo + hi, j_lo, RLX_AGENT);   // the next note's guess
                 const int total = t + 1 - j_lo;
                 const int chunk = (total + S - 1) / S;
                 const int j0 = j_lo + sp * chunk, j1 = min(t + 1, j0 + chunk);

@@ -45,6 +45,8 @@ class GreedyDecoder:
         self.use_pair = os.environ.get("SPN_DEC_PAIR", "1") != "0" and not self.legacy_launches
         self.pair_groups = 0       # workgroups of that launch (0: shape not supported, the five launches run)
         self.pair_front = self.pair_tail = False   # the note's input projections / the LM head's input projection ride in that launch
+        self.pair_fallbacks = 0    # how often a timed-out hand-off made this engine fall back to the five launches per pair (see _pair_failed)
+        self._pair_fault_inject = False   # test hook: start with the error word set, as after a timed-out hand-off
         tr = m.transformer
         types = tuple(tr.layer_types)
         self.cross = 'c' in types
@@ -111,7 +113,10 @@ class GreedyDecoder:
         if self.use_pair:
             self.pair_groups = ops.dec_pair_groups(d, self.heads, self.kvh, self.g.numel(), S)
             if self.pair_groups > torch.cuda.get_device_properties(dev).multi_processor_count:
-                self.pair_groups = 0   # every workgroup of that launch must be resident at once, one per CU
+                # every workgroup of that launch must be resident at once, one per CU.  This compares against the device's CU COUNT only:
+                # a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) or another kernel holding CUs is not visible here -- then a hand-off poll
+                # runs into its bound, the kernel sets *err, and _pair_failed() falls back to the five launches per pair.
+                self.pair_groups = 0
         if self.pair_groups:   # hand-off granules of the persistent layer-pair launch ({epoch, value} words: zero = no epoch)
             zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
@@ -122,6 +127,8 @@ class GreedyDecoder:
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
+            if self._pair_fault_inject:
+                self.pair_err.fill_(9)
             self.pair_stamps = ([torch.zeros(self.pair_groups * 8, device=dev, dtype=torch.int64) for _ in range(n_self)]
                                 if os.environ.get("SPN_DEC_PAIR_STAMPS", "0") == "1" else None)   # tuning aid (tools/bench_dec_pair.py)
         tr = m.transformer
@@ -478,9 +485,26 @@ class GreedyDecoder:
             self.pair_chains = {k: ops.DecPairChain(v, self.dev, ext if (ext and k == 0) else None) for k, v in self.pair_chains.items()}
         return self.pair_chains
 
-    def _pair_check(self):
-        if self.pair_groups and int(self.pair_err.item()):
-            raise RuntimeError(f"decode engine: a hand-off of the persistent layer launch timed out (code {int(self.pair_err.item())})")
+    def _pair_failed(self) -> bool:
+        """True when a hand-off poll of the persistent layer launch ran into its bound (`*err` != 0: that launch and every later one of
+        the render returned early, so whatever they were to produce is garbage).  The engine then drops the persistent launch for the
+        rest of its life -- error word cleared, chains and the captured graph released -- and the CALLER re-runs the notes through the five
+        launches per pair, which give bit-identical results (tests/test_dec_pair_gpu.py).  Typical causes: another process or stream
+        held CUs for longer than the poll bound (~0.3 s), or a CU-masked environment in which not all workgroups are resident."""
+        if not self.pair_groups:
+            return False
+        code = int(self.pair_err.item())
+        if code == 0:
+            return False
+        import warnings
+        warnings.warn(f"decode engine: a hand-off of the persistent layer launch timed out (code {code}); falling back to the five "
+                      f"launches per layer pair for this engine (same tokens, ~25 % slower per note)", RuntimeWarning, stacklevel=3)
+        self.pair_err.zero_()
+        self.use_pair, self.pair_groups = False, 0
+        self.pair_chains, self.pair_front, self.pair_tail = {}, False, False
+        self.graph = None
+        self.pair_fallbacks += 1
+        return True
 
     # -- public ----------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -489,6 +513,12 @@ class GreedyDecoder:
         """tokens / tokens_masked: [1, L, K] int64 on the GPU; returns (filled tokens, number of decoded positions).
         context: [1, L, d] rows concatenated per note (context_emb_mode 'cat') or [1, n_ctx, d] attended as a whole ('attention',
         with its key mask `context_mask` [1, n_ctx])."""
+        out = self._run_once(tokens, tokens_masked, context, style, mask_token_id, context_mask)
+        if self._pair_failed():      # (clears the error, switches the persistent launch off) -> the same window through the five launches
+            out = self._run_once(tokens, tokens_masked, context, style, mask_token_id, context_mask)
+        return out
+
+    def _run_once(self, tokens, tokens_masked, context, style, mask_token_id, context_mask):
         m = self.m
         L = tokens.shape[1]
         self._alloc(L)
@@ -523,7 +553,6 @@ class GreedyDecoder:
         if self.use_graph and n_steps > 2:
             step(dims)                              # warm-up (also position 0), eager
             torch.cuda.synchronize()
-            self._pair_check()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 step(dims)                          # recorded, not executed; every replay reads *pos on the device
@@ -534,7 +563,6 @@ class GreedyDecoder:
             for _ in range(n_steps):
                 step(dims)
         self.n_steps = n_steps
-        self._pair_check()
         return self.seq2d[None], n_steps
 
     def caches(self):
@@ -753,22 +781,31 @@ class RenderSession(GreedyDecoder):
         if batched_prefill and c == 0 and Lin - 1 - n_new >= self.prefill_min:
             self.prefill(Lin - 1 - n_new)
             c = self.length
-        self.pos2.fill_(c)
         if self.sampling is not None:   # a fresh stream per call: positions repeat after a cut, (seed, position, key) must not
             self.sampling["calls"] += 1
             self.seed_dev.fill_((self.sampling["calls"] * 0x9E3779B1) & 0x7FFFFFFF)
         steps = Lin - 1 - c
-        done = 0
-        if self.use_graph and self.graph is None and steps > 0:
-            self._step_fn(self.dims)                 # first step eager (warms every lazily built operand), then record once
-            done = 1
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_fn(self.dims)
-            self.graph = g
-        for _ in range(steps - done):
-            self.graph.replay() if self.use_graph else self._step_fn(self.dims)
+        for attempt in (0, 1):
+            self.pos2.fill_(c)
+            done = 0
+            if self.use_graph and self.graph is None and steps > 0:
+                self._step_fn(self.dims)                 # first step eager (warms every lazily built operand), then record once
+                done = 1
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_fn(self.dims)
+                self.graph = g
+            for _ in range(steps - done):
+                self.graph.replay() if self.use_graph else self._step_fn(self.dims)
+            if attempt or not self._pair_failed():
+                break
+            # a hand-off of the persistent launch timed out somewhere in these steps: rows >= c of every cache, the decoded tokens and the
+            # running key norms are garbage.  Rows < c came from earlier, checked calls (or the batched prefill, which has no persistent
+            # launch): restore the inputs and the key-norm bound from them, then run the same steps through the five launches per pair.
+            self.seq2d[c:Lin].copy_(tokens[c:Lin], non_blocking=True)
+            for i, k in enumerate(self.kmax2):
+                k.zero_() if c == 0 else k.copy_(self.kc[i][:c].view(c, self.kvh, 64).pow(2).sum(-1).amax(0))
         self.steps_run += steps
         self.length = Lin - 1
         self.n_steps = self.length

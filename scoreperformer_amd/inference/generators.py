@@ -263,8 +263,8 @@ class ScorePerformerGenerator:
                     session.truncate(caches.length)
                 rows = session.decode(torch.from_numpy(model_in), torch.from_numpy(doubled), score_embs, perf_embs, n_new,
                                       batched_prefill=self.prefill == "engine")
-                gen_tokens = rows.cpu().numpy()                                # the loop's one D2H copy per chord group
-                session._pair_check()                                          # (the stream is drained: reading the error word costs nothing)
+                gen_tokens = rows.cpu().numpy()                                # the loop's one D2H copy per chord group (decode() has checked
+                                                                               # the persistent launch's error word and re-run if it had to)
                 caches = _EngineCache(start_idx, session.length)
                 session.tag = caches
             else:

@@ -26,9 +26,10 @@ class GradSync:
         it needs a process group and raises without one (no silent fall-back to the torch path).
         `persistent_backward`: the process-wide `gemm_persist_bwd` knob (csrc/tuning.h) -- input-gradient GEMMs walk their tiles with
         one persistent block per CU, which is only safe when NO other kernel holds CUs during the backward (a concurrent all-reduce
-        starves the blocks that land on its CUs).  None (default) leaves the knob alone; True asks for the walk and is honoured only
-        when this object reduces nothing itself (`active` is False) -- the caller vouches that nobody else reduces during backward
-        either; False switches it off.  `close()` restores the value found at construction."""
+        starves the blocks that land on its CUs).  An ACTIVE object (it launches all-reduces from inside backward) always forces the knob
+        to 0, whatever this argument says and whatever an earlier object left behind.  Otherwise: None (default) leaves the knob alone;
+        True asks for the walk -- the caller vouches that nobody else reduces during backward either; False switches it off.  `close()`
+        (also the context manager's exit and `__del__`) restores the value found at construction."""
         if transport not in ("torch", "spn"):
             raise ValueError(f"unknown transport {transport!r}")
         self.arena, self.group = arena, group
@@ -44,7 +45,8 @@ class GradSync:
                 from .comm import NativeComm
                 self.native = NativeComm.from_group(group)
         self._knob_before = None
-        if persistent_backward is not None and not dry_run:
+        on_gpu = bool(getattr(getattr(arena, "grads", None), "is_cuda", False))    # (the gloo tests drive this class with host tensors)
+        if not dry_run and (persistent_backward is not None or (self.active and on_gpu)):
             from . import lib
             self._knob_before = lib.get_tuning("gemm_persist_bwd")
             lib.set_tuning("gemm_persist_bwd", 1.0 if (persistent_backward and not self.active) else 0.0)
@@ -167,6 +169,20 @@ class GradSync:
         if self.native is not None:
             self.native.close()
             self.native = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            if self._knob_before is not None:
+                self.close()
+        except BaseException:   # noqa: BLE001 -- interpreter teardown: the binding may be gone
+            pass
 
     def begin_step(self):
         if not self.active:

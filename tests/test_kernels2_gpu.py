@@ -117,6 +117,78 @@ def test_mmd_forward_backward(N, D):
     assert float(yt.grad[w == 0].abs().max()) == 0.0
 
 
+def test_mmd_loss_more_rows_than_the_cap_but_fewer_valid_ones_equals_the_oracle():
+    """`MMDLoss.forward` (mmd_transformer.py:511-520): the reference gathers the VALID latents first and subsets only if MORE THAN 4096
+    of them remain.  The product never gathers (no host sync): with > 4096 ROWS it keeps the 4096 largest random keys, invalid rows
+    last -- so 6000 rows of which 3000 are valid must give exactly the oracle's value on the valid rows, forward and backward.
+    (The benchmark configuration b=64, n=2048 takes this branch on three of four levels every step.)"""
+    from oracle import ref_cpu
+    from scoreperformer_amd.models.scoreperformer.mmd_transformer import MMDLoss
+    g = torch.Generator().manual_seed(77)
+    N, D = 6000, 8
+    y = (0.8 * torch.randn(N, D, generator=g) + 0.1)
+    z = torch.randn(256, D, generator=g)
+    valid = torch.zeros(N, dtype=torch.bool)
+    valid[torch.randperm(N, generator=g)[:3000]] = True
+    yr = y.clone().requires_grad_(True)
+    ref = ref_cpu.compute_mmd(z, yr[valid])
+    ref.backward()
+    crit = MMDLoss()
+    assert N > crit.max_num_latents >= 3000
+    for seed in (0, 1):                                   # whatever keys are drawn, the selection holds every valid row
+        torch.manual_seed(seed)
+        yt = y.to(DEV).view(3, 2000, D).clone().requires_grad_(True)
+        got = crit(yt, mask=valid.to(DEV).view(3, 2000), z=z.to(DEV))
+        assert abs(float(got) - float(ref)) < 1e-5 + 1e-4 * abs(float(ref)), (float(got), float(ref))
+        got.backward()
+        gt = yt.grad.view(N, D).cpu()
+        assert rel_err(gt, yr.grad) < 1e-3
+        assert float(gt[~valid].abs().max()) == 0.0
+
+
+def test_mmd_loss_subset_of_more_than_the_cap_valid_rows_is_uniform_and_unbiased():
+    """More than 4096 valid latents: the reference computes the loss on `latents[randperm(n)[:4096]]` (mmd_transformer.py:515-517), a
+    uniform subset without replacement.  The product's top-k-of-random-keys selection must pick exactly 4096 rows, all of them valid,
+    every valid row equally often, and the loss averaged over draws must agree with the exact expectation of the reference's estimator
+    (computed with the oracle's kernel means on the full set: the diagonal of the y-y kernel weighs 1/4096 instead of 1/n)."""
+    from oracle import ref_cpu
+    from scoreperformer_amd.models.scoreperformer.mmd_transformer import MMDLoss
+    g = torch.Generator().manual_seed(78)
+    N, D, n_valid, cap, draws = 6500, 4, 6000, 4096, 100
+    y = 0.7 * torch.randn(N, D, generator=g) + 0.3 * (torch.arange(N)[:, None] / N)     # a drift along the rows: position matters
+    z = torch.randn(256, D, generator=g)
+    valid = torch.zeros(N, dtype=torch.bool)
+    valid[torch.randperm(N, generator=g)[:n_valid]] = True
+    yv = y[valid]
+    kyy = float(ref_cpu.gaussian_kernel_mean(yv, yv))
+    off = (kyy * n_valid * n_valid - n_valid) / (n_valid * (n_valid - 1))               # mean over i != j
+    expect = float(ref_cpu.gaussian_kernel_mean(z, z)) + (1.0 / cap + (cap - 1) / cap * off) \
+        - 2 * float(ref_cpu.gaussian_kernel_mean(z, yv))
+    crit = MMDLoss()
+    assert crit.max_num_latents == cap
+    yd, vd, zd = y.to(DEV), valid.to(DEV), z.to(DEV)
+    torch.manual_seed(5)
+    vals, picked = [], torch.zeros(N, device=DEV)
+    for _ in range(draws):
+        yt = yd.clone().requires_grad_(True)
+        v = crit(yt, mask=vd, z=zd)
+        v.backward()
+        sel = yt.grad.abs().sum(-1) > 0
+        assert int(sel.sum()) == cap and not bool((sel & ~vd).any())
+        picked += sel.float()
+        vals.append(float(v))
+    vals = torch.tensor(vals, dtype=torch.float64)
+    se = float(vals.std()) / draws ** 0.5
+    assert abs(float(vals.mean()) - expect) < 4 * se + 1e-6, (float(vals.mean()), expect, se)
+    assert float(vals.std()) > 0                                                        # the draws do differ
+    freq = (picked / draws)[vd].cpu()
+    p = cap / n_valid
+    sd = (p * (1 - p) / draws) ** 0.5
+    assert float((freq - p).abs().max()) < 5.5 * sd                                      # 6000 rows: max |z| ~ 4
+    half = n_valid // 2
+    assert abs(float(freq[:half].mean()) - float(freq[half:].mean())) < 5 * sd / half ** 0.5 * 2 ** 0.5 + 1e-3
+
+
 def test_cross_entropy_forward_backward():
     from scoreperformer_amd import ops
     g = torch.Generator().manual_seed(4)

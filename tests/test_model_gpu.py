@@ -473,3 +473,97 @@ def test_render_session_serves_cross_attending_decoders(dev):
     sess.reset()
     got = sess.decode(tokens[0].to(dev), maskedb[0].to(dev), ctx, sty, n).cpu().numpy()
     assert (got == want[-n:]).all()
+
+
+@pytest.mark.parametrize("tag", ["incl", "excl"])
+def test_latent_dropout_matches_reference_golden(dev, tag):
+    """base.yaml:119-126 trains with latent_dropout [0, .1, .2, .4]: the reference's own per-level drop masks (recorded from
+    `dropout_latent_mask`, mmd_transformer.py:537-542) go through `_drop_override`; embeddings, the combined inclusive / exclusive
+    mask incl. the dead-pan exemption (mmd_transformer.py:249-253,284-291), loss and every gradient norm must match the reference."""
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config
+    fix = dict(np.load(os.path.join(GOLD, "latent_dropout.npz"), allow_pickle=False))
+    kw = dict(preset="tiny", num_tokens=SMALL_VOCAB, latent_dropout=[0.0, 0.1, 0.2, 0.4])
+    cfg = model_config(**kw)
+    cfg.perf_encoder.inclusive_latent_dropout = tag == "incl"
+    model = ScorePerformer.init(cfg)
+    assert model.perf_encoder.inclusive_latent_dropout == (tag == "incl")
+    model.load_state_dict(filled_state_dict(model, seed=0), strict=True)
+    arena = ParamArena(model, dev)
+    model.train()
+    batch = {k[3:]: torch.from_numpy(v).to(dev) for k, v in fix.items() if k.startswith("in/")}
+    model.perf_encoder._z_override = [torch.from_numpy(fix[f"{tag}/z/{i}"]).to(dev) for i in range(4)]
+    model.perf_encoder._drop_override = [torch.from_numpy(fix[f"{tag}/drop/{i}"][..., 0]).to(dev) if f"{tag}/drop/{i}" in fix else None
+                                         for i in range(4)]
+    out = model(**batch)
+    enc = out.perf_encoder
+    np.testing.assert_array_equal(enc.dropout_mask.cpu().numpy(), fix[f"{tag}/dropout_mask"])
+    full, emb = enc.full_embeddings.detach().float().cpu().numpy(), enc.embeddings.detach().float().cpu().numpy()
+    assert np.abs(full - fix[f"{tag}/full_embeddings"]).max() <= 0.03 * np.abs(fix[f"{tag}/full_embeddings"]).max() + 1e-3
+    assert np.abs(emb - fix[f"{tag}/embeddings"]).max() <= 0.03 * np.abs(fix[f"{tag}/embeddings"]).max() + 1e-3
+    assert (emb[fix[f"{tag}/dropout_mask"]] == 0).all() and (emb != full).any()
+    pre = f"{tag}/losses/"
+    ref_losses = {k[len(pre):]: float(v) for k, v in fix.items() if k.startswith(pre)}
+    assert set(out.losses) == set(ref_losses)
+    for k, v in ref_losses.items():
+        assert abs(float(out.losses[k]) - v) <= 2e-2 * max(1.0, abs(v)), (k, float(out.losses[k]), v)
+    assert abs(float(out.loss) - float(fix[f"{tag}/loss"])) <= 2e-2 * float(fix[f"{tag}/loss"])
+    hs = out.perf_decoder.hidden_state.detach().float().cpu().numpy()
+    assert np.abs(hs - fix[f"{tag}/hidden_state"]).max() <= 0.03 * np.abs(fix[f"{tag}/hidden_state"]).max()
+    arena.zero_grad()
+    out.loss.backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    bad, checked = [], 0
+    for k, v in fix.items():
+        if k.startswith(f"{tag}/gradnorm/"):
+            got = float(named[k[len(tag) + 10:]].grad.double().norm())
+            checked += 1
+            if abs(got - float(v)) > 0.06 * float(v) + 2e-3:
+                bad.append((k, got, float(v)))
+        if k.startswith(f"{tag}/grad/"):
+            g = named[k[len(tag) + 6:]].grad.float().cpu().numpy()
+            assert np.abs(g - v).max() <= 0.06 * np.abs(v).max() + 1e-4, k
+    assert checked > 100 and not bad, bad[:10]
+
+
+def test_latent_dropout_own_draws(dev):
+    """Without the override the product draws its own masks: whole latent vectors per segment, never on the `mean` level, never in a
+    dead-pan sample, inclusive across levels (a note dropped on the bar level is dropped on beat and onset level too), and at the
+    configured rates; eval mode drops nothing (mmd_transformer.py:284-291,351-362)."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    p = [0.0, 0.1, 0.2, 0.4]
+    cfg = model_config("tiny", num_tokens=SMALL_VOCAB, latent_dropout=p)
+    torch.manual_seed(3)
+    model = ScorePerformer.init(cfg)
+    ParamArena(model, dev)
+    model.train()
+    batch = {k: v.to(dev) for k, v in synthetic_batch(64, 128, num_tokens=SMALL_VOCAB, ragged=True, seed=9).items()}
+    batch["deadpan_mask"][:8] = True
+    out = model(**batch).perf_encoder
+    dm, full, emb = out.dropout_mask, out.full_embeddings, out.embeddings
+    L = list(cfg.perf_encoder.latent_dim)
+    lv = [t[..., 0] for t in dm.split(L, dim=-1)]
+    for t, piece in zip(lv, dm.split(L, dim=-1)):
+        assert bool((piece == t[..., None]).all())             # whole vectors
+    assert not bool(lv[0].any()) and not bool(dm[:8].any()) and not bool(dm[~batch["perf_mask"]].any())
+    assert bool((lv[1] <= lv[2]).all()) and bool((lv[2] <= lv[3]).all())          # inclusive
+    # constant within a segment (the bar level only: the synthetic beat / onset ids are drawn independently of the bars, so a beat may
+    # straddle a bar line and the INCLUSIVE beat mask changes there)
+    same = batch["bars"][:, 1:] == batch["bars"][:, :-1]
+    assert bool((lv[1][:, 1:] == lv[1][:, :-1])[same & batch["perf_mask"][:, 1:]].all())
+    assert bool((lv[1][:, 1:] != lv[1][:, :-1]).any())
+    live = batch["perf_mask"][8:]
+    want = [1 - (1 - p[1]), 1 - (1 - p[1]) * (1 - p[2]), 1 - (1 - p[1]) * (1 - p[2]) * (1 - p[3])]
+    for t, w in zip(lv[1:], want):
+        got = float(t[8:][live].float().mean())
+        assert abs(got - w) < 0.05, (got, w)
+    assert bool((emb == full * (~dm)).all())
+    model.eval()
+    with torch.no_grad():
+        ev = model(**batch).perf_encoder
+    assert ev.dropout_mask is None and ev.embeddings is ev.full_embeddings or bool((ev.embeddings == ev.full_embeddings).all())

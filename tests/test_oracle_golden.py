@@ -129,3 +129,55 @@ def test_oracle_greedy_matches_reference_cached_decode_with_cross_attention():
                                      context_mask=torch.from_numpy(fix["in/score_mask"]))
     np.testing.assert_array_equal(intended.numpy()[:, :3], fix["out/tokens"][:, :3])
     assert (intended.numpy() != fix["out/tokens"]).any()
+
+
+@pytest.mark.parametrize("tag", ["incl", "excl"])
+def test_oracle_latent_dropout_matches_reference(tag):
+    """Latent dropout as base.yaml:119-126 trains it (`latent_dropout=[0, .1, .2, .4]`): the reference's own per-level drop masks
+    (`dropout_latent_mask`, mmd_transformer.py:537-542, recorded by oracle/refimport/make_golden_latent_dropout.py) fed to the oracle
+    must reproduce the reference's embeddings after dropping, its inclusive / exclusive combined mask (mmd_transformer.py:249-253), the
+    dead-pan exemption (mmd_transformer.py:284-291), the loss and every gradient norm -- the gradient has to pass through
+    `embeddings * ~drop_mask` into the decoder's adaptive LayerNorms."""
+    fix = load("latent_dropout")
+    kw = dict(preset="tiny", num_tokens=SMALL_VOCAB, latent_dropout=[0.0, 0.1, 0.2, 0.4])
+    cfg = model_config(**kw)
+    cfg.perf_encoder.inclusive_latent_dropout = tag == "incl"
+    sd = filled_state_dict(ScorePerformer.init(model_config(**kw)), seed=0)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith("token_values") else v)
+          for k, v in sd.items()}
+    from oracle.weights import canonical
+    leaves = {}
+    for k in list(sd):
+        c = canonical(k)
+        sd[k] = leaves.setdefault(c, sd[k])
+    batch = {k[3:]: torch.from_numpy(v) for k, v in fix.items() if k.startswith("in/")}
+    assert bool(batch["deadpan_mask"].any()) and not bool(batch["perf_mask"].all())      # one dead-pan, ragged lengths
+    z = [torch.from_numpy(fix[f"{tag}/z/{i}"]) for i in range(4)]
+    drops = [torch.from_numpy(fix[f"{tag}/drop/{i}"]) if f"{tag}/drop/{i}" in fix else None for i in range(4)]
+    assert drops[0] is None and all(d is not None and bool(d.any()) for d in drops[1:])
+    out = ref_cpu.score_performer_forward(sd, cfg, batch, z, training=True, drop_masks=drops)
+    np.testing.assert_array_equal(out["perf_dropout_mask"].numpy(), fix[f"{tag}/dropout_mask"])
+    np.testing.assert_allclose(out["perf_full_embeddings"].detach().numpy(), fix[f"{tag}/full_embeddings"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(out["perf_embeddings"].detach().numpy(), fix[f"{tag}/embeddings"], atol=3e-5, rtol=1e-4)
+    assert (fix[f"{tag}/embeddings"] != fix[f"{tag}/full_embeddings"]).any()
+    np.testing.assert_allclose(out["hidden_state"].detach().numpy(), fix[f"{tag}/hidden_state"], atol=3e-5, rtol=1e-4)
+    assert abs(float(out["loss"]) - float(fix[f"{tag}/loss"])) < 2e-5
+    pre = f"{tag}/losses/"
+    ref_losses = {k[len(pre):]: float(v) for k, v in fix.items() if k.startswith(pre)}
+    assert set(out["losses"]) == set(ref_losses)
+    for k, v in ref_losses.items():
+        assert abs(float(out["losses"][k]) - v) < 2e-5, k
+    out["loss"].backward()
+    checked = 0
+    for k, v in fix.items():
+        if k.startswith(f"{tag}/gradnorm/"):
+            name_ = k[len(tag) + 10:]
+            g = sd[name_].grad
+            assert g is not None, name_
+            assert abs(float(g.double().norm()) - float(v)) <= 1e-4 * max(1.0, float(v)), name_
+            checked += 1
+        if k.startswith(f"{tag}/grad/"):
+            np.testing.assert_allclose(sd[k[len(tag) + 6:]].grad.numpy(), v, atol=2e-5, rtol=2e-4)
+    assert checked > 100
+    if tag == "excl":      # the exclusive mask differs from the inclusive one on the same draws
+        assert (fix["incl/dropout_mask"] != fix["excl/dropout_mask"]).any()
