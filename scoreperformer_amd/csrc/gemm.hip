@@ -452,6 +452,10 @@ __device__ __forceinline__ uint32_t pp_voffset_lin(int ld, int row0, int wave, i
     return (uint32_t)(((long)(row0 + x) * ld + kc * 8) * 2);
 }
 
+// wave-private LDS slab exchange (lane A writes, lane B of the same wave reads): order the accesses for the compiler; no instruction
+#define PP_SLAB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 // ---- tile epilogue shared by the 256x256 ping-pong kernel and the 256x128 duo kernel -----------------------------------------
 // A wave holds 128 rows x 64 columns of C as acc[i][j] (32-row block i, 32-column block j; operand-swapped MFMA: lane l owns row
 // l & 31 and, per register quad q, the 4 consecutive columns 8q + 4(l >> 5) ..).  Rows start at cm0 + 128 wr; plain GEMM: columns
@@ -471,42 +475,72 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
         // result is bit-identical to the two-kernel path.  The u blocks come in and the du blocks leave through the wave's LDS slab
         // as whole 128-byte row segments; the column sums of du (the bias gradient of the input projection) are taken from the
         // staged du blocks (bf16-rounded, as the consumer GEMMs see them) and left in row cm0/128 + wr of the partial buffer g.ws.
+        //
+        // Round 4: this epilogue is VALU-ISSUE bound (two waves per SIMD x ~7.8 k instructions per tile and wave were 2/3 of the
+        // launch), so it is written for instruction count:
+        //   * no per-element row guard: u and du are addressed through RAW BUFFER resources that end at row M -- rows past M read
+        //     zeros (value = gate = 0  =>  both du halves are exactly 0, so the column sums need no mask either) and their stores
+        //     are dropped by the bounds check; every tile issues exactly the same instructions (the hand-counted vmcnt holds on
+        //     edge tiles as well) and the exec mask is never touched (the guarded version had 310 exec-mask regions per tile);
+        //   * ONE sigmoid per element (v_exp + v_rcp are quarter-rate) for SiLU and its derivative;
+        //   * the counter hash of the dropout mask starts from a per-block base (row counter + first column pair), one v_add per pair;
+        //   * column sums by transposed LDS reads (ds_read_b64_tr_b16: 4 rows of one column per lane) + v_dot2c_f32_bf16 against
+        //     (1, 1): 24 instructions per staged block instead of 80.
         constexpr int ACT = GLU - 3;
-        bf16_t* DU = reinterpret_cast<bf16_t*>(g.C);
         const int I = g.N;
         const int colw = cn0 + wc * 64;                       // first of this wave's 64 gated outputs
         const int rl = lane & 31, hl = lane >> 5;
-        // The u blocks (32 rows x 64 value columns, 32 x 64 gate columns per 32-row block i) arrive by LDS DMA into this wave's 16 KiB
-        // of the (now dead) operand ring: no registers, two 32-row blocks (4 x 4 KiB) in flight while one is processed.  LDS image of a
+        // The u blocks (32 rows x 64 value columns, 32 x 64 gate columns per 32-row block i) arrive by LDS DMA into this wave's 16 KiB of the
+        // (now dead) operand ring: no registers, two 32-row blocks (4 x 4 KiB) in flight while one is processed.  LDS image of a
         // block: [32 rows][8 chunks of 16 B], chunk position = source chunk ^ ((row >> 1) & 7) (swizzle on the SOURCE address).
-        const u32x4 rsU = spn_buffer_rsrc(g.G, 0x7fffffffu);
+        // (the launcher guarantees M * ld * 2 < 2^32 for both)
+        const u32x4 rsU = spn_buffer_rsrc(g.G, (uint32_t)((long)g.M * g.ldg * 2));
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(uint32_t)((long)g.M * g.ldc * 2), 0x00020000);
         const uint32_t ring_w = spn_lds_addr(ring);
-        auto issue_u = [&](int i) __attribute__((always_inline)) {   // block i -> ring slots 2 (i & 1) (value), 2 (i & 1) + 1 (gate)
-            const int mrow0 = cm0 + wr * 128 + 32 * i;
-            uint32_t vo[4];
+        // per-lane byte offsets: the ROW part lives in the vector offset (the bounds check covers vector + immediate offset only, the scalar
+        // offset -- used for the value / gate column half -- is not checked)
+        uint32_t vo[4];                                       // u rows it * 8 + (lane >> 3) of the NEXT block to request
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = it * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-                vo[it] = (uint32_t)(((long)min(mrow0 + r, g.M - 1) * g.ldg + colw + c * 8) * 2);
-            }
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            vo[it] = (uint32_t)(((long)(cm0 + wr * 128 + r) * g.ldg + colw + c * 8) * 2);
+        }
+        const uint32_t vo_step = (uint32_t)(32 * g.ldg * 2);
+        auto issue_u = [&](int i) __attribute__((always_inline)) {   // blocks are requested in order i = 0, 1, 2, 3 -> ring slots 2 (i & 1), 2 (i & 1) + 1
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
                 const uint32_t dst = ring_w + (uint32_t)((2 * (i & 1) + part) * 4096);
                 spn_dma16x2(rsU, dst, vo[0], vo[1], (uint32_t)(part * I) * 2u);
                 spn_dma16x2(rsU, dst + 2048u, vo[2], vo[3], (uint32_t)(part * I) * 2u);
             }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) vo[it] += vo_step;
         };
         issue_u(0); issue_u(1);
-        float csum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};          // [value / gate][column 2c, 2c + 1], c = lane & 31; rows 16 hl .. of every block
+#ifdef SPN_GEMM_TIMING
+        long long est[13];
+        est[0] = __builtin_amdgcn_s_memrealtime();
+#define ESTAMP(k_) est[k_] = __builtin_amdgcn_s_memrealtime()
+#else
+#define ESTAMP(k_) do {} while (0)
+#endif
+        uint32_t so = (uint32_t)(((long)(cm0 + wr * 128 + (lane >> 3)) * g.ldc + colw + (lane & 7) * 8) * 2);   // du row (lane >> 3) of block 0
+        const uint32_t so_step8 = (uint32_t)(8 * g.ldc * 2);
+        float csum[2] = {0.f, 0.f};                           // [value / gate] of column colw + lane, all rows of the wave's slab
+        const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+        const uint32_t thr16 = g.thr16;
+        const float ks = g.keep_scale;
+        // hash base of this lane's first column pair; the pairs of (j, q, e) follow at constant distances (ffn_drop_bits: x0 = rowc + pair * C)
+        const uint32_t hcol = __umul24((uint32_t)(colw >> 1) + 2u * (uint32_t)hl, 0xEBCA77u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int mrow0 = cm0 + wr * 128 + 32 * i;
-            // VM counter, oldest first (DMA = 8 instructions per block, S = the 8 stores of a block):
-            //   block 0: DMA0 DMA1 | block 1: DMA1 S0 DMA2 | block 2: DMA2 S1 DMA3 | block 3: DMA3 S2
-            // A row tile that hangs over M may skip store instructions (all lanes off): it waits for everything instead of counting.
-            if (cm0 + PP_BM > g.M) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (i == 0 || i == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            // VM counter, oldest first (U = the 8 DMA instructions of a block, S = its 8 stores), at the top of block i:
+            //   i = 0: U0 U1 | i = 1: U1 U2 S0 | i = 2: U2 S0 U3 S1 | i = 3: U3 S1 S2      (loads and stores retire in order)
+            if (i == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (i == 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (i == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            ESTAMP(1 + 3 * i);
             uint2 uv[2][4], ug[2][4];                          // this lane's value / gate pieces: row rl, columns 32 j + 8 q + 4 hl ..
             const char* blk = ring + (2 * (i & 1)) * 4096;
 #pragma unroll
@@ -522,49 +556,79 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 issue_u(i + 2);
             }
-            const int m = mrow0 + rl;
-            const bool row_ok = m < g.M;
-            const uint32_t rowc = ffn_drop_rowc(m, g.seed);
+            // d = dg rounded to bf16 first (what the unfused GEMM stores and spn_act_bwd reads), then the dropout mask of spn_act_fwd / spn_act_bwd
+            float d[2][4][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t p0 = pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), p1 = pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    d[j][q][0] = __uint_as_float(p0 << 16); d[j][q][1] = __uint_as_float(p0 & 0xffff0000u);
+                    d[j][q][2] = __uint_as_float(p1 << 16); d[j][q][3] = __uint_as_float(p1 & 0xffff0000u);
+                }
+            if (thr16) {
+                const uint32_t hb = ffn_drop_rowc(cm0 + wr * 128 + 32 * i + rl, g.seed) + hcol;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            uint32_t x = hb + (uint32_t)(16 * j + 4 * q + e) * 0xEBCA77u;     // = rowc + umul24(pair, C): the pairs stay below 2^24
+                            x ^= x >> 11; x = __umul24(x, 0xD35A2Du) + (x >> 8);
+                            x ^= x >> 13; x = __umul24(x, 0x9E3B35u) + (x >> 9);
+                            x ^= x >> 15;
+                            const float s0 = d[j][q][2 * e] * ks, s1 = d[j][q][2 * e + 1] * ks;
+                            d[j][q][2 * e] = (x & 0xffffu) >= thr16 ? s0 : 0.f;
+                            d[j][q][2 * e + 1] = (x >> 16) >= thr16 ? s1 : 0.f;
+                        }
+            }
             uint2 pa[2][4], pg[2][4];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint2 pd;   // dg rounded to bf16 first: what the unfused GEMM stores and spn_act_bwd reads
-                    pd.x = pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]); pd.y = pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                    float d[4] = {bf2f(pd.x & 0xffff), bf2f(pd.x >> 16), bf2f(pd.y & 0xffff), bf2f(pd.y >> 16)};
-                    if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (common.h: ffn_drop_bits)
-                        const int col = colw + 32 * j + 8 * q + 4 * hl;
-                        const uint32_t h0 = ffn_drop_bits(rowc, (uint32_t)(col >> 1)), h1 = ffn_drop_bits(rowc, (uint32_t)(col >> 1) + 1u);
-                        d[0] = (h0 & 0xffffu) >= g.thr16 ? d[0] * g.keep_scale : 0.f;
-                        d[1] = (h0 >> 16) >= g.thr16 ? d[1] * g.keep_scale : 0.f;
-                        d[2] = (h1 & 0xffffu) >= g.thr16 ? d[2] * g.keep_scale : 0.f;
-                        d[3] = (h1 >> 16) >= g.thr16 ? d[3] * g.keep_scale : 0.f;
-                    }
-                    const float a[4] = {bf2f(uv[j][q].x & 0xffff), bf2f(uv[j][q].x >> 16), bf2f(uv[j][q].y & 0xffff), bf2f(uv[j][q].y >> 16)};
-                    const float t[4] = {bf2f(ug[j][q].x & 0xffff), bf2f(ug[j][q].x >> 16), bf2f(ug[j][q].y & 0xffff), bf2f(ug[j][q].y >> 16)};
+                    const float a[4] = {__uint_as_float(uv[j][q].x << 16), __uint_as_float(uv[j][q].x & 0xffff0000u),
+                                        __uint_as_float(uv[j][q].y << 16), __uint_as_float(uv[j][q].y & 0xffff0000u)};
+                    const float t[4] = {__uint_as_float(ug[j][q].x << 16), __uint_as_float(ug[j][q].x & 0xffff0000u),
+                                        __uint_as_float(ug[j][q].y << 16), __uint_as_float(ug[j][q].y & 0xffff0000u)};
                     float da[4], dt[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        da[e] = row_ok ? d[e] * (ACT == 0 ? silu_f(t[e]) : gelu_f(t[e])) : 0.f;
-                        dt[e] = row_ok ? d[e] * a[e] * (ACT == 0 ? silu_grad(t[e]) : gelu_grad(t[e])) : 0.f;
+                        if constexpr (ACT == 0) {   // silu_f / silu_grad of common.h on ONE sigmoid (same expressions, same rounding)
+                            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-t[e]));
+                            da[e] = d[j][q][e] * (t[e] * sg);
+                            dt[e] = d[j][q][e] * a[e] * (sg * (1.f + t[e] * (1.f - sg)));
+                        } else {
+                            da[e] = d[j][q][e] * gelu_f(t[e]);
+                            dt[e] = d[j][q][e] * a[e] * gelu_grad(t[e]);
+                        }
                     }
                     pa[j][q].x = pack_bf2(da[0], da[1]); pa[j][q].y = pack_bf2(da[2], da[3]);
                     pg[j][q].x = pack_bf2(dt[0], dt[1]); pg[j][q].y = pack_bf2(dt[2], dt[3]);
                 }
+#ifdef SPN_GEMM_TIMING
+            asm volatile("" :: "v"(pa[1][3].y), "v"(pg[1][3].y));
+            ESTAMP(2 + 3 * i);
+#endif
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
+                PP_SLAB_SYNC();
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         *reinterpret_cast<uint2*>(stg + rl * 128 + ((((8 * j + 2 * q + hl) ^ rl) & 15) << 3)) = part == 0 ? pa[j][q] : pg[j][q];
-                if (g.ws) {   // column sums of the staged block: lane c = lane & 31 owns columns 2c, 2c + 1 and rows 16 hl .. 16 hl + 15
+                PP_SLAB_SYNC();
+                if (g.ws) {   // column sums of the staged block: lane l owns column l; a transposed read hands it rows 4 t .. 4 t + 3 of that column
+                    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+                    const int gq = lane >> 4, p = lane & 15;
 #pragma unroll
-                    for (int rr = 0; rr < 16; ++rr) {
-                        const int r = 16 * hl + rr;
-                        const uint32_t w = *reinterpret_cast<const uint32_t*>(stg + r * 128 + (((((rl >> 1)) ^ r) & 15) << 3) + (rl & 1) * 4);
-                        csum[part][0] += bf2f(w & 0xffff); csum[part][1] += bf2f(w >> 16);
+                    for (int t = 0; t < 8; ++t) {
+                        const int rr = 4 * t + (p >> 2), sl = 4 * gq + (p & 3);
+                        const bf16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(stg + rr * 128 + (((sl ^ rr) & 15) << 3)));
+                        csum[part] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 0, 1), ones, csum[part], false);
+                        csum[part] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 2, 3), ones, csum[part], false);
                     }
                 }
 #pragma unroll
@@ -572,31 +636,48 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                     const int r = it * 8 + (lane >> 3), chunk = lane & 7;
                     uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
                     if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                    const int mo = mrow0 + r;
-                    // interior row tiles issue exactly 8 store instructions per block and wave (the vmcnt counts above rely on it)
-                    if (mo < g.M) *reinterpret_cast<uint4*>(DU + (long)mo * g.ldc + part * I + colw + chunk * 8) = val;
+                    // every tile issues exactly 8 store instructions per block and wave (the vmcnt counts above rely on it): rows past M are
+                    // dropped by the buffer's bounds check, not by the exec mask
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsD, (int)(so + (uint32_t)it * so_step8), part * I * 2, 0);
                 }
             }
+            so += 4u * so_step8;
+            ESTAMP(3 + 3 * i);
         }
+#ifdef SPN_GEMM_TIMING
+        if (g.dbg && wr == 0 && wc == 0 && lane == 0) {   // wave 0 of the workgroup: epilogue stamps relative to its start (tools/duo_timeline.py)
+            long long* o = g.dbg + 32 + 5 * (long)g.tx * g.ty + 13 * (long)blockIdx.x;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) o[k] = est[k];
+        }
+#endif
         // the partial buffer has ceil(M / 128) rows: a wave slab that starts at or beyond M (last row tile, 0 < M % 256 <= 128) owns none
         if (g.ws && cm0 + wr * 128 < g.M) {
             float* P = reinterpret_cast<float*>(g.ws) + (long)(cm0 / 128 + wr) * (2 * I);
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const float s0 = csum[part][0] + __shfl_xor(csum[part][0], 32, 64), s1 = csum[part][1] + __shfl_xor(csum[part][1], 32, 64);
-                if (hl == 0) *reinterpret_cast<f32x2*>(P + part * I + colw + 2 * rl) = f32x2{s0, s1};
-            }
+            P[colw + lane] = csum[0];
+            P[I + colw + lane] = csum[1];
         }
     } else if constexpr (GLU != 0) {
         // u = x W^T + b leaves in its natural [value | gate] layout (the backward re-reads it), rounded to bf16 FIRST; the gated
-        // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit
-        bf16_t* U = reinterpret_cast<bf16_t*>(g.C);
-        const int chunks = g.N >> 3;
+        // output is computed from the rounded values, so it equals spn_act_fwd on the stored u bit for bit.
+        // Round 4 (as the gated backward above): u and g leave through RAW BUFFER stores whose resources end at row M -- no exec-mask
+        // guard, every tile issues exactly 24 store instructions per wave (the persistent walk credits them on edge tiles too); the
+        // dropout hash starts from a per-block base; the gated output is staged with the XOR key on row >> 2 (64-byte rows: the 16 rows
+        // of a quarter-wave then hit 16 distinct bank groups; keyed on the row itself the write was a 2-way conflict, the
+        // SQ_LDS_BANK_CONFLICT cycles that only this kernel had in profiles/r03_gemm_pmc.txt).
+        const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(uint32_t)((long)g.M * g.ldc * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(g.G, 0, (int)(uint32_t)((long)g.M * g.ldg * 2), 0x00020000);
+        const int row = lane & 31, hl = lane >> 5;
+        // u: row (lane >> 3) of a block, chunk lane & 7 = (value | gate half, 8 columns); g: row (lane >> 2), chunk lane & 3
+        uint32_t so_u = (uint32_t)(((long)(cm0 + wr * 128 + (lane >> 3)) * g.ldc + ((lane & 7) >> 2) * g.N + cn0 + wc * 32 + (lane & 3) * 8) * 2);
+        uint32_t so_g = (uint32_t)(((long)(cm0 + wr * 128 + (lane >> 2)) * g.ldg + cn0 + wc * 32 + (lane & 3) * 8) * 2);
+        const uint32_t su8 = (uint32_t)(8 * g.ldc * 2), sg16 = (uint32_t)(16 * g.ldg * 2);
+        const uint32_t thr16 = g.thr16;
+        const float ks = g.keep_scale;
+        const uint32_t hcol = __umul24((uint32_t)((cn0 + wc * 32) >> 1) + 2u * (uint32_t)hl, 0xEBCA77u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = lane & 31;
-            const int m = cm0 + wr * 128 + 32 * i + row;
-            uint2 go[4];
+            float o[4][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 a = f32x4{acc[i][0][4 * q], acc[i][0][4 * q + 1], acc[i][0][4 * q + 2], acc[i][0][4 * q + 3]} + bv[q];
@@ -604,46 +685,56 @@ __device__ __forceinline__ void pp_store_tile(const GemmArgs& g, f32x16 (&acc)[4
                 uint2 pa, pt;
                 pa.x = pack_bf2(a[0], a[1]); pa.y = pack_bf2(a[2], a[3]);
                 pt.x = pack_bf2(t[0], t[1]); pt.y = pack_bf2(t[2], t[3]);
-                const int slot = 2 * q + (lane >> 5);   // 8-byte slot of the 64-byte value half; the gate half is slots 8..15
+                const int slot = 2 * q + hl;   // 8-byte slot of the 64-byte value half; the gate half is slots 8..15
                 *reinterpret_cast<uint2*>(stg + row * 128 + (((slot ^ row) & 15) << 3)) = pa;
                 *reinterpret_cast<uint2*>(stg + row * 128 + ((((8 + slot) ^ row) & 15) << 3)) = pt;
-                const float ar[4] = {bf2f(pa.x & 0xffff), bf2f(pa.x >> 16), bf2f(pa.y & 0xffff), bf2f(pa.y >> 16)};
-                const float tr[4] = {bf2f(pt.x & 0xffff), bf2f(pt.x >> 16), bf2f(pt.y & 0xffff), bf2f(pt.y >> 16)};
-                float o[4];
+                const float ar[4] = {__uint_as_float(pa.x << 16), __uint_as_float(pa.x & 0xffff0000u), __uint_as_float(pa.y << 16), __uint_as_float(pa.y & 0xffff0000u)};
+                const float tr[4] = {__uint_as_float(pt.x << 16), __uint_as_float(pt.x & 0xffff0000u), __uint_as_float(pt.y << 16), __uint_as_float(pt.y & 0xffff0000u)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
-                if (g.thr16) {   // the mask of spn_act_fwd / spn_act_bwd (common.h: ffn_drop_bits)
-                    const int col = cn0 + wc * 32 + 8 * q + (lane >> 5) * 4;
-                    const uint32_t rowc = ffn_drop_rowc(m, g.seed);
-                    const uint32_t h0 = ffn_drop_bits(rowc, (uint32_t)(col >> 1)), h1 = ffn_drop_bits(rowc, (uint32_t)(col >> 1) + 1u);
-                    o[0] = (h0 & 0xffffu) >= g.thr16 ? o[0] * g.keep_scale : 0.f;
-                    o[1] = (h0 >> 16) >= g.thr16 ? o[1] * g.keep_scale : 0.f;
-                    o[2] = (h1 & 0xffffu) >= g.thr16 ? o[2] * g.keep_scale : 0.f;
-                    o[3] = (h1 >> 16) >= g.thr16 ? o[3] * g.keep_scale : 0.f;
-                }
-                go[q].x = pack_bf2(o[0], o[1]); go[q].y = pack_bf2(o[2], o[3]);
+                for (int e = 0; e < 4; ++e) o[q][e] = ar[e] * (GLU == 1 ? silu_f(tr[e]) : gelu_f(tr[e]));
             }
+            if (thr16) {   // the mask of spn_act_fwd / spn_act_bwd (common.h: ffn_drop_bits), hash base hoisted
+                const uint32_t hb = ffn_drop_rowc(cm0 + wr * 128 + 32 * i + row, g.seed) + hcol;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        uint32_t x = hb + (uint32_t)(4 * q + e) * 0xEBCA77u;
+                        x ^= x >> 11; x = __umul24(x, 0xD35A2Du) + (x >> 8);
+                        x ^= x >> 13; x = __umul24(x, 0x9E3B35u) + (x >> 9);
+                        x ^= x >> 15;
+                        const float s0 = o[q][2 * e] * ks, s1 = o[q][2 * e + 1] * ks;
+                        o[q][2 * e] = (x & 0xffffu) >= thr16 ? s0 : 0.f;
+                        o[q][2 * e + 1] = (x >> 16) >= thr16 ? s1 : 0.f;
+                    }
+            }
+            PP_SLAB_SYNC();
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int r = it * 8 + (lane >> 3), chunk = lane & 7;
                 uint4 val = *reinterpret_cast<const uint4*>(stg + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
                 if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                const int mo = cm0 + wr * 128 + 32 * i + r;
-                const int no = (chunk >> 2) * g.N + cn0 + wc * 32 + (chunk & 3) * 8;
-                if (mo < g.M) *reinterpret_cast<uint4*>(U + (long)mo * g.ldc + no) = val;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsU, (int)(so_u + (uint32_t)it * su8), 0, 0);
             }
-            // the gated output through the same slab: 64-byte rows, 8 slots
+            so_u += 4u * su8;
+            PP_SLAB_SYNC();
+            // the gated output through the same slab: 64-byte rows, 8 slots of 8 bytes, slot index XOR (row >> 2)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<uint2*>(stg + row * 64 + ((((2 * q + (lane >> 5)) ^ row) & 7) << 3)) = go[q];
+            for (int q = 0; q < 4; ++q) {
+                uint2 go;
+                go.x = pack_bf2(o[q][0], o[q][1]); go.y = pack_bf2(o[q][2], o[q][3]);
+                *reinterpret_cast<uint2*>(stg + row * 64 + ((((2 * q + hl) ^ (row >> 2)) & 7) << 3)) = go;
+            }
+            PP_SLAB_SYNC();
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int r = it * 16 + (lane >> 2), chunk = lane & 3;
-                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 64 + (((chunk ^ (r >> 1)) & 3) << 4));
-                if (r & 1) val = uint4{val.z, val.w, val.x, val.y};
-                const int mo = cm0 + wr * 128 + 32 * i + r;
-                if (mo < g.M) *reinterpret_cast<uint4*>(g.G + (long)mo * g.ldg + cn0 + wc * 32 + chunk * 8) = val;
+                uint4 val = *reinterpret_cast<const uint4*>(stg + r * 64 + (((chunk ^ (r >> 3)) & 3) << 4));
+                if ((r >> 2) & 1) val = uint4{val.z, val.w, val.x, val.y};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsG, (int)(so_g + (uint32_t)it * sg16), 0, 0);
             }
+            so_g += 2u * sg16;
+            PP_SLAB_SYNC();
         }
     } else {
     if constexpr (ES == 4) {
@@ -1014,8 +1105,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
             set_tile(m0, n0);
             prologue();
         }
-        // interior tiles issue exactly NSX store instructions per wave; edge tiles fewer: no credit for them (a stronger wait)
-        extra = GLUF ? ((has_next && cm0 + PP_BM <= ge.M) ? 1 : 0)
+        // interior tiles issue exactly NSX store instructions per wave; edge tiles fewer: no credit for them (a stronger wait).  The gated
+        // epilogue stores through bounds-checked buffer resources: every tile issues all 24, rows past M are dropped by the hardware
+        extra = GLUF ? (has_next ? 1 : 0)
                     : ((has_next && cm0 + PP_BM <= ge.M && cn0 + PP_BN <= ge.N && !ge.residual && !ge.accumulate && !ge.rowmask) ? 1 : 0);
     }
     pp_store_tile<OutT, GLU>(ge, acc, bv, C, lead, cm0, cn0, wr, wc, lane, stg, PERSIST ? nullptr : smem + wave * 16384);
@@ -1063,6 +1155,9 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+#ifdef SPN_GEMM_TIMING
+    const long long tl_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same clock on every CU (tools/duo_timeline.py)
+#endif
     // tile order as in the ping-pong kernel: XCD-contiguous, column groups of `ngroup` n-tiles, m-tiles down each group
     int m0, n0;
     {
@@ -1159,8 +1254,22 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
         bv[jq] = g.bias ? *reinterpret_cast<const f32x4*>(g.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();   // every wave is done with the operand ring: its first 16 KiB become the four staging slabs
+#ifdef SPN_GEMM_TIMING
+    const long long tl_loop = __builtin_amdgcn_s_memrealtime();
+#endif
     // gated backward: the four staging slabs, then 16 KiB per wave for the u blocks that arrive by LDS DMA (80 KiB in all)
     pp_store_tile<OutT, GLU>(g, acc, bv, C, true, m0, n0, wr, wc, lane, smem + wave * 4096, GLU >= 3 ? smem + 16384 + wave * 16384 : nullptr);
+#ifdef SPN_GEMM_TIMING
+    if (g.dbg) {   // per workgroup: start, end of the main loop, end of the epilogue (wave 0, stores acknowledged), HW_ID, XCC_ID
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long tl_end = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            long long* o = g.dbg + 32 + 5 * (long)blockIdx.x;
+            o[0] = tl_start; o[1] = tl_loop; o[2] = tl_end;
+            o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+    }
+#endif
 }
 
 // ---- split-K plumbing -------------------------------------------------------------------------------------
@@ -1462,6 +1571,7 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
     SPN_REQUIRE(((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)u) | ((uintptr_t)gout)) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
                 "spn_gemm_glu: operands must be 16-byte aligned");
     SPN_REQUIRE((long)M * lda * 2 < (1L << 31) && 2l * I * ldb * 2 < (1L << 31), "spn_gemm_glu: operand spans 2 GiB or more");
+    SPN_REQUIRE((long)M * ldu * 2 < (1L << 32) && (long)M * ldg * 2 < (1L << 32), "spn_gemm_glu: u or g spans 4 GiB or more (32-bit buffer offsets)");
     SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu: act is 0 (SiLU) or 1 (GELU)");
     GemmArgs g;
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)W; g.C = u; g.bias = bias; g.residual = nullptr; g.rowmask = nullptr;
@@ -1498,6 +1608,7 @@ extern "C" int spn_gemm_glu_bwd(const void* dy, const void* W2, const void* u, v
     SPN_REQUIRE(((((uintptr_t)dy) | ((uintptr_t)W2) | ((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && (!colsum_partial || (((uintptr_t)colsum_partial) & 7) == 0),
                 "spn_gemm_glu_bwd: operands must be 16-byte aligned");
     SPN_REQUIRE((long)M * lddy * 2 < (1L << 31) && (long)K * ldw * 2 < (1L << 31), "spn_gemm_glu_bwd: operand spans 2 GiB or more");
+    SPN_REQUIRE((long)M * ldu * 2 < (1L << 32) && (long)M * lddu * 2 < (1L << 32), "spn_gemm_glu_bwd: u or du spans 4 GiB or more (32-bit buffer offsets)");
     SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu_bwd: act is 0 (SiLU) or 1 (GELU)");
     GemmArgs g;
     memset(&g, 0, sizeof(g));
