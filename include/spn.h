@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -176,6 +176,9 @@ int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w, int N, in
                 spn_stream_t s);
 int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, int D, const float* coef, float* dy,
                 spn_stream_t s);
+/* scalar tail of compute_mmd (mmd_transformer.py:529-534) in one launch; n = max(sums[3], 1).  g == null: out[0] = the MMD value from
+ * spn_mmd_fwd's sums; g != null (device scalar dL/dmmd): out[0..1] = the two coefficients spn_mmd_bwd takes */
+int spn_mmd_scalars(const float* sums /* [4] */, int Z, const float* g, float* out, spn_stream_t s);
 
 /* ---- optimizer (experiments/optimizers.py:151-169: clip_grad_norm_ + torch.optim.AdamW) over the flat arena */
 int spn_sumsq(const float* g, long n, float* out /* ACCUMULATED */, spn_stream_t s);

@@ -396,6 +396,24 @@ extern "C" int spn_segment_gather(const float* src, const long* seg, const float
     return SPN_OK;
 }
 
+// The scalar tail of compute_mmd (mmd_transformer.py:529-534) on the device, one launch: with n = max(sum w, 1)
+//   g == null:  out[0] = kzz / Z^2 + kyy / n^2 - 2 kzy / (Z n)                         (the loss value)
+//   g != null:  out[0] = g / n^2,  out[1] = -2 g / (Z n)                                (the coefficients spn_mmd_bwd takes)
+// (as separate tensor ops these were ~10 + ~8 launches of one-element kernels per latent level)
+__global__ void mmd_scalars_kernel(const float* __restrict__ sums, float Z, const float* __restrict__ g, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float n = fmaxf(sums[3], 1.f);
+    if (g) { out[0] = g[0] / (n * n); out[1] = -2.f * g[0] / (Z * n); }
+    else out[0] = sums[0] / (Z * Z) + sums[1] / (n * n) - 2.f * sums[2] / (Z * n);
+}
+
+extern "C" int spn_mmd_scalars(const float* sums, int Z, const float* g, float* out, hipStream_t s) {
+    SPN_REQUIRE(sums && out && Z > 0, "spn_mmd_scalars: bad arguments");
+    hipLaunchKernelGGL(mmd_scalars_kernel, dim3(1), dim3(64), 0, s, sums, (float)Z, g, out);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 // sums[4] fp32 (zeroed by caller): kzz, kyy (weighted), kzy (weighted), sum of weights
 extern "C" int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w, int N, int D, float* sums, hipStream_t s) {
     SPN_REQUIRE(z && y && w && sums && Z > 0 && N > 0 && D > 0 && D <= MMD_MAXD, "spn_mmd_fwd: bad arguments (D <= 64)");

@@ -259,13 +259,34 @@ def _fork_grad(dres, x):
     return dres if dres.stride(-1) == 1 else dres.contiguous()
 
 
+class _SplitGrad:
+    """The gradient buffer of a tensor that SplitColsFn cut into column slices: a consumer that can write its slice's gradient in place
+    (HeadCEFn: the output of its input-gradient GEMM) asks for `slice(i)`; SplitColsFn.backward then finds the data already where it
+    belongs and skips the copy."""
+
+    def __init__(self, shape, dtype, widths):
+        self.shape, self.dtype, self.widths = tuple(shape), dtype, tuple(widths)
+        self.offs = [0]
+        for w in widths:
+            self.offs.append(self.offs[-1] + w)
+        self.buf = None
+
+    def slice(self, i, device):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, device=device, dtype=self.dtype)
+        return self.buf.narrow(-1, self.offs[i], self.widths[i])
+
+
 class SplitColsFn(Function):
     """x[..., off_i : off_i + w_i] for consecutive widths, as ONE autograd node: the backward packs the slice gradients into a
-    single buffer (one strided copy per slice) instead of autograd's zero-filled full-width tensor plus an add per slice."""
+    single buffer (slices written in place by their producers are left alone, the others take one strided copy, runs of slices
+    without a gradient one zero fill per run) instead of autograd's zero-filled full-width tensor plus an add per slice."""
 
     @staticmethod
     def forward(ctx, x, *widths):
         ctx.widths, ctx.shape, ctx.dt = widths, x.shape, x.dtype
+        ctx.holder = _SplitGrad(x.shape, x.dtype, widths)
+        ctx.set_materialize_grads(False)   # a slice nobody used arrives as None (one zero fill per RUN of them), not as a zero tensor to copy
         outs, off = [], 0
         for w in widths:
             outs.append(x.narrow(-1, off, w))
@@ -275,23 +296,39 @@ class SplitColsFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
-        dx = torch.empty(ctx.shape, device=grads[0].device if grads[0] is not None else next(g for g in grads if g is not None).device,
-                         dtype=ctx.dt)
-        off = 0
+        h = ctx.holder
+        if all(g is None for g in grads):
+            return (None,) * (1 + len(ctx.widths))
+        dev = next(g for g in grads if g is not None).device
+        dx = h.buf if h.buf is not None else torch.empty(ctx.shape, device=dev, dtype=ctx.dt)
+        h.buf = None                      # (a second backward through a retained graph starts from a fresh buffer)
+        off, zero_from = 0, None
         for w, g in zip(ctx.widths, grads):
-            dst = dx.narrow(-1, off, w)
             if g is None:
-                dst.zero_()
+                zero_from = off if zero_from is None else zero_from
             else:
-                dst.copy_(g)
+                if zero_from is not None:
+                    dx.narrow(-1, zero_from, off - zero_from).zero_()
+                    zero_from = None
+                dst = dx.narrow(-1, off, w)
+                if not (g.data_ptr() == dst.data_ptr() and g.dtype == dst.dtype and g.shape == dst.shape and g.stride() == dst.stride()):
+                    dst.copy_(g)
             off += w
-        if off < ctx.shape[-1]:
-            dx.narrow(-1, off, ctx.shape[-1] - off).zero_()
+        end = ctx.shape[-1]
+        if zero_from is not None or off < end:
+            start = zero_from if zero_from is not None else off
+            dx.narrow(-1, start, end - start).zero_()
         return (dx,) + (None,) * len(ctx.widths)
 
 
 def split_cols(x, widths):
-    return SplitColsFn.apply(x, *widths)
+    outs = SplitColsFn.apply(x, *widths)
+    node = outs[0].grad_fn
+    holder = getattr(node, "holder", None)
+    if holder is not None:
+        for i, o in enumerate(outs):
+            o._spn_split = (holder, i)
+    return outs
 
 
 def layer_norm(x, gamma, beta, *, out_fp32=False, eps=1e-5, fork=False):
@@ -307,6 +344,40 @@ ADALN_GB_DTYPE = F32 if _os.environ.get("SPN_ADALN_GB", "bf16") == "fp32" else B
 # D = 512, C = 64: the forward computes the projection on the matrix cores inside the LayerNorm kernel (fp32 gamma / beta in registers,
 # nothing but the bf16 gamma rows for the backward is written); SPN_ADALN_FUSED=0 restores GEMM + LayerNorm
 ADALN_FUSED = _os.environ.get("SPN_ADALN_FUSED", "1") != "0" and ADALN_GB_DTYPE == BF16
+
+
+class _CondGrad:
+    def __init__(self):
+        self.buf = None
+
+
+class ShareCondFn(Function):
+    """Identity on the condition tensor of a stack of adaptive norms.  Every AdaLayerNormFn of the stack ADDS its condition gradient to
+    one fp32 buffer (the epilogue of its dcond GEMM accumulates) and returns None; this node, which autograd runs after all of them,
+    hands the sum on -- instead of autograd's out-of-place add per norm (11 adds of [b, n, C] fp32 per decoder pass)."""
+
+    @staticmethod
+    def forward(ctx, cond):
+        ctx.holder = _CondGrad()
+        ctx.set_materialize_grads(False)
+        return cond.view_as(cond)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        buf, ctx.holder.buf = ctx.holder.buf, None
+        if buf is None:
+            return g
+        return buf if g is None else buf.add_(g)
+
+
+def share_cond(cond):
+    """`cond` for the adaptive norms of one stack: gradient contributions meet in one buffer (see ShareCondFn)."""
+    if not (torch.is_grad_enabled() and cond.requires_grad and cond.is_cuda and cond.dtype == F32):
+        return cond
+    out = ShareCondFn.apply(cond)
+    out._spn_condgrad = out.grad_fn.holder
+    return out
 
 
 class AdaLayerNormFn(Function):
@@ -334,6 +405,7 @@ class AdaLayerNormFn(Function):
             y, mean, rstd = ops.layernorm_fwd(x, None, None, gb, out_dtype=F32 if out_fp32 else BF16, eps=eps)
         ctx.save_for_backward(x, c2, gb, mean, rstd)
         ctx.weight_ref, ctx.bias_ref, ctx.cond_shape, ctx.cond_dtype = weight, bias, cond.shape, cond.dtype
+        ctx.condgrad = getattr(cond, "_spn_condgrad", None)
         _pend(weight); _pend(bias)
         return (y.view(x.shape), x.view_as(x)) if fork else y.view(x.shape)
 
@@ -350,8 +422,15 @@ class AdaLayerNormFn(Function):
                                     want_dx16=True)
         dcond = None
         if ctx.needs_input_grad[1]:
-            dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
-            dcond = dcond.view(ctx.cond_shape)
+            h = ctx.condgrad
+            if h is not None and ctx.cond_dtype == F32:     # the stack's shared buffer (ShareCondFn): first norm writes, the others add
+                if h.buf is None:
+                    h.buf = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=F32).view(ctx.cond_shape)
+                else:
+                    ops.gemm(dgb, bf16_weight(weight), tb=True, out=h.buf.view(-1, h.buf.shape[-1]), accumulate=True)
+            else:
+                dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
+                dcond = dcond.view(ctx.cond_shape)
         dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(dgb, c2, ta=True, tb=True, out=out, accumulate=acc), weight.shape)
         main = _main_grad(bias)
         db = None
@@ -727,6 +806,48 @@ def mish(x):
 # embedding tables and tuple gather
 # ---------------------------------------------------------------------------------------------------------
 
+class _TableGrads:
+    """ONE zero-initialised fp32 buffer for the gradients of the tables of a TableBuildFn call.  Every consumer of a table that knows the
+    protocol (the tuple gathers of the encoders and the decoder, the tied LM head) ACCUMULATES its contribution in place -- the scatter
+    kernel and the GEMM epilogue both add -- and returns None to autograd; TableBuildFn.backward, which autograd runs once every
+    consumer is done (also when all of them returned None), takes the sums from here and adds whatever other consumers handed to
+    autograd the ordinary way.  Saves autograd's out-of-place add per (table, consumer) (~40 launches and 4 zero fills per step).
+    Rows are padded to a multiple of 8 per table (the LM head's dW GEMM works on the padded vocabulary)."""
+
+    def __init__(self, shapes, device):
+        self.shapes, self.device = [tuple(s) for s in shapes], device
+        self.offs = [0]
+        for v, e in self.shapes:
+            self.offs.append(self.offs[-1] + ((v + 7) // 8) * 8 * e)
+        self.reset()
+
+    def reset(self):
+        self.buf, self.touched = None, [False] * len(self.shapes)
+
+    def padded(self, i):
+        """[V padded to 8, E] accumulation target of table i (marks it as touched)."""
+        if self.buf is None:
+            self.buf = torch.zeros(self.offs[-1], device=self.device, dtype=F32)
+        self.touched[i] = True
+        v, e = self.shapes[i]
+        return self.buf[self.offs[i]:self.offs[i + 1]].view(-1, e)
+
+    def view(self, i):
+        return self.padded(i)[:self.shapes[i][0]]
+
+    def collected(self, i):
+        return self.buf[self.offs[i]:self.offs[i + 1]].view(-1, self.shapes[i][1])[:self.shapes[i][0]] if self.touched[i] else None
+
+
+def share_table_grads(tables):
+    """Attach the shared gradient buffer of TableBuildFn's node to its output tables (models/scoreperformer/embeddings.build_tables)."""
+    node = tables[0].grad_fn if len(tables) else None
+    holder = getattr(node, "tgrads", None)
+    if holder is not None:
+        for i, t in enumerate(tables):
+            t._spn_tgrad = (holder, i)
+
+
 class TableBuildFn(Function):
     """All per-key tables of one embedding set (modules/transformer/embeddings.py:118-152).  Inputs are the flattened
     per-key parameter lists: tv*n, w0*n, [b0*n, w1*n, b1*n if dense], [iw*n if has_iw]."""
@@ -746,6 +867,12 @@ class TableBuildFn(Function):
                                          ids_mask=ids_mask)
         ctx.cfg = (n, dense, discrete, has_iw, ids_mask)
         ctx.lists = (tv, w0, b0, w1, h1)
+        ctx.params = params
+        for p in params[n:]:
+            if p.requires_grad:
+                _pend(p)
+        ctx.tgrads = _TableGrads([t.shape for t in tables], tables[0].device) if any(p.requires_grad for p in params[n:]) else None
+        ctx.set_materialize_grads(False)
         return tuple(tables)
 
     @staticmethod
@@ -754,7 +881,14 @@ class TableBuildFn(Function):
         n, dense, discrete, has_iw, ids_mask = ctx.cfg
         tv, w0, b0, w1, h1 = ctx.lists
         det = lambda lst: [t.detach() for t in lst] if lst is not None else None
-        dts = [d if d is not None else torch.zeros(tv[i].numel(), w0[i].numel(), device=w0[i].device) for i, d in enumerate(dtables)]
+        dts = []
+        for i, d in enumerate(dtables):
+            own = ctx.tgrads.collected(i) if ctx.tgrads is not None else None     # what the in-place consumers accumulated
+            if own is not None:
+                d = own if d is None else own.add_(d)
+            dts.append(d if d is not None else torch.zeros(tv[i].numel(), w0[i].numel(), device=w0[i].device))
+        if ctx.tgrads is not None:
+            ctx.tgrads.reset()            # (the views in `dts` keep the buffer alive; a retained graph starts a fresh one)
         dw0, db0, dw1, db1, diw = ops.table_build_bwd(det(tv), det(w0), det(b0), det(w1), dts, h1, has_iw=has_iw, dense=dense,
                                                       discrete=discrete, ids_mask=ids_mask)
         grads: List[Optional[torch.Tensor]] = [None] * n                       # token_values (buffer)
@@ -763,6 +897,24 @@ class TableBuildFn(Function):
             grads += db0 + dw1 + db1
         if has_iw:
             grads += diw
+        # ~60 small parameters (12 keys x {w0, b0, w1, b1, index rows}): handed to autograd each costs an AccumulateGrad add_ launch; with
+        # an arena they are added into their gradient views by one multi-tensor launch
+        mains, adds, live = [], [], []
+        for i, (p, g) in enumerate(zip(ctx.params, grads)):
+            if g is None or not p.requires_grad:
+                continue
+            m = _main_grad(p)
+            if m is None:
+                mains = None
+                break
+            mains.append(m); adds.append(g.reshape(m.shape)); live.append(i)
+        if mains:
+            torch._foreach_add_(mains, adds)
+            for i in live:
+                hook = getattr(ctx.params[i], "_spn_grad_ready", None)
+                if hook is not None:
+                    hook()
+                grads[i] = None
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -776,6 +928,7 @@ class EmbedFn(Function):
                                       beta.detach() if beta is not None else None, eps)
         ctx.save_for_backward(tokens, mean, rstd, *tabs)
         ctx.gamma_ref, ctx.beta_ref = gamma, beta
+        ctx.tgrads = [getattr(t, "_spn_tgrad", None) for t in tables]
         for p in (gamma, beta):
             if p is not None and p.requires_grad:
                 _pend(p)
@@ -794,8 +947,12 @@ class EmbedFn(Function):
             fused = g_main is not None and b_main is not None
             dgamma = g_main if fused else torch.zeros(D, device=dy.device, dtype=F32)
             dbeta = b_main if fused else torch.zeros(D, device=dy.device, dtype=F32)
+        shared = all(tg is not None for tg in ctx.tgrads) and len(ctx.tgrads) > 0
+        outs = [h.view(i) for h, i in ctx.tgrads] if shared else None      # accumulate into the tables' shared gradient buffer
         dts = ops.embed_bwd(tabs, tokens, to_bf16(dy), gamma.detach() if gamma is not None else None, mean, rstd,
-                            dgamma=dgamma, dbeta=dbeta, padding_idx=0)
+                            dgamma=dgamma, dbeta=dbeta, padding_idx=0, out=outs)
+        if shared:
+            dts = [None] * len(ctx.tgrads)     # TableBuildFn.backward collects them from the shared buffer
         if fused:
             for p in (gamma, beta):
                 hook = getattr(p, "_spn_grad_ready", None)
@@ -842,6 +999,7 @@ class HeadCEFn(Function):
                 lse, sums, am = ops.ce_fwd(logits, V, labels, ignore_index=ignore_index, want_argmax=want_argmax)
         ctx.save_for_backward(e2, table, logits, lse, labels, sums, tpad)
         ctx.cfg = (ignore_index, e.shape, bias)
+        ctx.esplit, ctx.tgrad = getattr(e, "_spn_split", None), getattr(table, "_spn_tgrad", None)
         ctx.mark_non_differentiable(logits)
         if am is not None:
             ctx.mark_non_differentiable(am)
@@ -862,11 +1020,22 @@ class HeadCEFn(Function):
         if tpad is None:
             tpad = torch.zeros((Vp, K), device=e2.device, dtype=BF16)
             ops.cast(table.detach(), BF16, out=tpad[:V])
-        de = ops.gemm(dl, tpad, tb=True, out_dtype=BF16).view(e_shape) if ctx.needs_input_grad[0] else None
+        de = None
+        if ctx.needs_input_grad[0]:
+            if ctx.esplit is not None and ctx.esplit[0].dtype == BF16:   # straight into this key's columns of the split tensor's gradient
+                holder, i = ctx.esplit
+                de = holder.slice(i, dl.device)
+                ops.gemm(dl, tpad, tb=True, out=de.view(-1, K))
+            else:
+                de = ops.gemm(dl, tpad, tb=True, out_dtype=BF16).view(e_shape)
         dtab = None
         if ctx.needs_input_grad[1]:
-            full = ops.gemm(dl, e2, ta=True, tb=True, out_dtype=F32)  # [Vp, K]
-            dtab = full[:V]
+            if ctx.tgrad is not None:      # added to the table's shared gradient buffer (functional._TableGrads)
+                holder, i = ctx.tgrad
+                ops.gemm(dl, e2, ta=True, tb=True, out=holder.padded(i), accumulate=True)  # [Vp, K], pad rows stay zero
+            else:
+                full = ops.gemm(dl, e2, ta=True, tb=True, out_dtype=F32)  # [Vp, K]
+                dtab = full[:V]
         db = ops.colsum(dl)[:V] if bias is not None else None
         return de, dtab, db, None, None, None, None, None
 
@@ -928,22 +1097,47 @@ def mask_rows(x, mask, invert=False):
     return MaskRowsFn.apply(x, mask, invert)
 
 
+class ExpSlopesFn(Function):
+    """slopes = exp(log-slopes) of a learned ALiBi bias (modules/transformer/embeddings.py:310-317).  The backward folds the chain rule
+    and the gradient accumulation into ONE launch on the arena's gradient view (d log-slope += slope * d slope) instead of autograd's
+    mul + AccumulateGrad add_ (two one-row kernels per attention layer)."""
+
+    @staticmethod
+    def forward(ctx, logslopes):
+        s = logslopes.detach().exp()
+        ctx.save_for_backward(s)
+        ctx.ref = logslopes
+        _pend(logslopes)
+        return s
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ds):
+        (s,) = ctx.saved_tensors
+        p = ctx.ref
+        main = _main_grad(p)
+        if main is None:
+            return ds * s
+        main.addcmul_(ds.reshape(main.shape).to(main.dtype), s.reshape(main.shape))
+        hook = getattr(p, "_spn_grad_ready", None)
+        if hook is not None:
+            hook()
+        return None
+
+
 class MMDFn(Function):
     """compute_mmd(z, y[w>0]) with 0/1 row weights w instead of a boolean gather (mmd_transformer.py:511-534)."""
 
     @staticmethod
     def forward(ctx, y, w, z):
         sums = ops.mmd_fwd(z, y, w)
-        Z = float(z.shape[0])
-        n = sums[3].clamp_min(1.0)
-        mmd = sums[0] / (Z * Z) + sums[1] / (n * n) - 2.0 * sums[2] / (Z * n)
-        ctx.save_for_backward(y, w, z, n)
+        mmd = ops.mmd_scalars(sums, z.shape[0])          # kzz / Z^2 + kyy / n^2 - 2 kzy / (Z n), n = max(sum w, 1): one launch
+        ctx.save_for_backward(y, w, z, sums)
         return mmd
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        y, w, z, n = ctx.saved_tensors
-        Z = float(z.shape[0])
-        coef = torch.stack([g / (n * n), -2.0 * g / (Z * n)]).float().contiguous()
+        y, w, z, sums = ctx.saved_tensors
+        coef = ops.mmd_scalars(sums, z.shape[0], g)      # (g / n^2, -2 g / (Z n)): one launch
         return ops.mmd_bwd(z, y, w, coef), None, None

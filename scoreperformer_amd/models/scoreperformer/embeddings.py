@@ -60,6 +60,8 @@ def build_tables(embs: List[nn.Module]) -> List[Tensor]:
             if has_iw:
                 flat += list(cols[5])
             tables = F_.TableBuildFn.apply(len(chunk), dense, discrete, has_iw, ids_mask, *flat)
+            if torch.is_grad_enabled():
+                F_.share_table_grads(tables)
             for m, t in zip(chunk, tables):
                 cache[key(m)] = t
     return [cache[key(m)] for m in embs]
@@ -288,7 +290,7 @@ class _HeadBase(nn.Module):
                     lg, _, _ = F_.HeadCEFn.apply(e, table, bias, None, ignore_index, False, None, None)
                     return lg.view(*e.shape[:-1], lg.shape[-1])
                 logits.defer(key, thunk)
-                sums[key] = torch.zeros(2, device=e.device, dtype=torch.float32)
+                sums[key] = F_.ops.zeros_small(2, e.device)
                 continue
             lab = labels[..., i] if labels is not None else None
             lg, sm, am = F_.HeadCEFn.apply(e, table, bias, lab, ignore_index, want_argmax, self.ce_state, key)

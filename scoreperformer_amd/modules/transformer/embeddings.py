@@ -242,4 +242,8 @@ class LearnedALiBiPositionalBias(ALiBiPositionalBias):
         self.learned_logslopes = nn.Parameter(torch.log(self.slopes))
 
     def get_slopes(self):
-        return self.learned_logslopes.exp()
+        p = self.learned_logslopes
+        if p.is_cuda and p.requires_grad and torch.is_grad_enabled():
+            from ... import functional as F_
+            return F_.ExpSlopesFn.apply(p)
+        return p.exp()

@@ -100,6 +100,8 @@ class Transformer(nn.Module, Constructor):
         x = x[:, -1:] if has_cache else x
         if has_cache and style_embeddings is not None:
             style_embeddings = style_embeddings[:, -1:]
+        if self.ada_norm and style_embeddings is not None:
+            style_embeddings = F_.share_cond(style_embeddings)   # the norms' condition gradients accumulate in one buffer
         x = F_.cast(x, torch.float32)  # fp32 residual stream
         ctx_b = F_.cast(context, torch.bfloat16) if context is not None else None
 

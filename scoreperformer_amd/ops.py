@@ -283,7 +283,7 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
         o = o.contiguous()
     strides = (c_long * 21)(*_bnhd_strides(q), *ks, *vs, *_bnhd_strides(o), *_bnhd_strides(dq), *dks, *dvs)
     delta = torch.empty((b, h, nq), device=q.device, dtype=F32)
-    dslope = torch.zeros(h, device=q.device, dtype=F32) if want_dslope else None
+    dslope = zeros_small(h, q.device) if want_dslope else None
     kmask = _mask_u8(kmask)
     call("spn_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
          ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
@@ -400,7 +400,7 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     x2 = _rows2d(x)
     T, N = x2.shape
     if out is None:
-        out = torch.zeros(N, device=x.device, dtype=F32)
+        out = zeros_small(N, x.device)
     call("spn_colsum", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(out), c_long(T), c_int(N), stream_ptr())
     return out
 
@@ -562,19 +562,25 @@ def embed_fwd(tables, tokens, gamma, beta, eps: float = 1e-5):
     return y, mean, rstd
 
 
-def embed_bwd(tables, tokens, dy, gamma, mean, rstd, *, dgamma=None, dbeta=None, padding_idx: int = 0):
-    """Returns list of dtables (fp32, fresh); dgamma/dbeta accumulated in place."""
+def embed_bwd(tables, tokens, dy, gamma, mean, rstd, *, dgamma=None, dbeta=None, padding_idx: int = 0, out=None):
+    """Returns list of dtables (fp32, fresh -- or `out`: contiguous fp32 [V, E] tensors the kernel ADDS to); dgamma/dbeta accumulated in place."""
     tokens, B, t_len, tbs, tts = _tok_view(tokens)
     T = B * t_len
     V = [t.shape[0] for t in tables]
     E = [t.shape[1] for t in tables]
     dev = tables[0].device
     dy2 = _rows2d(dy)
-    buf = torch.zeros(sum(v * e for v, e in zip(V, E)), device=dev, dtype=F32)
-    dts, off = [], 0
-    for v, e in zip(V, E):
-        dts.append(buf[off:off + v * e].view(v, e))
-        off += v * e
+    if out is not None:
+        dts = list(out)
+        for d, v, e in zip(dts, V, E):
+            if d.dtype != F32 or tuple(d.shape) != (v, e) or not d.is_contiguous():
+                raise SpnError("embed_bwd: out tables must be contiguous fp32 [V, E]")
+    else:
+        buf = torch.zeros(sum(v * e for v, e in zip(V, E)), device=dev, dtype=F32)
+        dts, off = [], 0
+        for v, e in zip(V, E):
+            dts.append(buf[off:off + v * e].view(v, e))
+            off += v * e
     ws = torch.empty(2 * T, device=dev, dtype=F32) if gamma is not None else None
     call("spn_embed_bwd", c_int(len(tables)), _ptr_array(tables), _ptr_array(dts), _int_array(V), _int_array(E), ptr(tokens),
          c_long(tbs), c_long(tts), c_int(t_len), ptr(dy2), c_long(dy2.stride(0)), ptr(gamma), ptr(mean), ptr(rstd), ptr(dgamma),
@@ -605,13 +611,13 @@ def ce_fwd(logits: torch.Tensor, V: int, labels: torch.Tensor, *, ignore_index: 
     if lg.shape[0] != T:
         raise SpnError("ce_fwd: logits rows != labels")
     lse = torch.empty(T, device=lg.device, dtype=F32)
-    sums = torch.zeros(2, device=lg.device, dtype=F32)
+    sums = zeros_small(2, lg.device)
     am = torch.empty(T, device=lg.device, dtype=torch.int32) if want_argmax else None
     if eval_spec is not None:
         tv, weighted = eval_spec
         if tv is not None and (tv.dtype != F32 or tv.numel() < V or not tv.is_contiguous() or tv.device != lg.device):
             raise SpnError("ce_fwd: token values must be a contiguous fp32 [V] tensor on the logits' device")
-        metrics = torch.zeros(2, device=lg.device, dtype=F32)
+        metrics = zeros_small(2, lg.device)
         call("spn_ce_fwd_eval", ptr(lg), c_int(_dt(lg)), c_long(lg.stride(0)), ptr(labels), c_long(lbs), c_long(lts), c_int(t_len),
              c_int(ignore_index), ptr(lse), ptr(sums), ptr(am), ptr(tv), c_int(int(bool(weighted))), ptr(metrics), c_long(T), c_int(V),
              stream_ptr())
@@ -677,10 +683,49 @@ def segment_gather(src: torch.Tensor, seg: torch.Tensor, *, counts: Optional[tor
     return out
 
 
+class _SmallZeros:
+    """Small fp32 accumulators that have to start at zero (atomic targets, partial sums): slices of a 64 KiB block that is cleared by ONE
+    fill when it is allocated, instead of one fill launch per accumulator (~80 per train step).  A slice is handed out exactly once --
+    an exhausted block is dropped, never recycled -- so this is plain allocation batching: no aliasing, no lifetime rule."""
+    BLOCK = 16384   # floats
+
+    def __init__(self):
+        self.blocks = {}
+
+    def take(self, n: int, device) -> torch.Tensor:
+        if n > 1024:
+            return torch.zeros(n, device=device, dtype=F32)
+        step = (n + 63) // 64 * 64       # 256-byte granules keep every slice aligned for vector accesses
+        key = (device.type, device.index)
+        blk = self.blocks.get(key)
+        if blk is None or blk[1] + step > self.BLOCK:
+            blk = [torch.zeros(self.BLOCK, device=device, dtype=F32), 0]
+            self.blocks[key] = blk
+        out = blk[0][blk[1]:blk[1] + n]
+        blk[1] += step
+        return out
+
+
+_SMALL_ZEROS = _SmallZeros()
+
+
+def zeros_small(n: int, device) -> torch.Tensor:
+    return _SMALL_ZEROS.take(int(n), torch.device(device))
+
+
+def mmd_scalars(sums: torch.Tensor, Z: int, g: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g None: the MMD value (0-dim) from mmd_fwd's sums; g (device scalar dL/dmmd): the [2] coefficient vector mmd_bwd takes."""
+    out = torch.empty(2 if g is not None else 1, device=sums.device, dtype=F32)
+    if g is not None:
+        g = g.reshape(1).float().contiguous()
+    call("spn_mmd_scalars", ptr(sums), c_int(int(Z)), ptr(g), ptr(out), stream_ptr())
+    return out if g is not None else out[0]
+
+
 def mmd_fwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """sums[4] = (sum k(z,z), sum w w k(y,y), sum w k(z,y), sum w)."""
     z, y, w = z.contiguous(), y.contiguous(), w.contiguous()
-    sums = torch.zeros(4, device=y.device, dtype=F32)
+    sums = zeros_small(4, y.device)
     call("spn_mmd_fwd", ptr(z), c_int(z.shape[0]), ptr(y), ptr(w), c_int(y.shape[0]), c_int(y.shape[1]), ptr(sums), stream_ptr())
     return sums
 
@@ -699,7 +744,7 @@ def mmd_bwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor, coef: torch.Tenso
 
 def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:
-        out = torch.zeros(1, device=g.device, dtype=F32)
+        out = zeros_small(1, g.device)
     call("spn_sumsq", ptr(g), c_long(g.numel()), ptr(out), stream_ptr())
     return out
 

@@ -27,7 +27,7 @@ def main():
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
-    cfg = model_config("c3", max_seq_len=max(args.seq, 256), dropout=args.dropout)
+    cfg = model_config("c3", max_seq_len=max(args.seq, 256), dropout=args.dropout, latent_dropout=[0.0, 0.1, 0.2, 0.4])
     model = ScorePerformer.init(cfg)
     arena = ParamArena(model, dev)
     model.train()
