@@ -347,9 +347,18 @@ def roofline_leg(ops, step, args):
                    "note": "LayerNorm / AdaLN forward+backward (and activation kernels of shapes the fused GEMM epilogues do not take: the "
                            "FFN activation forward and backward live in GEMM epilogues); algorithmic bytes, each operand counted once"}
 
-    traffic, traffic_note = None, None
     here = os.path.dirname(os.path.abspath(__file__))
-    for fname in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+    hbm_path = os.path.join(here, "profiles", "r04_hbm_traffic.json")
+    if os.path.exists(hbm_path):   # counter bytes / algorithmic bytes of the HBM-bound kernels (tools/pmc_step_traffic.sh: separate --pmc passes)
+        with open(hbm_path) as fh:
+            hj = json.load(fh)
+        elementwise["traffic"] = {"source": "STORED PROFILE profiles/r04_hbm_traffic.json (" + hj.get("measured", "") + "), not re-measured by this run",
+                                  "correction": hj.get("correction"),
+                                  "per_kernel": {k: {"counter_bytes_per_launch": v["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
+                                                     "counter_over_algorithmic": v["counter_over_algorithmic"]}
+                                                 for k, v in hj["kernels"].items() if k.startswith(("ln_", "adaln", "embed_", "attn_", "adamw"))}}
+    traffic, traffic_note = None, None
+    for fname in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
         tpath = os.path.join(here, "profiles", fname)
         if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
             with open(tpath) as fh:
@@ -419,7 +428,18 @@ def decode_leg(args, dev):
     wbytes = (dec_params + tables) * 4
     cache_bytes = 6 * 2 * 64 * 4 * (L / 2)
     per_note = wbytes + cache_bytes
-    return {"workload": f"C5 greedy render, seq {L}, batch 1, hipGraph-replayed decode engine (fp32), tokens bit-exact vs the fp32 reference on the fixtures",
+    traffic = None
+    hbm_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_hbm_traffic.json")
+    if os.path.exists(hbm_path):
+        with open(hbm_path) as fh:
+            hj = json.load(fh)
+        v = hj["kernels"].get("dec_pair_kernel")
+        if v:
+            traffic = {"source": "STORED PROFILE profiles/r04_hbm_traffic.json (" + hj.get("measured", "") + ")", "kernel": "dec_pair_kernel",
+                       "counter_bytes_per_launch": v["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
+                       "counter_over_algorithmic": v["counter_over_algorithmic"]}
+    return {"traffic": traffic,
+            "workload": f"C5 greedy render, seq {L}, batch 1, hipGraph-replayed decode engine (fp32), tokens bit-exact vs the fp32 reference on the fixtures",
             "notes": notes, "us_per_note": best / notes * 1e6, "notes_per_s": notes / best, "masks_left": int((out == 1).sum()),
             "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": per_note / (best / notes) / 1e9,
                          "frac": per_note / (best / notes) / 1e9 / 8000.0, "algorithmic_bytes_per_note": per_note,
