@@ -273,8 +273,11 @@ def _emb_keys(sd: SD, prefix: str) -> List[str]:
 # A2  TupleTokenEmbeddings            models/scoreperformer/embeddings.py:121-165,213-267
 # --------------------------------------------------------------------------------------
 
-def tuple_embed_one(sd: SD, prefix: str, tokens: Tensor, te_cfg, keys: List[str]) -> Tensor:
-    embs = [F.embedding(tokens[..., i], table_weight(sd, f"{prefix}embs.{k}.", te_cfg), padding_idx=0)
+def tuple_embed_one(sd: SD, prefix: str, tokens, te_cfg, keys: List[str]) -> Tensor:
+    """`tokens`: one [b, n, K] tensor, or a list of them = the multi-sequence `pre-sum` form (embeddings.py:231-241: per-key embeddings of
+    the sequences summed before norm / projection)."""
+    seqs = list(tokens) if isinstance(tokens, (list, tuple)) else [tokens]
+    embs = [sum(F.embedding(t[..., i], table_weight(sd, f"{prefix}embs.{k}.", te_cfg), padding_idx=0) for t in seqs)
             for i, k in enumerate(keys)]
     mode = _get(te_cfg, "mode", "cat")
     if mode == "cat":
@@ -298,6 +301,8 @@ def tuple_embed(sd: SD, prefix: str, seqs: List[Tensor], te_cfg, keys: List[str]
             + sd[prefix + "project_multiemb.bias"]
     if mm.startswith("post"):
         return sum(tuple_embed_one(sd, prefix, t, te_cfg, keys) for t in seqs)
+    if mm == "pre-sum":
+        return tuple_embed_one(sd, prefix, list(seqs), te_cfg, keys)
     raise NotImplementedError(mm)
 
 

@@ -106,3 +106,24 @@ def variant2_inputs(name: str, batch):
     if mode == "mixlm":
         out["masked_perf"] = batch["masked_perf"]
     return out
+
+
+# ---- third variant set (round 4): the embedding modes that are the reference's DEFAULTS but that no shipped recipe keeps --------------
+# `multiseq_mode="pre-sum"` (embeddings.py:171,231-241: the decoder's two sequences are summed per key before norm / projection) and
+# `TupleTokenEmbeddings(mode="sum")` (embeddings.py:66-69,117,141: per-key embeddings of one common width summed, only normalised).
+NAMES3 = ["multiseq_pre_sum", "emb_mode_sum"]
+
+
+def variant3_config(name: str):
+    base = lambda **kw: model_config(preset="tiny", num_tokens=SMALL_VOCAB, **kw)   # noqa: E731
+    if name == "multiseq_pre_sum":
+        c = base()
+        c["perf_decoder"]["token_embeddings"]["multiseq_mode"] = "pre-sum"
+        return c
+    if name == "emb_mode_sum":          # width = model width: `sum` mode never projects (embeddings.py:141); the tied head needs the
+        c = base(lm_head="lm")          # concatenated layout, so the untied head
+        for k in ("score_encoder", "perf_encoder", "perf_decoder"):
+            c[k]["token_embeddings"].update(mode="sum", emb_dims=int(c["dim"]))
+        c["perf_decoder"]["token_embeddings"]["multiseq_mode"] = "pre-sum"
+        return c
+    raise KeyError(name)

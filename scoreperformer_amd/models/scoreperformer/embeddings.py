@@ -95,9 +95,11 @@ class TupleTokenEmbeddings(nn.Module, Constructor):
                  tie_keys: Optional[Dict[str, str]] = None):
         super().__init__()
         self.mode = mode
-        if mode != "cat":
-            raise NotImplementedError("TupleTokenEmbeddings mode 'sum' is not used by any shipped recipe and is not "
-                                      "implemented by the gather kernel (DESIGN.md 'out of scope')")
+        if mode not in ("cat", "sum"):
+            raise ValueError(f"TupleTokenEmbeddings mode {mode!r}: 'cat' or 'sum'")
+        if mode == "sum":
+            assert isinstance(emb_dims, int) or all(e == list(emb_dims.values())[0] for e in emb_dims.values()), \
+                "`emb_dims` in TupleTokenEmbeddings' `sum` mode should be the same for all keys."
         continuous_keys = continuous
         if isinstance(continuous, bool):
             continuous_keys = [key for key in num_tokens] if continuous else []
@@ -119,7 +121,7 @@ class TupleTokenEmbeddings(nn.Module, Constructor):
                                       token_values=token_values.get(key, None), padding_idx=0)
             else:
                 embeddings[key] = nn.Embedding(num, emb_dim, padding_idx=0)
-            total_emb_dim += emb_dim
+            total_emb_dim += emb_dim if mode == "cat" else emb_dim - total_emb_dim     # `sum`: the common width (embeddings.py:117)
         self.embs = nn.ModuleDict(embeddings)
         self.norm = LayerNorm(total_emb_dim) if emb_norm else nn.Identity()
         if total_emb_dim != project_emb_dim:
@@ -141,12 +143,30 @@ class TupleTokenEmbeddings(nn.Module, Constructor):
     def tables(self) -> List[Tensor]:
         return build_tables(list(self.embs.values()))
 
-    def _forward_project(self, tokens: Tensor) -> Tensor:
-        """gather + concat + LayerNorm (one kernel) and the projection GEMM; tokens int64 [b, n, >= K] (any strides)."""
+    def _forward_project(self, tokens: Union[Tensor, List[Tensor]]) -> Tensor:
+        """gather + concat + LayerNorm (one kernel) and the projection GEMM; tokens int64 [b, n, >= K] (any strides).
+        A LIST of token tensors is the multi-sequence `pre-sum` form (embeddings.py:231-241): the per-key embeddings of the sequences are
+        summed before norm / projection.  `sum` mode (embeddings.py:141): the per-key embeddings are summed instead of concatenated and
+        only normalised.  Both run as gather kernels without the norm (one launch per sequence), an fp32 sum and the LayerNorm kernel --
+        no shipped recipe takes them, so they are not fused further."""
         has_norm = isinstance(self.norm, nn.LayerNorm)
-        e = F_.EmbedFn.apply(tokens, self.norm.weight if has_norm else None, self.norm.bias if has_norm else None,
-                             self.norm.eps if has_norm else 1e-5, *self.tables())
-        # quirk kept from the reference: `cat` mode calls project_emb unconditionally (embeddings.py:139)
+        seqs = list(tokens) if isinstance(tokens, (list, tuple)) else [tokens]
+        if self.mode == "cat" and len(seqs) == 1:
+            e = F_.EmbedFn.apply(seqs[0], self.norm.weight if has_norm else None, self.norm.bias if has_norm else None,
+                                 self.norm.eps if has_norm else 1e-5, *self.tables())
+            # quirk kept from the reference: `cat` mode calls project_emb unconditionally (embeddings.py:139)
+            return F_.linear(e, self.project_emb.weight, self.project_emb.bias)
+        tabs = self.tables()
+        e = None
+        for t in seqs:                                  # [b, n, sum E] per sequence, no norm
+            part = F_.EmbedFn.apply(t, None, None, 1e-5, *tabs).float()
+            e = part if e is None else e + part
+        if self.mode == "sum":                          # sum over the keys: [b, n, K, E] -> [b, n, E]
+            e = e.unflatten(-1, (len(tabs), -1)).sum(dim=-2)
+        if has_norm:
+            e = F_.layer_norm(e, self.norm.weight, self.norm.bias, eps=self.norm.eps, out_fp32=self.mode == "sum")
+        if self.mode == "sum":
+            return e
         return F_.linear(e, self.project_emb.weight, self.project_emb.bias)
 
     def forward(self, x: Tensor, values: Optional[Tensor] = None, cache: Optional[Tensor] = None,
@@ -200,8 +220,10 @@ class MultiSeqTupleTokenEmbeddings(TupleTokenEmbeddings):
             token_emb = proj[0]
             for p in proj[1:]:
                 token_emb = token_emb + p
+        elif self.multiseq_mode == "pre-sum":
+            token_emb = self._forward_project(list(tokens))
         else:
-            raise NotImplementedError("multiseq_mode 'pre-sum' is not used by any shipped recipe")
+            return None       # (the reference's silent fall-through for an unknown mode, embeddings.py:257-258)
         if cache is not None:
             token_emb = torch.cat([cache, token_emb], dim=1)
         return token_emb

@@ -82,8 +82,12 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         Attention(dim=64, num_mem_kv=2)
     from scoreperformer_amd.models.scoreperformer.embeddings import TupleTokenEmbeddings
-    with pytest.raises(NotImplementedError):
-        TupleTokenEmbeddings({"A": 8}, 8, mode="sum")
+    with pytest.raises(ValueError):
+        TupleTokenEmbeddings({"A": 8}, 8, mode="mean")
+    with pytest.raises(AssertionError, match="should be the same for all keys"):      # embeddings.py:66-69
+        TupleTokenEmbeddings({"A": 8, "B": 8}, {"A": 8, "B": 16}, mode="sum")
+    te = TupleTokenEmbeddings({"A": 8, "B": 9}, 16, mode="sum", project_emb_dim=16)   # `sum`: one common width, no projection
+    assert te.total_emb_dim == 16 and not hasattr(te, "project_emb")
 
 
 def test_model_variants_construct_with_reference_layouts():
