@@ -279,7 +279,8 @@ def roofline_leg(ops, step, args):
     for name, f, t, tag in gemm:
         _, lay, dt = tag.split(":")
         if dt.endswith("+glu_bwd"):   # gated backward epilogue: the two-workgroups-per-CU kernel unless the knob says otherwise
-            kname = ("gemm_duo_kernel<true, unsigned short, 3>" if lib.get_tuning("glu_bwd_duo") else
+            kname = ("gemm_duo8_glu_bwd_kernel<0>" if lib.get_tuning("glu_bwd_duo") >= 2 else
+                     "gemm_duo_kernel<true, unsigned short, 3>" if lib.get_tuning("glu_bwd_duo") else
                      "gemm_pp_kernel<false, true, unsigned short, 3>")
         else:
             # the name rocprofv3 prints: the library's dispatch restated (csrc/gemm.hip: launch_pp / dispatch) -- short or narrow

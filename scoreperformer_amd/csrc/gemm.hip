@@ -1272,6 +1272,239 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmArgs g) {
 #endif
 }
 
+// ---- 256x128 "duo8" kernel: the gated backward with EIGHT waves per workgroup, two workgroups per CU -------------------------------
+// tools/duo_timeline.py (per-workgroup stamps of the duo kernel above, profiles/r04_duo_timeline.txt) showed where the gated backward
+// spends its time: the two workgroups of a CU do run in anti-phase (75 % of a workgroup's epilogue lies under the other's main loop), but
+// the epilogue is ONE wave per SIMD issuing ~4 200 dependent VALU instructions (4 ns each: a SIMD issues for a single wave at ~0.6 of
+// its two-wave rate, tools/issue_probe.hip) and takes as long as the main loop.  Here a workgroup is 8 waves with 64x64 wave tiles
+// (acc[2][2]: 64 registers), <= 128 VGPRs, so FOUR waves share a SIMD: two of one workgroup in their epilogue (half the rows each,
+// issuing alternately) while the other workgroup's two run the main loop.  Same 256x128 tile, K tile 32, three LDS-DMA stages (72 KiB).
+//   * stage pieces: A 16 x 1 KiB (2 per wave), B 8 x 1 KiB (1 per wave): 3 DMA instructions per wave and stage
+//   * epilogue (GLU >= 3 only): a wave's two 32-row blocks go one after the other through its OWN 8 KiB of the dead ring -- the u block
+//     (value 4 KiB | gate 4 KiB) arrives by LDS DMA, every lane reads its 8-byte pieces, and writes du back IN PLACE (same bytes, same
+//     swizzle: no second slab, no cross-lane hazard); the rows then leave as whole 128-byte segments through bounds-checked buffer
+//     stores, the next block's DMA is requested as soon as the read-back has returned.  Arithmetic exactly as pp_store_tile<.., 3>.
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_duo8_glu_bwd_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;           // 4 x 2 waves: rows 64 wr .., columns 64 wc ..
+#ifdef SPN_GEMM_TIMING
+    const long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
+    int m0, n0;
+    {
+        const int nwg = g.tx * g.ty, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        const int G = g.ngroup, per = G * g.ty;
+        const int c = wg / per, within = wg - c * per;
+        const int gw = min(G, g.tx - c * G);
+        m0 = (within / gw) * DU_BM;
+        n0 = (c * G + within % gw) * DU_BN;
+    }
+    const int nt = g.K / DU_BK;
+    const u32x4 rsA = spn_buffer_rsrc(g.A, 0x7fffffffu), rsB = spn_buffer_rsrc(g.B, 0x7fffffffu);
+    const uint32_t lds0 = spn_lds_addr(smem);
+    uint32_t voA[2], voB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = (wave * 2 + i) * 64 + lane, row = L >> 2, kc = (L & 3) ^ ((row >> 2) & 3);
+        voA[i] = (uint32_t)(((long)min(m0 + row, g.M - 1) * g.lda + kc * 8) * 2);
+    }
+    {   // B stored [K][N] (N-contiguous): image [32 k][128 n] as the ping-pong kernel's
+        const int L = wave * 64 + lane;
+        const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
+        voB = (uint32_t)(((long)krow * g.ldb + min(n0 + rc * 8, g.N - 8)) * 2);
+    }
+    auto issue = [&](int t) {
+        const uint32_t dst = lds0 + (uint32_t)((t % DU_STAGES) * DU_STAGE_BYTES);
+        const uint32_t k0 = (uint32_t)t * DU_BK;
+        spn_dma16x2(rsA, dst + (uint32_t)(wave * 2) * 1024u, voA[0], voA[1], k0 * 2u);
+        spn_dma16(rsB, dst + DU_A_BYTES + (uint32_t)wave * 1024u, voB, k0 * (uint32_t)g.ldb * 2u);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    issue(0);
+    if (nt > 1) issue(1);
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // this wave's 3 pieces of stage t (stage t+1 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue(t + 2);
+        const char* sa = smem + (t % DU_STAGES) * DU_STAGE_BYTES;
+        const char* sb = sa + DU_A_BYTES;
+        bf16x8 af[2][2], bf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j][ks] = pp_read_frag<true>(sb, 64 * wc + 32 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i][ks] = *reinterpret_cast<const bf16x8*>(sa + du_kc_off(wr * 64 + 32 * i + (lane & 31), ks * 2 + (lane >> 5)));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // every wave is done with the operand ring: 8 KiB of it per wave become the u / du block
+#ifdef SPN_GEMM_TIMING
+    const long long tl_loop = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // ---- epilogue: activation backward on the wave's 64 rows x 64 gated outputs (see pp_store_tile<.., 3> for the arithmetic) ----
+    const int I = g.N;
+    const int colw = n0 + wc * 64;
+    const int rl = lane & 31, hl = lane >> 5;
+    char* blk = smem + wave * 8192;                       // [value 4 KiB | gate 4 KiB], rows of 128 B, 16-byte chunk c at c ^ ((row >> 1) & 7)
+    const uint32_t blk_w = spn_lds_addr(blk);
+    const u32x4 rsU = spn_buffer_rsrc(g.G, (uint32_t)((long)g.M * g.ldg * 2));
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(uint32_t)((long)g.M * g.ldc * 2), 0x00020000);
+    uint32_t vo[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        vo[it] = (uint32_t)(((long)(m0 + wr * 64 + r) * g.ldg + colw + c * 8) * 2);
+    }
+    const uint32_t vo_step = (uint32_t)(32 * g.ldg * 2);
+    auto issue_u = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            spn_dma16x2(rsU, blk_w + (uint32_t)(part * 4096), vo[0], vo[1], (uint32_t)(part * I) * 2u);
+            spn_dma16x2(rsU, blk_w + (uint32_t)(part * 4096) + 2048u, vo[2], vo[3], (uint32_t)(part * I) * 2u);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) vo[it] += vo_step;
+    };
+    issue_u();
+    uint32_t so = (uint32_t)(((long)(m0 + wr * 64 + (lane >> 3)) * g.ldc + colw + (lane & 7) * 8) * 2);
+    const uint32_t so_step8 = (uint32_t)(8 * g.ldc * 2);
+    float csum[2] = {0.f, 0.f};
+    const bf16x2_t ones = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+    const uint32_t thr16 = g.thr16;
+    const float ks_ = g.keep_scale;
+    const uint32_t hcol = __umul24((uint32_t)(colw >> 1) + 2u * (uint32_t)hl, 0xEBCA77u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // VM counter at the top of block i: i = 0: U0 | i = 1: U1 S0 (U1 was requested before block 0's stores were issued)
+        if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const uint32_t hb = ffn_drop_rowc(m0 + wr * 64 + 32 * i + rl, g.seed) + hcol;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s_ = 8 * j + 2 * q + hl;
+                const int o = rl * 128 + ((((s_ >> 1) ^ ((rl >> 1) & 7)) & 7) << 4) + (s_ & 1) * 8;
+                const uint2 uv = *reinterpret_cast<const uint2*>(blk + o);
+                const uint2 ug = *reinterpret_cast<const uint2*>(blk + 4096 + o);
+                const uint32_t p0 = pack_bf2(acc[i][j][4 * q], acc[i][j][4 * q + 1]), p1 = pack_bf2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                float d[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+                if (thr16) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        uint32_t x = hb + (uint32_t)(16 * j + 4 * q + e) * 0xEBCA77u;
+                        x ^= x >> 11; x = __umul24(x, 0xD35A2Du) + (x >> 8);
+                        x ^= x >> 13; x = __umul24(x, 0x9E3B35u) + (x >> 9);
+                        x ^= x >> 15;
+                        const float s0 = d[2 * e] * ks_, s1 = d[2 * e + 1] * ks_;
+                        d[2 * e] = (x & 0xffffu) >= thr16 ? s0 : 0.f;
+                        d[2 * e + 1] = (x >> 16) >= thr16 ? s1 : 0.f;
+                    }
+                }
+                const float a[4] = {__uint_as_float(uv.x << 16), __uint_as_float(uv.x & 0xffff0000u), __uint_as_float(uv.y << 16), __uint_as_float(uv.y & 0xffff0000u)};
+                const float t[4] = {__uint_as_float(ug.x << 16), __uint_as_float(ug.x & 0xffff0000u), __uint_as_float(ug.y << 16), __uint_as_float(ug.y & 0xffff0000u)};
+                float da[4], dt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (ACT == 0) {
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-t[e]));
+                        da[e] = d[e] * (t[e] * sg);
+                        dt[e] = d[e] * a[e] * (sg * (1.f + t[e] * (1.f - sg)));
+                    } else {
+                        da[e] = d[e] * gelu_f(t[e]);
+                        dt[e] = d[e] * a[e] * gelu_grad(t[e]);
+                    }
+                }
+                uint2 pa, pg;
+                pa.x = pack_bf2(da[0], da[1]); pa.y = pack_bf2(da[2], da[3]);
+                pg.x = pack_bf2(dt[0], dt[1]); pg.y = pack_bf2(dt[2], dt[3]);
+                // in place: this lane's own 8 bytes of the value / gate image (nobody else reads or writes them before the wave-level sync)
+                *reinterpret_cast<uint2*>(blk + o) = pa;
+                *reinterpret_cast<uint2*>(blk + 4096 + o) = pg;
+            }
+        PP_SLAB_SYNC();
+        if (g.ws) {   // column sums: lane l owns column l of the 64; a transposed read hands it rows 4 t .. 4 t + 3 of that column
+            typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+            const int gq = lane >> 4, p = lane & 15;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int rr = 4 * t + (p >> 2), sl = 4 * gq + (p & 3);
+                    const bf16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (lds_bf16x4*)(blk + part * 4096 + rr * 128 + ((((sl >> 1) ^ ((rr >> 1) & 7)) & 7) << 4) + (sl & 1) * 8));
+                    csum[part] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 0, 1), ones, csum[part], false);
+                    csum[part] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(w, w, 2, 3), ones, csum[part], false);
+                }
+        }
+        uint4 val[2][4];
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), chunk = lane & 7;
+                val[part][it] = *reinterpret_cast<const uint4*>(blk + part * 4096 + r * 128 + (((chunk ^ (r >> 1)) & 7) << 4));
+            }
+        if (i == 0) {   // the block has been read back: its 8 KiB take the next block's u (requested BEFORE the stores below are issued)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PP_SLAB_SYNC();
+            issue_u();
+        }
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[part][it]), rsD, (int)(so + (uint32_t)it * so_step8), part * I * 2, 0);
+        so += 4u * so_step8;
+    }
+    // the partial buffer has one row per 128 rows of M: the two 64-row waves of a 128-row slab (wr = 2k, 2k + 1, same wc: waves w, w + 2)
+    // meet through the upper wave's (now dead) LDS block; rows past M contributed exact zeros
+    if (g.ws) {   // (kernel argument: uniform over the workgroup)
+        float* red = reinterpret_cast<float*>(blk);
+        if (wr & 1) { red[lane] = csum[0]; red[64 + lane] = csum[1]; }
+        __syncthreads();
+        if (!(wr & 1) && m0 + wr * 64 < g.M) {
+            const float* other = reinterpret_cast<const float*>(smem + (wave + 2) * 8192);
+            float* P = reinterpret_cast<float*>(g.ws) + (long)((m0 + wr * 64) / 128) * (2 * I);
+            P[colw + lane] = csum[0] + other[lane];
+            P[I + colw + lane] = csum[1] + other[64 + lane];
+        }
+    }
+#ifdef SPN_GEMM_TIMING
+    if (g.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long tl_end = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            long long* o = g.dbg + 32 + 5 * (long)blockIdx.x;
+            o[0] = tl_start; o[1] = tl_loop; o[2] = tl_end;
+            o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        }
+    }
+#endif
+}
+
 // ---- split-K plumbing -------------------------------------------------------------------------------------
 // K slices write their partial products to a workspace [splits][M][N] with plain stores and one small kernel sums them into C
 // (deterministic; fp32 atomics into C cost up to half of the weight-gradient GEMMs: ~16K atomics per block through L2).
@@ -1624,6 +1857,23 @@ extern "C" int spn_gemm_glu_bwd(const void* dy, const void* W2, const void* u, v
 #endif
     // Two 4-wave workgroups per CU (256x128 tiles): this epilogue moves 4 bytes of u / du per output through HBM and takes twice as
     // long as the K = 512 main loop, so what matters is that one workgroup's main loop runs under the other's epilogue
+    if (spn_tune_i(SPN_TUNE_GLU_BWD_DUO) >= 2 && K % DU_BK == 0) {   // eight waves per workgroup (gemm_duo8_glu_bwd_kernel)
+        g.tx = I / DU_BN; g.ty = cdiv(M, DU_BM);
+        const int ng = spn_tune_i(SPN_TUNE_GEMM_DUO_NGROUP);
+        g.ngroup = ng > 0 ? ng : 8;
+        if (g.ngroup > g.tx) g.ngroup = g.tx;
+        if (act == 0) {
+            static std::atomic<unsigned> optin{0};
+            spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo8_glu_bwd_kernel<0>), DU_LDS_BYTES);
+            hipLaunchKernelGGL((gemm_duo8_glu_bwd_kernel<0>), dim3(g.tx * g.ty), dim3(512), DU_LDS_BYTES, stream, g);
+        } else {
+            static std::atomic<unsigned> optin{0};
+            spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_duo8_glu_bwd_kernel<1>), DU_LDS_BYTES);
+            hipLaunchKernelGGL((gemm_duo8_glu_bwd_kernel<1>), dim3(g.tx * g.ty), dim3(512), DU_LDS_BYTES, stream, g);
+        }
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
     if (spn_tune_i(SPN_TUNE_GLU_BWD_DUO) && K % DU_BK == 0) {
         constexpr int DUO_LDS = 16384 + 4 * 16384;
         g.tx = I / DU_BN; g.ty = cdiv(M, DU_BM);

@@ -19,7 +19,8 @@ enum SpnTune {
     SPN_TUNE_GEMM_DUO,             // 0 off; 1 = two 4-wave workgroups per CU (256x128 tiles) where measured faster; 2 = wherever eligible; 1
     SPN_TUNE_GEMM_DUO_NGROUP,      // n-tiles per column group of the duo kernel's tile order; 8
     SPN_TUNE_GEMM_STAGGER,         // persistent GEMM: start delay spread over the 32 CU slots of an XCD, in units of 1024 shader cycles (0 = off); 0
-    SPN_TUNE_GLU_BWD_DUO,          // gated-backward GEMM (spn_gemm_glu_bwd): 1 = two workgroups per CU (256x128 tiles), 0 = ping-pong kernel; 1
+    SPN_TUNE_GLU_BWD_DUO,          // gated-backward GEMM (spn_gemm_glu_bwd): 2 = two 8-wave workgroups per CU (256x128 tiles, 64x64 wave tiles),
+                                   // 1 = two 4-wave workgroups per CU, 0 = ping-pong kernel; 2
     SPN_TUNE_GEMM_PERSIST_BWD,     // 1 = the persistent walk also for input-gradient GEMMs (N-contiguous B).  Only safe when no other kernel holds CUs
                                    // during the backward (a concurrent all-reduce starves the blocks that land on its CUs): the host sets it; 0
     SPN_TUNE_COUNT

@@ -242,10 +242,21 @@ def _glu_case(M, I, K, act, p, ops):
 
 @pytest.mark.parametrize("M,I,K,act,p", [(256, 256, 256, 0, 0.0), (904, 512, 512, 0, 0.1), (4096, 2048, 512, 1, 0.1),
                                          (8192 + 8, 2048, 512, 0, 0.1), (131008, 2048, 512, 0, 0.1)])
-def test_gemm_glu_bwd_equals_gemm_then_activation_backward(M, I, K, act, p):
+@pytest.mark.parametrize("duo", [2, 1, 0])
+def test_gemm_glu_bwd_equals_gemm_then_activation_backward(M, I, K, act, p, duo):
     """Gated backward epilogue: du and the bias column sums equal the input-gradient GEMM followed by the stand-alone activation
-    backward, bit for bit (dg rounded to bf16 at the same point, same dropout mask), at edge row counts and at the benchmark's shape."""
-    from scoreperformer_amd import ops
+    backward, bit for bit (dg rounded to bf16 at the same point, same dropout mask), at edge row counts and at the benchmark's shape;
+    on all three tile kernels (two 8-wave workgroups per CU = the default, two 4-wave workgroups, the ping-pong kernel)."""
+    from scoreperformer_amd import lib, ops
+    old = lib.get_tuning("glu_bwd_duo")
+    lib.set_tuning("glu_bwd_duo", duo)
+    try:
+        _glu_bwd_case(M, I, K, act, p, ops)
+    finally:
+        lib.set_tuning("glu_bwd_duo", old)
+
+
+def _glu_bwd_case(M, I, K, act, p, ops):
     gen = torch.Generator(device="cuda").manual_seed(M + I + 1)
     dy = (torch.randn(M, K, device="cuda", generator=gen) * 0.5).bfloat16()
     w2 = (torch.randn(K, I, device="cuda", generator=gen) * K ** -0.5).bfloat16()
@@ -264,7 +275,7 @@ def test_gemm_glu_bwd_equals_gemm_then_activation_backward(M, I, K, act, p):
     assert torch.equal(du2.view(torch.int16), du.view(torch.int16))
 
 
-@pytest.mark.parametrize("duo", [0, 1])
+@pytest.mark.parametrize("duo", [0, 1, 2])
 @pytest.mark.parametrize("M", [8200, 9000, 256 + 128, 256 + 8, 512 - 8])
 def test_gemm_glu_bwd_partial_rows_stay_inside_the_buffer(M, duo):
     """The column-sum partial buffer is [ceil(M / 128), 2I] (include/spn.h).  With 0 < M % 256 <= 128 the last 256-row tile's second
