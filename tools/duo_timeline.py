@@ -29,6 +29,9 @@ def main():
         build()
         return
     lib = ctypes.CDLL(OUT)
+    duo = float(os.environ.get("DUO", 2))     # 2: two 8-wave workgroups per CU (default), 1: two 4-wave workgroups (with per-block epilogue stamps)
+    lib.spn_set_tuning(b"glu_bwd_duo", ctypes.c_double(duo))
+    print(f"glu_bwd_duo = {duo:.0f}")
     M, I, K = 131072, 2048, 512
     p_drop = float(os.environ.get("P", 0.1))
     dev = torch.device("cuda")
