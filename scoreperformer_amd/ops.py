@@ -686,23 +686,29 @@ def segment_gather(src: torch.Tensor, seg: torch.Tensor, *, counts: Optional[tor
 class _SmallZeros:
     """Small fp32 accumulators that have to start at zero (atomic targets, partial sums): slices of a 64 KiB block that is cleared by ONE
     fill when it is allocated, instead of one fill launch per accumulator (~80 per train step).  A slice is handed out exactly once --
-    an exhausted block is dropped, never recycled -- so this is plain allocation batching: no aliasing, no lifetime rule."""
+    an exhausted block is dropped, never recycled -- so this is plain allocation batching: no aliasing, no lifetime rule.
+    While a stream is being captured into a graph the fill has to be part of the graph (a replay must find zeros again), so a capture
+    gets a tensor and a fill of its own."""
     BLOCK = 16384   # floats
 
     def __init__(self):
+        import threading
         self.blocks = {}
+        self.lock = threading.Lock()
 
     def take(self, n: int, device) -> torch.Tensor:
-        if n > 1024:
+        if n > 1024 or (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
             return torch.zeros(n, device=device, dtype=F32)
         step = (n + 63) // 64 * 64       # 256-byte granules keep every slice aligned for vector accesses
-        key = (device.type, device.index)
-        blk = self.blocks.get(key)
-        if blk is None or blk[1] + step > self.BLOCK:
-            blk = [torch.zeros(self.BLOCK, device=device, dtype=F32), 0]
-            self.blocks[key] = blk
-        out = blk[0][blk[1]:blk[1] + n]
-        blk[1] += step
+        # one block per (device, stream): the fill is ordered on the stream that allocates the block, and so is every later user of a slice
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+        with self.lock:
+            blk = self.blocks.get(key)
+            if blk is None or blk[1] + step > self.BLOCK:
+                blk = [torch.zeros(self.BLOCK, device=device, dtype=F32), 0]
+                self.blocks[key] = blk
+            out = blk[0][blk[1]:blk[1] + n]
+            blk[1] += step
         return out
 
 
