@@ -4,6 +4,7 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o tools/_bin/ln_bw_probe tools/ln_bw_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -15,6 +16,11 @@ __device__ __forceinline__ float wsum(float v) {
 template <int RED, int R2>
 __global__ __launch_bounds__(256) void probe(const float* __restrict__ x, const unsigned short* __restrict__ dy, const float* __restrict__ dres,
                                              float* __restrict__ dx, unsigned short* __restrict__ dx16, int T, int rows_per_block) {
+    // PROBE_LDS (compile-time): a dummy LDS allocation that caps the resident blocks per CU (160 KiB / PROBE_LDS), i.e. the occupancy
+#ifdef PROBE_LDS
+    __shared__ float occupancy_cap[PROBE_LDS / 4];
+    if (T < 0) occupancy_cap[threadIdx.x] = 1.f;
+#endif
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T, r0 + rows_per_block);
     for (int row = r0 + w * R2; row < r1; row += 4 * R2) {
@@ -65,7 +71,12 @@ int main() {
     const int T = 131072; const long n = (long)T * 512;
     float *x, *dres, *dx; unsigned short *dy, *dx16;
     hipMalloc(&x, n * 4); hipMalloc(&dres, n * 4); hipMalloc(&dx, n * 4); hipMalloc(&dy, n * 2); hipMalloc(&dx16, n * 2);
-    hipMemset(x, 0, n * 4); hipMemset(dres, 0, n * 4); hipMemset(dy, 0, n * 2);
+    // PROBE_FILL=1: pseudo-random operand bytes instead of zeros (the memory system moves zeros at lower power: up to 15 % faster)
+    if (getenv("PROBE_FILL")) {
+        unsigned* h = (unsigned*)malloc(n * 4); unsigned s = 12345u;
+        for (long i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = (s & 0x007fffffu) | 0x3f000000u; }
+        hipMemcpy(x, h, n * 4, hipMemcpyHostToDevice); hipMemcpy(dres, h, n * 4, hipMemcpyHostToDevice); hipMemcpy(dy, h, n * 2, hipMemcpyHostToDevice); free(h);
+    } else { hipMemset(x, 0, n * 4); hipMemset(dres, 0, n * 4); hipMemset(dy, 0, n * 2); }
     for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
         run<0, 1>(x, dy, dres, dx, dx16, T, blocks);
         run<1, 1>(x, dy, dres, dx, dx16, T, blocks);
