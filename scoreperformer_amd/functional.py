@@ -230,7 +230,7 @@ class LayerNormFn(Function):
         if dy is None:   # only the residual branch was used
             return dres, None, None, None, None, None
         dres = _fork_grad(dres, x)
-        dyb = to_bf16(dy.reshape(-1, D))
+        dyb = _bf16_grad(dy, D)        # (the bf16 copy a LayerNorm backward further down the graph left on dy, else a cast)
         dgamma = dbeta = None
         g_main = _main_grad(gamma) if gamma is not None else None
         b_main = _main_grad(beta) if beta is not None else None
@@ -417,7 +417,7 @@ class AdaLayerNormFn(Function):
         D = x.shape[-1]
         if dy is None:
             dy = torch.zeros(x.shape, device=x.device, dtype=BF16)
-        dyb = to_bf16(dy.reshape(-1, D))
+        dyb = _bf16_grad(dy, D)
         dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dres=_fork_grad(dres, x), dx_dtype=x.dtype, want_dgb=True,
                                     want_dx16=True)
         dcond = None

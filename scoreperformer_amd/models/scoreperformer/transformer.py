@@ -117,7 +117,11 @@ class TupleTransformer(nn.Module, Constructor):
         if self.pos_emb is not None:
             x = x + self.pos_emb(x).to(x.dtype)
         if isinstance(self.emb_norm, nn.LayerNorm):
-            x = self.emb_norm(x)
+            # encoders (nothing concatenated, no input projection): the norm writes the fp32 residual stream itself -- as bf16 it was cast
+            # up by the layer stack right away (one pass forward, one backward, per encoder)
+            will_cat = ((context is not None and self.context_emb_mode == EmbeddingModes.CONCAT)
+                        or (style_embeddings is not None and self.style_emb_mode == EmbeddingModes.CONCAT))
+            x = self.emb_norm(x, out_fp32=not will_cat and not isinstance(self.project_emb, nn.Linear))
         parts = [x]
         if context is not None and self.context_emb_mode == EmbeddingModes.CONCAT:
             parts.append(context[:, :x.shape[1]])
