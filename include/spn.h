@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -127,6 +127,10 @@ int spn_act_fwd(const void* u, long ldu, void* out, long ldo, long T, int I, int
 int spn_act_bwd(const void* u, long ldu, const void* dout, long lddo, void* du, long lddu, long T, int I, int act, int glu,
                 float p_drop, unsigned seed, float* colsum /* optional: += column sums of du (bias gradient) */,
                 float* colsum_ws /* scratch, 4096 * width floats, required with colsum */, spn_stream_t s);
+/* stand-alone nn.Dropout on [rows, D] (models/scoreperformer/transformer.py:122,184 `emb_dropout`; modules/transformer/feedforward.py:58 behind
+ * a post-activation LayerNorm): y = keep ? x / (1 - p) : 0, counter-based mask of (seed, row, column) as in spn_act_fwd, so the backward is
+ * the same call on dy with the same seed.  dtype 0 = fp32, 1 = bf16 (x and y alike); y may alias x */
+int spn_dropout(const void* x, long ldx, void* y, long ldy, int dtype, long rows, int D, float p_drop, unsigned seed, spn_stream_t s);
 int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* y, int y_dtype, long y_bs, long y_ts,
              const uint8_t* rowmask, long B, long t_len, int D, spn_stream_t s);
 int spn_colsum(const void* x, int x_dtype, long ldx, float* out /* ACCUMULATED */, long T, int N, spn_stream_t s);

@@ -346,6 +346,51 @@ extern "C" int spn_cast(const void* x, int x_dtype, long x_bs, long x_ts, void* 
     return SPN_OK;
 }
 
+// Stand-alone dropout of a [T, D] tensor (nn.Dropout where no producing kernel can carry it: `emb_dropout` of
+// models/scoreperformer/transformer.py:122,184 and the Dropout behind a post-activation LayerNorm, feedforward.py:58): y = keep ? x / (1 - p)
+// : 0 with the counter-based mask of the FFN kernels (common.h: ffn_drop_bits on (row, column pair), 16-bit threshold).  The mask is a
+// function of (seed, row, column) only, so the backward is the SAME call on dy with the same seed.
+namespace {
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, long rows, int D, uint32_t thr16, float keep_scale,
+                               uint32_t seed) {
+    const int chunks = D / 8;
+    const long total = rows * chunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long t = idx / chunks;
+        const int c = (int)(idx % chunks) * 8;
+        float f[8];
+        if constexpr (sizeof(T) == 2) {
+            unpack8(*reinterpret_cast<const uint4*>(x + t * ldx + c), f);
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + t * ldx + c), b = *reinterpret_cast<const f32x4*>(x + t * ldx + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+        }
+        drop8(f, t, c >> 3, seed, thr16, keep_scale);
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(y + t * ldy + c) = pack8f(f);
+        } else {
+            *reinterpret_cast<f32x4*>(y + t * ldy + c) = f32x4{f[0], f[1], f[2], f[3]};
+            *reinterpret_cast<f32x4*>(y + t * ldy + c + 4) = f32x4{f[4], f[5], f[6], f[7]};
+        }
+    }
+}
+}  // namespace
+
+// dtype: 0 = fp32, 1 = bf16 (x and y alike); D and the row strides multiples of 8; y may alias x
+extern "C" int spn_dropout(const void* x, long ldx, void* y, long ldy, int dtype, long rows, int D, float p_drop, unsigned seed, hipStream_t s) {
+    SPN_REQUIRE(x && y && rows > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (dtype == 0 || dtype == 1) && p_drop >= 0.f && p_drop < 1.f,
+                "spn_dropout: bad arguments (D and row strides multiples of 8, 0 <= p < 1)");
+    const uint32_t thr = thr16_of(p_drop);
+    const float ks = 1.f / (1.f - (float)thr / 65536.f);
+    const int g = grid_for(rows * (D / 8));
+    if (dtype == 1) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(g), dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, D, thr, ks, seed);
+    else hipLaunchKernelGGL((dropout_kernel<float>), dim3(g), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, rows, D, thr, ks, seed);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
 // out[N] (fp32) += column sums of x [T, N]
 extern "C" int spn_colsum(const void* x, int x_dtype, long ldx, float* out, long T, int N, hipStream_t s) {
     SPN_REQUIRE(x && out && T > 0 && N > 0, "spn_colsum: bad arguments");

@@ -735,6 +735,26 @@ def cat_cast(*parts):
     return CatCastFn.apply(*parts)
 
 
+class DropoutFn(Function):
+    """nn.Dropout as one kernel (ops.dropout); the backward re-derives the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop: float):
+        ctx.p, ctx.seed = p_drop, next_seed()
+        return ops.dropout(x.contiguous() if x.stride(-1) != 1 else x, p_drop, ctx.seed)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return ops.dropout(dy.contiguous() if dy.stride(-1) != 1 else dy, ctx.p, ctx.seed), None
+
+
+def dropout(x, p_drop: float, training: bool = True):
+    if not training or p_drop <= 0.0:
+        return x
+    return DropoutFn.apply(x, float(p_drop))
+
+
 class CastFn(Function):
     @staticmethod
     def forward(ctx, x, dtype, rowmask):

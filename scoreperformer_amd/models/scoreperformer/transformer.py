@@ -71,8 +71,6 @@ class TupleTransformer(nn.Module, Constructor):
                  style_emb_dim: Optional[int] = None, style_emb_mode: str = EmbeddingModes.CONCAT, lm_head=None,
                  regression_head=None):
         super().__init__()
-        if emb_dropout > 0.:
-            raise NotImplementedError("emb_dropout > 0 is not used by any shipped recipe")
         stack_cfg = transformer if transformer is not None else TransformerConfig(_target_="default")
         emb_cfg = token_embeddings if token_embeddings is not None else TupleTokenEmbeddingsConfig()
         self.dim, self.max_seq_len = dim, max_seq_len
@@ -92,7 +90,7 @@ class TupleTransformer(nn.Module, Constructor):
         if self.pos_emb is not None:
             nn.init.kaiming_normal_(self.pos_emb.emb.weight)
         self.emb_norm = LayerNorm(dim) if emb_norm else nn.Identity()
-        self.emb_dropout = nn.Identity()
+        self.emb_dropout = nn.Dropout(emb_dropout) if emb_dropout > 0. else nn.Identity()   # (the forward runs F_.dropout with its p)
         width_in = dim + (self.context_emb_dim if cat_context else 0) + (self.style_emb_dim if cat_style else 0)
         self.project_emb = nn.Linear(width_in, dim) if width_in != dim else nn.Identity()
         self.lm_head = (TupleTokenHeadsRegistry.instantiate(config=lm_head, dim=dim, embeddings=self.token_emb)
@@ -133,6 +131,7 @@ class TupleTransformer(nn.Module, Constructor):
                 style_embeddings = None
         if len(parts) > 1:
             x = F_.cat_cast(*parts)
+        x = F_.dropout(x, getattr(self.emb_dropout, "p", 0.0), self.training)      # behind the concatenation (transformer.py:184; 0 in every shipped recipe)
         if isinstance(self.project_emb, nn.Linear):
             x = F_.linear(x, self.project_emb.weight, self.project_emb.bias, out_fp32=True)
 

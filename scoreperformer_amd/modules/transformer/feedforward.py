@@ -44,17 +44,16 @@ class FeedForward(nn.Module, Constructor):
     def forward(self, x, residual=None):
         p = self.dropout if self.training else 0.0
         has_ln = isinstance(self.ff[1], nn.LayerNorm)
-        if has_ln and p > 0:
-            raise NotImplementedError("post_act_ln together with dropout (not used by any recipe)")
         out = self.ff[3]
         if self.glu and not has_ln:   # one autograd node for the block (activation backward inside the output projection's dX GEMM)
             proj = self.ff[0].proj
             return F_.feed_forward_glu(x, proj.weight, proj.bias, out.weight, out.bias, residual=residual, act=self.act_code, p_drop=p)
+        p_act = 0.0 if has_ln else p     # with a post-activation LayerNorm the Dropout sits BEHIND the norm (feedforward.py:56-59)
         if self.glu:
-            g = self.ff[0](x, p_drop=p)
+            g = self.ff[0](x, p_drop=p_act)
         else:
             lin = self.ff[0][0]
-            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p, bias=lin.bias)
+            g = F_.glu_act(F_.linear(x, lin.weight, lin.bias), act=self.act_code, glu=False, p_drop=p_act, bias=lin.bias)
         if has_ln:
-            g = F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps)
+            g = F_.dropout(F_.layer_norm(g, self.ff[1].weight, self.ff[1].bias, eps=self.ff[1].eps), p, self.training)
         return F_.linear(g, out.weight, out.bias, residual=residual, out_fp32=residual is not None)

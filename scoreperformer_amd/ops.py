@@ -395,6 +395,19 @@ def act_bwd_can_fuse_colsum(width: int, glu: bool) -> bool:
     return chunks > 0 and (chunks % 256 == 0 or 256 % chunks == 0)
 
 
+def dropout(x: torch.Tensor, p_drop: float, seed: int) -> torch.Tensor:
+    """Stand-alone dropout of [.., D] (fp32 or bf16, unit inner stride, D a multiple of 8): kept entries scaled by 1 / (1 - p), mask a
+    function of (seed, row, column) -- calling it again on the gradient with the same seed is the backward."""
+    require_gpu(x)
+    x2 = _rows2d(x)
+    if x2.dtype not in (F32, BF16) or x2.shape[1] % 8 or x2.stride(0) % 8:
+        raise SpnError("dropout: fp32 / bf16 rows with a width and row stride that are multiples of 8")
+    y = torch.empty(x2.shape, device=x.device, dtype=x2.dtype)
+    call("spn_dropout", ptr(x2), c_long(x2.stride(0)), ptr(y), c_long(y.stride(0)), c_int(0 if x2.dtype == F32 else 1), c_long(x2.shape[0]),
+         c_int(x2.shape[1]), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())
+    return y.view(x.shape)
+
+
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[N] (fp32) += column sums of x [T, N]."""
     x2 = _rows2d(x)

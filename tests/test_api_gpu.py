@@ -154,3 +154,47 @@ def test_ablation_recipe_variants_match_the_reference_loss(dev, name):
     for k, v in losses.items():
         assert abs(float(out.losses[k]) - v) < 3e-2 * max(1.0, abs(v)), k
     assert bool(torch.isfinite(arena.grads).all())
+
+
+def test_emb_dropout_and_post_act_ln_dropout_run_on_the_hip_path(dev):
+    """`emb_dropout > 0` (models/scoreperformer/transformer.py:122,184: behind the concatenation, in front of the input projection) and
+    `post_act_ln=True` with dropout (feedforward.py:56-59: the Dropout sits behind the LayerNorm): parity is statistical by construction
+    (counter-based masks), so: eval mode equals the no-dropout model exactly, training mode differs, gradients flow, and with p -> 0
+    the training loss meets the eval loss."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    from scoreperformer_amd.modules.transformer.feedforward import FeedForward
+    torch.manual_seed(2)
+    cfg = model_config("tiny")
+    for k in ("score_encoder", "perf_encoder", "perf_decoder"):
+        cfg[k]["emb_dropout"] = 0.3
+    model = ScorePerformer.init(cfg)
+    arena = ParamArena(model, dev)
+    batch = {k: v.to(dev) for k, v in synthetic_batch(2, 64, seed=4, ragged=True).items()}
+    z = [torch.randn(256, d, generator=torch.Generator().manual_seed(i)).to(dev) for i, d in enumerate(cfg["perf_encoder"]["latent_dim"])]
+    model.perf_encoder._z_override = z
+    model.eval()
+    with torch.no_grad():
+        ev = float(model(**batch).loss)
+    model.train()
+    out = model(**batch)
+    assert abs(float(out.loss) - ev) > 1e-4                      # the masks bite
+    arena.zero_grad()
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    for m in model.modules():
+        if hasattr(m, "emb_dropout") and hasattr(m.emb_dropout, "p"):
+            m.emb_dropout.p = 1e-6
+    assert abs(float(model(**batch).loss) - ev) < 5e-3
+    # post-activation LayerNorm + dropout
+    ff = FeedForward(dim=128, mult=2, glu=True, swish=True, post_act_ln=True, dropout=0.25).to(dev)
+    x = torch.randn(2, 40, 128, device=dev).bfloat16().requires_grad_(True)
+    ff.eval()
+    y0 = ff(x)
+    ff.train()
+    y1 = ff(x)
+    assert not torch.equal(y0, y1)
+    y1.float().sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0

@@ -409,3 +409,28 @@ def test_adaln_forward_with_the_projection_inside_the_kernel(T):
             F_.ADALN_FUSED = True
     for a, b_ in zip(*outs):
         assert rel_err(a, b_) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_standalone_dropout_forward_backward(dtype):
+    """ops.dropout / F_.dropout (spn_dropout: `emb_dropout`, the Dropout behind a post-activation LayerNorm): kept entries scaled by
+    1 / (1 - p), the drop rate is p, the backward applies the SAME mask to the gradient, p = 0 / eval are the identity."""
+    from scoreperformer_amd import functional as F_, ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(4, 1000, 512, generator=g) + 3.0).to(DEV).to(dtype)       # no zeros in x: dropped <=> y == 0
+    p = 0.2
+    y = ops.dropout(x, p, seed=77)
+    kept = y != 0
+    rate = 1.0 - float(kept.float().mean())
+    assert abs(rate - p) < 5 * (p * (1 - p) / x.numel()) ** 0.5 + 1e-4, rate
+    torch.testing.assert_close(y[kept].float(), (x[kept].float() / (1 - p)).to(dtype).float(), rtol=2e-2 if dtype == torch.bfloat16 else 2e-5, atol=0)   # (p is quantised to 16 bits: 1 / (1 - p) within 4e-6)
+    assert torch.equal(ops.dropout(x, p, seed=77), y) and not torch.equal(ops.dropout(x, p, seed=78) != 0, kept)
+    # rows and columns are not correlated: the keep rate per row and per column stays within 6 sigma
+    assert float((kept.float().mean(-1) - (1 - p)).abs().max()) < 6 * (p * (1 - p) / 512) ** 0.5
+    assert float((kept.view(-1, 512).float().mean(0) - (1 - p)).abs().max()) < 6 * (p * (1 - p) / 4000) ** 0.5
+    xr = x.clone().requires_grad_(True)
+    out = F_.dropout(xr, p, training=True)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xr.grad != 0, out != 0)
+    torch.testing.assert_close(xr.grad[out != 0].float(), torch.full_like(xr.grad[out != 0].float(), 1 / (1 - p)), rtol=1e-2, atol=0)
+    assert F_.dropout(xr, p, training=False) is xr and F_.dropout(xr, 0.0) is xr
