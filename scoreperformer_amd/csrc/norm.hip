@@ -173,6 +173,98 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
     }
 }
 
+// The two launches of the residual stream's norms (39 per step at C3), without a single condition inside the row loop: x, the residual
+// gradient and dx are fp32, dy bf16, the bf16 copy of dx is wanted, the row is exactly NV * 256 wide.  ADA = false: affine weight, the
+// gamma / beta gradients accumulate; ADA = true: per-token bf16 gamma rows, the (dy * xhat | dy) rows are written.  Same arithmetic and
+// association order as ln_bwd_kernel (results are bit-identical); what differs is the instruction stream: in the general kernel every
+// load sits behind a run-time null / width test in its own basic block, and hipcc's wait-count pass then waits for the FIRST 256-column
+// chunk's loads (and, at the loop header, for the previous row's stores) before the second chunk's loads are issued -- half the bytes
+// in flight per wave and one more exposed latency per row (4.9 TB/s where the access mix streams 5.85, profiles/r04_ln_bwd_variants.txt).
+template <int NV, bool ADA>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+                                                          const float* __restrict__ gamma, const bf16_t* __restrict__ gbh, long ldgb,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ dres, long lddres, float* __restrict__ dx, long lddx,
+                                                          bf16_t* __restrict__ dx16, long lddx16, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, bf16_t* __restrict__ dgb, long lddgb, int T,
+                                                          int rows_per_block) {
+    constexpr int D = NV * 256;
+    __shared__ float red[4][64 * NV * 4 + 4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    f32x4 pg[NV], pb[NV], gam_r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        pg[i] = f32x4{0.f, 0.f, 0.f, 0.f}; pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gam_r[i] = ADA ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4);
+    }
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(T, row_begin + rows_per_block);
+    for (int row = row_begin + w; row < row_end; row += 4) {
+        // every operand of the row is requested before anything is waited for
+        f32x4 xv[NV], dr[NV], ga[NV];
+        uint2 du[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            xv[i] = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + col);
+            du[i] = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + col);
+            dr[i] = *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col);
+            ga[i] = ADA ? IO<bf16_t>::load4(gbh + (long)row * ldgb + col) : gam_r[i];
+        }
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], gq[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            const f32x4 d = f32x4{bf2f(du[i].x & 0xffff), bf2f(du[i].x >> 16), bf2f(du[i].y & 0xffff), bf2f(du[i].y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = (xv[i][e] - mu) * rs;
+                gq[i][e] = d[e] * ga[i][e];
+                s1 += gq[i][e];
+                s2 += gq[i][e] * xh[i][e];
+            }
+            if (ADA) {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = d[e] * xh[i][e];
+                IO<bf16_t>::store4(dgb + (long)row * lddgb + col, t);
+                IO<bf16_t>::store4(dgb + (long)row * lddgb + D + col, d);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { pg[i][e] += d[e] * xh[i][e]; pb[i][e] += d[e]; }
+            }
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (lane + 64 * i) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rs * (gq[i][e] - s1 - xh[i][e] * s2);
+            o += dr[i];
+            *reinterpret_cast<f32x4*>(dx + (long)row * lddx + col) = o;
+            IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);
+        }
+    }
+    if (!ADA) {
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[w][(lane + 64 * i) * 4 + e] = pass == 0 ? pg[i][e] : pb[i][e];
+            __syncthreads();
+            for (int col = threadIdx.x; col < D; col += 256) {
+                const float sum = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+                atomicAdd((pass == 0 ? dgamma : dbeta) + col, sum);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 template <typename TIn, typename TOut>
 int launch_fwd(int nv, dim3 grid, hipStream_t s, const void* x, long ldx, const float* gamma, const float* beta, const void* gb,
                long ldgb, int gb16, void* y, long ldy, float* mean, float* rstd, int T, int D, float eps) {
@@ -234,6 +326,18 @@ int ln_bwd_impl(const void* x, int x_dtype, long ldx, const void* dy, long lddy,
     int rpb = cdiv(T, bwd_blocks);
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));
+    // the residual stream's two launches (fp32 x / dx / residual gradient, bf16 copy wanted, 256- or 512-wide rows): the branch-free kernel
+    if (x_dtype == 0 && dx_dtype == 0 && dres && dx16 && (D == 256 || D == 512) &&
+        ((gb && gb16 && dgb && !gamma && !dgamma) || (!gb && gamma && dgamma && dbeta && !dgb))) {
+        const bool ada = gb != nullptr;
+#define LNF(NV_, ADA_) hipLaunchKernelGGL((ln_bwd_fast_kernel<NV_, ADA_>), grid, dim3(256), 0, stream, (const float*)x, ldx, (const bf16_t*)dy, lddy, gamma, \
+                                          (const bf16_t*)gb, ldgb, mean, rstd, dres, lddres, (float*)dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, rpb)
+        if (D == 512) { if (ada) LNF(2, true); else LNF(2, false); }
+        else { if (ada) LNF(1, true); else LNF(1, false); }
+#undef LNF
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
     int rc;
 #define LNB(TI_, TD_) launch_bwd<TI_, TD_>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, gb16, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb)
     if (x_dtype == 0 && dx_dtype == 0) rc = LNB(float, float);
