@@ -294,10 +294,42 @@ __global__ __launch_bounds__(256) void embed_bwd_stats_kernel(GatherDesc d, cons
         key_of[i] = kk;
     }
     const int row_begin = blockIdx.x * rows_per_block, row_end = min(T, row_begin + rows_per_block);
+    // rows that are exactly NV * 256 wide (the step's 12 keys x 128): no column test inside the row loop, so that every load of a row --
+    // NV table-row pieces, NV dy pieces -- is in flight before the first wait (behind a per-chunk test each chunk's loads sat in their own
+    // basic block and hipcc waited for one chunk before requesting the next: six serial trips per row, 1.7 TB/s); gamma stays in registers
+    const bool full = d.D == NV * 256;
+    f32x4 gam_r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) gam_r[i] = full ? *reinterpret_cast<const f32x4*>(gamma + (lane + 64 * i) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int row = row_begin + w; row < row_end; row += 4) {
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
         const int tok_l = lane < d.nkeys ? (int)tokens[(long)(row / t_len) * tok_bs + (long)(row % t_len) * tok_ts + lane] : 0;
+        if (full) {
+            f32x4 xva[NV]; uint2 ua[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = (lane + 64 * i) * 4;
+                const int kk = key_of[i];
+                const long tok = __shfl(tok_l, kk, 64);
+                xva[i] = *reinterpret_cast<const f32x4*>(d.table[kk] + tok * d.width[kk] + (col - d.col0[kk]));
+                ua[i] = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + col);
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float dyv[4] = {bf2f(ua[i].x & 0xffff), bf2f(ua[i].x >> 16), bf2f(ua[i].y & 0xffff), bf2f(ua[i].y >> 16)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xva[i][e] - mu) * rs, gq = dyv[e] * gam_r[i][e];
+                    s1 += gq; s2 += gq * xh;
+                    pg[i][e] += dyv[e] * xh; pb[i][e] += dyv[e];
+                }
+            }
+            s1 = wave_sum(s1) / (float)d.D;
+            s2 = wave_sum(s2) / (float)d.D;
+            if (lane == 0) { s1o[row] = s1; s2o[row] = s2; }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (lane + 64 * i) * 4;
