@@ -180,11 +180,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
 // load sits behind a run-time null / width test in its own basic block, and hipcc's wait-count pass then waits for the FIRST 256-column
 // chunk's loads (and, at the loop header, for the previous row's stores) before the second chunk's loads are issued -- half the bytes
 // in flight per wave and one more exposed latency per row (4.9 TB/s where the access mix streams 5.85, profiles/r04_ln_bwd_variants.txt).
-template <int NV, bool ADA>
-__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
+// FORK = the residual gradient is added and the bf16 copy of an fp32 dx is written (the pre-norm fork of the layer stack); without it
+// (norms outside the stack: embedding norms, the LM head's 1536-wide norm, bf16 in and out) neither pointer is touched.
+template <typename TIn, typename TDx, int NV, bool ADA, bool FORK>
+__global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const TIn* __restrict__ x, long ldx, const bf16_t* __restrict__ dy, long lddy,
                                                           const float* __restrict__ gamma, const bf16_t* __restrict__ gbh, long ldgb,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ dres, long lddres, float* __restrict__ dx, long lddx,
+                                                          const float* __restrict__ dres, long lddres, TDx* __restrict__ dx, long lddx,
                                                           bf16_t* __restrict__ dx16, long lddx16, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, bf16_t* __restrict__ dgb, long lddgb, int T,
                                                           int rows_per_block) {
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (lane + 64 * i) * 4;
-            xv[i] = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + col);
+            xv[i] = IO<TIn>::load4(x + (long)row * ldx + col);
             du[i] = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + col);
-            dr[i] = *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col);
+            dr[i] = FORK ? *reinterpret_cast<const f32x4*>(dres + (long)row * lddres + col) : f32x4{0.f, 0.f, 0.f, 0.f};
             ga[i] = ADA ? IO<bf16_t>::load4(gbh + (long)row * ldgb + col) : gam_r[i];
         }
         const float mu = mean[row], rs = rstd[row];
@@ -244,9 +246,9 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const float* __restric
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = rs * (gq[i][e] - s1 - xh[i][e] * s2);
-            o += dr[i];
-            *reinterpret_cast<f32x4*>(dx + (long)row * lddx + col) = o;
-            IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);
+            if (FORK) o += dr[i];
+            IO<TDx>::store4(dx + (long)row * lddx + col, o);
+            if (FORK) IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);
         }
     }
     if (!ADA) {
@@ -327,17 +329,23 @@ int ln_bwd_impl(const void* x, int x_dtype, long ldx, const void* dy, long lddy,
     rpb = ((rpb + 3) / 4) * 4;
     dim3 grid(cdiv(T, rpb));
     // the residual stream's two launches (fp32 x / dx / residual gradient, bf16 copy wanted, 256- or 512-wide rows): the branch-free kernel
+#define LNF(TI_, TD_, NV_, ADA_, FORK_) hipLaunchKernelGGL((ln_bwd_fast_kernel<TI_, TD_, NV_, ADA_, FORK_>), grid, dim3(256), 0, stream, (const TI_*)x, ldx, \
+        (const bf16_t*)dy, lddy, gamma, (const bf16_t*)gb, ldgb, mean, rstd, dres, lddres, (TD_*)dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, rpb)
     if (x_dtype == 0 && dx_dtype == 0 && dres && dx16 && (D == 256 || D == 512) &&
         ((gb && gb16 && dgb && !gamma && !dgamma) || (!gb && gamma && dgamma && dbeta && !dgb))) {
         const bool ada = gb != nullptr;
-#define LNF(NV_, ADA_) hipLaunchKernelGGL((ln_bwd_fast_kernel<NV_, ADA_>), grid, dim3(256), 0, stream, (const float*)x, ldx, (const bf16_t*)dy, lddy, gamma, \
-                                          (const bf16_t*)gb, ldgb, mean, rstd, dres, lddres, (float*)dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, rpb)
-        if (D == 512) { if (ada) LNF(2, true); else LNF(2, false); }
-        else { if (ada) LNF(1, true); else LNF(1, false); }
-#undef LNF
+        if (D == 512) { if (ada) LNF(float, float, 2, true, true); else LNF(float, float, 2, false, true); }
+        else { if (ada) LNF(float, float, 1, true, true); else LNF(float, float, 1, false, true); }
         SPN_LAUNCH_CHECK();
         return SPN_OK;
     }
+    // affine norms outside the layer stack, bf16 in and out, rows of exactly 512 or 1536 (the embedding norms, the LM head's norm)
+    if (x_dtype == 1 && dx_dtype == 1 && !dres && !dx16 && !gb && !dgb && gamma && dgamma && dbeta && (D == 512 || D == 1536)) {
+        if (D == 512) LNF(bf16_t, bf16_t, 2, false, false); else LNF(bf16_t, bf16_t, 6, false, false);
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
+#undef LNF
     int rc;
 #define LNB(TI_, TD_) launch_bwd<TI_, TD_>(nv, grid, stream, x, ldx, dy, lddy, gamma, gb, ldgb, gb16, mean, rstd, dres, lddres, dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, D, rpb)
     if (x_dtype == 0 && dx_dtype == 0) rc = LNB(float, float);
