@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -93,6 +93,12 @@ int spn_layernorm_fwd_gb16(const void* x, int x_dtype, long ldx, const void* gb1
 int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
                            const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx,
                            void* dx16, long lddx16, void* dgb, long lddgb, int T, int D, spn_stream_t stream);
+/* the same, and the column sums of the dgb rows (= the bias gradient of the condition Linear, modules/layers.py:38) are ACCUMULATED into
+ * dgb_colsum [2D] fp32 by the same pass, from the unrounded products: no second read of dgb */
+int spn_layernorm_bwd_gb16_colsum(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
+                                  const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype, long lddx,
+                                  void* dx16, long lddx16, void* dgb, long lddgb, float* dgb_colsum /* [2D] ACCUMULATED */, int T, int D,
+                                  spn_stream_t stream);
 
 /* AdaptiveLayerNorm FORWARD with the condition projection INSIDE the kernel (modules/layers.py:31-47: gamma | beta = Linear(condition),
  * never materialised as [T, 2D] rows by a K = 64 GEMM).  spn_adaln_ok: 1 when the fused kernel takes the shape (D = 512, C = 64);

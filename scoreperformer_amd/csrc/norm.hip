@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
                 for (int e = 0; e < 4; ++e) t[e] = d[e] * xh[i][e];
                 IO<bf16_t>::store4(dgb + (long)row * lddgb + col, t);
                 IO<bf16_t>::store4(dgb + (long)row * lddgb + D + col, d);
-            } else if (dgamma) {
+            }
+            if (dgamma) {   // affine: the gamma / beta gradients; adaptive (with dgb): the column sums of the dgb rows = the condition Linear's bias gradient
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pg[i][e] += d[e] * xh[i][e]; pb[i][e] += d[e]; }
             }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TIn* __restrict__ x, 
             if (dx16) IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);   // bf16 copy = the next backward GEMM's operand
         }
     }
-    if (dgamma && !dgb) {
+    if (dgamma) {
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -233,7 +234,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const TIn* __restrict_
                 for (int e = 0; e < 4; ++e) t[e] = d[e] * xh[i][e];
                 IO<bf16_t>::store4(dgb + (long)row * lddgb + col, t);
                 IO<bf16_t>::store4(dgb + (long)row * lddgb + D + col, d);
-            } else {
+            }
+            if (!ADA || dgamma) {   // (adaptive + dgamma: the column sums of the rows just written = the bias gradient of the condition Linear)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pg[i][e] += d[e] * xh[i][e]; pb[i][e] += d[e]; }
             }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fast_kernel(const TIn* __restrict_
             if (FORK) IO<bf16_t>::store4(dx16 + (long)row * lddx16 + col, o);
         }
     }
-    if (!ADA) {
+    if (!ADA || dgamma) {
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -332,7 +334,7 @@ int ln_bwd_impl(const void* x, int x_dtype, long ldx, const void* dy, long lddy,
 #define LNF(TI_, TD_, NV_, ADA_, FORK_) hipLaunchKernelGGL((ln_bwd_fast_kernel<TI_, TD_, NV_, ADA_, FORK_>), grid, dim3(256), 0, stream, (const TI_*)x, ldx, \
         (const bf16_t*)dy, lddy, gamma, (const bf16_t*)gb, ldgb, mean, rstd, dres, lddres, (TD_*)dx, lddx, (bf16_t*)dx16, lddx16, dgamma, dbeta, (bf16_t*)dgb, lddgb, T, rpb)
     if (x_dtype == 0 && dx_dtype == 0 && dres && dx16 && (D == 256 || D == 512) &&
-        ((gb && gb16 && dgb && !gamma && !dgamma) || (!gb && gamma && dgamma && dbeta && !dgb))) {
+        ((gb && gb16 && dgb && !gamma && (!dgamma) == (!dbeta)) || (!gb && gamma && dgamma && dbeta && !dgb))) {
         const bool ada = gb != nullptr;
         if (D == 512) { if (ada) LNF(float, float, 2, true, true); else LNF(float, float, 2, false, true); }
         else { if (ada) LNF(float, float, 1, true, true); else LNF(float, float, 1, false, true); }
@@ -380,6 +382,16 @@ extern "C" int spn_layernorm_bwd(const void* x, int x_dtype, long ldx, const voi
                                  float* dbeta, void* dgb, long lddgb, int T, int D, hipStream_t stream) {
     return ln_bwd_impl(x, x_dtype, ldx, dy, lddy, gamma, gb, ldgb, 0, mean, rstd, dres, lddres, dx, dx_dtype, lddx, dx16, lddx16, dgamma,
                        dbeta, dgb, lddgb, T, D, stream);
+}
+// as spn_layernorm_bwd_gb16, and the column sums of the dgb rows it writes are ACCUMULATED into dgb_colsum [2D] (fp32; the bias gradient of the
+// Linear that produced the (gamma | beta) rows) by the same pass -- from the unrounded fp32 products, no second read of dgb
+extern "C" int spn_layernorm_bwd_gb16_colsum(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
+                                             const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,
+                                             long lddx, void* dx16, long lddx16, void* dgb, long lddgb, float* dgb_colsum, int T, int D,
+                                             hipStream_t stream) {
+    SPN_REQUIRE(gb16 && dgb && dgb_colsum, "spn_layernorm_bwd_gb16_colsum: gb, dgb and the column-sum target are required");
+    return ln_bwd_impl(x, x_dtype, ldx, dy, lddy, nullptr, gb16, ldgb, 1, mean, rstd, dres, lddres, dx, dx_dtype, lddx, dx16, lddx16,
+                       dgb_colsum, dgb_colsum + D, dgb, lddgb, T, D, stream);
 }
 extern "C" int spn_layernorm_bwd_gb16(const void* x, int x_dtype, long ldx, const void* dy, long lddy, const void* gb16, long ldgb,
                                       const float* mean, const float* rstd, const float* dres, long lddres, void* dx, int dx_dtype,

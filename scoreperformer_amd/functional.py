@@ -418,8 +418,11 @@ class AdaLayerNormFn(Function):
         if dy is None:
             dy = torch.zeros(x.shape, device=x.device, dtype=BF16)
         dyb = _bf16_grad(dy, D)
+        main = _main_grad(bias)
+        fused_db = main is not None and gb.dtype == BF16 and main.is_contiguous() and main.dtype == F32
+        # (with an arena the bias gradient = the column sums of dgb comes out of the LayerNorm backward's own pass)
         dx, dgb = ops.layernorm_bwd(x, dyb, None, gb, mean, rstd, dres=_fork_grad(dres, x), dx_dtype=x.dtype, want_dgb=True,
-                                    want_dx16=True)
+                                    want_dx16=True, dgb_colsum=main.view(-1) if fused_db else None)
         dcond = None
         if ctx.needs_input_grad[1]:
             h = ctx.condgrad
@@ -432,10 +435,10 @@ class AdaLayerNormFn(Function):
                 dcond = ops.gemm(dgb, bf16_weight(weight), tb=True, out_dtype=BF16 if ctx.cond_dtype == BF16 else F32)
                 dcond = dcond.view(ctx.cond_shape)
         dw = _accumulate_wgrad(weight, lambda out, acc: ops.gemm(dgb, c2, ta=True, tb=True, out=out, accumulate=acc), weight.shape)
-        main = _main_grad(bias)
         db = None
         if main is not None:
-            ops.colsum(dgb, out=main)
+            if not fused_db:
+                ops.colsum(dgb, out=main)
             hook = getattr(bias, "_spn_grad_ready", None)
             if hook is not None:
                 hook()

@@ -157,9 +157,10 @@ def layernorm_fwd(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional
 def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tensor], gb: Optional[torch.Tensor],
                   mean: torch.Tensor, rstd: torch.Tensor, *, dres: Optional[torch.Tensor] = None, dx_dtype=F32,
                   dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None, want_dgb: bool = False,
-                  want_dx16: bool = False):
+                  want_dx16: bool = False, dgb_colsum: Optional[torch.Tensor] = None):
     """Returns (dx, dgb).  dgamma/dbeta (fp32 [D]) are accumulated in place when given.  `want_dx16`: the kernel also writes
-    a bf16 copy of an fp32 dx, attached as `dx._spn_bf16` (the operand of the next backward GEMM; saves its cast pass)."""
+    a bf16 copy of an fp32 dx, attached as `dx._spn_bf16` (the operand of the next backward GEMM; saves its cast pass).
+    `dgb_colsum` (bf16 gb rows + want_dgb only): fp32 [2D], the column sums of the dgb rows are accumulated into it by the same pass."""
     x2, dy2 = _rows2d(x), _rows2d(dy)
     if dy2.dtype != BF16:
         raise SpnError("layernorm_bwd: dy must be bf16")
@@ -171,6 +172,16 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tenso
         gb = _rows2d(gb)
     if dres is not None:
         dres = _rows2d(dres)
+    if gb is not None and gb.dtype == BF16 and dgb_colsum is not None:
+        if dgb is None or dgb_colsum.dtype != F32 or dgb_colsum.numel() != 2 * D or not dgb_colsum.is_contiguous():
+            raise SpnError("layernorm_bwd: dgb_colsum needs want_dgb and a contiguous fp32 [2D] target")
+        call("spn_layernorm_bwd_gb16_colsum", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gb),
+             c_long(gb.stride(0)), ptr(mean), ptr(rstd), ptr(dres), c_long(dres.stride(0) if dres is not None else 0), ptr(dx),
+             c_int(_dt(dx)), c_long(dx.stride(0)), ptr(dx16), c_long(D), ptr(dgb), c_long(2 * D), ptr(dgb_colsum), c_int(T), c_int(D),
+             stream_ptr())
+        if dx16 is not None:
+            dx._spn_bf16, dx._spn_bf16_ver = dx16, dx._version
+        return dx, dgb
     if gb is not None and gb.dtype == BF16:
         call("spn_layernorm_bwd_gb16", ptr(x2), c_int(_dt(x2)), c_long(x2.stride(0)), ptr(dy2), c_long(dy2.stride(0)), ptr(gb),
              c_long(gb.stride(0)), ptr(mean), ptr(rstd), ptr(dres), c_long(dres.stride(0) if dres is not None else 0), ptr(dx),
@@ -892,9 +903,10 @@ def adaln_fwd(x, cond, w, bias, eps=1e-5, want_gamma=True):  # noqa: F811
     return PROFILE.wrap("ln_fwd", float(by), f"T{n // x.shape[-1]} D{x.shape[-1]} ada-fused", lambda: _adaln_fwd_raw(x, cond, w, bias, eps, want_gamma))
 
 
-def layernorm_bwd(x, dy, gamma, gb, mean, rstd, *, dres=None, dx_dtype=F32, dgamma=None, dbeta=None, want_dgb=False, want_dx16=False):  # noqa: F811
+def layernorm_bwd(x, dy, gamma, gb, mean, rstd, *, dres=None, dx_dtype=F32, dgamma=None, dbeta=None, want_dgb=False, want_dx16=False,  # noqa: F811
+                  dgb_colsum=None):
     run = lambda: _ln_bwd_raw(x, dy, gamma, gb, mean, rstd, dres=dres, dx_dtype=dx_dtype, dgamma=dgamma, dbeta=dbeta,   # noqa: E731
-                              want_dgb=want_dgb, want_dx16=want_dx16)
+                              want_dgb=want_dgb, want_dx16=want_dx16, dgb_colsum=dgb_colsum)
     if not PROFILE.enabled:
         return run()
     n = x.numel()

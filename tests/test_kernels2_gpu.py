@@ -434,3 +434,25 @@ def test_standalone_dropout_forward_backward(dtype):
     assert torch.equal(xr.grad != 0, out != 0)
     torch.testing.assert_close(xr.grad[out != 0].float(), torch.full_like(xr.grad[out != 0].float(), 1 / (1 - p)), rtol=1e-2, atol=0)
     assert F_.dropout(xr, p, training=False) is xr and F_.dropout(xr, 0.0) is xr
+
+
+@pytest.mark.parametrize("T,D", [(4099, 512), (1000, 256), (777, 384)])
+def test_adaptive_layernorm_backward_leaves_the_bias_column_sums(T, D):
+    """spn_layernorm_bwd_gb16_colsum: the column sums of the (dy * xhat | dy) rows -- the bias gradient of the condition Linear
+    (modules/layers.py:38) -- accumulate into a [2D] target in the LayerNorm backward's own pass (branch-free kernel at D = 256 / 512,
+    the general kernel elsewhere); dx and the dgb rows are those of the call without the target."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(T + D)
+    x = torch.randn(T, D, generator=g).to(DEV)
+    gb = (torch.randn(T, 2 * D, generator=g) * 0.5 + 1.0).to(DEV).bfloat16()
+    dy = torch.randn(T, D, generator=g).to(DEV).bfloat16()
+    dres = torch.randn(T, D, generator=g).to(DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, None, None, gb)
+    dx0, dgb0 = ops.layernorm_bwd(x, dy, None, gb, mean, rstd, dres=dres, want_dgb=True, want_dx16=True)
+    target = torch.full((2 * D,), 3.0, device=DEV)
+    dx1, dgb1 = ops.layernorm_bwd(x, dy, None, gb, mean, rstd, dres=dres, want_dgb=True, want_dx16=True, dgb_colsum=target)
+    assert torch.equal(dx0, dx1) and torch.equal(dgb0.view(torch.int16), dgb1.view(torch.int16))
+    assert torch.equal(dx1._spn_bf16.view(torch.int16), dx0._spn_bf16.view(torch.int16))
+    xh = (x - mean[:, None]) * rstd[:, None]
+    exact = torch.cat([(dy.float() * xh).sum(0), dy.float().sum(0)])
+    assert rel_err(target - 3.0, exact) < 2e-4
