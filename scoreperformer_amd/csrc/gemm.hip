@@ -1512,10 +1512,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int ldc, int N, long total4, int accumulate) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const long e = i * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ws + e);
-        for (int z = 1; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + z * slice + e);
+        // eight slices' loads in flight at a time, added in slice order (the sum is the one a slice-by-slice loop forms; that loop waited for
+        // every load before it requested the next: up to 64 serial trips per element)
         float* dst = C + (e / N) * ldc + (e % N);
-        if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        f32x4 old = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accumulate) old = *reinterpret_cast<const f32x4*>(dst);
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + e);
+        int z = 1;
+        for (; z + 8 <= splits; z += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(ws + (long)(z + u) * slice + e);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + (long)z * slice + e);
+        if (accumulate) v += old;
         *reinterpret_cast<f32x4*>(dst) = v;
     }
 }
