@@ -456,3 +456,33 @@ def test_adaptive_layernorm_backward_leaves_the_bias_column_sums(T, D):
     xh = (x - mean[:, None]) * rstd[:, None]
     exact = torch.cat([(dy.float() * xh).sum(0), dy.float().sum(0)])
     assert rel_err(target - 3.0, exact) < 2e-4
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(5000, 4, 572, False, False), (5000, 20, 544, False, False), (300, 32, 512, False, False),
+                                        (5000, 572, 8, False, True), (8, 572, 5000, True, True), (32, 544, 3000, True, True),
+                                        (130, 70, 200, False, False), (4, 16, 70000, True, True)])
+def test_exact_fp32_gemm_all_tile_shapes(M, N, K, ta, tb):
+    """spn_gemm_f32 (VAE heads `MMDVAE.linear`, mmd_transformer.py:53-56, and their backward contractions): the 64x64 tile and the two
+    skinny tiles (N <= 32: 64x16; M <= 32: 16x64), with bias, row mask, accumulation and the split-K weight-gradient path, against torch
+    fp32 -- exact up to summation order."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(DEV)
+    b = torch.randn((K, N) if tb else (N, K), generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    A = a.t() if ta else a
+    B = b if tb else b.t()
+    ref = A.double() @ B.double()
+    tol = 2e-6 * float(ref.abs().max()) * max(1.0, (K / 512) ** 0.5)
+    out = ops.gemm_f32(a, b, ta=ta, tb=tb)
+    assert float((out.double() - ref).abs().max()) < tol
+    out = ops.gemm_f32(a, b, ta=ta, tb=tb, bias=bias, alpha=0.5)
+    assert float((out.double() - (0.5 * ref + bias.double())).abs().max()) < tol
+    base = torch.randn(M, N, generator=g).to(DEV)
+    acc = base.clone()
+    ops.gemm_f32(a, b, ta=ta, tb=tb, out=acc, accumulate=True)
+    assert float((acc.double() - (base.double() + ref)).abs().max()) < tol
+    if not ta:
+        mask = (torch.rand(M, generator=g) < 0.7).to(DEV)
+        out = ops.gemm_f32(a, b, ta=ta, tb=tb, bias=bias, rowmask=mask)
+        assert float((out.double() - (ref + bias.double()) * mask[:, None].double()).abs().max()) < tol
