@@ -732,19 +732,27 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
     const long nq_part = (long)a.b * a.h * a.nqt64;
     const int ch = lane & 7;
     float vmax = 0.f, dmin = __builtin_inff();   // max |row|^2; query rows: min q_i . k_i' with the row's own key i' = i + off
+    // all eight passes' rows are requested before the first one is reduced (rows past the end re-read the last row and are not counted):
+    // pass by pass, every load was waited for before the next was issued -- eight serial trips to memory per 64-row tile
+    uint4 u[8], uk[8];
+    bool own[8];
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int row = min((is_q ? x : x - a.nqt64) * 64 + pass * 8 + (lane >> 3), n - 1);
+        const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
+        const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
+        own[pass] = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
+        const bf16_t* pk = own[pass] ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
+        u[pass] = *reinterpret_cast<const uint4*>(p + ch * 8);
+        uk[pass] = *reinterpret_cast<const uint4*>(pk + ch * 8);
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int row = (is_q ? x : x - a.nqt64) * 64 + pass * 8 + (lane >> 3);
         float v = 0.f, d = 0.f;
-        bool own_ok = false;
-        if (row < n) {
-            const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
-            const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
-            own_ok = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
-            const bf16_t* pk = own_ok ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
-            const uint4 u = *reinterpret_cast<const uint4*>(p + ch * 8);
-            const uint4 uk = *reinterpret_cast<const uint4*>(pk + ch * 8);
-            const uint32_t w[4] = {u.x, u.y, u.z, u.w}, wk[4] = {uk.x, uk.y, uk.z, uk.w};
+        const bool own_ok = own[pass];
+        {
+            const uint32_t w[4] = {u[pass].x, u[pass].y, u[pass].z, u[pass].w}, wk[4] = {uk[pass].x, uk[pass].y, uk[pass].z, uk[pass].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float lo = bf2f(w[e] & 0xffff), hi_ = bf2f(w[e] >> 16);
