@@ -33,6 +33,70 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const TL* __restrict__ logi
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float loss = 0.f, cnt = 0.f, hit = 0.f, dist = 0.f;
     // a wave walks rows with a grid stride: one pair of (same-address) atomics per BLOCK at the end, not per 4 rows
+    if (V <= 256) {
+        // Vocabularies of the tuple keys (<= 260 incl. specials; the predicted ones <= 165): the row lives in four registers per lane, read
+        // ONCE (the two-pass loop read it twice behind a max reduction), and the NEXT row and its label are requested before this row's
+        // reductions -- the chain load -> max -> exp -> sum -> label -> logit[label] was five dependent trips per row and wave.
+        // Same per-lane order of the maximum search and of the exponential sum as the general loop below: identical results.
+        const long stride = (long)gridDim.x * 4;
+        auto fetch = [&](long row, float (&v)[4], long& lab) __attribute__((always_inline)) {
+            const long r = row < T ? row : T - 1;
+            const TL* lr = logits + r * ld;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = lane + 64 * i;
+                const float x = ld_logit(lr + (c < V ? c : V - 1));      // (clamped address, masked VALUE: no test around the load)
+                v[i] = c < V ? x : -INFINITY;
+            }
+            lab = labels[(r / t_len) * lab_bs + (r % t_len) * lab_ts];
+        };
+        float vn[4]; long labn;
+        long row = (long)blockIdx.x * 4 + w;
+        if (row < T) fetch(row, vn, labn);
+        for (; row < T; row += stride) {
+            float v[4] = {vn[0], vn[1], vn[2], vn[3]};
+            const long lab = labn;
+            fetch(row + stride, vn, labn);
+            // maximum by the DPP ladder, arg-max = the smallest index that holds it (torch.argmax's tie rule) by a second ladder on the
+            // negated index (indices < 256 are exact in fp32) -- the shuffle-based pair reduction was twelve LDS-crossbar round trips per row
+            const float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+            float cand = -1.0e9f;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) if (v[i] == m) cand = -(float)(lane + 64 * i);
+            int am = (int)(-wave_max(cand));
+            am = am < V ? am : 0;                                   // (a row of NaNs matches nothing: index 0, as the general loop gives)
+            float sx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (lane + 64 * i < V) sx += __expf(v[i] - m);
+            sx = wave_sum(sx);
+            const float l = m + __logf(sx);
+            if (EVAL && lab != ignore_index && tv && weighted) {
+                const float target = tv[lab];
+                float dd = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (lane + 64 * i < V) dd += __expf(v[i] - l) * fabsf(target - tv[lane + 64 * i]);
+                dist += dd;
+            }
+            // logit[label]: held by lane label % 64 in slot label / 64 (the label is the same in every lane)
+            float at_lab = 0.f;
+            if (lab != ignore_index) {
+                const int slot = (int)(lab >> 6);
+                const float pick = slot == 0 ? v[0] : slot == 1 ? v[1] : slot == 2 ? v[2] : v[3];
+                at_lab = __shfl(pick, (int)(lab & 63), 64);
+            }
+            if (lane == 0) {
+                lse[row] = l;
+                if (argmax) argmax[row] = am;
+                if (lab != ignore_index) {
+                    loss += l - at_lab; cnt += 1.f;
+                    if (EVAL) {
+                        hit += am == lab ? 1.f : 0.f;
+                        if (tv && !weighted) dist += fabsf(tv[am] - tv[lab]);
+                    }
+                }
+            }
+        }
+    } else
     for (long row = (long)blockIdx.x * 4 + w; row < T; row += (long)gridDim.x * 4) {
         const TL* lr = logits + row * ld;
         float m = -INFINITY;
