@@ -1,4 +1,6 @@
-import sys; sys.path.insert(0, "/root/repo")
+"""Time the cross-entropy forward (spn_ce_fwd) at the step's shape: T = 131008 rows, the vocabularies of the four predicted keys."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scoreperformer_amd import ops
 dev = torch.device("cuda"); T = 131008
