@@ -464,8 +464,8 @@ def mmd_heads(
         latents.append(lat)
         embs.append(emb)
         drops.append(drop.expand_as(emb))
-        if hierarchical:
-            out = torch.cat([out, emb], dim=-1)
+        if hierarchical:      # mmd_transformer.py:255-262
+            out = torch.cat([out, emb], dim=-1) if bool(_get(cfg, "hierarchical_with_context", True)) else emb
         y = lat[lmask]
         losses[f"MMD/{mode}"] = loss_w * compute_mmd(z_samples[i], y)
         if deadpan_zero:

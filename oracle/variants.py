@@ -110,8 +110,9 @@ def variant2_inputs(name: str, batch):
 
 # ---- third variant set (round 4): the embedding modes that are the reference's DEFAULTS but that no shipped recipe keeps --------------
 # `multiseq_mode="pre-sum"` (embeddings.py:171,231-241: the decoder's two sequences are summed per key before norm / projection) and
-# `TupleTokenEmbeddings(mode="sum")` (embeddings.py:66-69,117,141: per-key embeddings of one common width summed, only normalised).
-NAMES3 = ["multiseq_pre_sum", "emb_mode_sum"]
+# `TupleTokenEmbeddings(mode="sum")` (embeddings.py:66-69,117,141: per-key embeddings of one common width summed, only normalised);
+# plus two style-encoder variants: `hierarchical_with_context=False` and the per-note `aggregate_mode="same"`.
+NAMES3 = ["multiseq_pre_sum", "emb_mode_sum", "hier_no_context", "agg_same"]
 
 
 def variant3_config(name: str):
@@ -125,5 +126,16 @@ def variant3_config(name: str):
         for k in ("score_encoder", "perf_encoder", "perf_decoder"):
             c[k]["token_embeddings"].update(mode="sum", emb_dims=int(c["dim"]))
         c["perf_decoder"]["token_embeddings"]["multiseq_mode"] = "pre-sum"
+        return c
+    if name == "hier_no_context":       # mmd_transformer.py:152-156,255-262: level i reads ONLY level i - 1's embeddings (no hidden states)
+        c = base()
+        c["perf_encoder"]["hierarchical_with_context"] = False
+        return c
+    if name == "agg_same":              # mmd_transformer.py:19,343-344: one latent per NOTE (no aggregation) as the last level
+        c = base()
+        c["perf_encoder"]["aggregate_mode"] = ["mean", "bar_mean", "same"]
+        c["perf_encoder"]["latent_dim"] = [16, 8, 8]
+        c["perf_encoder"]["latent_dropout"] = [0.0, 0.0, 0.0]
+        c["perf_decoder"]["style_emb_dim"] = 32
         return c
     raise KeyError(name)

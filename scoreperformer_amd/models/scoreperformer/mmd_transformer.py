@@ -78,7 +78,9 @@ class HierLatentsFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, hidden, mask, hierarchical: bool, modes, segs, seg_sizes, *wb):
+    def forward(ctx, hidden, mask, hierarchical, modes, segs, seg_sizes, *wb):
+        # hierarchical: False, True (level i reads the hidden states AND the embeddings of the levels before it: a column prefix of `wide`)
+        # or "no-context" (level i > 0 reads ONLY level i - 1's embeddings: `hierarchical_with_context=False`, mmd_transformer.py:255-262)
         b, n, d = hidden.shape
         nl = len(modes)
         Ws, bs = wb[:nl], wb[nl:]
@@ -90,8 +92,21 @@ class HierLatentsFn(Function):
         saved, latents, lmasks = [], [], []
         off = d
         for i, mode in enumerate(modes):
-            d_in = off if hierarchical else d
-            x_view = wide[..., :d_in]
+            if hierarchical == "no-context" and i > 0:
+                lo, d_in = off - Ls[i - 1], Ls[i - 1]
+            else:
+                lo, d_in = 0, (off if hierarchical else d)
+            x_view = wide[..., lo:lo + d_in]
+            if mode == EmbeddingAggregateModes.SAME:   # one latent per note, no aggregation (mmd_transformer.py:343-344)
+                agg = x_view.contiguous()
+                lmask = mask
+                lat = ops.gemm_f32(agg, Ws[i].detach(), bias=bs[i].detach(), rowmask=lmask).view(b, n, Ls[i])
+                ops.cast(lat, torch.float32, rowmask=mask, out=wide[..., off:off + Ls[i]])
+                saved.append((None, None, n, None, agg, lmask, d_in, off, lo))
+                latents.append(lat)
+                lmasks.append(lmask)
+                off += Ls[i]
+                continue
             if mode == EmbeddingAggregateModes.MEAN:   # masked mean over the sequence (mmd_transformer.py:325-327)
                 seg_a, S, seg_g = notmask, 2, zeros_seg
             elif mode in SEGMENT_MODES:
@@ -107,7 +122,7 @@ class HierLatentsFn(Function):
                 lmask = ops.rows_all_nonzero(agg)                     # mmd_transformer.py:342
             lat = ops.gemm_f32(agg, Ws[i].detach(), bias=bs[i].detach(), rowmask=lmask).view(b, agg.shape[1], Ls[i])
             ops.segment_gather(lat, seg_g, rowmask=mask, out=wide[..., off:off + Ls[i]])
-            saved.append((seg_a, seg_g, S, counts, agg, lmask, d_in, off))
+            saved.append((seg_a, seg_g, S, counts, agg, lmask, d_in, off, lo))
             latents.append(lat)
             lmasks.append(lmask)
             off += Ls[i]
@@ -133,9 +148,12 @@ class HierLatentsFn(Function):
             ops.cast(d_emb.contiguous(), torch.float32, rowmask=mask, out=dwide[..., d:])
         dWs, dbs = [None] * nl, [None] * nl
         for i in reversed(range(nl)):
-            seg_a, seg_g, S, counts, agg, lmask, d_in, off = ctx.saved[i]
+            seg_a, seg_g, S, counts, agg, lmask, d_in, off, lo = ctx.saved[i]
             S_g = agg.shape[1]
-            dlat = ops.segment_sum(dwide[..., off:off + Ls[i]], seg_g, S_g, rowmask=mask)
+            if modes[i] == EmbeddingAggregateModes.SAME:
+                dlat = ops.cast(dwide[..., off:off + Ls[i]], torch.float32, rowmask=mask)
+            else:
+                dlat = ops.segment_sum(dwide[..., off:off + Ls[i]], seg_g, S_g, rowmask=mask)
             if d_lats[i] is not None:
                 dlat = dlat + d_lats[i]
             dlat = ops.mask_rows(dlat, lmask)
@@ -143,9 +161,12 @@ class HierLatentsFn(Function):
             dWs[i] = ops.gemm_f32(dl2, agg.view(-1, d_in), ta=True, tb=True)
             dbs[i] = ops.colsum(dl2)
             dagg = ops.gemm_f32(dl2, Ws[i].detach(), tb=True).view(b, S_g, d_in)
+            if modes[i] == EmbeddingAggregateModes.SAME:
+                dwide[..., lo:lo + d_in] += dagg                      # (rare path: a plain strided add)
+                continue
             if modes[i] == EmbeddingAggregateModes.MEAN:
                 dagg = torch.cat([dagg, torch.zeros_like(dagg)], dim=1)
-            ops.segment_gather(dagg, seg_a, counts=counts, out=dwide[..., :d_in], accumulate=True)
+            ops.segment_gather(dagg, seg_a, counts=counts, out=dwide[..., lo:lo + d_in], accumulate=True)
         d_hidden = ops.cast(dwide[..., :d], torch.float32, rowmask=mask)
         return (d_hidden, None, None, None, None, None, *dWs, *dbs)
 
@@ -183,8 +204,6 @@ class MMDTupleTransformer(TupleTransformer):
             '`hierarchical` mode can only be used with multiple VAE heads'
         self.hierarchical = hierarchical
         self.hierarchical_with_context = hierarchical_with_context
-        if hierarchical and not hierarchical_with_context:
-            raise NotImplementedError("hierarchical_with_context=False is not used by any shipped recipe")
         if not isinstance(latent_dim, int):
             latent_dropout = [latent_dropout] * len(latent_dim) if isinstance(latent_dropout, (int, float)) else list(latent_dropout)
         self.aggregate_mode, self.latent_dim, self.latent_dropout = aggregate_mode, latent_dim, latent_dropout
@@ -198,8 +217,8 @@ class MMDTupleTransformer(TupleTransformer):
             input_dim = dim
             for mode, latent_dim_i in zip(aggregate_mode, latent_dim):
                 self.vae_head[mode] = MMDVAE(input_dim=input_dim, latent_dim=latent_dim_i)
-                if self.hierarchical:
-                    input_dim += latent_dim_i
+                if self.hierarchical:       # mmd_transformer.py:152-156
+                    input_dim = input_dim + latent_dim_i if self.hierarchical_with_context else latent_dim_i
             self.embedding_dim = sum(latent_dim)
         self.criterion = MMDLoss()
         self.loss_weight = loss_weight
@@ -263,7 +282,8 @@ class MMDTupleTransformer(TupleTransformer):
             mx = torch.stack([s.max() for s in live]).tolist() if live else []
             it = iter(mx)
             sizes = [int(next(it)) + 1 if s is not None else 1 for s in segs]
-        outs = HierLatentsFn.apply(hidden, mask.contiguous(), self.hierarchical, tuple(modes), tuple(segs), tuple(sizes),
+        hier = ("no-context" if not self.hierarchical_with_context else True) if self.hierarchical else False
+        outs = HierLatentsFn.apply(hidden, mask.contiguous(), hier, tuple(modes), tuple(segs), tuple(sizes),
                                    *[h.linear.weight for h in heads], *[h.linear.bias for h in heads])
         nl = len(modes)
         embeddings, lat_list, lmasks = outs[0], list(outs[1:1 + nl]), list(outs[1 + nl:])
@@ -296,6 +316,8 @@ class MMDTupleTransformer(TupleTransformer):
                     note = torch.zeros((b, n), dtype=torch.bool, device=hidden.device)
                 elif mode == EmbeddingAggregateModes.MEAN:
                     note = dm.view(b, 1).expand(b, n)
+                elif segs[i] is None:           # `same`: one latent per note
+                    note = dm.view(b, n)
                 else:
                     note = torch.gather(dm.view(b, -1), 1, segs[i])
                 if self.inclusive_latent_dropout:
