@@ -511,8 +511,15 @@ def score_performer_forward(
     pe_cfg = cfg["perf_encoder"]
     # the style encoder reads the noisy performance when the batch carries one (model.py:296-298)
     enc_in, enc_mask = batch.get("noisy_perf", perf), batch.get("noisy_perf_mask", pmask)
+    am = pe_cfg["aggregate_mode"]
+    if (am if isinstance(am, str) else list(am)[0]) == "isolated_bar_mean":
+        # mmd_transformer.py:186-189: the style encoder reads the bar tokens MASKed (ids above EOS = 3 -> MASK = 1); the block-diagonal
+        # attention mask it also builds (190-200) is dropped by TupleTransformer.forward's **kwargs and never reaches the layers
+        enc_in = enc_in.clone()
+        bar_col = enc_in[..., 0]
+        bar_col[bar_col > 3] = 1
     hidden, _ = tuple_transformer(sd, "perf_encoder.", pe_cfg, [enc_in], causal=False, mask=enc_mask)
-    segs = {"bar_mean": batch["bars"], "beat_mean": batch["beats"], "onset_mean": batch["onsets"]}
+    segs = {"bar_mean": batch["bars"], "beat_mean": batch["beats"], "onset_mean": batch["onsets"], "isolated_bar_mean": batch["bars"]}
     enc = mmd_heads(sd, "perf_encoder.", pe_cfg, hidden, enc_mask, segs, batch["deadpan_mask"], z_samples,
                     training=training, drop_masks=drop_masks)
     dcfg = cfg["perf_decoder"]

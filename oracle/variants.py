@@ -112,7 +112,7 @@ def variant2_inputs(name: str, batch):
 # `multiseq_mode="pre-sum"` (embeddings.py:171,231-241: the decoder's two sequences are summed per key before norm / projection) and
 # `TupleTokenEmbeddings(mode="sum")` (embeddings.py:66-69,117,141: per-key embeddings of one common width summed, only normalised);
 # plus two style-encoder variants: `hierarchical_with_context=False` and the per-note `aggregate_mode="same"`.
-NAMES3 = ["multiseq_pre_sum", "emb_mode_sum", "hier_no_context", "agg_same"]
+NAMES3 = ["multiseq_pre_sum", "emb_mode_sum", "hier_no_context", "agg_same", "isolated_bar"]
 
 
 def variant3_config(name: str):
@@ -137,5 +137,12 @@ def variant3_config(name: str):
         c["perf_encoder"]["latent_dim"] = [16, 8, 8]
         c["perf_encoder"]["latent_dropout"] = [0.0, 0.0, 0.0]
         c["perf_decoder"]["style_emb_dim"] = 32
+        return c
+    if name == "isolated_bar":          # mmd_transformer.py:186-200: the style encoder reads bar tokens masked; its block-diagonal attention
+        c = base()                      # mask is built and then dropped by TupleTransformer.forward (never reaches the layer stack)
+        c["perf_encoder"]["aggregate_mode"] = ["isolated_bar_mean", "beat_mean"]
+        c["perf_encoder"]["latent_dim"] = [16, 8]
+        c["perf_encoder"]["latent_dropout"] = [0.0, 0.0]
+        c["perf_decoder"]["style_emb_dim"] = 24
         return c
     raise KeyError(name)

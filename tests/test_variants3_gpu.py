@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "variants3.npz"))
 
 
-@pytest.mark.parametrize("name", ["multiseq_pre_sum", "emb_mode_sum", "hier_no_context", "agg_same"])
+@pytest.mark.parametrize("name", ["multiseq_pre_sum", "emb_mode_sum", "hier_no_context", "agg_same", "isolated_bar"])
 def test_variant_set_3_matches_the_reference(dev, name):
     from oracle.variants import SMALL_VOCAB, variant3_config
     from oracle.weights import filled_state_dict
