@@ -1,0 +1,53 @@
+"""profiles/r04_hbm_traffic.json from the raw per-kernel counter files of tools/pmc_step_traffic.sh: counter bytes per launch (FETCH_SIZE x 2 per the
+gfx950 correction + WRITE_SIZE) against the ALGORITHMIC bytes of each HBM-bound kernel at the C3 shape (T = 131072 tokens, D = 512).
+usage: python tools/hbm_traffic_summary.py profiles/r04_step_traffic_raw.json profiles/r04_decode_traffic_raw.json profiles/r04_hbm_traffic.json"""
+import json
+import sys
+
+raw = json.load(open(sys.argv[1]))["kernels"]
+dec = json.load(open(sys.argv[2]))["kernels"]
+T, D = 131072, 512
+
+
+def find(prefix):
+    for k in raw:
+        if k.startswith(prefix):
+            return k
+    return None
+
+
+alg = [
+    ("ln_bwd_fast_kernel<float, float, 2, false, true>", "affine norm of the layer stack: x 4 + dy 2 + d_residual 4 read, dx 4 + bf16 copy 2 written = 16 B per element", 16 * T * D),
+    ("ln_bwd_fast_kernel<float, float, 2, true, true>", "adaptive norm: + bf16 gamma rows 2 read, (dy*xhat | dy) rows 4 written = 22 B per element", 22 * T * D),
+    ("ln_fwd_kernel<float, unsigned short, 2>", "x fp32 read + y bf16 written: 6 B per element", 6 * T * D),
+    ("adaln_fwd_kernel", "x 4 read + y 2 + gamma rows 2 written + 128 B of condition per token", 8 * T * D + 128 * T),
+    ("embed_bwd_stats_kernel<6>", "dy bf16 [T, 1536] read once (tables: 640 KB, L2-resident) + token tuples + 2 floats per row written", 2 * T * 1536 + 8 * T + 8 * T * 12),
+    ("embed_bwd_scatter_mfma_kernel", "dy bf16 [T, 1536] read once + per-row statistics (16 B) per key block", 2 * T * 1536 + 12 * 16 * T),
+    ("embed_fwd_wide_kernel<3>", "token tuples 96 B per row read, y bf16 [T, 1536] written", 96 * T + 2 * T * 1536),
+    ("attn_fwd_kernel<true>", "Q + O 2 x 134 MB, MQA K + V 33.5 MB, keep bits 1 bit per score = 268 MB written, lse 4 MB", 2 * 134.2e6 + 33.5e6 + 268.4e6 + 4.2e6),
+    ("attn_bwd_dq_kernel<true, true>", "Q + dO 268 MB read, dQ 134 MB written, MQA K + V 33.5 MB, keep bits 268 MB read, lse / delta 8 MB", 268.4e6 + 134.2e6 + 33.5e6 + 268.4e6 + 8.4e6),
+    ("attn_bwd_dkv_kernel<true>", "Q + dO 268 MB read (8 heads share K/V), keep bits 268 MB read, K + V 33.5 MB read, dK + dV 33.5 MB written, lse / delta 8 MB", 268.4e6 + 268.4e6 + 33.5e6 + 33.5e6 + 8.4e6),
+    ("gemm_duo8_glu_bwd_kernel<0>", "u read + du written 2 x 1074 MB, dy operand 134 MB, W2 2 MB, column-sum partials 17 MB", 2 * 1073.7e6 + 134.2e6 + 2.1e6 + 16.8e6),
+    ("gemm_pp_kernel<false, false, unsigned short, 1, true>", "x operand 134 MB + W1 4 MB read, u 1074 MB + g 537 MB written", 134.2e6 + 4.2e6 + 1073.7e6 + 536.9e6),
+    ("adamw_kernel", "30 B per parameter (p, g, m, v read; p, m, v, bf16 copy written; g zeroed): 71.9 M parameters", 71895400 * 30),
+]
+out = {"measured": "round 4, tools/pmc_step_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, C3 step b=64 n=2048 dropout 0.1, final tree)",
+       "correction": "FETCH_SIZE x 2 (gfx950: wide streaming reads tallied at half their bytes, MI355X_MICROARCH.md); WRITE_SIZE as printed; both count Infinity-Cache hits",
+       "kernels": {}}
+for name, desc, a in alg:
+    k = name if name in raw else find(name.split("<")[0])
+    if k is None:
+        continue
+    r = raw[k]
+    out["kernels"][k] = {"launches_sampled": r["launches"], "counter_bytes_per_launch": round(r["hbm_bytes_per_launch"]), "fetch_bytes_x2": round(r["fetch_bytes_x2"]),
+                         "write_bytes": round(r["write_bytes"]), "algorithmic_bytes_per_launch": round(a),
+                         "counter_over_algorithmic": round(r["hbm_bytes_per_launch"] / a, 3), "algorithmic": desc}
+if "dec_pair_kernel" in dec:
+    r = dec["dec_pair_kernel"]
+    out["kernels"]["dec_pair_kernel"] = {"launches_sampled": r["launches"], "counter_bytes_per_launch": round(r["hbm_bytes_per_launch"]), "fetch_bytes_x2": round(r["fetch_bytes_x2"]),
+                                         "write_bytes": round(r["write_bytes"]), "algorithmic_bytes_per_launch": round(107.9e6),
+                                         "counter_over_algorithmic": round(r["hbm_bytes_per_launch"] / 107.9e6, 3),
+                                         "algorithmic": "one note of the C5 decoder (L = 384 in this pass): 6 layer pairs of fp32 weights (15 MB each) + projections + K/V rows inside the ALiBi reach"}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+for k, v in out["kernels"].items():
+    print(f"{v['counter_over_algorithmic']:6.2f}  {v['counter_bytes_per_launch'] / 1e6:8.1f} MB vs {v['algorithmic_bytes_per_launch'] / 1e6:8.1f}  {k}")
