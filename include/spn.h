@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, the head phase of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -293,6 +293,10 @@ int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, i
  *       x0 = Wm . xin + bm                                                   (spn_dec_fused_gemv of the multi-sequence projection)
  *       x  = Wp . (LN?(x0) | ctx[*pos + 1] | style[*pos + 1]) + bp           (spn_dec_cat_gemv)
  *   tail (behind the last pair):  e_out = Wh . LN(x), the normalised x mirrored  (spn_dec_fused_gemv of the LM head's input projection)
+ *   head (behind the tail; hn = 0: none, needs the tail): the arg-max LM head of spn_dec_head over e -- LayerNorm(e) slice . table_q^T
+ *       per decoded key q < hn, banned ids, arg-max (ties to the lower id), written to tokens[(*pos + 1) * tok_ld + hdim[q]] where that
+ *       cell holds mask_id; *pos_next = *pos + 1.  e travels to the feed-forward workgroups as granules (ge), their per-key partial
+ *       maxima to the key's first workgroup as granules (gh).
  * Same arithmetic as those launches. */
 typedef struct spn_dec_chain_ext {
     const float* Wm; long ld_m; const float* bm; const float* xin; int Km;          /* [d, Km], Km <= 1024 */
@@ -305,6 +309,11 @@ typedef struct spn_dec_chain_ext {
     const float* Wh; long ld_h; int Nh;                                              /* [Nh, d], Nh <= 16 h S */
     int normh; const float* gamh; const float* beth; float epsh;                     /* as norm1 of a pair */
     float* e_out; float* xn_out; long xn_ld;                                         /* [Nh]; null, or xn_out[*pos * ld + k] = LN(x)[k] */
+    int hn; int hD;                                                                  /* decoded keys (<= 16), width of e (= Nh <= 2048) */
+    const float* htable[16]; int hV[16]; int hwidth[16]; int hcol0[16]; int hdim[16]; /* per key: [V, width] table, slice of e, token column */
+    const float* hgamma; const float* hbeta; float heps; unsigned hban;              /* the head's LayerNorm over e; bit v < 32 set = id v banned */
+    long* tokens; long tok_ld; int mask_id; int* pos_next;                           /* as spn_dec_head */
+    unsigned long long* ge; unsigned long long* gh;                                  /* granules [Nh], [16 * 16 * 2] (zeroed once per render) */
 } spn_dec_chain_ext;
 int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
                       const spn_dec_chain_ext* ext_dev, spn_stream_t s);

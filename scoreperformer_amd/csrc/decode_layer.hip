@@ -199,8 +199,9 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     // Optional phases around the chain (spn_dec_chain_ext): in FRONT of the first pair the two input projections of the note (B
     // workgroups: x0 = Wm . xin + bm, then x = Wp . (LN?(x0) | context row | style row) + bp), BEHIND the last pair the LM head's input
     // projection e = Wh . LN(x) (A workgroups).  Their epochs use pair number 31.
-    const bool front = ext && ext->Wm, tail = ext && ext->Wh;
+    const bool front = ext && ext->Wm, tail = ext && ext->Wh, head = tail && ext->hn > 0;
     const unsigned efront = ebase + 8u * 31u;
+    const unsigned ehead = efront + 2u;   // e (tail -> head workgroups); + 1: the per-key partial maxima
 
     if (b < nA) {
         // ================================================ A: q|k|v rows, attention split ==================================================
@@ -380,7 +381,9 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 if (lane == 0) {
                     if (r0 < Nh) ext->e_out[r0] = y[0];
                     if (r0 + 1 < Nh) ext->e_out[r0 + 1] = y[1];
+                    outv[2 * w] = y[0]; outv[2 * w + 1] = y[1];
                 }
+                if (head) publish16(ext->ge, b * 16, Nh, ehead, outv, tid);
             }
         }
         return;
@@ -436,6 +439,124 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (tid < 32 && bc * 32 + tid < inner) put(a.gg + bc * 32 + tid, e0 + 4, outc[tid]);   // one store instruction: 2 whole lines
             STAMP(5);
             if (l + 1 < n_layers) request(layers[l + 1]);
+        }
+        if (head) {
+            // ---- head: the arg-max LM head of dec_head_kernel (decode.hip) over e = Wh . LN(x), which the tail publishes as granules --------
+            // Work items (key q, slab sl) with SL slabs per key go round the feed-forward workgroups; a slab's rows are v = 8 sl + w, + 8 SL, ...
+            // The logit of a row is the expression of dec_head_kernel (fma chain over k = lane, lane + 64, ..., then the wave ladder), and
+            // the arg-max with ties to the lower id is a total order, so how the rows are dealt out does not matter.
+            const int n = ext->hn, D = ext->hD, nC = (int)gridDim.x - nA - nB;
+            const int SL = min(16, max(1, nC / n)), items = n * SL;
+            float* bvs = sm;                          // per-wave best value / id of the current item
+            int* bis = reinterpret_cast<int*>(sl);
+            float rw[4][4];
+            auto load_rows = [&](float (&dst)[4][4], const float* tab, int V, int W, int vb, int vstep) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* row = tab + (long)min(vb + u * vstep, V - 1) * W;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dst[u][c] = (lane + 64 * c < W) ? row[lane + 64 * c] : 0.f;
+                }
+            };
+            // the first item's first rows and the norm's affine rows do not depend on e: requested before the poll
+            const int it0 = bc;
+            if (it0 < items) {
+                const int q = it0 / SL, s0 = it0 - q * SL;
+                if (ext->hwidth[q] <= 256 && s0 * 8 + w < ext->hV[q]) load_rows(rw, ext->htable[q], ext->hV[q], ext->hwidth[q], s0 * 8 + w, 8 * SL);
+            }
+            if (it0 < items) {
+                __syncthreads();
+                gather(ext->ge, D, ehead, xs, tid, err);
+                __syncthreads();
+                // LayerNorm statistics of e, the arithmetic of dec_head_kernel (256 threads own k = tid, tid + 256, ...)
+                float s = 0.f;
+                if (tid < 256) for (int k = tid; k < D; k += 256) s += xs[k];
+                s = wave_sum(s);
+                if (tid < 256 && lane == 0) red[w] = s;
+                __syncthreads();
+                const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)D;
+                float q2 = 0.f;
+                if (tid < 256) for (int k = tid; k < D; k += 256) { const float t_ = xs[k] - mu; q2 += t_ * t_; }
+                q2 = wave_sum(q2);
+                if (tid < 256 && lane == 0) red[4 + w] = q2;
+                __syncthreads();
+                const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + ext->heps);
+                for (int it = it0; it < items; it += nC) {
+                    const int q = it / SL, s0 = it - q * SL;
+                    const int c0 = ext->hcol0[q], W = ext->hwidth[q], V = ext->hV[q];
+                    const float* tab = ext->htable[q];
+                    const int vstep = 8 * SL;
+                    for (int k = tid; k < W; k += NT) xs[c0 + k] = (xs[c0 + k] - mu) * rs * ext->hgamma[c0 + k] + ext->hbeta[c0 + k];
+                    __syncthreads();
+                    float best = -INFINITY;
+                    int idx = 0x7fffffff;
+                    auto take = [&](int v, float acc) __attribute__((always_inline)) {
+                        acc = wave_sum(acc);
+                        if (v < 32 && ((ext->hban >> v) & 1u)) acc = -INFINITY;
+                        if (acc > best || (acc == best && v < idx)) { best = acc; idx = v; }
+                    };
+                    int vb = s0 * 8 + w;
+                    if (W <= 256) {
+                        if (it != it0 && vb < V) load_rows(rw, tab, V, W, vb, vstep);
+                        for (; vb < V; vb += 4 * vstep) {
+                            float rn[4][4];
+                            const bool more = vb + 4 * vstep < V;
+                            if (more) load_rows(rn, tab, V, W, vb + 4 * vstep, vstep);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int v = vb + u * vstep;
+                                if (v >= V) break;
+                                float acc = 0.f;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (lane + 64 * c < W) acc = fmaf(rw[u][c], xs[c0 + lane + 64 * c], acc);
+                                take(v, acc);
+                            }
+                            if (more) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) rw[u][c] = rn[u][c];
+                            }
+                        }
+                    } else {
+                        for (int v = vb; v < V; v += vstep) {
+                            const float* row = tab + (long)v * W;
+                            float acc = 0.f;
+                            for (int k = lane; k < W; k += 64) acc = fmaf(row[k], xs[c0 + k], acc);
+                            take(v, acc);
+                        }
+                    }
+                    if (lane == 0) { bvs[w] = best; bis[w] = idx; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        for (int r = 1; r < NW; ++r) if (bvs[r] > best || (bvs[r] == best && bis[r] < idx)) { best = bvs[r]; idx = bis[r]; }
+                        outv[0] = best; outv[1] = __int_as_float(idx);
+                    }
+                    __syncthreads();
+                    if (tid < 2) put(ext->gh + (q * 16 + s0) * 2 + tid, ehead + 1u, outv[tid]);   // one store instruction, one line
+                }
+                // the first slab's workgroup of a key picks the winner among the key's slabs and writes the token
+                for (int it = it0; it < items; it += nC) {
+                    const int q = it / SL, s0 = it - q * SL;
+                    if (s0 != 0) continue;
+                    __syncthreads();
+                    gather(ext->gh + q * 32, 2 * SL, ehead + 1u, xs, tid, err);
+                    __syncthreads();
+                    if (tid == 0) {
+                        float best = 0.f;
+                        int idx = 0;
+                        for (int r = 0; r < SL; ++r) {
+                            const float bvv = xs[2 * r];
+                            const int bii = __float_as_int(xs[2 * r + 1]);
+                            if (r == 0 || bvv > best || (bvv == best && bii < idx)) { best = bvv; idx = bii; }
+                        }
+                        long* cell = ext->tokens + (long)(t + 1) * ext->tok_ld + ext->hdim[q];
+                        if (*cell == ext->mask_id) *cell = idx;
+                    }
+                }
+            }
+            if (bc == 0 && tid == 0 && ext->pos_next) *ext->pos_next = t + 1;
         }
         return;
     }
@@ -676,6 +797,13 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
                     "spn_dec_pairs_ext: front projections: Km <= 1024, d + context + style <= 2048, 16-byte aligned rows");
     }
     if (e.Wh) SPN_REQUIRE(e.e_out && e.Nh >= 1 && e.Nh <= 16 * f.h * f.S && (e.ld_h % 4) == 0, "spn_dec_pairs_ext: tail projection: at most 16 h S rows");
+    if (e.hn) {
+        SPN_REQUIRE(e.Wh && e.hn >= 1 && e.hn <= 16 && e.hD == e.Nh && e.hD <= 2048 && e.hD % 2 == 0 && e.hgamma && e.hbeta && e.tokens && e.ge && e.gh,
+                    "spn_dec_pairs_ext: head phase: needs the tail, 1 to 16 keys, e of even width <= 2048, norm, tokens and granule buffers");
+        for (int q = 0; q < e.hn; ++q)
+            SPN_REQUIRE(e.htable[q] && e.hV[q] >= 1 && e.hwidth[q] >= 1 && e.hcol0[q] >= 0 && e.hcol0[q] + e.hwidth[q] <= e.hD && e.hdim[q] >= 0,
+                        "spn_dec_pairs_ext: head phase: bad key record");
+    }
     hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

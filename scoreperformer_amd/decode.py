@@ -122,8 +122,8 @@ class GreedyDecoder:
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
             self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
-            self.pair_g2 = dict(gf=zg(d), gxf=zg(d))
-            self.pair_front = self.pair_tail = False
+            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2))
+            self.pair_front = self.pair_tail = self.pair_head = False
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -322,7 +322,8 @@ class GreedyDecoder:
             ops.dec_embed_proj(self.tables, self.seq2d, self.masked2d, pos, te.project_emb.weight.data, te.project_emb.bias.data, self.proj_cat,
                                gamma=gam, beta=bet, eps=eps)
         fold_cat = isinstance(m.project_emb, nn.Linear) and not self.legacy_launches
-        chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail) if self.pair_groups else {}
+        self.cur_dims = list(dims)
+        chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail, latched and len(dims) <= 16) if self.pair_groups else {}
         if not self.pair_front:   # (else: first phase of the persistent launch)
             ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x0 if fold_cat else self.x, bias=te.project_multiemb.bias.data,
                                pos=pos, y2=self.tok_emb, y2_ld=d)
@@ -382,6 +383,8 @@ class GreedyDecoder:
             if not self.pair_tail:   # (else: last phase of the persistent launch)
                 ops.dec_fused_gemv(self.head_Wt, self.x, self.e_head, norm=mode, gamma=g_, beta=b_, eps=eps_, pos=pos,
                                    xn_out=self.hid[-1], xn_ld=d)
+            if self.pair_tail and self.pair_head:   # (the head was the last phase of the persistent launch, position advance included)
+                return
             offs = [0]
             for w in head.split_dims:
                 offs.append(offs[-1] + w)
@@ -408,7 +411,7 @@ class GreedyDecoder:
         ops.dec_copy_row(self.h, self.hid[-1], pos, d, dst_ld=d)
         self._head_tail(dims)
 
-    def _pair_chains(self, front_ok: bool = False, tail_ok: bool = False):
+    def _pair_chains(self, front_ok: bool = False, tail_ok: bool = False, head_ok: bool = False):
         """{index of the first layer of a chain of ('a', 'f') pairs: ops.DecPairChain}: consecutive pairs the persistent launch can take
         run as ONE launch.  Built on first use (the eager warm-up step), then reused (hipGraph capture included).  When one chain covers
         the whole decoder, the note's two input projections (front_ok) and the LM head's input projection (tail_ok) become phases of the
@@ -482,8 +485,36 @@ class GreedyDecoder:
                     ext.update(Wh=self.head_Wt, ld_h=self.head_Wt.stride(0), Nh=self.head_Wt.shape[0], normh=mode, gamh=g_, beth=b_, epsh=eps_,
                                e_out=self.e_head, xn_out=self.hid[-1], xn_ld=d)
                     self.pair_tail = True
+                    # ... and the arg-max LM head itself (greedy decoding: sampling keeps its own launch), so that a note is TWO launches
+                    if (head_ok and self.sampling is None and te.total_emb_dim == self.head_Wt.shape[0] and te.total_emb_dim <= 2048
+                            and te.total_emb_dim % 2 == 0 and os.environ.get("SPN_DEC_PAIR_HEAD", "1") != "0"):
+                        ext.update(self._head_ext(), ge=self.pair_g2["ge"], gh=self.pair_g2["gh"])
+                        self.pair_head = True
             self.pair_chains = {k: ops.DecPairChain(v, self.dev, ext if (ext and k == 0) else None) for k, v in self.pair_chains.items()}
         return self.pair_chains
+
+    def _drop_chains(self):
+        """Forget the argument records of the persistent launch (rebuilt by the next step): its set of phases is about to change."""
+        if self.pair_groups:
+            self.pair_chains, self.pair_front, self.pair_tail, self.pair_head = {}, False, False, False
+
+    def _head_ext(self):
+        """The head-phase fields of spn_dec_chain_ext for the CURRENT run (token buffer, tables and decoded keys change from run to run)."""
+        te, head = self.m.token_emb, self.m.lm_head
+        dims = list(self.cur_dims)
+        offs = [0]
+        for w in head.split_dims:
+            offs.append(offs[-1] + w)
+        tabs = [self.tables[dim] for dim in dims]
+        return dict(hn=len(dims), hD=te.total_emb_dim, htable=tabs, hV=[t.shape[0] for t in tabs], hwidth=[t.shape[1] for t in tabs],
+                    hcol0=[offs[dim] for dim in dims], hdim=dims, hgamma=head.norm.weight.data, hbeta=head.norm.bias.data, heps=head.norm.eps,
+                    hban=0b11, tokens=self.seq2d, tok_ld=self.seq2d.stride(0), mask_id=1, pos_next=self.pos_next)
+
+    def _refresh_head_ext(self, dims):
+        """Before the notes of a run: point the head phase of an already built chain at this run's token buffer / tables / keys."""
+        self.cur_dims = list(dims)
+        if self.pair_groups and self.pair_chains and self.pair_head:
+            self.pair_chains[0].update_ext(**self._head_ext())
 
     def _pair_failed(self) -> bool:
         """True when a hand-off poll of the persistent layer launch ran into its bound (`*err` != 0: that launch and every later one of
@@ -501,7 +532,7 @@ class GreedyDecoder:
                       f"launches per layer pair for this engine (same tokens, ~25 % slower per note)", RuntimeWarning, stacklevel=3)
         self.pair_err.zero_()
         self.use_pair, self.pair_groups = False, 0
-        self.pair_chains, self.pair_front, self.pair_tail = {}, False, False
+        self.pair_chains, self.pair_front, self.pair_tail, self.pair_head = {}, False, False, False
         self.graph = None
         self.pair_fallbacks += 1
         return True
@@ -549,6 +580,7 @@ class GreedyDecoder:
                 tab[p_] = first - 1 + (t_ - 1)
             self.stale_tab = torch.tensor(tab, device=self.dev, dtype=torch.int32)
         step = self._step_fused if self.fused else self._step
+        self._refresh_head_ext(dims)
         self.pos2.zero_()
         if self.use_graph and n_steps > 2:
             step(dims)                              # warm-up (also position 0), eager
@@ -633,6 +665,7 @@ class RenderSession(GreedyDecoder):
         if sampling is None:
             if self.sampling is not None:
                 self.sampling, self.graph = None, None
+                self._drop_chains()              # the arg-max head may ride in the persistent launch again
             return
         head = self.m.lm_head
         if not (isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and self.fused):
@@ -644,6 +677,8 @@ class RenderSession(GreedyDecoder):
         temperature = float(sampling.get("temperature", 1.0))
         if self.sampling is None or self.sampling["temperature"] != temperature:
             self.graph = None
+            if self.sampling is None:
+                self._drop_chains()              # sampling keeps the LM head in its own launch (spn_dec_head_sample)
             self.sampling = {"topk": torch.tensor(ks, device=self.dev, dtype=torch.int32), "temperature": temperature, "ks": ks,
                              "calls": int(sampling.get("seed", 0))}
         elif self.sampling["ks"] != ks:

@@ -1076,7 +1076,10 @@ class DecChainExt(ctypes.Structure):
                 ("Wp", _P), ("ld_p", _L), ("bp", _P), ("cat_gamma", _P), ("cat_beta", _P), ("cat_eps", _F),
                 ("ctx", _P), ("ctx_ld", _L), ("ctx_w", _I), ("style", _P), ("style_ld", _L), ("style_w", _I), ("y2p", _P), ("y2p_ld", _L),
                 ("gf", _P), ("gxf", _P), ("Wh", _P), ("ld_h", _L), ("Nh", _I), ("normh", _I), ("gamh", _P), ("beth", _P), ("epsh", _F),
-                ("e_out", _P), ("xn_out", _P), ("xn_ld", _L)]
+                ("e_out", _P), ("xn_out", _P), ("xn_ld", _L),
+                ("hn", _I), ("hD", _I), ("htable", _P * 16), ("hV", _I * 16), ("hwidth", _I * 16), ("hcol0", _I * 16), ("hdim", _I * 16),
+                ("hgamma", _P), ("hbeta", _P), ("heps", _F), ("hban", ctypes.c_uint), ("tokens", _P), ("tok_ld", _L), ("mask_id", _I),
+                ("pos_next", _P), ("ge", _P), ("gh", _P)]
 
 
 def _fill_struct(a, kw, keep, what):
@@ -1087,6 +1090,19 @@ def _fill_struct(a, kw, keep, what):
             setattr(a, name, None if v is None else v.data_ptr())
             if v is not None:
                 keep.append(v)
+        elif isinstance(ctype, type) and issubclass(ctype, ctypes.Array):   # fixed-size arrays: a list of tensors (pointers) or of ints
+            arr = getattr(a, name)
+            vals = list(v) if v is not None else []
+            if len(vals) > len(arr):
+                raise SpnError(f"{what}: {name} takes at most {len(arr)} entries")
+            for i in range(len(arr)):
+                x = vals[i] if i < len(vals) else None
+                if ctype._type_ is ctypes.c_void_p:
+                    arr[i] = None if x is None else x.data_ptr()
+                    if x is not None:
+                        keep.append(x)
+                else:
+                    arr[i] = int(x) if x is not None else 0
         else:
             setattr(a, name, v if v is not None else 0)
     if kw:
@@ -1107,8 +1123,20 @@ class DecPairChain:
         self.ext = self.ext_dev = None
         if ext:                                          # front / tail phases of the same launch: spn_dec_chain_ext
             self.ext = DecChainExt()
+            self._ext_kw = dict(ext)
             _fill_struct(self.ext, ext, self.keep, "dec_pairs_ext")
             self.ext_dev = torch.frombuffer(bytearray(bytes(self.ext)), dtype=torch.uint8).to(device)
+
+    def update_ext(self, **fields):
+        """Change fields of the extension record (per-run operands: token buffer, tables) on the host AND in the device copy the launch
+        reads; stream-ordered, so launches enqueued afterwards see the new record.  Not for use under graph capture."""
+        cur = {name: getattr(self, "_ext_kw", {}).get(name) for name, _ in DecChainExt._fields_}
+        cur.update(fields)
+        self._ext_kw = {k: v for k, v in cur.items() if v is not None}
+        keep = []
+        _fill_struct(self.ext, self._ext_kw, keep, "dec_pairs_ext")
+        self.keep_ext = keep
+        self.ext_dev.copy_(torch.frombuffer(bytearray(bytes(self.ext)), dtype=torch.uint8))
 
     def launch(self):
         if self.ext is not None:
