@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, the head phase of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -314,9 +314,23 @@ typedef struct spn_dec_chain_ext {
     const float* hgamma; const float* hbeta; float heps; unsigned hban;              /* the head's LayerNorm over e; bit v < 32 set = id v banned */
     long* tokens; long tok_ld; int mask_id; int* pos_next;                           /* as spn_dec_head */
     unsigned long long* ge; unsigned long long* gh;                                  /* granules [Nh], [16 * 16 * 2] (zeroed once per render) */
+    /* embed phase (en = 0: none; needs the front, whose xin it replaces): the two token-tuple embeddings of the note and their projection,
+     * spn_dec_embed_proj: xin[seq * eN + n] = We[n, :] . LN(concat_k etable_k[token_k]) + be[n], tokens tok_a[*pos] (seq 0) and
+     * tok_b[*pos + 1] (seq 1); the attention workgroups compute it (eR <= 2 rows per wave) and hand it to the front as granules (gin). */
+    int en; int eD; int eN; int eR;                                                  /* keys (<= 16), embedding width (<= 2048), rows per sequence, rows per wave */
+    const float* etable[16]; int ewidth[16]; int ecol0[16];
+    const long* tok_a; const long* tok_b; long etok_ld;
+    const float* egamma; const float* ebeta; float eeps;                             /* LayerNorm of the embedding (null gamma: none) */
+    const float* We; long ld_e; const float* be;
+    unsigned long long* gin;                                                         /* granules [2 eN] */
+    /* AdaLN rows of the NEXT note (rW = null: none), the rider of spn_dec_step_begin one note early: ry[par + n] = rW[n, :] .
+     * rx[min(*pos + 2, rx_rows - 1), :] + rbias[n] with par = ada_par on even *pos, 0 on odd *pos; the adaptive norms (mode 2) of THIS
+     * note read their (gamma | beta) rows at + ada_par when *pos is odd.  The caller computes the first note's rows (spn_dec_gemv). */
+    const float* rW; long r_ldw; int rN; int rK; const float* rx; long rx_ld; int rx_rows; const float* rbias; float* ry; long ada_par;
 } spn_dec_chain_ext;
 int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
                       const spn_dec_chain_ext* ext_dev, spn_stream_t s);
+int spn_dec_struct_size(int which); /* sizeof(spn_dec_pair_args) (0) / sizeof(spn_dec_chain_ext) (1): lets a binding check its record layout */
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,
                  const int* pos, float* part /* n*slabs*2 */, int* counter /* n, zeroed once */, int slabs,

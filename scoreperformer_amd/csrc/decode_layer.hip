@@ -202,6 +202,11 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const bool front = ext && ext->Wm, tail = ext && ext->Wh, head = tail && ext->hn > 0;
     const unsigned efront = ebase + 8u * 31u;
     const unsigned ehead = efront + 2u;   // e (tail -> head workgroups); + 1: the per-key partial maxima
+    const unsigned eemb = efront + 4u;    // the projected token embeddings (attention workgroups -> front)
+    const bool emb = front && ext->en > 0;
+    // adaptive norms read their (gamma | beta) rows from the buffer of this note's parity (spn_dec_chain_ext.ada_par)
+    const long apar = (ext && (t & 1)) ? ext->ada_par : 0;
+#define ADA(mode_, ptr_) (((mode_) == 2 && (ptr_)) ? (ptr_) + apar : (ptr_))
 
     if (b < nA) {
         // ================================================ A: q|k|v rows, attention split ==================================================
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 wq[i][0] = wq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r0 + i < N1) load_row<2>(wq[i], a.Wqkv + (long)(r0 + i) * a.ld_qkv, d, lane);
             }
-            n1 = norm_regs(d, a.norm1, a.gam1, a.bet1, tid);
+            n1 = norm_regs(d, a.norm1, ADA(a.norm1, a.gam1), a.bet1, tid);
         };
         // Key / value rows of this workgroup's split, requested BEFORE the query exists: the split's key range depends on the query only
         // through the first key inside the ALiBi reach (j_lo), which is rounded down to a multiple of 256 (more keys than necessary, never
@@ -251,6 +256,56 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 }
             }
         };
+        if (emb && !err_in && b * 8 * ext->eR < 2 * ext->eN) {
+            // ---- embed: xin = We . LN(concat_k table_k[token_k]) + be for both sequences (dec_embed_proj_kernel, decode.hip): this workgroup's
+            //      8 eR rows of ONE sequence; every workgroup rebuilds that sequence's embedding in LDS with the statistics of the 256-thread kernel ----
+            const int N = ext->eN, R = ext->eR, D = ext->eD, gr0 = (b * 8 + w) * R;
+            const int seq = (b * 8 * R) / N;
+            f32x4 we[2][8];
+            float bev[2] = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) we[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int n = gr0 + i - seq * N;
+                if (i < R && gr0 + i < 2 * N) {   // weight row and bias do not depend on the tokens: requested first
+                    load_row<8>(we[i], ext->We + (long)n * ext->ld_e, D, lane);
+                    if (ext->be) bev[i] = ext->be[n];
+                }
+            }
+            const long* tok = (seq ? ext->tok_b : ext->tok_a) + (long)(t + seq) * ext->etok_ld;
+            float s = 0.f;
+            if (tid < 256) for (int c = tid; c < D; c += 256) {
+                int kk = 0;
+                for (int q = 1; q < ext->en; ++q) if (c >= ext->ecol0[q]) kk = q;
+                const float v = ext->etable[kk][tok[kk] * ext->ewidth[kk] + (c - ext->ecol0[kk])];
+                xs[c] = v;
+                s += v;
+            }
+            if (ext->egamma) {
+                s = wave_sum(s);
+                if (tid < 256 && lane == 0) red[w] = s;
+                __syncthreads();
+                const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)D;
+                float q2 = 0.f;
+                if (tid < 256) for (int c = tid; c < D; c += 256) { const float t_ = xs[c] - mu; q2 += t_ * t_; }
+                q2 = wave_sum(q2);
+                if (tid < 256 && lane == 0) red[4 + w] = q2;
+                __syncthreads();
+                const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + ext->eeps);
+                if (tid < 256) for (int c = tid; c < D; c += 256) xs[c] = (xs[c] - mu) * rs * ext->egamma[c] + ext->ebeta[c];
+            }
+            __syncthreads();
+            float y[2];
+            dot_rows<8, 2>(we, xs, D, lane, y);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) if (i < R) outv[w * R + i] = ext->be ? y[i] + bev[i] : y[i];
+            }
+            __syncthreads();
+            if (tid < 8 * R && b * 8 * R + tid < 2 * N) put(ext->gin + b * 8 * R + tid, eemb, outv[tid]);
+            __syncthreads();   // xs / outv are reused below
+        }
         request(a0);
         if (own1 && !front) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
         if (err_in) return;   // an earlier launch of this render timed out: do not wait again
@@ -369,7 +424,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 wh[i][0] = wh[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r0 + i < Nh) load_row<2>(wh[i], ext->Wh + (long)(r0 + i) * ext->ld_h, d, lane);
             }
-            const NormRegs nh = norm_regs(d, ext->normh, ext->gamh, ext->beth, tid);
+            const NormRegs nh = norm_regs(d, ext->normh, ADA(ext->normh, ext->gamh), ext->beth, tid);
             if (b * 16 < Nh) {
                 __syncthreads();
                 gather(al.gxo, d, ebase + 8u * (unsigned)al.layer + 5u, xs, tid, err);
@@ -409,10 +464,38 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     if (a.b1) { b1v[i] = a.b1[r0 + i]; b1g[i] = a.b1[r0 + i + inner]; }
                 }
             }
-            n2 = norm_regs(d, a.norm2, a.gam2, a.bet2, tid);
+            n2 = norm_regs(d, a.norm2, ADA(a.norm2, a.gam2), a.bet2, tid);
         };
         request(a0);
         if (err_in) return;
+        if (ext && ext->rW) {
+            // ---- the NEXT note's AdaLN (gamma | beta) rows: ry[n] = rW[n, :] . style row + rbias[n], the rider GEMV of dec_embed_proj_kernel
+            //      (one wave per row, K <= 256: one chunk per lane), into the buffer of the next note's parity.  These workgroups idle until the
+            //      first x1 arrives; the rows' first reader is the next launch ----
+            const int rN = ext->rN, rK = ext->rK, nCw = ((int)gridDim.x - nA - nB) * NW;
+            const float* x = ext->rx + (long)min(t + 2, ext->rx_rows - 1) * ext->rx_ld;
+            float* yo = ext->ry + ((t & 1) ? 0 : ext->ada_par);
+            const bool in = lane * 4 < rK;
+            const f32x4 xv = in ? *reinterpret_cast<const f32x4*>(x + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n0 = bc * NW + w; n0 < rN; n0 += 8 * nCw) {
+                f32x4 wv[8];
+                float bz[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int n = min(n0 + u * nCw, rN - 1);
+                    wv[u] = in ? *reinterpret_cast<const f32x4*>(ext->rW + (long)n * ext->r_ldw + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    bz[u] = ext->rbias ? ext->rbias[n] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int n = n0 + u * nCw;
+                    float acc = 0.f;
+                    if (in) acc += wv[u][0] * xv[0] + wv[u][1] * xv[1] + wv[u][2] * xv[2] + wv[u][3] * xv[3];
+                    acc = wave_sum(acc);
+                    if (lane == 0 && n < rN) yo[n] = ext->rbias ? acc + bz[u] : acc;
+                }
+            }
+        }
         for (int l = 0; l < n_layers; ++l) {
             const spn_dec_pair_args& a = layers[l];
             const unsigned e0 = ebase + 8u * (unsigned)a.layer;
@@ -595,7 +678,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 if (ext->bm) bmv[i] = ext->bm[r0 + i];
             }
         }
-        for (int k = tid; k < Km; k += NT) xs[k] = ext->xin[k];
+        if (!emb) for (int k = tid; k < Km; k += NT) xs[k] = ext->xin[k];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (r0 + i < d) { load_row<8>(wp[i], ext->Wp + (long)(r0 + i) * ext->ld_p, Kc, lane); if (ext->bp) bpv[i] = ext->bp[r0 + i]; }
@@ -610,6 +693,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         const NormRegs nc = norm_regs(d, 1, ext->cat_gamma, ext->cat_beta, tid);
         request(a0);
         if (err_in) return;
+        if (emb) gather(ext->gin, Km, eemb, xs, tid, err);   // the embed phase of the attention workgroups
         __syncthreads();
         float y[2];
         dot_rows<4, 2>(wm, xs, Km, lane, y);
@@ -738,6 +822,8 @@ extern "C" int spn_dec_pair_groups(int d, int h, int kvh, int inner, int S) {
     return nA + nB + nC;
 }
 
+extern "C" int spn_dec_struct_size(int which) { return which == 0 ? (int)sizeof(spn_dec_pair_args) : (which == 1 ? (int)sizeof(spn_dec_chain_ext) : -1); }
+
 // `host`: the n argument records (validated here); `dev`: the same n records in DEVICE memory (the launch reads them there: a chain of
 // pairs does not fit the kernel-argument segment).  The caller keeps both alive and identical; nothing is copied or allocated here.
 // every workgroup of the launch polls results of the others: all of them must be resident at once, one per CU
@@ -797,6 +883,20 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
                     "spn_dec_pairs_ext: front projections: Km <= 1024, d + context + style <= 2048, 16-byte aligned rows");
     }
     if (e.Wh) SPN_REQUIRE(e.e_out && e.Nh >= 1 && e.Nh <= 16 * f.h * f.S && (e.ld_h % 4) == 0, "spn_dec_pairs_ext: tail projection: at most 16 h S rows");
+    if (e.en) {
+        SPN_REQUIRE(e.Wm && e.en >= 1 && e.en <= 16 && e.eD >= 4 && e.eD <= 2048 && e.eD % 4 == 0 && e.eN >= 1 && 2 * e.eN == e.Km && (e.eR == 1 || e.eR == 2) &&
+                    e.eN % (8 * e.eR) == 0 && 2 * e.eN <= f.h * f.S * 8 * e.eR && e.tok_a && e.tok_b && e.We && (e.ld_e % 4) == 0 && e.gin &&
+                    (!e.egamma || e.ebeta),
+                    "spn_dec_pairs_ext: embed phase: needs the front with Km = 2 eN, eD <= 2048 in whole float4, eN in whole workgroups of 8 eR rows that the h S attention workgroups cover");
+        int col = 0;
+        for (int q = 0; q < e.en; ++q) {
+            SPN_REQUIRE(e.etable[q] && e.ewidth[q] >= 1 && e.ecol0[q] == col, "spn_dec_pairs_ext: embed phase: key columns must be consecutive");
+            col += e.ewidth[q];
+        }
+        SPN_REQUIRE(col == e.eD, "spn_dec_pairs_ext: embed phase: key widths must add up to eD");
+    }
+    if (e.rW) SPN_REQUIRE(e.rN >= 1 && e.rK >= 4 && e.rK <= 256 && e.rK % 4 == 0 && (e.r_ldw % 4) == 0 && e.rx && (e.rx_ld % 4) == 0 && e.rx_rows >= 1 && e.ry && e.ada_par >= e.rN,
+                          "spn_dec_pairs_ext: rider: K <= 256 in whole float4, two row buffers ada_par >= rN floats apart");
     if (e.hn) {
         SPN_REQUIRE(e.Wh && e.hn >= 1 && e.hn <= 16 && e.hD == e.Nh && e.hD <= 2048 && e.hD % 2 == 0 && e.hgamma && e.hbeta && e.tokens && e.ge && e.gh,
                     "spn_dec_pairs_ext: head phase: needs the tail, 1 to 16 keys, e of even width <= 2048, norm, tokens and granule buffers");

@@ -117,13 +117,14 @@ class GreedyDecoder:
                 # a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) or another kernel holding CUs is not visible here -- then a hand-off poll
                 # runs into its bound, the kernel sets *err, and _pair_failed() falls back to the five launches per pair.
                 self.pair_groups = 0
+        self.pair_front = self.pair_tail = self.pair_head = self.pair_embed = False
         if self.pair_groups:   # hand-off granules of the persistent layer-pair launch ({epoch, value} words: zero = no epoch)
             zg = lambda n: torch.zeros(n, device=dev, dtype=torch.int64)
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
             self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
-            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2))
-            self.pair_front = self.pair_tail = self.pair_head = False
+            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2), gin=zg(2048))
+            self.pair_front = self.pair_tail = self.pair_head = self.pair_embed = False
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
             self.pair_err = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -139,7 +140,10 @@ class GreedyDecoder:
             if ada:
                 self.ada_W = torch.cat([n.linear.weight.data.float() for n in ada], 0).contiguous()
                 self.ada_b = torch.cat([n.linear.bias.data.float() for n in ada], 0).contiguous()
-                self.gb_all = z(len(ada), 2 * d)
+                # two row sets: the persistent launch computes the NEXT note's rows while this note's are in use (spn_dec_chain_ext.ada_par);
+                # every other path uses set 0
+                self.gb_both = z(2, len(ada), 2 * d)
+                self.gb_all = self.gb_both[0]
                 self.ada_rows = {id(n): i for i, n in enumerate(ada)}
         head = m.lm_head
         if isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection:
@@ -294,18 +298,31 @@ class GreedyDecoder:
             return 1, None, None, norm.eps          # no condition: plain normalisation (gamma = 1, beta = 0)
         return 1, norm.weight.data, norm.bias.data, norm.eps
 
-    def _step_fused(self, dims: List[int]):
-        m, d, pos = self.m, self.dim, self.pos
-        te, tr = m.token_emb, m.transformer
-        has_norm = isinstance(te.norm, nn.LayerNorm)
-        gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
-        head, fn = m.lm_head, tr.final_norm
+    def _step_plan(self, dims: List[int]):
+        """(fused_tail, latched, fold_cat, chains) of a fused step; builds the persistent launch's argument records on first use (no launch)."""
+        m = self.m
+        head, fn = m.lm_head, m.transformer.final_norm
         fused_tail = (isinstance(head, TupleTokenTiedLMHead) and head.reuse_projection and not isinstance(fn, nn.Identity)
                       and not self.reference_compat)
         # A dependent launch costs >= 4 us under graph replay whatever it does (profiles/, one-thread kernel), so three of them are
         # folded away: the position advance (latch protocol of ops.dec_step_begin; needs the fused head as the step's last launch), the
         # AdaLN-row GEMV (position-only input: rides in the first launch), the concatenation (prologue of the projection GEMV)
         latched = fused_tail and not self.legacy_launches
+        fold_cat = isinstance(m.project_emb, nn.Linear) and not self.legacy_launches
+        self.cur_dims = list(dims)
+        chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail, latched and len(dims) <= 16) if self.pair_groups else {}
+        return fused_tail, latched, fold_cat, chains
+
+    def _step_fused(self, dims: List[int]):
+        m, d, pos = self.m, self.dim, self.pos
+        te, tr = m.token_emb, m.transformer
+        has_norm = isinstance(te.norm, nn.LayerNorm)
+        gam, bet, eps = (te.norm.weight.data, te.norm.bias.data, te.norm.eps) if has_norm else (None, None, 1e-5)
+        head, fn = m.lm_head, tr.final_norm
+        fused_tail, latched, fold_cat, chains = self._step_plan(dims)
+        if self.pair_embed:   # embeddings, layer stack, LM head and position advance: ONE launch (csrc/decode_layer.hip)
+            chains[0].launch()
+            return
         en = m.emb_norm if isinstance(m.emb_norm, nn.LayerNorm) else None
         cat_args = dict(gamma=en.weight.data if en is not None else None, beta=en.bias.data if en is not None else None,
                         eps=en.eps if en is not None else 1e-5, ctx=self.ctx2d if m.context_emb_mode == "cat" else None,
@@ -321,9 +338,6 @@ class GreedyDecoder:
         else:   # both sequences' tuple embeddings and their projection: one launch (4 before)
             ops.dec_embed_proj(self.tables, self.seq2d, self.masked2d, pos, te.project_emb.weight.data, te.project_emb.bias.data, self.proj_cat,
                                gamma=gam, beta=bet, eps=eps)
-        fold_cat = isinstance(m.project_emb, nn.Linear) and not self.legacy_launches
-        self.cur_dims = list(dims)
-        chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail, latched and len(dims) <= 16) if self.pair_groups else {}
         if not self.pair_front:   # (else: first phase of the persistent launch)
             ops.dec_fused_gemv(te.project_multiemb.weight.data, self.proj_cat, self.x0 if fold_cat else self.x, bias=te.project_multiemb.bias.data,
                                pos=pos, y2=self.tok_emb, y2_ld=d)
@@ -490,13 +504,32 @@ class GreedyDecoder:
                             and te.total_emb_dim % 2 == 0 and os.environ.get("SPN_DEC_PAIR_HEAD", "1") != "0"):
                         ext.update(self._head_ext(), ge=self.pair_g2["ge"], gh=self.pair_g2["gh"])
                         self.pair_head = True
+                # ... and, in front, the two token-tuple embeddings with their projection (+ the NEXT note's AdaLN rows): ONE launch per note
+                if self.pair_front and self.pair_head and os.environ.get("SPN_DEC_PAIR_EMBED", "1") != "0":
+                    We = te.project_emb.weight.data
+                    N, D = We.shape
+                    nA = self.heads * self.attn_splits
+                    R = -(-2 * N // (nA * 8))
+                    K_r = self.ada_W.shape[1] if self.ada_rows else 4
+                    if (R in (1, 2) and N % (8 * R) == 0 and 2 * N == Wm.shape[1] and D % 4 == 0 and D <= 2048 and We.stride(0) % 4 == 0
+                            and K_r % 4 == 0 and K_r <= 256):
+                        has_norm = isinstance(te.norm, nn.LayerNorm)
+                        ext.update(self._embed_ext(), eD=D, eN=N, eR=R, egamma=te.norm.weight.data if has_norm else None,
+                                   ebeta=te.norm.bias.data if has_norm else None, eeps=te.norm.eps if has_norm else 1e-5,
+                                   We=We, ld_e=We.stride(0), be=te.project_emb.bias.data, gin=self.pair_g2["gin"])
+                        if self.ada_rows:
+                            ext.update(rW=self.ada_W, r_ldw=self.ada_W.stride(0), rN=self.ada_W.shape[0], rK=K_r, rbias=self.ada_b,
+                                       ry=self.gb_both, ada_par=self.gb_both.stride(0))
+                        for rec in self.pair_chains[0]:          # no launch in front any more: the position comes from where the head leaves it
+                            rec["pos"] = self.pos_next
+                        self.pair_embed = True
             self.pair_chains = {k: ops.DecPairChain(v, self.dev, ext if (ext and k == 0) else None) for k, v in self.pair_chains.items()}
         return self.pair_chains
 
     def _drop_chains(self):
         """Forget the argument records of the persistent launch (rebuilt by the next step): its set of phases is about to change."""
         if self.pair_groups:
-            self.pair_chains, self.pair_front, self.pair_tail, self.pair_head = {}, False, False, False
+            self.pair_chains, self.pair_front, self.pair_tail, self.pair_head, self.pair_embed = {}, False, False, False, False
 
     def _head_ext(self):
         """The head-phase fields of spn_dec_chain_ext for the CURRENT run (token buffer, tables and decoded keys change from run to run)."""
@@ -510,11 +543,40 @@ class GreedyDecoder:
                     hcol0=[offs[dim] for dim in dims], hdim=dims, hgamma=head.norm.weight.data, hbeta=head.norm.bias.data, heps=head.norm.eps,
                     hban=0b11, tokens=self.seq2d, tok_ld=self.seq2d.stride(0), mask_id=1, pos_next=self.pos_next)
 
+    def _embed_ext(self):
+        """The per-run fields of the embed phase (token buffers, tables, style rows)."""
+        tabs = list(self.tables)
+        col0 = [0]
+        for t_ in tabs:
+            col0.append(col0[-1] + t_.shape[1])
+        kw = dict(en=len(tabs), etable=tabs, ewidth=[t_.shape[1] for t_ in tabs], ecol0=col0[:-1], tok_a=self.seq2d, tok_b=self.masked2d,
+                  etok_ld=self.seq2d.stride(0))
+        if self.ada_rows:
+            kw.update(rx=self.style2d, rx_ld=self.style2d.stride(0), rx_rows=self.style2d.shape[0])
+        return kw
+
     def _refresh_head_ext(self, dims):
-        """Before the notes of a run: point the head phase of an already built chain at this run's token buffer / tables / keys."""
+        """Before the notes of a run: point the head / embed phases of an already built chain at this run's token buffers / tables / keys."""
         self.cur_dims = list(dims)
         if self.pair_groups and self.pair_chains and self.pair_head:
-            self.pair_chains[0].update_ext(**self._head_ext())
+            kw = self._head_ext()
+            if self.pair_embed:
+                if self.seq2d.stride(0) != self.masked2d.stride(0):
+                    raise ValueError("decode engine: the two token arrays must share their row stride")
+                kw.update(self._embed_ext())
+            self.pair_chains[0].update_ext(**kw)
+
+    def _prime_note(self, dims, t0: int):
+        """Before the first note (position t0) of a run.  One launch per note (pair_embed): every note's launch computes the NEXT note's
+        AdaLN rows, so the first note's rows are computed here, into the row set of its parity."""
+        self.cur_dims = list(dims)
+        if not (self.fused and self.pair_groups):
+            return
+        if not self.pair_chains:
+            self._step_plan(dims)                    # builds the chains (no launch)
+        if self.pair_embed and self.ada_rows:
+            ops.dec_gemv(self.ada_W, self.style2d, self.gb_both[t0 & 1].view(-1), bias=self.ada_b, pos=self.pos_next,
+                         x_ld=self.style2d.stride(0), x_off=1)
 
     def _pair_failed(self) -> bool:
         """True when a hand-off poll of the persistent layer launch ran into its bound (`*err` != 0: that launch and every later one of
@@ -532,7 +594,7 @@ class GreedyDecoder:
                       f"launches per layer pair for this engine (same tokens, ~25 % slower per note)", RuntimeWarning, stacklevel=3)
         self.pair_err.zero_()
         self.use_pair, self.pair_groups = False, 0
-        self.pair_chains, self.pair_front, self.pair_tail, self.pair_head = {}, False, False, False
+        self.pair_chains, self.pair_front, self.pair_tail, self.pair_head, self.pair_embed = {}, False, False, False, False
         self.graph = None
         self.pair_fallbacks += 1
         return True
@@ -582,6 +644,8 @@ class GreedyDecoder:
         step = self._step_fused if self.fused else self._step
         self._refresh_head_ext(dims)
         self.pos2.zero_()
+        if self.fused:
+            self._prime_note(dims, 0)
         if self.use_graph and n_steps > 2:
             step(dims)                              # warm-up (also position 0), eager
             torch.cuda.synchronize()
@@ -822,6 +886,8 @@ class RenderSession(GreedyDecoder):
         steps = Lin - 1 - c
         for attempt in (0, 1):
             self.pos2.fill_(c)
+            if self.fused and steps > 0:
+                self._prime_note(self.dims, c)
             done = 0
             if self.use_graph and self.graph is None and steps > 0:
                 self._step_fn(self.dims)                 # first step eager (warms every lazily built operand), then record once

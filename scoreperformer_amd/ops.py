@@ -1079,7 +1079,12 @@ class DecChainExt(ctypes.Structure):
                 ("e_out", _P), ("xn_out", _P), ("xn_ld", _L),
                 ("hn", _I), ("hD", _I), ("htable", _P * 16), ("hV", _I * 16), ("hwidth", _I * 16), ("hcol0", _I * 16), ("hdim", _I * 16),
                 ("hgamma", _P), ("hbeta", _P), ("heps", _F), ("hban", ctypes.c_uint), ("tokens", _P), ("tok_ld", _L), ("mask_id", _I),
-                ("pos_next", _P), ("ge", _P), ("gh", _P)]
+                ("pos_next", _P), ("ge", _P), ("gh", _P),
+                ("en", _I), ("eD", _I), ("eN", _I), ("eR", _I), ("etable", _P * 16), ("ewidth", _I * 16), ("ecol0", _I * 16),
+                ("tok_a", _P), ("tok_b", _P), ("etok_ld", _L), ("egamma", _P), ("ebeta", _P), ("eeps", _F), ("We", _P), ("ld_e", _L), ("be", _P),
+                ("gin", _P),
+                ("rW", _P), ("r_ldw", _L), ("rN", _I), ("rK", _I), ("rx", _P), ("rx_ld", _L), ("rx_rows", _I), ("rbias", _P), ("ry", _P),
+                ("ada_par", _L)]
 
 
 def _fill_struct(a, kw, keep, what):
@@ -1114,6 +1119,10 @@ class DecPairChain:
     `records`: one dict per pair with the fields of spn_dec_pair_args (tensors as tensors, None = null)."""
 
     def __init__(self, records, device, ext=None):
+        for which, st in ((0, DecPairArgs), (1, DecChainExt)):
+            if load().spn_dec_struct_size(which) != ctypes.sizeof(st):
+                raise SpnError(f"{st.__name__}: record layout differs from include/spn.h ({ctypes.sizeof(st)} bytes here, "
+                               f"{load().spn_dec_struct_size(which)} in the library)")
         self.n = len(records)
         self.host = (DecPairArgs * self.n)()
         self.keep = []                                   # the tensors behind the raw pointers

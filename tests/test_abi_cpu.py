@@ -101,3 +101,13 @@ def test_dec_pair_groups_is_a_host_function():
     assert handle.spn_dec_pair_groups(128, 2, 1, 512, 16) == 32 + 8 + 16
     assert handle.spn_dec_pair_groups(1024, 16, 1, 4096, 16) == 0               # wider than the kernel's register plan
     assert handle.spn_dec_pair_groups(512, 8, 1, 2048, 32) == 0                 # more splits than the merge holds
+
+
+def test_decode_record_layouts_match_the_header():
+    """The ctypes mirrors of spn_dec_pair_args / spn_dec_chain_ext have the size the compiled header gives them (no GPU needed)."""
+    import ctypes
+    from scoreperformer_amd import ops
+    from scoreperformer_amd.lib import load
+    handle = load()
+    assert handle.spn_dec_struct_size(0) == ctypes.sizeof(ops.DecPairArgs)
+    assert handle.spn_dec_struct_size(1) == ctypes.sizeof(ops.DecChainExt)

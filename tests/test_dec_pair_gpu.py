@@ -49,7 +49,7 @@ def test_pair_launch_equals_the_five_launches_bit_for_bit(dev, monkeypatch, pres
     assert len(chains) == 1 and sum(c.n for c in chains.values()) == len(e1.kc)   # ALL layer pairs of a note run as one launch
     assert n0 == n1 == L - 1 and int(e1.pair_err.item()) == 0
     assert e1.pair_front and e1.pair_tail      # the note's input projections and the LM head's input projection ride in the same launch
-    assert e1.pair_head                        # ... and so does the arg-max LM head (greedy): two launches per note
+    assert e1.pair_head and e1.pair_embed      # ... and so do the arg-max LM head (greedy) and the token embeddings: ONE launch per note
     assert torch.equal(t0, t1)
     for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
         assert torch.equal(a[:n1], b[:n1])
@@ -200,5 +200,44 @@ def test_head_phase_equals_the_head_launch(dev, monkeypatch):
     for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
         assert torch.equal(a[:n1], b[:n1])
     toks2, n2 = e1.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)   # same engine, fresh buffers
+    torch.cuda.synchronize()
+    assert n2 == n1 and torch.equal(toks2, t1) and int(e1.pair_err.item()) == 0
+
+
+@pytest.mark.parametrize("kw", [{}, {"style_emb_mode": "cat"}])
+def test_embed_phase_equals_the_embed_launch(dev, monkeypatch, kw):
+    """The token-tuple embeddings + their projection as the first phase of the persistent launch, with the NEXT note's AdaLN rows computed
+    one note early into the row set of its parity (spn_dec_chain_ext.en / rW), against the same engine with spn_dec_step_begin in front:
+    same tokens, same caches, also on a second run of the same engine and from an odd first position."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import GreedyDecoder
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    L = 131
+    torch.manual_seed(7)
+    model = ScorePerformer.init(model_config("tiny", max_seq_len=L, **kw))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=17, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    tokens = batch["masked_perf"].clone()
+    tokens[:, 0] = batch["perf"][:, 0]
+    monkeypatch.setenv("SPN_DEC_PAIR", "1")
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPN_DEC_PAIR_EMBED", flag)
+        eng = GreedyDecoder(model.perf_decoder.model, L)
+        toks, n = eng.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
+        torch.cuda.synchronize()
+        assert eng.pair_head and eng.pair_embed == (flag == "1") and int(eng.pair_err.item()) == 0
+        res.append((eng, toks.clone(), n))
+    (e0, t0, n0), (e1, t1, n1) = res
+    assert n0 == n1 == L - 1 and torch.equal(t0, t1)
+    for a, b in zip(e0.hid + e0.kc + e0.vc + [e0.tok_emb], e1.hid + e1.kc + e1.vc + [e1.tok_emb]):
+        assert torch.equal(a[:n1], b[:n1])
+    toks2, n2 = e1.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
     torch.cuda.synchronize()
     assert n2 == n1 and torch.equal(toks2, t1) and int(e1.pair_err.item()) == 0
