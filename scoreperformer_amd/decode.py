@@ -62,6 +62,8 @@ class GreedyDecoder:
         self.stale_tab = None      # reference_compat: int32 [max_len] device table, position -> row of the final hiddens the head reads
         self.nk_dev = None         # render sessions with a cross-attending decoder: int32 device scalar, valid context rows
         self.graph = None
+        self.graph_multi = None
+        self.graph_notes = max(1, int(os.environ.get("SPN_DEC_GRAPH_NOTES", "16")))   # notes per graph replay (1: one note per replay)
         self.sampling = None       # None = arg-max; dict(topk=int32 device tensor [n dims], temperature=float) = top-k sampling
 
     # -- buffers -------------------------------------------------------------------------------------------
@@ -595,7 +597,7 @@ class GreedyDecoder:
         self.pair_err.zero_()
         self.use_pair, self.pair_groups = False, 0
         self.pair_chains, self.pair_front, self.pair_tail, self.pair_head, self.pair_embed = {}, False, False, False, False
-        self.graph = None
+        self.graph = self.graph_multi = None
         self.pair_fallbacks += 1
         return True
 
@@ -652,7 +654,19 @@ class GreedyDecoder:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 step(dims)                          # recorded, not executed; every replay reads *pos on the device
-            for _ in range(n_steps - 1):
+            # A graph launch costs ~7 us on the device between two replays, a dependency edge INSIDE a graph ~2 us: notes are replayed
+            # GRAPH_NOTES at a time (the position lives on the device, so a graph of U steps is U copies of the same launches)
+            U, rest = self.graph_notes, n_steps - 1
+            if U > 1 and rest >= 2 * U:
+                gU = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gU):
+                    for _ in range(U):
+                        step(dims)
+                for _ in range(rest // U):
+                    gU.replay()
+                rest -= (rest // U) * U
+                self.graph_multi = gU
+            for _ in range(rest):
                 g.replay()
             self.graph = g
         else:
@@ -728,7 +742,7 @@ class RenderSession(GreedyDecoder):
         two, or changing the temperature, re-records the step graph."""
         if sampling is None:
             if self.sampling is not None:
-                self.sampling, self.graph = None, None
+                self.sampling, self.graph, self.graph_multi = None, None, None
                 self._drop_chains()              # the arg-max head may ride in the persistent launch again
             return
         head = self.m.lm_head
@@ -740,7 +754,7 @@ class RenderSession(GreedyDecoder):
         ks = [max(1, min(k, v)) for k, v in zip(ks, V)]
         temperature = float(sampling.get("temperature", 1.0))
         if self.sampling is None or self.sampling["temperature"] != temperature:
-            self.graph = None
+            self.graph = self.graph_multi = None
             if self.sampling is None:
                 self._drop_chains()              # sampling keeps the LM head in its own launch (spn_dec_head_sample)
             self.sampling = {"topk": torch.tensor(ks, device=self.dev, dtype=torch.int32), "temperature": temperature, "ks": ks,
@@ -897,7 +911,23 @@ class RenderSession(GreedyDecoder):
                 with torch.cuda.graph(g):
                     self._step_fn(self.dims)
                 self.graph = g
-            for _ in range(steps - done):
+            rest = steps - done
+            U = self.graph_notes
+            if self.use_graph and U > 1 and rest >= U:        # GRAPH_NOTES notes per replay (see GreedyDecoder._run_once)
+                if self.graph_multi is None:
+                    if not done:                              # (a capture needs a current stream that has run the step before)
+                        self.graph.replay()
+                        rest -= 1
+                    torch.cuda.synchronize()
+                    gU = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gU):
+                        for _ in range(U):
+                            self._step_fn(self.dims)
+                    self.graph_multi = gU
+                for _ in range(rest // U):
+                    self.graph_multi.replay()
+                rest -= (rest // U) * U
+            for _ in range(rest):
                 self.graph.replay() if self.use_graph else self._step_fn(self.dims)
             if attempt or not self._pair_failed():
                 break
