@@ -1,6 +1,7 @@
 """Same-box A/B of the C5 greedy decode (L notes, batch 1) under environment flags of the decode engine, interleaved:
     python tools/bench_dec_flags.py 4096 SPN_DEC_PAIR_HEAD=0 SPN_DEC_PAIR_HEAD=1 [...]
-Every variant is "NAME=value[,NAME=value]"; tokens must be identical across variants."""
+Every variant is "NAME=value[,NAME=value]" (NAME = an environment variable, or tune.<knob> for a knob of csrc/tuning.h, which keeps
+its value until another variant sets it); tokens must be identical across variants."""
 import os
 import sys
 import time
@@ -10,6 +11,7 @@ import torch  # noqa: E402
 
 
 def main():
+    from scoreperformer_amd import lib
     from scoreperformer_amd.arena import ParamArena
     from scoreperformer_amd.models import ScorePerformer
     from scoreperformer_amd.modules.sampling import top_k
@@ -37,7 +39,10 @@ def main():
                 os.environ.pop(n, None)
             for kv in v.split(","):
                 k, _, val = kv.partition("=")
-                os.environ[k] = val
+                if k.startswith("tune."):           # a knob of csrc/tuning.h (read at every launch / graph capture)
+                    lib.set_tuning(k[5:], float(val))
+                else:
+                    os.environ[k] = val
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = dec.unmask_tokens(tokens, batch["masked_perf"], context=enc.score_embeddings, style_embeddings=enc.perf_embeddings,
