@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _engines(dev, preset, L, monkeypatch, **cfg_kw):
+def _engines(dev, preset, L, monkeypatch, attn_splits=16, mask_all=False, **cfg_kw):
     from scoreperformer_amd.arena import ParamArena
     from scoreperformer_amd.decode import GreedyDecoder
     from scoreperformer_amd.models import ScorePerformer
@@ -28,12 +28,14 @@ def _engines(dev, preset, L, monkeypatch, **cfg_kw):
         enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
                                      bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
                                      compute_loss=False)
+    if mask_all:            # every key of every note after the first is decoded (12 keys instead of the recipe's 4)
+        batch["masked_perf"][:, 1:, :] = 1
     tokens = batch["masked_perf"].clone()
     tokens[:, 0] = batch["perf"][:, 0]
     out = []
     for flag in ("0", "1"):
         monkeypatch.setenv("SPN_DEC_PAIR", flag)
-        eng = GreedyDecoder(model.perf_decoder.model, L)
+        eng = GreedyDecoder(model.perf_decoder.model, L, attn_splits=attn_splits)
         toks, n = eng.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
         torch.cuda.synchronize()
         out.append((eng, toks.clone(), n))
@@ -241,3 +243,20 @@ def test_embed_phase_equals_the_embed_launch(dev, monkeypatch, kw):
     toks2, n2 = e1.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
     torch.cuda.synchronize()
     assert n2 == n1 and torch.equal(toks2, t1) and int(e1.pair_err.item()) == 0
+
+
+def test_one_launch_note_with_two_embedding_rows_per_wave_and_with_more_keys_than_head_workgroups(dev, monkeypatch):
+    """Corners of the phases around the chain: (a) 12 key splits -> 24 attention workgroups for 256 embedding rows: two rows per wave
+    (eR = 2); (b) d = 64, one head, all 12 keys decoded -> 8 feed-forward workgroups for 12 keys: a workgroup takes several (key, slab)
+    items of the head phase.  Tokens and caches equal the five-launch engine's."""
+    (e0, t0, n0), (e1, t1, n1) = _engines(dev, "tiny", 90, monkeypatch, attn_splits=12)
+    assert e1.pair_embed and e1.pair_head and e1.pair_chains[0].ext.eR == 2 and int(e1.pair_err.item()) == 0
+    assert n0 == n1 and torch.equal(t0, t1)
+    for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
+        assert torch.equal(a[:n1], b[:n1])
+    (e0, t0, n0), (e1, t1, n1) = _engines(dev, "tiny", 70, monkeypatch, mask_all=True, dim=64, heads=1, emb_dims=16)
+    assert e1.pair_embed and e1.pair_head and e1.pair_chains[0].ext.hn == 12 and int(e1.pair_err.item()) == 0
+    assert e1.g.numel() // 32 < 12                                  # fewer feed-forward workgroups than keys
+    assert n0 == n1 and torch.equal(t0, t1) and not (t1[0, 1:] == 1).any()
+    for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
+        assert torch.equal(a[:n1], b[:n1])
