@@ -90,6 +90,13 @@ def norm(sd: SD, prefix: str, x: Tensor, cond: Optional[Tensor], ada: bool) -> T
 # A6/A7  Attention                 modules/transformer/attention.py:107-222, attend.py:58-126
 # --------------------------------------------------------------------------------------
 
+# Dropout in a training-mode comparison.  torch's dropout draws cannot be reproduced by a kernel that derives its masks from counters, so
+# the comparison goes the other way: the test reads the masks the product used (attention probabilities: [b, h, i, j]; feed-forward
+# activations: [.., inner]) and this oracle applies exactly those -- DROP_FEED(kind, prefix, tensor) returns tensor * keep / (1 - p) for
+# the module whose state_dict prefix is `prefix` (kind "attn": attend.py:122; "ffn": feedforward.py:57-60).  None = no dropout (p = 0).
+DROP_FEED = None
+
+
 def attention(
         sd: SD, prefix: str, x: Tensor, *, heads: int, causal: bool, alibi: bool = True,
         context: Optional[Tensor] = None, mask: Optional[Tensor] = None, context_mask: Optional[Tensor] = None,
@@ -143,6 +150,8 @@ def attention(
     neg = -torch.finfo(dots.dtype).max // 2  # attend.py:102,105
     dots = torch.where(allowed, dots, torch.full_like(dots, neg))
     attn = dots.softmax(dim=-1)
+    if DROP_FEED is not None:  # attend.py:122: F.dropout on the probabilities, with the masks of the run under test (see DROP_FEED)
+        attn = DROP_FEED("attn", prefix, attn)
     out = attn @ v  # b h i d
     out = out.transpose(1, 2).reshape(b, n, heads * dh) @ wo.t()
     if mask is not None:  # attention.py:216-218
@@ -170,6 +179,8 @@ def feed_forward(sd: SD, prefix: str, x: Tensor, *, glu: bool, swish: bool) -> T
         h = act(h)
     if prefix + "ff.1.weight" in sd:  # post_act_ln
         h = layer_norm(h, sd[prefix + "ff.1.weight"], sd[prefix + "ff.1.bias"])
+    if DROP_FEED is not None:  # feedforward.py:57-60: ff.2 = nn.Dropout between the (normalised) activation and the output projection
+        h = DROP_FEED("ffn", prefix, h)
     out = h @ sd[prefix + "ff.3.weight"].t()
     if prefix + "ff.3.bias" in sd:
         out = out + sd[prefix + "ff.3.bias"]
