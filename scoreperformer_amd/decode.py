@@ -547,6 +547,8 @@ class GreedyDecoder:
 
     def _embed_ext(self):
         """The per-run fields of the embed phase (token buffers, tables, style rows)."""
+        if self.seq2d.stride(0) != self.masked2d.stride(0):
+            raise ValueError("decode engine: the two token arrays must share their row stride")
         tabs = list(self.tables)
         col0 = [0]
         for t_ in tabs:
@@ -563,8 +565,6 @@ class GreedyDecoder:
         if self.pair_groups and self.pair_chains and self.pair_head:
             kw = self._head_ext()
             if self.pair_embed:
-                if self.seq2d.stride(0) != self.masked2d.stride(0):
-                    raise ValueError("decode engine: the two token arrays must share their row stride")
                 kw.update(self._embed_ext())
             self.pair_chains[0].update_ext(**kw)
 
