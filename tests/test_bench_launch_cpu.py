@@ -66,3 +66,61 @@ def test_main_self_launches_only_without_a_launcher(monkeypatch):
     except SystemExit as exc:
         assert "WORLD_SIZE=2" in str(exc.code)
     assert len(seen) == 1
+
+
+# ---- transport agreement of bench.pick_transport under two gloo ranks (no GPU): whatever fails on whichever rank, both ranks leave with the
+#      SAME answer and have issued the same torch.distributed collectives (a rank that bailed out early would leave the other one waiting) ----
+
+def _transport_worker(rank, world, port, mode, q):
+    import os
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from scoreperformer_amd import comm
+    if mode == "unavailable_on_rank1" and rank == 1:
+        def boom():
+            raise RuntimeError("no RCCL here")
+        comm.available = boom
+    elif mode == "id_fails_on_rank0":   # stage 1 passes everywhere, then rank 0 cannot make the RCCL id: the id broadcast must still happen
+        comm.available = lambda: None
+
+        def no_id():
+            raise RuntimeError("ncclGetUniqueId failed")
+        if rank == 0:
+            comm.unique_id = no_id
+    torch.cuda.synchronize = lambda *a, **k: None            # (the check synchronises the device it does not have here)
+    args = types.SimpleNamespace(dp_transport="auto")
+    transport, note = bench.pick_transport(args, dist, torch.device("cpu"))
+    # a collective AFTER the choice: both ranks must still be in step
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    q.put((rank, transport, note, float(t)))
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["unavailable_on_rank1", "id_fails_on_rank0"])
+def test_transport_choice_is_agreed_by_both_ranks_whatever_fails(mode):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_transport_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0, mode
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1] == res[1][1] == "torch", res          # no GPU here: the native transport cannot pass its check on either rank
+    assert res[0][3] == res[1][3] == 3.0
