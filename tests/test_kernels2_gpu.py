@@ -89,6 +89,10 @@ def test_segment_count_sum_gather(d, S, mode):
     ops.segment_gather(src, seg, out=wide[..., 4:4 + d], accumulate=True)
     assert rel_err(wide[..., 4:4 + d], before[..., 4:4 + d] + torch.gather(src, 1, seg[..., None].expand(b, t, d))) < 1e-6
     assert torch.equal(wide[..., :4], before[..., :4]) and torch.equal(wide[..., 4 + d:], before[..., 4 + d:])
+    # sums of a column slice of a wider buffer: 16-byte aligned offsets take the four-columns-per-thread kernel, others the scalar one
+    for off in (4, 2):
+        xs = wide[..., off:off + d]
+        assert rel_err(ops.segment_sum(xs, seg, S, rowmask=mask), torch.einsum("bts,btd->bsd", onehot, xs * mask[..., None])) < 1e-5
 
 
 @pytest.mark.parametrize("N,D", [(1500, 32), (300, 8), (2100, 4)])
