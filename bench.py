@@ -31,13 +31,22 @@ def parse():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dp", action="store_true", help="N=1 only: run the bucketed RCCL all-reduce path on a one-rank group")
-    ap.add_argument("--dp-transport", choices=("auto", "torch", "spn"), default=os.environ.get("SPN_DP_TRANSPORT", "auto"),
-                    help="gradient all-reduce through libspn.so's own RCCL wrapper (spn_comm_allreduce) or torch.distributed; auto = spn, "
-                         "checked against torch.distributed on a small buffer at start-up, torch when that check fails on any rank")
+    ap.add_argument("--dp-transport", choices=("auto", "torch", "spn"), default=os.environ.get("SPN_DP_TRANSPORT", "torch"),
+                    help="gradient all-reduce through torch.distributed (default: the communicator that exists already; the only transport "
+                         "that has run with more than one rank) or libspn.so's own RCCL wrapper (spn_comm_allreduce: opt-in until a "
+                         "multi-rank run of it has been observed); auto = spn after a start-up check against torch.distributed on a small "
+                         "buffer, torch when that check fails on any rank.  spn / auto run their start-up under --dp-init-timeout")
+    ap.add_argument("--dp-init-timeout", type=float, default=float(os.environ.get("SPN_DP_INIT_TIMEOUT", 120.0)),
+                    help="seconds the native communicator's collective start-up (id broadcast, ncclCommInitRank, probe all-reduce) may take "
+                         "before this rank prints a message and EXITS with status 3 (a hung ncclCommInitRank cannot be cancelled; the "
+                         "launcher then ends the other ranks)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dp1-forced", action="store_true", help="skip the N = 1 `dp1_forced` object (cost of gemm_persist_bwd = 0 and of "
+                    "the bucketed all-reduce on a one-rank group, measured after the timed region)")
     ap.add_argument("--cpu-seq", type=int, default=2048)
     ap.add_argument("--cpu-batch", type=int, default=1, help="sequences of the CPU baseline sample (BASELINE.md section 4: b=1 at seq 2048)")
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-threads", type=int, nargs="*", default=[16, 32, 64],
+                    help="thread counts the CPU baseline tries (one full step each after a warm-up); `value` is measured at the fastest")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time one CPU step with one thread per core the process may run on "
                     "(off by default: 256 threads on the GPU box took 679 s for one step, profiles/r04_bench_a.json)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline after one warm-up (median reported)")
@@ -58,14 +67,11 @@ def flops_per_token_fwd(seq, d=512, h=8, dh=64, layers=18, inner=2048):
 
 def launch_command(argv, gpus, port=None):
     """The command `python bench.py --gpus N` turns into when no launcher started it: one rank per GPU under torch.distributed.run on
-    this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
-    if port is None:
-        import socket
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve).  Without an explicit port the LAUNCHER picks a free
+    one itself (`--standalone`: a c10d store on port 0) -- probing for a free port here and handing it over later is a race."""
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}"]
+    rdzv = ["--standalone", "--local-addr", "127.0.0.1"] if port is None else ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    return head + rdzv + [os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
 
 
 def self_launch(args, argv):
@@ -81,7 +87,32 @@ def self_launch(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
-    return subprocess.call(cmd, env=env)
+    return run_child(cmd, env)
+
+
+def run_child(cmd, env):
+    """The launcher as a child in its OWN process group; SIGTERM / SIGINT / SIGHUP of this process are passed on to the whole group (the
+    launcher and its N ranks), so a timeout or Ctrl-C of the parent does not leave ranks running.  Returns the child's exit code."""
+    import signal
+    import subprocess
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def relay(signum, _frame):
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+    old = {sg: signal.signal(sg, relay) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+    try:
+        return child.wait()
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
 
 
 def main():
@@ -125,19 +156,21 @@ def main():
     opt = FusedAdamW(arena, lr=2e-4, weight_decay=1e-6, grad_clip=2.0)
     transport, transport_note = pick_transport(args, dist, dev)
     # the persistent tile walk of the input-gradient GEMMs is only safe while no all-reduce kernel holds CUs during the backward
-    sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp, transport=transport,
-                    persistent_backward=(dist is None) if "SPN_GEMM_PERSIST_BWD" not in os.environ else None)
-    batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev)
-    # segment-slot counts are known to the (host-side) input pipeline: pass them as python ints, no device read-back
-    model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in
-                                         (("bar_mean", "bars"), ("beat_mean", "beats"), ("onset_mean", "onsets"))}
+    with Deadline(args.dp_init_timeout if transport == "spn" else 0, "the native communicator's collective initialisation (--dp-transport spn)"):
+        sync = GradSync(arena, dist.group.WORLD if dist is not None else None, force=args.force_dp, transport=transport,
+                        persistent_backward=(dist is None) if "SPN_GEMM_PERSIST_BWD" not in os.environ else None)
+    holder = {"sync": sync}
+    # segment-slot counts are known to the (host-side) input pipeline: they travel with the batch as python ints (`segment_bounds`, what
+    # data.MixedLMScorePerformanceCollator emits for a real batch), so the forward reads nothing back from the device
+    batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev, with_bounds=True)
     torch.manual_seed(4321 + rank)  # distinct MMD samples per rank
 
     def step():
-        sync.begin_step()
+        gs = holder["sync"]
+        gs.begin_step()
         out = model(**batch)
         out.loss.backward()
-        sync.finish()
+        gs.finish()
         opt.step(grad_scale=1.0 / world)
         return out
 
@@ -185,6 +218,8 @@ def main():
         roof = roofline_leg(ops, step, args)
         if rank == 0:
             result["roofline"] = roof
+    if rank == 0 and world == 1 and dist is None and not args.no_dp1_forced:
+        result["dp1_forced"] = dp1_forced_leg(args, arena, dev, holder, step, lib_mod, GradSync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 measurement
         result["cpu_baseline"] = cpu_baseline_leg(cfg, cpu_state, args, model, dev)
     if rank == 0 and world == 1 and not args.no_decode:         # secondary object: C5 greedy render, outside the timed region
@@ -208,14 +243,50 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+class Deadline:
+    """Wall-clock guard for a collective start-up that cannot be cancelled (a second ncclCommInitRank in a process that already holds
+    torch's communicator, an id broadcast a peer never joins): a timer THREAD of this process; on expiry it writes one line to stderr and
+    ends the process with status 3 -- `os._exit`, no clean-up that could block on the hung call, never a re-exec.  Under a launcher the
+    non-zero exit of one rank ends the job."""
+
+    def __init__(self, seconds, what, _exit=os._exit):
+        self.seconds, self.what, self._exit, self._timer = float(seconds), what, _exit, None
+
+    def _expire(self):
+        sys.stderr.write(f"bench.py: rank {os.environ.get('RANK', '0')}: {self.what} did not finish within {self.seconds:.0f} s -- giving up "
+                         f"(exit 3).  Re-run with --dp-transport torch.\n")
+        sys.stderr.flush()
+        self._exit(3)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self._expire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
 def pick_transport(args, dist, dev):
-    """Which all-reduce carries the gradient buckets.  `auto`: libspn.so's own RCCL wrapper (spn_comm_*, include/spn.h) after a
-    start-up check -- a small buffer reduced through it must equal the same buffer reduced by torch.distributed on EVERY rank;
-    otherwise (init error, wrong sum) all ranks agree on torch.distributed.  Nothing is re-executed; the process group exists already."""
+    """Which all-reduce carries the gradient buckets.  Default `torch`: torch.distributed's communicator, which exists already.  `auto`:
+    libspn.so's own RCCL wrapper (spn_comm_*, include/spn.h) after a start-up check -- a small buffer reduced through it must equal the
+    same buffer reduced by torch.distributed on EVERY rank; otherwise (init error, wrong sum) all ranks agree on torch.distributed.
+    Nothing is re-executed; the process group exists already.  The whole check runs under a wall-clock `Deadline`
+    (`--dp-init-timeout`): a rank that is still inside it when the time is up exits with status 3."""
     if dist is None:
         return "torch", "single process: no all-reduce"
     if args.dp_transport != "auto":
-        return args.dp_transport, "as requested"
+        return args.dp_transport, "as requested" if args.dp_transport == "spn" else "default: torch.distributed's own communicator"
+    with Deadline(getattr(args, "dp_init_timeout", 120.0), "the native transport's start-up check (--dp-transport auto)"):
+        return _probe_native_transport(dist, dev)
+
+
+def _probe_native_transport(dist, dev):
     # stage 1, NO collective inside: can every rank reach RCCL through the library at all (symbols resolve, an id can be made)?  A rank that
     # failed here while the others entered the communicator's collective init would leave them waiting for it.
     pre, why = 1, ""
@@ -247,6 +318,57 @@ def pick_transport(args, dist, dev):
     flag = torch.tensor([ok], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return ("spn", why) if int(flag) == 1 else ("torch", "native transport check failed on some rank (" + why + "): torch.distributed")
+
+
+def dp1_forced_leg(args, arena, dev, holder, step, lib_mod, GradSync):
+    """N = 1 only, outside the timed region: what the data-parallel machinery costs BEFORE any second GPU exists, so that an N > 1 line
+    can be compared like for like.  Three short measurements of the same step (1 warm-up + `n` timed steps each, device-synchronised):
+    the headline configuration (`gemm_persist_bwd` = 1, no gradient hooks), the same with `gemm_persist_bwd` = 0 (what every N > 1 run
+    uses: no persistent tile walk under an all-reduce), and `--force-dp`: the bucketed all-reduce from inside backward on a ONE-rank
+    RCCL group (hooks, bucket bookkeeping, 9 ncclAllReduce launches of 32 MiB per step that move nothing)."""
+    n = 3
+
+    def timed():
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    knob = lib_mod.get_tuning("gemm_persist_bwd")
+    out = {"steps_each": n, "gemm_persist_bwd_at_n1": int(knob)}
+    plain_sync = holder["sync"]
+    try:
+        out["persist_bwd_1_ms_per_step"] = timed() if knob else None
+        lib_mod.set_tuning("gemm_persist_bwd", 0.0)
+        out["persist_bwd_0_ms_per_step"] = timed()
+        import torch.distributed as dist
+        made_group = not dist.is_initialized()
+        if made_group:   # an in-process store: no port, no rendezvous
+            dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
+        forced = GradSync(arena, dist.group.WORLD, force=True, transport="torch")
+        holder["sync"] = forced
+        try:
+            out["force_dp_ms_per_step"] = timed()
+            out["force_dp_buckets"] = len(forced.buckets)
+        finally:
+            holder["sync"] = plain_sync
+            forced.close()
+            if made_group:
+                dist.destroy_process_group()
+        if out.get("persist_bwd_1_ms_per_step"):
+            out["persist_bwd_cost_ms"] = out["persist_bwd_0_ms_per_step"] - out["persist_bwd_1_ms_per_step"]
+        out["dp_machinery_cost_ms"] = out["force_dp_ms_per_step"] - out["persist_bwd_0_ms_per_step"]
+        out["note"] = ("same box, same process, after the timed region: an N > 1 line runs gemm_persist_bwd = 0 plus the bucketed "
+                       "all-reduce; compare its ms_per_step with force_dp_ms_per_step, not with the N = 1 headline")
+    except Exception as exc:  # noqa: BLE001 -- a secondary object: the headline line must not depend on it
+        out["error"] = repr(exc)
+    finally:
+        holder["sync"] = plain_sync
+        lib_mod.set_tuning("gemm_persist_bwd", knob)
+    return out
 
 
 def _collect(ops, step, n=2):
@@ -481,15 +603,20 @@ def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
     n = args.cpu_seq
     host = os.cpu_count() or 1
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host
-    threads = max(1, min(usable, args.cpu_threads))
+    want = args.cpu_threads if isinstance(args.cpu_threads, (list, tuple)) else [args.cpu_threads]
+    cands = sorted({max(1, min(usable, int(c))) for c in (want or [32])})
     # the oracle has no latent-dropout draws of its own (masks are injected in the tests): the baseline runs the recipe without it
     cfg_cpu = copy.deepcopy(cfg)
     batch = synthetic_batch(args.cpu_batch, n, seed=99)
     z = [torch.randn(256, d) for d in cfg["perf_encoder"]["latent_dim"]]
     toks = args.cpu_batch * n
     t_all = time.perf_counter()
-    _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, threads)            # warm-up (allocator, thread pool, first-touch)
-    runs = [_cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, threads) for _ in range(max(1, args.cpu_reps))]
+    _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, cands[len(cands) // 2])   # warm-up (allocator, thread pool, first-touch)
+    # thread sweep: ONE full step per candidate count; the fastest is the count `value` is measured at (BASELINE.md section 4 says "all
+    # host cores": on a 256-core box that is two orders of magnitude slower than 32 threads, see `all_host_cores` below)
+    sweep = {c: _cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, c) for c in cands}
+    threads = min(sweep, key=lambda c: sweep[c][2])
+    runs = [sweep[threads]] + [_cpu_full_step(ref_cpu, cfg_cpu, cpu_state, batch, z, threads) for _ in range(max(0, args.cpu_reps - 1))]
     med = [statistics.median(r[i] for r in runs) for i in range(3)]
     out = runs[-1][3]
     sections = {"forward": {"s": med[0], "note_tokens_per_s": toks / med[0]},
@@ -514,26 +641,28 @@ def cpu_baseline_leg(cfg, cpu_state, args, model=None, dev=None):
         sd_now = {k: v.detach().clone() for k, v in model.state_dict().items()}
         model.load_state_dict(cpu_state)     # (the arena's load hook refreshes the bf16 compute copies)
         model.eval()
-        bounds = model.perf_encoder.segment_bounds
-        model.perf_encoder.segment_bounds = None
         model.perf_encoder._z_override = [t.to(dev) for t in z]
         with torch.no_grad():
             g = model(**{k: v.to(dev) for k, v in batch.items()})
         gl = float(g.loss)
         parity = {"gpu_loss": gl, "cpu_loss": float(out["loss"].detach()), "abs_diff": abs(gl - float(out["loss"].detach())),
                   "per_key": {k: [float(g.losses[k]), float(out["losses"][k].detach())] for k in out["losses"] if k in g.losses}}
-        model.perf_encoder._z_override, model.perf_encoder.segment_bounds = None, bounds
+        model.perf_encoder._z_override = None
         model.load_state_dict(sd_now)
         model.train()
-    if all_cores is None:
+    if all_cores is None and host == 256:   # the stored figure belongs to the 256-core GPU boxes only; any other host gets null + the pointer
         all_cores = {"cores": 256, "full_step_s": 679.5, "note_tokens_per_s": 3.01, "forward_backward_note_tokens_per_s": 4.41,
                      "sample": "STORED measurement (profiles/r04_bench_a.json, one warm-up + one timed step of the same sample with 256 torch "
                                "threads on a 256-core GPU box): two orders of magnitude SLOWER than 32 threads -- these operator sizes do "
                                "not feed 256 threads -- and 11 minutes of wall time, so it is not re-run by default (--cpu-all-cores)"}
+    all_cores_note = None if all_cores is not None else ("not measured on this host (--cpu-all-cores measures it; a 256-core GPU box took "
+                                                         "679 s per step, profiles/r04_bench_a.json)")
     return {"value": toks / med[2], "unit": "note-tokens/s", "cores": threads, "host_cores": host, "usable_cores": usable, "cpu_model": cpu_model,
-            "kind": "port", "sections": sections, "all_host_cores": all_cores, "parity": parity,
+            "kind": "port", "sections": sections, "all_host_cores": all_cores, "all_host_cores_note": all_cores_note, "parity": parity,
+            "thread_sweep": {str(c): {"full_step_s": r[2], "note_tokens_per_s": toks / r[2]} for c, r in sweep.items()},
             "sample": f"{args.cpu_batch} sequence(s) x {n} notes of the same C3 model, fp32, torch {torch.__version__} CPU: 1 warm-up + median of "
-                      f"{len(runs)} full train steps (forward, backward, global-norm clip + AdamW through oracle.ref_cpu) with {threads} threads; "
+                      f"{len(runs)} full train steps (forward, backward, global-norm clip + AdamW through oracle.ref_cpu) with {threads} threads "
+                      f"(the fastest of {cands}, one step each: `thread_sweep`); "
                       f"`value` = the full step; host has {host} cores ({cpu_model}); {wall:.0f} s wall for the whole leg",
             "cpu_loss": float(out["loss"].detach())}
 

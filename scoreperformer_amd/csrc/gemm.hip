@@ -1816,7 +1816,10 @@ extern "C" int spn_gemm_glu(const void* x, const void* W, void* u, void* gout, c
     SPN_REQUIRE(((((uintptr_t)x) | ((uintptr_t)W) | ((uintptr_t)u) | ((uintptr_t)gout)) & 15) == 0 && (!bias || (((uintptr_t)bias) & 15) == 0),
                 "spn_gemm_glu: operands must be 16-byte aligned");
     SPN_REQUIRE((long)M * lda * 2 < (1L << 31) && 2l * I * ldb * 2 < (1L << 31), "spn_gemm_glu: operand spans 2 GiB or more");
-    SPN_REQUIRE((long)M * ldu * 2 < (1L << 32) && (long)M * ldg * 2 < (1L << 32), "spn_gemm_glu: u or g spans 4 GiB or more (32-bit buffer offsets)");
+    // the PADDED extent: per-lane row offsets are formed for every row of the last 256-row tile, rows past M included -- they must not
+    // wrap back into the buffer (the hardware bounds check drops offsets >= the record count, not wrapped ones)
+    SPN_REQUIRE(cdiv(M, 256) * 256l * ldu * 2 < (1L << 32) && cdiv(M, 256) * 256l * ldg * 2 < (1L << 32),
+                "spn_gemm_glu: u or g (rows rounded up to 256) spans 4 GiB or more (32-bit buffer offsets)");
     SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu: act is 0 (SiLU) or 1 (GELU)");
     GemmArgs g;
     g.A = (const bf16_t*)x; g.B = (const bf16_t*)W; g.C = u; g.bias = bias; g.residual = nullptr; g.rowmask = nullptr;
@@ -1853,7 +1856,8 @@ extern "C" int spn_gemm_glu_bwd(const void* dy, const void* W2, const void* u, v
     SPN_REQUIRE(((((uintptr_t)dy) | ((uintptr_t)W2) | ((uintptr_t)u) | ((uintptr_t)du)) & 15) == 0 && (!colsum_partial || (((uintptr_t)colsum_partial) & 7) == 0),
                 "spn_gemm_glu_bwd: operands must be 16-byte aligned");
     SPN_REQUIRE((long)M * lddy * 2 < (1L << 31) && (long)K * ldw * 2 < (1L << 31), "spn_gemm_glu_bwd: operand spans 2 GiB or more");
-    SPN_REQUIRE((long)M * ldu * 2 < (1L << 32) && (long)M * lddu * 2 < (1L << 32), "spn_gemm_glu_bwd: u or du spans 4 GiB or more (32-bit buffer offsets)");
+    SPN_REQUIRE(cdiv(M, 256) * 256l * ldu * 2 < (1L << 32) && cdiv(M, 256) * 256l * lddu * 2 < (1L << 32),
+                "spn_gemm_glu_bwd: u or du (rows rounded up to 256) spans 4 GiB or more (32-bit buffer offsets)");
     SPN_REQUIRE(act == 0 || act == 1, "spn_gemm_glu_bwd: act is 0 (SiLU) or 1 (GELU)");
     GemmArgs g;
     memset(&g, 0, sizeof(g));

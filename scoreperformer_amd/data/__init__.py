@@ -1,3 +1,3 @@
-from .collators import (SeqInputs, SeqSegments, MixedLMScorePerformanceInputs, MixedLMScorePerformanceCollator)
+from .collators import (SeqInputs, SeqSegments, SegmentBounds, MixedLMScorePerformanceInputs, MixedLMScorePerformanceCollator)
 
-__all__ = ["SeqInputs", "SeqSegments", "MixedLMScorePerformanceInputs", "MixedLMScorePerformanceCollator"]
+__all__ = ["SeqInputs", "SeqSegments", "SegmentBounds", "MixedLMScorePerformanceInputs", "MixedLMScorePerformanceCollator"]

@@ -26,11 +26,22 @@ class SeqInputs:                                   # data/collators/common.py:8-
     lengths: torch.Tensor
 
 
+class SegmentBounds(dict):
+    """{"bar" | "beat" | "onset": largest segment id of the batch + 1} as python ints, taken from the host-side segment arrays the
+    collator concatenates anyway.  The reference reads `segments.max() + 1` back from the device in every forward
+    (models/scoreperformer/mmd_transformer.py:330); with these the forward needs no host read.  `.to()` returns the object itself so
+    that the trainer's `allocate_inputs` (`value.to(device)` over the input dict, models/base.py:26-27) passes it through."""
+
+    def to(self, *args, **kwargs):
+        return self
+
+
 @dataclass
 class SeqSegments:                                 # score_performance.py:18-22
     bar: Optional[torch.Tensor] = None
     beat: Optional[torch.Tensor] = None
     onset: Optional[torch.Tensor] = None
+    bounds: Optional[SegmentBounds] = None         # not in the reference: host-known slot counts (see SegmentBounds)
 
 
 @dataclass
@@ -119,9 +130,13 @@ class MixedLMScorePerformanceCollator:
         h = host.numpy()
         np.concatenate([s.score for s in batch], out=h[:o_perf].reshape(sum_s, Ks), casting="unsafe")
         np.concatenate([s.perf for s in batch], out=h[o_perf:o_seg].reshape(sum_p, Kp), casting="unsafe")
+        bounds = None
         if has_seg:
+            bounds = SegmentBounds()
             for j, name in enumerate(("bar", "beat", "onset")):
-                np.concatenate([getattr(s.segments, name) for s in batch], out=h[o_seg + j * sum_s:o_seg + (j + 1) * sum_s], casting="unsafe")
+                col = h[o_seg + j * sum_s:o_seg + (j + 1) * sum_s]
+                np.concatenate([getattr(s.segments, name) for s in batch], out=col, casting="unsafe")
+                bounds[name] = (max(int(col.max()), 0) if sum_s else 0) + 1        # padded positions hold segment id 0
         h[o_soff] = 0
         np.cumsum(n_s, out=h[o_soff + 1:o_poff], dtype=np.int32)
         h[o_poff] = 0
@@ -154,7 +169,7 @@ class MixedLMScorePerformanceCollator:
             scores=SeqInputs(t["score"], t["score_mask"], t["score_len"]),
             performances=perf,
             noisy_performances=noisy,
-            segments=SeqSegments(t["bar"], t["beat"], t["onset"]) if has_seg else None,
+            segments=SeqSegments(t["bar"], t["beat"], t["onset"], bounds) if has_seg else None,
             deadpan_mask=t["deadpan_mask"],
             masked_performances=SeqInputs(t["masked_perf"], t["perf_mask"].clone(), t["perf_len"]),   # score_performance.py:212
             labels=SeqInputs(t["labels"], perf.mask, perf.lengths),

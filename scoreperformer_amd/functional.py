@@ -270,8 +270,15 @@ class _SplitGrad:
         for w in widths:
             self.offs.append(self.offs[-1] + w)
         self.buf = None
+        self.written = set()
 
     def slice(self, i, device):
+        """The in-place target for slice i's gradient, ONCE per backward: a second consumer of the same slice (the head applied twice to
+        one slice) gets None and must return a tensor of its own -- two non-accumulating writers of one view would leave 2 x the second
+        gradient after autograd's sum."""
+        if i in self.written:
+            return None
+        self.written.add(i)
         if self.buf is None:
             self.buf = torch.empty(self.shape, device=device, dtype=self.dtype)
         return self.buf.narrow(-1, self.offs[i], self.widths[i])
@@ -301,7 +308,7 @@ class SplitColsFn(Function):
             return (None,) * (1 + len(ctx.widths))
         dev = next(g for g in grads if g is not None).device
         dx = h.buf if h.buf is not None else torch.empty(ctx.shape, device=dev, dtype=ctx.dt)
-        h.buf = None                      # (a second backward through a retained graph starts from a fresh buffer)
+        h.buf, h.written = None, set()    # (a second backward through a retained graph starts from a fresh buffer)
         off, zero_from = 0, None
         for w, g in zip(ctx.widths, grads):
             if g is None:
@@ -1048,8 +1055,9 @@ class HeadCEFn(Function):
             if ctx.esplit is not None and ctx.esplit[0].dtype == BF16:   # straight into this key's columns of the split tensor's gradient
                 holder, i = ctx.esplit
                 de = holder.slice(i, dl.device)
+            if de is not None:
                 ops.gemm(dl, tpad, tb=True, out=de.view(-1, K))
-            else:
+            else:                          # no split holder, or this slice already has an in-place writer in this backward
                 de = ops.gemm(dl, tpad, tb=True, out_dtype=BF16).view(e_shape)
         dtab = None
         if ctx.needs_input_grad[1]:

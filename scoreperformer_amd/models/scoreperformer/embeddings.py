@@ -223,7 +223,10 @@ class MultiSeqTupleTokenEmbeddings(TupleTokenEmbeddings):
         elif self.multiseq_mode == "pre-sum":
             token_emb = self._forward_project(list(tokens))
         else:
-            return None       # (the reference's silent fall-through for an unknown mode, embeddings.py:257-258)
+            # the reference returns None here (embeddings.py:257-258) and its caller then dies on `None + Tensor`; same outcome, said clearly.
+            # Raised where several sequences actually meet the unknown mode, not at construction: a single sequence never looks at it.
+            raise ValueError(f"MultiSeqTupleTokenEmbeddings: unknown multiseq_mode {self.multiseq_mode!r} "
+                             "(expected 'pre-sum', 'post-sum' / any 'post*', or 'post-cat')")
         if cache is not None:
             token_emb = torch.cat([cache, token_emb], dim=1)
         return token_emb

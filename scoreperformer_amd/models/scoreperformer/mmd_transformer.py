@@ -249,9 +249,18 @@ class MMDTupleTransformer(TupleTransformer):
             return onsets
         return None
 
+    @staticmethod
+    def _bound(bounds, mode: str) -> int:
+        """Slot count of a level from the input pipeline's bounds: keyed by aggregate mode (`segment_bounds` attribute) or by segment
+        name (`data.SegmentBounds`: "bar" / "beat" / "onset")."""
+        if mode in bounds:
+            return int(bounds[mode])
+        return int(bounds[{EmbeddingAggregateModes.BAR_MEAN: "bar", EmbeddingAggregateModes.ISOLATED_BAR_MEAN: "bar",
+                           EmbeddingAggregateModes.BEAT_MEAN: "beat", EmbeddingAggregateModes.ONSET_MEAN: "onset"}[mode]])
+
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, x_extra=None, latents=None, bars: Optional[Tensor] = None,
                 beats: Optional[Tensor] = None, onsets: Optional[Tensor] = None, deadpan_mask: Optional[Tensor] = None,
-                return_embeddings: bool = False, return_attn: bool = False, compute_loss: bool = True, **kwargs):
+                return_embeddings: bool = False, return_attn: bool = False, compute_loss: bool = True, segment_bounds=None, **kwargs):
         if latents is not None:
             raise NotImplementedError("externally supplied latents: use `latents_to_embeddings`")
         modes, Ls, drops, heads = self._levels()
@@ -273,8 +282,9 @@ class MMDTupleTransformer(TupleTransformer):
         # number of segment slots per level: `segments.max() + 1` (mmd_transformer.py:330).  The reference reads it back
         # from the device on every forward; here it can be supplied by the input pipeline (`segment_bounds`, python ints
         # per aggregate mode), else it costs ONE host read for all levels; `static_segments` uses the bound n + 4.
-        if self.segment_bounds is not None:
-            sizes = [int(self.segment_bounds[m]) if s is not None else 1 for m, s in zip(modes, segs)]
+        bounds = segment_bounds if segment_bounds is not None else self.segment_bounds
+        if bounds is not None:
+            sizes = [self._bound(bounds, m) if s is not None else 1 for m, s in zip(modes, segs)]
         elif self.static_segments:
             sizes = [n + 4 if s is not None else 1 for s in segs]
         else:

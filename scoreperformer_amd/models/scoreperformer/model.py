@@ -152,7 +152,7 @@ class ScorePerformer(_LMModeMixin, Model):
         self._init_mode(mode)
 
     def forward_encoders(self, perf=None, perf_mask=None, score=None, score_mask=None, bars=None, beats=None, onsets=None,
-                         deadpan_mask=None, compute_loss: bool = True):
+                         deadpan_mask=None, compute_loss: bool = True, segment_bounds=None):
         score_emb = perf_emb = None
         score_enc_out = perf_enc_out = None
         with shared_tables():
@@ -160,20 +160,26 @@ class ScorePerformer(_LMModeMixin, Model):
                 score_enc_out = self.score_encoder(score, mask=score_mask)
                 score_emb = score_enc_out.hidden_state
             if self.perf_encoder is not None:
+                extra = {} if segment_bounds is None else {"segment_bounds": segment_bounds}
                 perf_enc_out = self.perf_encoder(perf, mask=perf_mask, bars=bars, beats=beats, onsets=onsets,
-                                                 deadpan_mask=deadpan_mask, compute_loss=compute_loss)
+                                                 deadpan_mask=deadpan_mask, compute_loss=compute_loss, **extra)
                 perf_emb = perf_enc_out.embeddings
         return ScorePerformerEncoderOutputs(score_embeddings=score_emb, score_mask=score_mask, perf_embeddings=perf_emb,
                                             score_encoder=score_enc_out, perf_encoder=perf_enc_out)
 
     def forward(self, perf: Tensor, perf_mask=None, score=None, score_mask=None, noisy_perf=None, noisy_perf_mask=None,
-                masked_perf=None, labels=None, bars=None, beats=None, onsets=None, directions=None, deadpan_mask=None):
+                masked_perf=None, labels=None, bars=None, beats=None, onsets=None, directions=None, deadpan_mask=None,
+                segment_bounds=None):
+        """The reference's signature (model.py:280-293) plus `segment_bounds`: {"bar" | "beat" | "onset": max id + 1} python ints from
+        the input pipeline (`data.SegmentBounds`, emitted by the collator) -- with them the style encoder sizes its segment slots without
+        the reference's device read-back (mmd_transformer.py:330)."""
         if labels is not None and labels.is_cuda:
             mark_inputs_ready()
         with shared_tables():
             enc_out = self.forward_encoders(
                 perf=default(noisy_perf, perf), perf_mask=default(noisy_perf_mask, perf_mask), score=score,
-                score_mask=score_mask, bars=bars, beats=beats, onsets=onsets, deadpan_mask=deadpan_mask)
+                score_mask=score_mask, bars=bars, beats=beats, onsets=onsets, deadpan_mask=deadpan_mask,
+                segment_bounds=segment_bounds)
             dec_kwargs = dict(mask=perf_mask, style_embeddings=enc_out.perf_embeddings, context=enc_out.score_embeddings,
                               context_mask=enc_out.score_mask, labels=labels)
             if masked_perf is not None:
@@ -214,6 +220,8 @@ class ScorePerformer(_LMModeMixin, Model):
             d["masked_perf"] = inputs.masked_performances.tokens
         if getattr(inputs, "segments", None) is not None:
             d["bars"], d["beats"], d["onsets"] = inputs.segments.bar, inputs.segments.beat, inputs.segments.onset
+            if getattr(inputs.segments, "bounds", None) is not None:   # data.SegmentBounds of the device collator: no read-back in forward
+                d["segment_bounds"] = inputs.segments.bounds
         if getattr(inputs, "directions", None) is not None:
             d["directions"] = inputs.directions
         if getattr(inputs, "deadpan_mask", None) is not None:

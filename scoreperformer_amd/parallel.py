@@ -45,11 +45,14 @@ class GradSync:
                 from .comm import NativeComm
                 self.native = NativeComm.from_group(group)
         self._knob_before = None
+        self._knob_set = None
+        self._hooked: List = []         # (object, attribute) pairs and hook handles this object installed: close() removes them
         on_gpu = bool(getattr(getattr(arena, "grads", None), "is_cuda", False))    # (the gloo tests drive this class with host tensors)
         if not dry_run and (persistent_backward is not None or (self.active and on_gpu)):
             from . import lib
             self._knob_before = lib.get_tuning("gemm_persist_bwd")
-            lib.set_tuning("gemm_persist_bwd", 1.0 if (persistent_backward and not self.active) else 0.0)
+            self._knob_set = 1.0 if (persistent_backward and not self.active) else 0.0
+            lib.set_tuning("gemm_persist_bwd", self._knob_set)
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
@@ -87,7 +90,8 @@ class GradSync:
         for idx, p in enumerate(self.arena.param_list):
             p._spn_grad_pending = (lambda i=idx: self._pending(i))
             p._spn_grad_ready = (lambda i=idx: self._ready(i))
-            p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._autograd_ready(i))
+            self._hooked.append(p)
+            self._hooked.append(p.register_post_accumulate_grad_hook(lambda _p, i=idx: self._autograd_ready(i)))
         for mod in self.arena.model.modules():
             for attr in getattr(mod, "_spn_fuse_groups", {}) or {}:
                 fused = getattr(mod, attr, None)
@@ -95,6 +99,7 @@ class GradSync:
                     idxs = [self._index_of(p) for p in fused._spn_parts]
                     fused._spn_grad_pending = (lambda ii=idxs: [self._pending(i) for i in ii])
                     fused._spn_grad_ready = (lambda ii=idxs: [self._ready(i) for i in ii])
+                    self._hooked.append(fused)
 
     def _index_of(self, p):
         for i, q in enumerate(self.arena.param_list):
@@ -161,11 +166,24 @@ class GradSync:
         return bufs[b]
 
     def close(self):
-        """Restore the `gemm_persist_bwd` knob this object changed (if it did) and drop the native communicator."""
+        """Restore the `gemm_persist_bwd` knob this object changed (if it did, and only while the knob still holds the value this object
+        wrote: a later object that set it again owns it now, and a late `close()` / garbage collection of this one must not re-enable the
+        persistent walk under the other's all-reduces), take this object's gradient hooks off the parameters (the arena can then be used
+        without it, or with a new object) and drop the native communicator."""
         if self._knob_before is not None:
             from . import lib
-            lib.set_tuning("gemm_persist_bwd", self._knob_before)
+            if lib.get_tuning("gemm_persist_bwd") == self._knob_set:
+                lib.set_tuning("gemm_persist_bwd", self._knob_before)
             self._knob_before = None
+        for h in self._hooked:
+            if hasattr(h, "remove"):
+                h.remove()
+            else:
+                for attr in ("_spn_grad_pending", "_spn_grad_ready"):
+                    if attr in getattr(h, "__dict__", {}):
+                        delattr(h, attr)
+        self._hooked = []
+        self.active = False
         if self.native is not None:
             self.native.close()
             self.native = None
@@ -187,6 +205,9 @@ class GradSync:
     def begin_step(self):
         if not self.active:
             return
+        if self._knob_set == 0.0 and self._knob_before is not None:
+            from . import lib
+            lib.set_tuning("gemm_persist_bwd", 0.0)     # re-asserted every step: nothing may switch the persistent walk on under an all-reduce
         self.handles, self.done, self.launched, self.events = [], set(), set(), []
         self.counts = [0] * len(self.arena.param_list)
         left = [0] * len(self.buckets)

@@ -102,8 +102,10 @@ def synthetic_batch(
         sos: bool = True,
         deadpan_p: float = 0.0,
         device: str = "cpu",
+        with_bounds: bool = False,
 ):
-    """Seeded synthetic MixedLM batch (SURVEY.md §8(d) 'Concrete synthetic inputs')."""
+    """Seeded synthetic MixedLM batch (SURVEY.md §8(d) 'Concrete synthetic inputs').  `with_bounds`: also `segment_bounds`, the
+    host-known slot counts the device collator emits with a real batch (`data.SegmentBounds`: the forward then reads nothing back)."""
     num_tokens = dict(num_tokens or PERFORMANCE_VOCAB)
     g = torch.Generator().manual_seed(seed)
     sizes = list(num_tokens.values())
@@ -137,4 +139,8 @@ def synthetic_batch(
     deadpan = torch.rand(batch, generator=g) < deadpan_p
     out = dict(perf=perf, perf_mask=mask, score=score, score_mask=mask.clone(), masked_perf=masked_perf,
                labels=labels, bars=bars, beats=beats, onsets=onsets, deadpan_mask=deadpan)
-    return {k: v.to(device) for k, v in out.items()}
+    out = {k: v.to(device) for k, v in out.items()}
+    if with_bounds:
+        from .data.collators import SegmentBounds
+        out["segment_bounds"] = SegmentBounds(bar=int(bars.max()) + 1, beat=int(beats.max()) + 1, onset=int(onsets.max()) + 1)
+    return out

@@ -75,3 +75,56 @@ def test_collate_train_evaluate_checkpoint_resume(tmp_path):
         for k in ma:
             assert abs(ma[k] - mb[k]) < 1e-2 * max(1.0, abs(ma[k])), k
     assert ref[-1][0] < ref[0][0] + 1.0                            # and it trains (loss does not blow up over the four steps)
+
+
+def test_composed_train_step_makes_no_host_synchronisation():
+    """The collator hands the segment slot counts over as python ints (`segments.bounds`, data.SegmentBounds; the reference reads
+    `segments.max() + 1` back from the device in every forward, mmd_transformer.py:330) and `model.sync_free` keeps every loss key, so
+    forward + backward + clip + AdamW of a collated batch enqueue work and never wait for the device: run under
+    torch.cuda.set_sync_debug_mode("error"), where any synchronising call raises."""
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena, FusedAdamW
+    from scoreperformer_amd.data import MixedLMScorePerformanceCollator, SegmentBounds
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, PERFORMANCE_VOCAB
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(1)
+    sizes = list(PERFORMANCE_VOCAB.values())
+    collate = MixedLMScorePerformanceCollator(**KW)
+    model = ScorePerformer.init(model_config("tiny", dropout=0.1))
+    model.load_state_dict(filled_state_dict(model, seed=4))
+    arena = ParamArena(model, dev)
+    model.train()
+    model.sync_free = True
+    opt = FusedAdamW(arena, lr=1e-3, weight_decay=1e-2, grad_clip=2.0)
+    losses = []
+    for i, lens in enumerate(([40, 64, 33], [57, 20, 48], [64, 64, 9])):
+        samples = make_samples(rng, sizes, lens)
+        collated = collate(samples)
+        bounds = collated.segments.bounds
+        assert isinstance(bounds, SegmentBounds)
+        assert bounds == {k: int(max(getattr(s.segments, k).max() for s in samples)) + 1 for k in ("bar", "beat", "onset")}
+        inputs = model.allocate_inputs(model.prepare_inputs(collated), dev)      # the trainer's two calls (trainer.py:440-447)
+        assert inputs["segment_bounds"] is bounds
+        torch.manual_seed(20 + i)
+        if i == 0:      # first step un-guarded: lazy one-time set-up (library load, workspaces, constant tables) may synchronise
+            out = model(**inputs); out.loss.backward(); opt.step()
+            torch.cuda.synchronize()
+            continue
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            out = model(**inputs)
+            out.loss.backward()
+            opt.step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        losses.append(float(out.loss.detach()))
+    assert len(losses) == 2 and all(np.isfinite(v) for v in losses)
+    # the bounds only size the segment slots: the same batch without them (one host read instead) gives the same loss
+    model.eval()
+    with torch.no_grad():
+        torch.manual_seed(22)
+        a = float(model(**inputs).loss)
+        torch.manual_seed(22)
+        b = float(model(**{k: v for k, v in inputs.items() if k != "segment_bounds"}).loss)
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)

@@ -9,5 +9,5 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; a=r["a
 print(sys.argv[1], "ms/step %.1f" % d["ms_per_step"], "gemm %.1f (%.0f TF/s)" % (r["gemm_ms_per_step"], r["achieved"]), "attn %.1f" % a["ms_per_step"], "elem %.1f" % e["ms_per_step"])'
 for i in $(seq $n); do
   (cd tools/_bin/tree_base && python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode 2>/dev/null | python -c "$fmt" base)
-  (cd $here && python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode 2>/dev/null | python -c "$fmt" new)
+  (cd $here && python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-decode --no-dp1-forced 2>/dev/null | python -c "$fmt" new)
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box sweep of library tuning knobs on the whole train step (ms per step; the default first and last)
-run() { env "$@" python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-roofline 2>/dev/null | python -c "
+run() { env "$@" python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-decode --no-dp1-forced --no-roofline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-40s %.2f ms/step' % ('$*', d['ms_per_step']))"; }
 run X=0

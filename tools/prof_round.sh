@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 # 1. train step
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-decode --no-roofline > /tmp/prof_step.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-decode --no-dp1-forced --no-roofline > /tmp/prof_step.log 2>&1
 find /tmp/prof_step -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${tag}_kernel_stats_step.csv \;
 tail -1 /tmp/prof_step.log | cut -c1-200
 # 2. decode
