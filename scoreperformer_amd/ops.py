@@ -740,7 +740,10 @@ class _SmallZeros:
             if blk is None or blk[1] + step > self.BLOCK:
                 blk = [torch.zeros(self.BLOCK, device=device, dtype=F32), 0]
                 self.blocks[key] = blk
-            out = blk[0][blk[1]:blk[1] + n]
+            # `.data`: a tensor on the same storage with a VERSION COUNTER OF ITS OWN.  Plain slices of one block would all share the
+            # block's counter, and an in-place torch op on any of them (AccumulateGrad's `grad += ...` on a bias gradient that came from
+            # here, clip_grad_norm_'s `mul_`) would invalidate every other slice that some autograd node has saved for its backward
+            out = blk[0].data[blk[1]:blk[1] + n]
             blk[1] += step
         return out
 

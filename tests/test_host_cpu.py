@@ -102,3 +102,35 @@ def test_model_variants_construct_with_reference_layouts():
     assert type(p.transformer).__name__ == "ScorePerformerARWrapper"
     tied = m.score_encoder.token_emb.embs["Bar"] is m.perf_decoder.model.token_emb.embs["Bar"]
     assert tied
+
+
+def test_small_zero_slices_do_not_share_a_version_counter():
+    """Accumulators handed out of one pooled block are independent tensors to autograd: an in-place op on one (AccumulateGrad's `+=` on a
+    bias gradient that came from the pool, when the reference's trainer accumulates over micro-batches) must not invalidate another one
+    that an autograd node saved for its backward (found by tests/test_trainer_loop_gpu.py: 'modified by an inplace operation')."""
+    import torch
+    from scoreperformer_amd import ops
+    a = ops.zeros_small(4, "cpu")
+    b = ops.zeros_small(8, "cpu")
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()    # same block ...
+    assert a.data_ptr() != b.data_ptr() and float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+
+    class Keep(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, saved):
+            ctx.save_for_backward(saved)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            (saved,) = ctx.saved_tensors          # raises if `saved`'s version moved since forward
+            return g * 2 + saved.sum(), None
+
+    x = torch.ones(3, requires_grad=True)
+    y = Keep.apply(x, a)
+    va = a._version
+    b.add_(1.0)                                  # ... but an in-place op on the neighbour
+    b.mul_(0.5)
+    assert a._version == va                      # leaves this slice's version alone
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.full((3,), 2.0))
