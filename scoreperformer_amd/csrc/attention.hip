@@ -201,12 +201,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         const int last = q0 + 127 + off;  // largest key index any row of this block may see
         nt = last < 0 ? 0 : min(nt, last / 64 + 1);
     }
+    int wave_lo = -0x40000000, wave_hi = 0x40000000;   // keys this WAVE's 32 rows can reach (the bound holds for every row of the block)
     {   // ALiBi band: key tiles further than the reach of this block's 128 rows contribute < 2^-band_log2 per probability
         const float reach = band_reach(a, bi, hi, kh, q0 / 64, 2, c1, slope2);
         if (reach < 1.0e9f) {
             const int d = (int)reach + 1;
             t_lo = max(0, q0 + off - d) / 64;
             nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
+            wave_lo = i_lo - d; wave_hi = i_hi + d;     // the block walks the union of its four waves' ranges; a wave sits out the rest
         }
     }
 
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
         // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
         const int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
-        if (cls == T_SKIP) continue;
+        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band
         const float j0f = (float)j0;
         uint32_t thr_t = a.thr8;
         if (DROP && a.thr_frac) {   // this block's threshold: thr8 + Bernoulli(frac16 / 65536), all-scalar (set_dropout)
@@ -502,12 +504,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const int last = q0 + 127 + off;
         nt = last < 0 ? 0 : min(nt, last / 64 + 1);
     }
-    {   // same ALiBi band as the forward (same bound inputs, same arithmetic)
+    int wave_lo = -0x40000000, wave_hi = 0x40000000;
+    {   // same ALiBi band as the forward (same bound inputs, same arithmetic, same per-wave range)
         const float reach = band_reach(a, bi, hi, kh, q0 / 64, 2, c1, slope2);
         if (reach < 1.0e9f) {
             const int d = (int)reach + 1;
             t_lo = max(0, q0 + off - d) / 64;
             nt = min(nt, (q0 + 127 + off + d) / 64 + 1);
+            wave_lo = i_lo - d; wave_hi = i_hi + d;
         }
     }
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const bool rows_ok = q0 + 32 * wv + 31 < a.nq;
         // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
         int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
-        if (cls == T_SKIP) continue;
+        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band
         if (!rows_ok && SLOPE_GRAD) cls = T_GEN;
         const float j0f = (float)j0;
 

@@ -166,15 +166,25 @@ __device__ __forceinline__ uint32_t block_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t drop_light(uint32_t x) { x ^= x >> 11; return __umul24(x, 0xD35A2Du) + (x >> 8); }
+// the seven cheaper words of a keep mask, chained from the strong one: w' = (w >> 8) * C + rot(w, 13) -- v_lshrrev + v_alignbit +
+// v_mad_u32_u24, three full-rate VALU slots (round 4: add, shift, xor, shift, mad).  The 24-bit multiply sees the word's HIGH bits, the
+// rotated addend puts its well-mixed middle bits under the product's weak low ones.  tools/dropmask_quality.py (numpy emulation on the
+// kernel's counter lattice, 2 M words): drop rate, per-bit rates, every in-word bit pair, key / row / diagonal neighbours at sampling
+// noise for thr8 = 1 .. 255, same as the five-slot chain; (w >> 8) * C + w, two slots, correlates bit pairs at 0.1 - 0.3 and is out.
+__device__ __forceinline__ uint32_t drop_light(uint32_t w) { return __umul24(w >> 8, 0xD35A2Du) + __builtin_amdgcn_alignbit(w, w, 13); }
 __device__ __forceinline__ uint32_t drop_keep32(uint32_t counter, uint32_t thr8) {
     uint32_t w = drop_hash(counter), acc = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        acc = ((thr8 >> k) & 1u) ? (acc | w) : (acc & w);   // thr8 is wave-uniform
-        if (k < 7) w = drop_light(w + 0x9E3779B1u);
+        // digit k of thr8 (wave-uniform, as a 0 / ~0 mask d in an SGPR): 1 -> acc | w, 0 -> acc & w  =  majority(acc, w, d): ONE
+        // v_bitop3_b32 (truth table 0xe8; the last digit writes the complement, 0x17, which is the keep mask).  Written as asm: from
+        // the C expression hipcc makes and + or + v_cndmask (three slots), or two bit operations when the mask is laundered.
+        const uint32_t d = 0u - ((thr8 >> k) & 1u);
+        if (k < 7) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(acc) : "v"(acc), "v"(w), "s"(d));
+        else asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x17" : "=v"(acc) : "v"(acc), "v"(w), "s"(d));
+        if (k < 7) w = drop_light(w);
     }
-    return ~acc;
+    return acc;
 }
 // Lanes l and l^1 hold neighbouring rows (or columns) of the same 2x2 blocks and need the same two hashes: each computes one
 // and they swap through DPP (quad_perm [1,0,3,2]), halving the hash count.

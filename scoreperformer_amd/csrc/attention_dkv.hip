@@ -213,20 +213,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
     // dependent global loads of band_reach (and ~110 scalar / vector instructions around them) sat in front of every tile request.
     constexpr int LIVE_WORDS = 16;   // up to 1024 (head, query tile) iterations; longer walks decide on the fly as before
     __shared__ unsigned long long live_mask[LIVE_WORDS];
-    auto is_live = [&](int it) {
+    // ... and the same question per WAVE (its 32 keys instead of the block's 128): the block walks the union, a wave sits out the
+    // iterations only its neighbours need (steep heads: a third of them)
+    __shared__ unsigned long long live_wave[4][LIVE_WORDS];
+    auto reach_of = [&](int it, float& r_lo) {
         const int hh = kh * heads_per_kv + it / (nqt - t_first);
         const int i0 = (t_first + it % (nqt - t_first)) * 64;
+        r_lo = (float)(i0 + off);
         const float reach = band_reach(a, bi, hh, kh, i0 / 64, 1, c1, a.slopes ? a.slopes[hh] * LOG2E : 0.f);
-        if (!(reach < 1.0e9f)) return true;
-        const float r_lo = (float)(i0 + off), r_hi = r_lo + 63.f;
-        return (float)j0 <= r_hi + reach && (float)(j0 + 127) >= r_lo - reach;
+        return reach < 1.0e9f ? reach : 3.0e38f;
+    };
+    auto is_live = [&](int it) {
+        float r_lo;
+        const float reach = reach_of(it, r_lo);
+        return (float)j0 <= r_lo + 63.f + reach && (float)(j0 + 127) >= r_lo - reach;
     };
     const bool masked_walk = n_iter <= 64 * LIVE_WORDS;
     if (masked_walk) {
         for (int base = 0; base < n_iter; base += 256) {
             const int it = base + tid;
-            const unsigned long long m = __ballot(it < n_iter && is_live(it));
+            float r_lo = 0.f;
+            const float reach = it < n_iter ? reach_of(it, r_lo) : -1.f;
+            const bool in = it < n_iter;
+            const unsigned long long m = __ballot(in && (float)j0 <= r_lo + 63.f + reach && (float)(j0 + 127) >= r_lo - reach);
             if (lane == 0) live_mask[(base >> 6) + w] = m;
+#pragma unroll
+            for (int wq = 0; wq < 4; ++wq) {
+                const float jl = (float)(j0 + 32 * wq);
+                const unsigned long long mw = __ballot(in && jl <= r_lo + 63.f + reach && jl + 31.f >= r_lo - reach);
+                if (lane == 0) live_wave[wq][(base >> 6) + w] = mw;
+            }
         }
         __syncthreads();
     }
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         const int r_lo = i0 + off, r_hi = r_lo + 63;
         int cls = T_GEN;
         if (a.causal && jw_lo > r_hi) cls = T_SKIP;
+        else if (masked_walk && !((__builtin_amdgcn_readfirstlane((int)(live_wave[wv][it >> 6] >> (it & 63))) & 1))) cls = T_SKIP;   // outside this wave's own band
         else if (keys_full && jw_hi <= r_lo) cls = T_LEFT;              // j - i <= 0 everywhere
         else if (keys_full && !a.causal && jw_lo >= r_hi) cls = T_RIGHT;
         if (cls == T_SKIP) { it = it_next; continue; }
