@@ -124,10 +124,17 @@ def attention(
     else:
         k = k.unsqueeze(1)
         v = v.unsqueeze(1)
+    key_mask = mask if context_mask is None else context_mask  # attention.py:144
+    if prefix + "mem_k" in sd:   # attention.py:146-153: learned memories [h, m, d] in front of the keys / values, always visible
+        assert not mqa and cache_k is None
+        mem_k, mem_v = sd[prefix + "mem_k"], sd[prefix + "mem_v"]
+        k = torch.cat([mem_k[None].expand(b, -1, -1, -1), k], dim=-2)
+        v = torch.cat([mem_v[None].expand(b, -1, -1, -1), v], dim=-2)
+        if key_mask is not None:
+            key_mask = F.pad(key_mask, (mem_k.shape[1], 0), value=True)
     j = k.shape[-2]
 
     dots = (q @ k.transpose(-1, -2)) * dh ** -0.5  # b h i j
-    key_mask = mask if context_mask is None else context_mask  # attention.py:144
     allowed = torch.ones(b, 1, n, j, dtype=torch.bool)
     if key_mask is not None:
         allowed = allowed & key_mask[:, None, None, :]

@@ -15,6 +15,10 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# measured on MI355X (profiles/r05_c5_decode_flips.json): the number of decoded tokens (of 16 380) that are not the fp32 oracle's arg-max.
+# Every one of them must be a near-tie (the oracle's second choice within 5e-5 of the largest logit); the bound is the observed count + a
+# margin of 2 for other boxes' rounding, not the 0.2 % the test accepted until round 4.
+MAX_FLIPS = 2
 
 
 def test_c5_decode_4096(dev):
@@ -71,6 +75,16 @@ def test_c5_decode_4096(dev):
             scale = float(lg[t][lg[t] > -1e30].abs().max())
             flips.append((d, t + 1, margin, scale, int(have[t]) == int(top2.indices[1])))
     assert checked >= 4 * (L - 2)
+    # "bit-exact" as a NUMBER: how many of the checked tokens differ from the oracle's arg-max, printed (pytest -s / -rP shows it) and,
+    # when SPN_PROFILE_DIR is set, stored next to the other measurements
+    record = {"config": "C5 greedy render, 4096 notes, batch 1, decode engine", "tokens_checked": checked, "flips": len(flips),
+              "flips_detail": [{"dim": d, "position": t, "top2_margin": m, "largest_logit": sc, "engine_token_is_second_choice": sec}
+                               for d, t, m, sc, sec in flips]}
+    print(f"C5 decode: {len(flips)} of {checked} decoded tokens differ from the fp32 oracle's arg-max")
+    if os.environ.get("SPN_PROFILE_DIR"):
+        import json
+        with open(os.path.join(os.environ["SPN_PROFILE_DIR"], "c5_decode_flips.json"), "w") as fh:
+            json.dump(record, fh, indent=1)
     bad = [f for f in flips if not (f[4] and f[2] <= 5e-5 * f[3] + 1e-6)]
     assert not bad, (len(flips), bad[:10])
-    assert len(flips) <= max(4, checked // 500), (len(flips), checked)   # near-ties are rare: at most 0.2 % of the tokens
+    assert len(flips) <= MAX_FLIPS, (len(flips), checked, flips[:10])

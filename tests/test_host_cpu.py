@@ -78,9 +78,10 @@ def test_synthetic_batch_follows_collator_contract():
 
 def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
-        Attention(dim=64, dim_head=32)
+        Attention(dim=64, dim_head=128)                      # narrower heads run zero-padded (tests/test_attention_options_*.py)
     with pytest.raises(NotImplementedError):
-        Attention(dim=64, num_mem_kv=2)
+        Attention(dim=64, max_attend=8)
+    assert tuple(Attention(dim=64, dim_head=32, num_mem_kv=2).mem_k.shape) == (8, 2, 32)   # attention.py:98-101
     from scoreperformer_amd.models.scoreperformer.embeddings import TupleTokenEmbeddings
     with pytest.raises(ValueError):
         TupleTokenEmbeddings({"A": 8}, 8, mode="mean")

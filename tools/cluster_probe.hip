@@ -13,8 +13,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// VALU mix of the forward's linear tile: fma, max3, exp, add, add_co + cndmask (dropout), cvt_pk, integer hash ops
-__device__ __forceinline__ void valu(int i, float (&r)[16], float c1, float c2) {
+// VALU mix of the forward's linear tile: fma, max3, exp, add, add_co + cndmask (dropout), cvt_pk, integer hash ops.  The index is a
+// TEMPLATE argument: with a run-time index a 250-iteration burst is not unrolled, r[i & 15] becomes a scratch access and every
+// "instruction" a memory round trip (the first version of this probe measured 200 cycles per VALU that way).
+template <int i>
+__device__ __forceinline__ void valu(float (&r)[16], float c1, float c2) {
     float& x = r[i & 15];
     float& y = r[(i + 5) & 15];
     switch (i % 11) {
@@ -32,6 +35,13 @@ __device__ __forceinline__ void valu(int i, float (&r)[16], float c1, float c2) 
     }
 }
 
+template <int I, int N>
+struct Burst {
+    static __device__ __forceinline__ void run(float (&r)[16], float c1, float c2) {
+        if constexpr (I < N) { valu<I>(r, c1, c2); Burst<I + 1, N>::run(r, c1, c2); }
+    }
+};
+
 template <int SHAPE, int V1, int V2>
 __global__ __launch_bounds__(1024) void probe(float* out, int iters, float seedv) {
     f32x16 acc32[4];
@@ -43,26 +53,22 @@ __global__ __launch_bounds__(1024) void probe(float* out, int iters, float seedv
     float r[16];
     for (int i = 0; i < 16; ++i) r[i] = seedv + threadIdx.x * 1e-3f + i;
     const float c1 = 0.999f + seedv, c2 = 0.001f + seedv;
-    // de-synchronise the waves of a SIMD the way independent workgroups are: wave w starts w * 1/3 tile late
-    for (int d = 0; d < (int)(threadIdx.x >> 8) * (V1 + V2) / 3; ++d) valu(d, r, c1, c2);
+    // de-synchronise the waves of a SIMD the way independent workgroups are: wave w starts w thirds of a burst late
+    for (int d = 0; d < (int)(threadIdx.x >> 8); ++d) Burst<0, (V1 + V2) / 3>::run(r, c1, c2);
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            if (SHAPE == 32) {
+            if (SHAPE == 0) {
+            } else if (SHAPE == 32) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc32[m & 3]) : "v"(a), "v"(b));
             } else {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[m & 7]) : "v"(a), "v"(b));
             }
-            if (half == 0) {
-#pragma unroll
-                for (int f = 0; f < V1; ++f) valu(f, r, c1, c2);
-            } else {
-#pragma unroll
-                for (int f = 0; f < V2; ++f) valu(f + 3, r, c1, c2);
-            }
+            if (half == 0) Burst<0, V1>::run(r, c1, c2);
+            else Burst<3, V2 + 3>::run(r, c1, c2);
         }
     }
     long long t1 = __builtin_amdgcn_s_memtime();
@@ -103,5 +109,6 @@ int main(int argc, char** argv) {
     run<16, 200, 60>("fwd diet (260 VALU)"); run<32, 200, 60>("fwd diet (260 VALU)");
     run<16, 120, 60>("bwd-like (180 VALU)"); run<32, 120, 60>("bwd-like (180 VALU)");
     run<16, 0, 0>("MFMA only"); run<32, 0, 0>("MFMA only");
+    run<0, 250, 90>("VALU only (339)"); run<0, 120, 60>("VALU only (180)");
     return 0;
 }
