@@ -146,6 +146,12 @@ __device__ __forceinline__ void spn_dma16(const u32x4 rs, uint32_t lds, uint32_t
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
+// the same without the leading s_nop 4: for call sites whose resource, LDS address and scalar offset all come from SALU instructions
+// (no VALU-written SGPR in reach); M0 is still written one wait state in front of its use
+__device__ __forceinline__ void spn_dma16_lean(const u32x4 rs, uint32_t lds, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
 // two pieces into consecutive KiB of LDS (the second piece's per-lane offset in voff1)
 __device__ __forceinline__ void spn_dma16x2(const u32x4 rs, uint32_t lds, uint32_t voff0, uint32_t voff1, uint32_t soff) {
     asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
