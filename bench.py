@@ -371,6 +371,13 @@ def dp1_forced_leg(args, arena, dev, holder, step, lib_mod, GradSync):
     return out
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the highest round present (stored counter profiles: they need their own rocprofv3 --pmc passes), or None."""
+    import glob
+    found = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_" + suffix)))
+    return found[-1] if found else None
+
+
 def _collect(ops, step, n=2):
     ops.PROFILE.enable()
     for _ in range(n):
@@ -471,19 +478,19 @@ def roofline_leg(ops, step, args):
                            "FFN activation forward and backward live in GEMM epilogues); algorithmic bytes, each operand counted once"}
 
     here = os.path.dirname(os.path.abspath(__file__))
-    hbm_path = os.path.join(here, "profiles", "r04_hbm_traffic.json")
-    if os.path.exists(hbm_path):   # counter bytes / algorithmic bytes of the HBM-bound kernels (tools/pmc_step_traffic.sh: separate --pmc passes)
+    hbm_path = _latest_profile("hbm_traffic.json")
+    if hbm_path:   # counter bytes / algorithmic bytes of the HBM-bound kernels (tools/pmc_step_traffic.sh: separate --pmc passes)
         with open(hbm_path) as fh:
             hj = json.load(fh)
-        elementwise["traffic"] = {"source": "STORED PROFILE profiles/r04_hbm_traffic.json (" + hj.get("measured", "") + "), not re-measured by this run",
+        elementwise["traffic"] = {"source": "STORED PROFILE profiles/" + os.path.basename(hbm_path) + " (" + hj.get("measured", "") + "), not re-measured by this run",
                                   "correction": hj.get("correction"),
                                   "per_kernel": {k: {"counter_bytes_per_launch": v["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
                                                      "counter_over_algorithmic": v["counter_over_algorithmic"]}
                                                  for k, v in hj["kernels"].items() if k.startswith(("ln_", "adaln", "embed_", "attn_", "adamw"))}}
     traffic, traffic_note = None, None
-    for fname in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
-        tpath = os.path.join(here, "profiles", fname)
-        if os.path.exists(tpath):   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
+    for tpath in [_latest_profile("gemm_traffic.json")]:
+        fname = os.path.basename(tpath) if tpath else ""
+        if tpath:   # HBM-side bytes per launch of the top shape from separate rocprofv3 --pmc passes (tools/pmc_traffic.sh)
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic = tj.get("hbm_bytes_per_launch")
@@ -552,13 +559,13 @@ def decode_leg(args, dev):
     cache_bytes = 6 * 2 * 64 * 4 * (L / 2)
     per_note = wbytes + cache_bytes
     traffic = None
-    hbm_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_hbm_traffic.json")
-    if os.path.exists(hbm_path):
+    hbm_path = _latest_profile("hbm_traffic.json")
+    if hbm_path:
         with open(hbm_path) as fh:
             hj = json.load(fh)
         v = hj["kernels"].get("dec_pair_kernel")
         if v:
-            traffic = {"source": "STORED PROFILE profiles/r04_hbm_traffic.json (" + hj.get("measured", "") + ")", "kernel": "dec_pair_kernel",
+            traffic = {"source": "STORED PROFILE profiles/" + os.path.basename(hbm_path) + " (" + hj.get("measured", "") + ")", "kernel": "dec_pair_kernel",
                        "counter_bytes_per_launch": v["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
                        "counter_over_algorithmic": v["counter_over_algorithmic"]}
     return {"traffic": traffic,

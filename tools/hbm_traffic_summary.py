@@ -31,7 +31,8 @@ alg = [
     ("gemm_pp_kernel<false, false, unsigned short, 1, true>", "x operand 134 MB + W1 4 MB read, u 1074 MB + g 537 MB written", 134.2e6 + 4.2e6 + 1073.7e6 + 536.9e6),
     ("adamw_kernel", "30 B per parameter (p, g, m, v read; p, m, v, bf16 copy written; g zeroed): 71.9 M parameters", 71895400 * 30),
 ]
-out = {"measured": "round 4, tools/pmc_step_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, C3 step b=64 n=2048 dropout 0.1, final tree)",
+ROUND = sys.argv[4] if len(sys.argv) > 4 else "round 4"
+out = {"measured": ROUND + ", tools/pmc_step_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, C3 step b=64 n=2048 dropout 0.1, final tree)",
        "correction": "FETCH_SIZE x 2 (gfx950: wide streaming reads tallied at half their bytes, MI355X_MICROARCH.md); WRITE_SIZE as printed; both count Infinity-Cache hits",
        "kernels": {}}
 for name, desc, a in alg:
