@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -192,6 +192,10 @@ int spn_mmd_scalars(const float* sums /* [4] */, int Z, const float* g, float* o
 
 /* ---- optimizer (experiments/optimizers.py:151-169: clip_grad_norm_ + torch.optim.AdamW) over the flat arena */
 int spn_sumsq(const float* g, long n, float* out /* ACCUMULATED */, spn_stream_t s);
+/* the same with a fixed summation order: identical bits for identical g on every launch and every rank (the clip coefficient of
+ * data-parallel replicas must not differ in its last bit).  ws: spn_sumsq_det_ws_floats() floats of caller-owned scratch. */
+int spn_sumsq_det_ws_floats(void);
+int spn_sumsq_det(const float* g, long n, float* out /* ACCUMULATED */, float* ws, spn_stream_t s);
 /* slot_mask: optional uint8 [n / 8], one flag per 8-element arena slot; 0 = the slot's parameter has no gradient this step (frozen or
  * unused: torch.optim.AdamW skips grad-is-None parameters -- no decay, no moments) and is left untouched; null = update everything */
 int spn_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, const uint8_t* slot_mask, long n,

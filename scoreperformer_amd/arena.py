@@ -46,6 +46,7 @@ class ParamArena:
         self.exp_avg_sq = torch.zeros(total, device=device, dtype=F32)
         self.shadow = torch.zeros(total, device=device, dtype=BF16)
         self._normsq = torch.zeros(1, device=device, dtype=F32)
+        self._normsq_ws = None      # scratch of the fixed-order gradient norm (made on first use: the library is loaded by then)
         # torch.optim.AdamW keeps ONE STEP COUNTER PER PARAMETER (bias corrections 1 - beta^own_step): a parameter that is frozen for a
         # while, or unused in some batches (an LM-head key without valid labels), falls behind the others
         self.steps: List[int] = [0] * len(params)
@@ -121,14 +122,24 @@ class ParamArena:
         self.grads.zero_()
 
     def grad_norm_sq(self) -> torch.Tensor:
+        """Sum of squares of the whole gradient arena, summed in a FIXED order: replicas that hold the same (all-reduced) gradient get
+        the same clip coefficient bit for bit and stay identical (a float-atomic sum differs in its last bit from rank to rank)."""
         self._normsq.zero_()
-        return ops.sumsq(self.grads, out=self._normsq)
+        if self._normsq_ws is None:
+            self._normsq_ws = torch.empty(ops.sumsq_ws_floats(), device=self.grads.device, dtype=F32)
+        return ops.sumsq(self.grads, out=self._normsq, ws=self._normsq_ws)
 
     def active_params(self) -> List[bool]:
         """Parameters torch.optim.AdamW would update now: `requires_grad` and a gradient was produced since the last step
         (the reference wraps AdamW over model.parameters(), which skips grad-is-None parameters: frozen by Model.freeze,
         models/base.py:95-102, or unused in the forward -- no weight decay, no moments; experiments/optimizers.py:151-169)."""
         touched = [bool(getattr(p, "_spn_touched", False)) for p in self.param_list]
+        if getattr(self, "all_trainable_active", False):
+            # data-parallel replicas (parallel.GradSync with more than one rank sets this): "was a gradient produced" is a LOCAL fact -- a
+            # key without valid labels in this rank's batch -- while the all-reduced gradient is the same everywhere; replicas that
+            # disagree on which parameters to step diverge.  Every trainable parameter is stepped with the reduced gradient (zero where
+            # no rank produced one: weight decay and moment decay only), with no flag exchange and no host read.
+            touched = [True] * len(touched)
         if not any(touched):   # gradients written into the arena out of band (no backward ran): every trainable parameter has one
             touched = [True] * len(touched)
         return [bool(p.requires_grad and t) for p, t in zip(self.param_list, touched)]

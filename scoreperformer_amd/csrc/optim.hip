@@ -22,6 +22,33 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// The same sum with a FIXED order (round 5): data-parallel replicas clip with the norm of the all-reduced gradient, which is bit-identical on
+// every rank -- but a sum of block partials by float atomicAdd arrives in a different order on every rank and every run, the clip
+// coefficient then differs in its last bit and the replicas drift apart one ulp per step (found by the first two-process run,
+// tests/test_dp_gpu.py).  Pass 1: block b writes its partial to ws[b] (same elements, same order every time); pass 2: ONE wave adds the
+// partials in index order (lane l: b = l, l + 64, ...; then the DPP ladder of wave_sum, the same association for every launch).
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ ws) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long n4 = n / 4;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = g4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[n4 * 4 + threadIdx.x]; acc += v * v; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const float* __restrict__ ws, int nb, float* __restrict__ out) {
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) acc += ws[b];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[0] += acc;
+}
+
 // normsq: device scalar (sum of squares of ALL grads, already reduced across whatever the caller wants);
 // grad_scale multiplies g before clipping (1/world_size for data-parallel sums, 1/loss_scale ...).
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -66,6 +93,19 @@ inline int grid_for(long total, int block = 256) { long g = (total + block - 1) 
 extern "C" int spn_sumsq(const float* g, long n, float* out, hipStream_t s) {
     SPN_REQUIRE(g && out && n > 0 && (((uintptr_t)g) & 15) == 0, "spn_sumsq: bad arguments (16-byte aligned)");
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, n, out);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// out[0] += sum(g^2), the same bits for the same g on every launch and every device (see sumsq_partial_kernel).  ws: caller-owned scratch
+// of spn_sumsq_det_ws_floats() floats.
+extern "C" int spn_sumsq_det_ws_floats(void) { return 2048; }
+extern "C" int spn_sumsq_det(const float* g, long n, float* out, float* ws, hipStream_t s) {
+    SPN_REQUIRE(g && out && ws && n > 0 && (((uintptr_t)g) & 15) == 0, "spn_sumsq_det: bad arguments (16-byte aligned, workspace required)");
+    const int nb = grid_for(n / 4 + 1);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, ws);
+    SPN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, ws, nb, out);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

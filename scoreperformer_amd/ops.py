@@ -784,11 +784,20 @@ def mmd_bwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor, coef: torch.Tenso
 # optimizer
 # ---------------------------------------------------------------------------------------------------------
 
-def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[0] += sum(g^2).  With `ws` (fp32 scratch of `sumsq_ws_floats()` elements): fixed summation order -- the same bits for the same
+    g on every launch and every rank (what the data-parallel clip needs); without: block partials by float atomics."""
     if out is None:
         out = zeros_small(1, g.device)
-    call("spn_sumsq", ptr(g), c_long(g.numel()), ptr(out), stream_ptr())
+    if ws is not None:
+        call("spn_sumsq_det", ptr(g), c_long(g.numel()), ptr(out), ptr(ws), stream_ptr())
+    else:
+        call("spn_sumsq", ptr(g), c_long(g.numel()), ptr(out), stream_ptr())
     return out
+
+
+def sumsq_ws_floats() -> int:
+    return int(load().spn_sumsq_det_ws_floats())
 
 
 def adamw_step(p, g, m, v, shadow, normsq, *, max_norm: float, grad_scale: float, lr: float, betas=(0.9, 0.999), eps=1e-8,

@@ -53,6 +53,8 @@ class GradSync:
             self._knob_before = lib.get_tuning("gemm_persist_bwd")
             self._knob_set = 1.0 if (persistent_backward and not self.active) else 0.0
             lib.set_tuning("gemm_persist_bwd", self._knob_set)
+        if self.active and self.world > 1 and not dry_run:
+            arena.all_trainable_active = True    # see ParamArena.active_params: replicas must agree on the set of parameters they step
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
@@ -183,6 +185,8 @@ class GradSync:
                     if attr in getattr(h, "__dict__", {}):
                         delattr(h, attr)
         self._hooked = []
+        if self.active and self.world > 1 and not self.dry_run and getattr(self.arena, "all_trainable_active", False):
+            self.arena.all_trainable_active = False
         self.active = False
         if self.native is not None:
             self.native.close()

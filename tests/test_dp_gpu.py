@@ -185,3 +185,107 @@ def test_native_comm_allreduce_is_stream_ordered(dev):
             assert float(y.float().min()) == 6.0 and float(y.float().max()) == 6.0
     finally:
         comm.close()
+
+
+def _two_process_worker(rank, world, port, q):
+    """One of two REAL processes sharing the box's GPU: the bench's own step (GradSync.begin_step / forward / backward with the bucketed
+    all-reduce launched from inside backward / finish / FusedAdamW with grad_scale = 1 / world) over a gloo group -- gloo reduces CUDA
+    tensors through the host, so two ranks can run on one device, which RCCL refuses."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.weights import filled_state_dict
+        from scoreperformer_amd.arena import ParamArena, FusedAdamW
+        from scoreperformer_amd.models import ScorePerformer
+        from scoreperformer_amd.parallel import GradSync
+        from scoreperformer_amd.synthetic import model_config, synthetic_batch
+
+        def fresh():
+            model = ScorePerformer.init(model_config("tiny", dropout=0.0))
+            model.load_state_dict(filled_state_dict(model, seed=5))
+            arena = ParamArena(model, dev)
+            model.train()
+            return model, arena
+
+        batch = synthetic_batch(2, 64, seed=40 + rank, ragged=True, device=dev, with_bounds=True)   # every rank its own batch
+        z = [torch.randn(256, d, generator=torch.Generator().manual_seed(7 * rank + i)).to(dev) for i, d in enumerate((32, 20, 8, 4))]
+        # this rank's own gradient, no synchronisation
+        model, arena = fresh()
+        model.perf_encoder._z_override = z
+        model(**batch).loss.backward()
+        local = arena.grads.clone()
+        # the data-parallel step
+        model, arena = fresh()
+        model.perf_encoder._z_override = z
+        opt = FusedAdamW(arena, lr=1e-3, weight_decay=0.0, grad_clip=1.0)
+        sync = GradSync(arena, dist.group.WORLD, bucket_mb=0.05, transport="torch")
+        assert sync.active and sync.world == 2 and len(sync.buckets) >= 3
+        sync.begin_step()
+        out = model(**batch)
+        out.loss.backward()
+        during = len(sync.launched)                     # buckets that left while backward was still running
+        sync.finish()
+        assert len(sync.launched) == len(sync.buckets)
+        reduced = arena.grads.clone()
+        active = arena.active_params()
+        assert all(a or not p_.requires_grad for a, p_ in zip(active, arena.param_list))   # replicas step the same parameter set
+        opt.step(grad_scale=1.0 / world)
+        for _ in range(4):                              # four more steps: the replicas must not drift (fixed-order gradient norm)
+            sync.begin_step()
+            model(**batch).loss.backward()
+            sync.finish()
+            opt.step(grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        # both ranks' local gradients, to rank 0's check
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = gathered[0] + gathered[1]
+        err = float((reduced - want).abs().max() / want.abs().max())
+        params = arena.params.clone()
+        plist = [torch.empty_like(params) for _ in range(world)]
+        dist.all_gather(plist, params)
+        rl = [torch.empty_like(reduced) for _ in range(world)]
+        dist.all_gather(rl, reduced)
+        diff = (plist[0] - plist[1]).abs()
+        bad = [(arena.names[i], float(diff[o:o + p_.numel()].max())) for i, (p_, o) in enumerate(zip(arena.param_list, arena.offsets))
+               if float(diff[o:o + p_.numel()].max()) > 0]
+        print(f"rank {rank}: reduced grads equal across ranks: {bool(torch.equal(rl[0], rl[1]))}; inactive here: "
+              f"{[arena.names[i] for i, a in enumerate(active) if not a]}; differing parameters: {bad[:8]}", flush=True)
+        q.put((rank, err, during, len(sync.buckets), bool(torch.equal(plist[0], plist[1])), float(out.loss.detach())))
+        sync.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_run_the_data_parallel_step_over_gloo():
+    """The first data-parallel run with MORE THAN ONE RANK and the real kernels: two processes on this box's GPU (gloo carries the CUDA
+    buckets; RCCL cannot put two ranks on one device).  Every rank's arena ends with the SUM of the two local gradients (2e-5: split-K
+    and scatter atomics reorder sums between the two runs of a rank), buckets leave while backward is still running, and after the
+    optimizer step (1 / world folded into the kernel) both ranks hold bit-identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_process_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, err, during, nb, same, loss in res:
+        assert err <= 2e-5, (rank, err)
+        assert 0 < during <= nb, (rank, during, nb)      # some buckets were launched from inside backward
+        assert same, "ranks diverged after the optimizer step"
+        assert loss == loss
+    assert res[0][5] != res[1][5]                        # (the two ranks really saw different batches)

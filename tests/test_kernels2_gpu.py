@@ -490,3 +490,31 @@ def test_exact_fp32_gemm_all_tile_shapes(M, N, K, ta, tb):
         mask = (torch.rand(M, generator=g) < 0.7).to(DEV)
         out = ops.gemm_f32(a, b, ta=ta, tb=tb, bias=bias, rowmask=mask)
         assert float((out.double() - (ref + bias.double()) * mask[:, None].double()).abs().max()) < tol
+
+
+def test_gradient_norm_has_a_fixed_summation_order():
+    """`spn_sumsq_det` (the clip's gradient norm): the same bits for the same gradient on every launch -- data-parallel replicas hold the
+    same all-reduced gradient and must get the same clip coefficient, or they drift apart an ulp per step (found by the first two-process
+    run, tests/test_dp_gpu.py).  72 M elements, 40 launches: one distinct result, equal to the fp64 sum to 1e-6; the float-atomic
+    version is checked to the same accuracy only (its bits do vary)."""
+    from scoreperformer_amd import ops
+    g = torch.randn(71895400, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2)) * 1e-2
+    ws = torch.empty(ops.sumsq_ws_floats(), device="cuda")
+    got = set()
+    for _ in range(40):
+        out = torch.zeros(1, device="cuda")
+        ops.sumsq(g, out=out, ws=ws)
+        got.add(out.view(torch.int32).item())
+    assert len(got) == 1, got
+    want = float(g.double().pow(2).sum())
+    val = torch.tensor([got.pop()], dtype=torch.int32).view(torch.float32).item()
+    assert abs(val - want) <= 1e-6 * want
+    out = torch.ones(1, device="cuda")
+    ops.sumsq(g, out=out, ws=ws)                      # accumulates onto what is there
+    assert abs(out.item() - (1.0 + want)) <= 1e-6 * want
+    out = torch.zeros(1, device="cuda")
+    ops.sumsq(g[: 1000003], out=out)                  # atomic version, ragged length
+    assert abs(out.item() - float(g[: 1000003].double().pow(2).sum())) <= 1e-5 * float(g[: 1000003].double().pow(2).sum())
+    out = torch.zeros(1, device="cuda")
+    ops.sumsq(g[: 1000000], out=out, ws=ws)           # fixed-order version on a short, 16-byte aligned slice
+    assert abs(out.item() - float(g[: 1000000].double().pow(2).sum())) <= 1e-6 * float(g[: 1000000].double().pow(2).sum())
