@@ -40,6 +40,10 @@ def parse():
                     help="seconds the native communicator's collective start-up (id broadcast, ncclCommInitRank, probe all-reduce) may take "
                          "before this rank prints a message and EXITS with status 3 (a hung ncclCommInitRank cannot be cancelled; the "
                          "launcher then ends the other ranks)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="test aid: gloo carries CUDA tensors through the host, so the whole N > 1 path of this file can run with several "
+                         "ranks on ONE GPU (with --one-device; RCCL refuses two ranks on a device).  Numbers from it mean nothing")
+    ap.add_argument("--one-device", action="store_true", help="test aid: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dp1-forced", action="store_true", help="skip the N = 1 `dp1_forced` object (cost of gemm_persist_bwd = 0 and of "
                     "the bucketed all-reduce on a one-rank group, measured after the timed region)")
@@ -124,6 +128,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.one_device:
+        if args.dist_backend != "gloo":
+            raise SystemExit("--one-device needs --dist-backend gloo (RCCL cannot put two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -132,7 +140,10 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from scoreperformer_amd import build as spn_build
     if rank == 0:
@@ -199,12 +210,14 @@ def main():
         "metric": "score-tokens/sec (train step: fwd+bwd+grad all-reduce+clip+AdamW), whole job", "value": value,
         "unit": "note-tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"C3 ScorePerformer train step: 6/6/6 layers d=512 h=8 MQA GLU-SiLUx4, MMD-VAE style encoder, "
+        "config": {"workload": (f"C3 ScorePerformer train step: 6/6/6 layers d=512 h=8 MQA GLU-SiLUx4" if args.preset == "c3" else
+                                f"preset `{args.preset}` (NOT the benchmark configuration) ScorePerformer train step") + ", MMD-VAE style encoder, "
                                f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel), "
                                f"latent dropout {list(cfg.perf_encoder.latent_dropout)} inclusive (recipes/scoreperformer/base.yaml:119-126)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss,
                    "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
+                   "dist_backend": (args.dist_backend + (" on ONE device: a test run, not a measurement" if args.one_device else "")) if dist is not None else None,
                    "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
                    # the two default approximations inside the 1e-3 parity budget (tests/test_parity_c2_gpu.py holds both settings to it)
                    "numerics": {"latent_dropout": list(cfg.perf_encoder.latent_dropout), "inclusive_latent_dropout": bool(cfg.perf_encoder.inclusive_latent_dropout),

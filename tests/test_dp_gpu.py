@@ -289,3 +289,28 @@ def test_two_processes_on_one_gpu_run_the_data_parallel_step_over_gloo():
         assert same, "ranks diverged after the optimizer step"
         assert loss == loss
     assert res[0][5] != res[1][5]                        # (the two ranks really saw different batches)
+
+
+def test_bench_runs_with_two_ranks_on_one_gpu_over_gloo():
+    """bench.py's own N > 1 path end to end -- launcher environment, process group, replicas from one seed, per-rank batches, the bucketed
+    all-reduce from inside backward, max-over-ranks timing, the instrumented roofline steps on every rank, rank 0's ONE JSON line, an
+    orderly shutdown -- with two ranks on this box's GPU (`--dist-backend gloo --one-device`: test aids; RCCL itself needs a device per
+    rank and is first exercised by the driver's scaling run).  Tiny model, short sequences: the numbers mean nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--standalone", "--local-addr", "127.0.0.1",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preset", "tiny", "--batch", "4", "--seq", "256",
+           "--dist-backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 alone prints, and prints one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["dp_transport"] == "torch" and d["config"]["gemm_persist_bwd"] == 0     # no persistent backward walk under an all-reduce
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and abs(d["value"] - 2 * 4 * 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "roofline" in d and "cpu_baseline" not in d and "dp1_forced" not in d              # N = 1 objects stay out of an N > 1 line
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]
