@@ -1331,6 +1331,180 @@ __global__ __launch_bounds__(256, 1) void gemm_ow_kernel(GemmArgs g) {
 #undef OW_PIN
 }
 
+// ---- the same kernel with REGISTER-staged operands (round 5, second attempt) -------------------------------------------------------
+// gemm_ow_kernel loses to the ping-pong kernel because a lone wave issues in order and one LDS-DMA instruction holds its issue port for
+// ~60 cycles -- twice the shadow of an MFMA.  The vendor library's fastest kernel on 8192^3 has this very shape (four waves, 128x128 wave
+// tiles) and stages through REGISTERS: buffer_load_dwordx4 into VGPRs and ds_write_b128 later are both short instructions.  Same here:
+// per K tile of 32 a wave issues 8 global loads (tile t + 3, into the register set tile t + 1 has just left), 8 LDS writes (tile
+// t + 1, loaded one and a half K tiles earlier), 16 fragment reads and 32 MFMAs, one of each kind per {2 MFMA} group.  Two LDS stages
+// suffice (tile t + 1 is written while tile t's second k step is read; 64 KiB), the barrier of a K tile sits between its two MFMA
+// blocks as before, and every wait is the compiler's own (plain loads and stores: hipcc counts vmcnt / lgkmcnt itself).
+// Same LDS images as gemm_ow_kernel (a lane writes the 16 bytes the DMA would have written for it), same tile order / split plan / epilogue.
+constexpr int OWR_LDS_BYTES = 2 * 4 * OW_HALF + 4 * 8192;
+
+template <bool TA, bool TB, typename OutT>
+__global__ __launch_bounds__(256, 1) void gemm_owr_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int nwg = g.tx * g.ty;
+    int first = blockIdx.y * gridDim.x + blockIdx.x, zid = blockIdx.z;
+    if (g.slice_xcd) {
+        const int L = first + nwg * (int)blockIdx.z;
+        zid = (L & 7) + 8 * (L / (8 * nwg));
+        first = (L >> 3) % nwg;
+    }
+    int m0, n0;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = first & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (first >> 3);
+        const int G = g.ngroup, mt = g.ty, per = G * mt;
+        const int c = wg / per, within = wg - c * per;
+        const int gw = min(G, g.tx - c * G);
+        m0 = (within / gw) * PP_BM;
+        n0 = (c * G + within % gw) * PP_BN;
+    }
+    const bool split = g.splitk > 1;
+    const bf16_t* A = g.A + (split ? 0 : (long)zid * g.sA);
+    const bf16_t* B = g.B + (split ? 0 : (long)zid * g.sB);
+    const int nt_all = g.K / OW_BK;
+    const int t_begin = split ? zid * g.kt_per_split : 0;
+    const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
+    if (nt <= 0 || first >= nwg) return;
+    const int kbase = t_begin * OW_BK;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    uint32_t vo[4][2];   // [kind: A lo, A hi, B lo, B hi][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vo[0][i] = ow_voffset<TA>(g.lda, m0, g.M, wave, lane, i);
+        vo[1][i] = ow_voffset<TA>(g.lda, m0 + 128, g.M, wave, lane, i);
+        vo[2][i] = ow_voffset<TB>(g.ldb, n0, g.N, wave, lane, i);
+        vo[3][i] = ow_voffset<TB>(g.ldb, n0 + 128, g.N, wave, lane, i);
+    }
+    const uint32_t kstepA = TA ? (uint32_t)OW_BK * g.lda * 2u : (uint32_t)OW_BK * 2u;
+    const uint32_t kstepB = TB ? (uint32_t)OW_BK * g.ldb * 2u : (uint32_t)OW_BK * 2u;
+    const uint32_t kbaseA = TA ? (uint32_t)kbase * g.lda * 2u : (uint32_t)kbase * 2u;
+    const uint32_t kbaseB = TB ? (uint32_t)kbase * g.ldb * 2u : (uint32_t)kbase * 2u;
+    u32x4 R[2][8];   // [tile parity][2 * kind + piece]: this lane's 16 bytes of each of its 8 pieces of a K tile
+    auto gload = [&](int par, int x, int t) __attribute__((always_inline)) {   // par, x compile-time
+        const int c = x >> 1, i = x & 1;
+        const bool isA = c < 2;
+        const uint32_t soff = isA ? kbaseA + (uint32_t)t * kstepA : kbaseB + (uint32_t)t * kstepB;
+        R[par][x] = __builtin_amdgcn_raw_buffer_load_b128(isA ? rsA : rsB, (int)vo[c][i], (int)soff, 0);
+    };
+    char* wlane = smem + wave * 2048 + lane * 16;   // + (stage * 4 + kind) * OW_HALF + piece * 1024
+    auto lwrite = [&](int par, int x, int stage) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(wlane + (stage * 4 + (x >> 1)) * OW_HALF + (x & 1) * 1024) = R[par][x];
+    };
+#define OW_PIN() __builtin_amdgcn_sched_barrier(0)
+#define OWR_A(t_) (smem + (((t_) & 1) * 4 + wr) * OW_HALF)
+#define OWR_B(t_) (smem + (((t_) & 1) * 4 + 2 + wc) * OW_HALF)
+    // prologue: tiles 0 and 1 into the two register sets, tile 0 into stage 0, tile 2 into the freed set (nt >= 8)
+#pragma unroll
+    for (int x = 0; x < 8; ++x) gload(0, x, 0);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) gload(1, x, 1);
+    f32x16 accL[4][2], accR[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
+#pragma unroll
+    for (int x = 0; x < 8; ++x) lwrite(0, x, 0);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) gload(0, x, 2);
+    __syncthreads();
+    bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[0][i] = ow_read_frag<TA>(OWR_A(0), 32 * i, 0, lane); fb[0][i] = ow_read_frag<TB>(OWR_B(0), 32 * i, 0, lane); }
+    auto mfma_pair = [&](int cur, int idx) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 2 * idx; m < 2 * idx + 2; ++m) {
+            const int i = m >> 2, j = m & 3;
+            if (j < 2) accL[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accL[i][j], 0, 0, 0);
+            else accR[i][j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accR[i][j - 2], 0, 0, 0);
+        }
+    };
+    // one K tile; PAR = its parity (register set and LDS stage are compile-time), MODE 0: steady (tile t + 3 exists), 1: tiles t + 1 .. exist
+    // but t + 3 does not, 2: the last tile
+#ifdef SPN_GEMM_TIMING
+    long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_amdgcn_s_memtime();
+    const long long t_start = tprev;
+#endif
+    auto ktile = [&](auto par_c, auto mode_c, const int t) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value, MODE = decltype(mode_c)::value;
+        constexpr bool MORE = MODE != 2, REFILL = MODE == 0;
+        const char* a_t = OWR_A(PAR);
+        const char* b_t = OWR_B(PAR);
+        TSTAMP(3);
+        // ---- block 0: k step 0 of tile t; reads its k step 1; writes tile t + 1 (register set PAR ^ 1) into stage PAR ^ 1 ----
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            mfma_pair(0, x);
+            if (x < 4) { fb[1][x] = ow_read_frag<TB>(b_t, 32 * x, 1, lane); fa[1][x] = ow_read_frag<TA>(a_t, 32 * x, 1, lane); }
+            if (MORE) lwrite(PAR ^ 1, x, PAR ^ 1);
+            if (REFILL) gload(PAR ^ 1, x, t + 3);   // into the register the write above has just read: two whole K tiles of lead
+            OW_PIN();
+        }
+        TSTAMP(0);
+        if (MORE) __syncthreads();   // tile t + 1 is in LDS for everybody; everybody's reads of tile t have returned
+        OW_PIN();
+        TSTAMP(1);
+        const char* a_n = OWR_A(PAR ^ 1);
+        const char* b_n = OWR_B(PAR ^ 1);
+        // ---- block 1: k step 1 of tile t; reads k step 0 of tile t + 1; requests tile t + 3 into the register set tile t + 1 has left ----
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            mfma_pair(1, x);
+            if (MORE && x < 4) { fb[0][x] = ow_read_frag<TB>(b_n, 32 * x, 0, lane); fa[0][x] = ow_read_frag<TA>(a_n, 32 * x, 0, lane); }
+            OW_PIN();
+        }
+        TSTAMP(2);
+    };
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        // nt = K / 32 is even (K is a multiple of 64) and >= 8: steady pairs up to tile nt - 5, then the fixed four-tile tail
+        int t = 0;
+        for (; t <= nt - 6; t += 2) { ktile(I0{}, I0{}, t); ktile(I1{}, I0{}, t + 1); }
+        ktile(I0{}, I0{}, nt - 4);    // requests the last tile
+        ktile(I1{}, I1{}, nt - 3);
+        ktile(I0{}, I1{}, nt - 2);
+        ktile(I1{}, I2{}, nt - 1);
+    }
+#undef OWR_A
+#undef OWR_B
+#ifdef SPN_GEMM_TIMING
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 3) && lane == 0) {
+        for (int k = 0; k < 8; ++k) g.dbg[(wave ? 8 : 0) + k] = seg[k];
+        if (wave == 0) g.dbg[16] = __builtin_amdgcn_s_memtime() - t_start;
+    }
+#endif
+    GemmKernargPtr gk = (GemmKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(gk));
+    const GemmArgs ge = kernarg_copy(gk);
+    OutT* C = reinterpret_cast<OutT*>(ge.C) + (long)zid * ge.sC;
+    const bool lead = !split || zid == 0;
+    char* stg = smem + 2 * 4 * OW_HALF + wave * 8192;
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int wcx = 2 * wc + half;
+        f32x4 bv[8];
+#pragma unroll
+        for (int jq = 0; jq < 8; ++jq) {
+            const int bn = min(n0 + wcx * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, ge.N - 4);
+            bv[jq] = (ge.bias && lead) ? *reinterpret_cast<const f32x4*>(ge.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pp_store_tile<OutT, 0>(ge, half ? accR : accL, bv, C, lead, m0, n0, wr, wcx, lane, stg, smem + wave * 16384);
+    }
+#undef OW_PIN
+}
+
 // ---- 256x128 "duo" kernel: TWO independent 4-wave workgroups per CU -----------------------------------------------------
 // The projections with d_model = 512 on the contraction side (K = 512: 8 K-tiles of 64) spend a third of a 256x256 tile's life in the
 // prologue (first DMA latency) and the epilogue (128-256 KiB of C per CU through a 64 B/clk store path) with the matrix pipe idle, and
@@ -1838,15 +2012,21 @@ int launch_ow(GemmArgs g, hipStream_t stream) {
         g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
     }
     g.kt_per_split *= PP_BK / OW_BK;
-    static std::atomic<unsigned> optin{0};
-    spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_ow_kernel<TA, TB, OutT>), OW_LDS_BYTES);
     dim3 grid(cdiv(g.N, PP_BN), cdiv(g.M, PP_BM), g.splitk > 1 ? g.splitk : g.batch);
     g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
     if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
     g.tx = grid.x; g.ty = grid.y;
     g.slice_xcd = (spn_tune_i(SPN_TUNE_GEMM_SLICE_XCD) && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
     g.stagger = 0;
-    hipLaunchKernelGGL((gemm_ow_kernel<TA, TB, OutT>), grid, dim3(256), OW_LDS_BYTES, stream, g);
+    if (spn_tune_i(SPN_TUNE_GEMM_OW) >= 3) {   // register-staged operands
+        static std::atomic<unsigned> optin_r{0};
+        spn_lds_optin(optin_r, reinterpret_cast<const void*>(&gemm_owr_kernel<TA, TB, OutT>), OWR_LDS_BYTES);
+        hipLaunchKernelGGL((gemm_owr_kernel<TA, TB, OutT>), grid, dim3(256), OWR_LDS_BYTES, stream, g);
+    } else {
+        static std::atomic<unsigned> optin{0};
+        spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_ow_kernel<TA, TB, OutT>), OW_LDS_BYTES);
+        hipLaunchKernelGGL((gemm_ow_kernel<TA, TB, OutT>), grid, dim3(256), OW_LDS_BYTES, stream, g);
+    }
     SPN_LAUNCH_CHECK();
     finish_split(g, plan, stream);
     SPN_LAUNCH_CHECK();
@@ -1936,7 +2116,8 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     if (variant == 9 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
     {
         const int ow = spn_tune_i(SPN_TUNE_GEMM_OW);
-        if (variant == 0 && ow && pp_eligible(g) && (ow >= 2 || ow_preferred(g))) return launch_ow<TA, TB, OutT>(g, stream);
+        // 1 / 2: LDS-DMA variant where preferred / everywhere; 3 / 4: register-staged variant where preferred / everywhere
+        if (variant == 0 && ow && pp_eligible(g) && (ow == 2 || ow == 4 || ow_preferred(g))) return launch_ow<TA, TB, OutT>(g, stream);
     }
     // measured (tools/bench_gemm.py): with the LDS-staged epilogue the 256x256 ping-pong kernel wins on every shape it can take
     if (variant == 0 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);

@@ -1,5 +1,5 @@
-"""GPU: the one-wave-per-SIMD GEMM kernel (csrc/gemm.hip gemm_ow_kernel: four waves per 256x256 tile, 128x128 wave tiles, K tile 32,
-four K tiles in a 16-slot LDS ring) against fp32 torch products of the same bf16 operands AND bit for bit against the ping-pong kernel
+"""GPU: the one-wave-per-SIMD GEMM kernels (csrc/gemm.hip: four waves per 256x256 tile, 128x128 wave tiles, K tile 32; gemm_ow_kernel with
+LDS-DMA operands in a 16-slot ring = knob 2, gemm_owr_kernel with register-staged operands and two LDS stages = knob 4) against fp32 torch products of the same bf16 operands AND bit for bit against the ping-pong kernel
 (same 16-wide k steps in the same order, same split-K plan, same epilogue: every output element sees the same sequence of roundings)."""
 import pytest
 import torch
@@ -20,10 +20,11 @@ def knob():
     lib.set_tuning("gemm_ow", before)
 
 
+@pytest.mark.parametrize("kv", [2, 4])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (512, 768, 1088), (1024, 512, 64 * 37), (4088, 640, 512), (392, 648, 320),
                                    (136, 1160, 256), (2048, 512, 4096)])
-def test_ow_kernel_layouts_edges_and_bit_identity(dev, knob, ta, tb, M, N, K):
+def test_ow_kernel_layouts_edges_and_bit_identity(dev, knob, kv, ta, tb, M, N, K):
     from scoreperformer_amd import ops
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     a = torch.randn(M, K, generator=g).to(dev).bfloat16()
@@ -32,14 +33,15 @@ def test_ow_kernel_layouts_edges_and_bit_identity(dev, knob, ta, tb, M, N, K):
     a_store = a.t().contiguous() if ta else a
     b_store = b if tb else b.t().contiguous()
     outs = {}
-    for v in (0, 2):
+    for v in (0, kv):
         knob(v)
         outs[v] = (ops.gemm(a_store, b_store, ta=ta, tb=tb, out_dtype=torch.float32), ops.gemm(a_store, b_store, ta=ta, tb=tb, out_dtype=torch.bfloat16))
-    assert rel_err(outs[2][0], ref) < 2e-3 and rel_err(outs[2][1], ref) < 1e-2
-    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert rel_err(outs[kv][0], ref) < 2e-3 and rel_err(outs[kv][1], ref) < 1e-2
+    assert torch.equal(outs[0][0], outs[kv][0]) and torch.equal(outs[0][1], outs[kv][1])
 
 
-def test_ow_kernel_epilogues_and_split_k(dev, knob):
+@pytest.mark.parametrize("kv", [2, 4])
+def test_ow_kernel_epilogues_and_split_k(dev, knob, kv):
     from scoreperformer_amd import ops
     g = torch.Generator().manual_seed(5)
     M, N, K = 768, 512, 320
@@ -53,7 +55,7 @@ def test_ow_kernel_epilogues_and_split_k(dev, knob):
     dy = torch.randn(T, 512, generator=g).to(dev).bfloat16()
     x = torch.randn(T, 256, generator=g).to(dev).bfloat16()
     got = {}
-    for v in (0, 2):
+    for v in (0, kv):
         knob(v)
         out = ops.gemm(a, w, out_dtype=torch.float32, bias=bias, residual=res, rowmask=mask, alpha=0.5)
         out16 = ops.gemm(a, w, out_dtype=torch.bfloat16, bias=bias)
@@ -61,21 +63,22 @@ def test_ow_kernel_epilogues_and_split_k(dev, knob):
         acc = torch.ones(512, 256, device=dev)
         ops.gemm(dy, x, ta=True, tb=True, out=acc, accumulate=True)
         got[v] = (out, out16, dw, acc)
-    out, out16, dw, acc = got[2]
+    out, out16, dw, acc = got[kv]
     assert rel_err(out, ref) < 2e-3
     assert rel_err(out16, a.float() @ w.float().t() + bias) < 1e-2
     assert rel_err(dw, dy.float().t() @ x.float()) < 2e-3
     assert rel_err(acc, 1 + dy.float().t() @ x.float()) < 2e-3
-    for p, q in zip(got[0], got[2]):
+    for p, q in zip(got[0], got[kv]):
         assert torch.equal(p, q)
 
 
-def test_ow_kernel_random_shape_screen(knob):
+@pytest.mark.parametrize("kv", [2, 4])
+def test_ow_kernel_random_shape_screen(knob, kv):
     """tools/stress_gemm.py (random shapes, every layout, full-tensor comparison) with the kernel forced wherever it is eligible."""
     import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("stress_gemm", os.path.join(root, "tools", "stress_gemm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    knob(2)
+    knob(kv)
     assert mod.run(60, 11, verbose=False) == 0

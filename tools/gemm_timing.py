@@ -11,6 +11,8 @@ LDA, LDB = E("LDA", M if TA else K), E("LDB", N if TB else K)
 a = torch.randn((K, M) if TA else (M, K), device=dev).bfloat16(); b = torch.randn((K, N) if TB else (N, K), device=dev).bfloat16()
 c = torch.empty(M, N, device=dev, dtype=torch.float32 if F32 else torch.bfloat16)
 dbg = torch.zeros(32, device=dev, dtype=torch.int64)
+if os.environ.get("OW"):   # one-wave-per-SIMD kernels: segments are block 0 / wait + barrier / block 1 / loop overhead per K tile of 32
+    lib.spn_set_tuning(b"gemm_ow", ctypes.c_double(float(os.environ["OW"])))
 if hasattr(lib, "spn_gemm_set_debug"):
     lib.spn_gemm_set_debug(ctypes.c_void_p(dbg.data_ptr()))
 P = ctypes.c_void_p
@@ -33,6 +35,12 @@ if FLAGS == 0 and LDA == K and LDB == K:
     print("relerr", f"{err:.2e} {err2:.2e}", "OK" if max(err, err2) < 1e-2 else "WRONG")
 print(f"{os.environ.get('LIB', '')} M={M} N={N} K={K}: {ms:.3f} ms {2.0*M*N*K/ms/1e9:.0f} TF/s")
 names = ["ds_read issue", "dma issue", "vmcnt wait", "barrier A", "lgkm wait", "mfma", "barrier B", "-"]
+if os.environ.get("OW"):
+    d = dbg.cpu().tolist(); nt = K // 32
+    for w, off in ((0, 0), (3, 8)):
+        print(f"wave {w}: per K tile of 32: block 0 {d[off]/nt:.0f}  lgkmcnt(0)+barrier {d[off+1]/nt:.0f}  block 1 {d[off+2]/nt:.0f}  between tiles {d[off+3]/nt:.0f}   (32 MFMAs = 1024 cycles of matrix pipe)")
+    print(f"main loop total {d[16]} cycles for {nt} K tiles = {d[16]/nt:.0f} per tile")
+    sys.exit(0)
 d = dbg.cpu().tolist(); ph = 4 * K // 64
 print(f"block (0,0): prologue + main loop {d[16]} cycles, epilogue (stores acknowledged) {d[17]} cycles")
 for g in range(2):
