@@ -286,9 +286,14 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         self.pad_token_id, self.mask_token_id, self.num_special_tokens = pad_token_id, mask_token_id, num_special_tokens
 
     def _engine_for(self, filled: Tensor, mask: Tensor, caches, banned, filter_logits_fn, filter_kwargs):
-        """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, one sequence, fresh caches, no padding."""
-        usable = (filled.is_cuda and filled.shape[0] == 1 and caches is None and not banned
+        """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, fresh caches, no padding -- one sequence, or
+        (round 5) several with the SAME layout of MASK sub-tokens, which is what the reference's loop assumes anyway (it takes the layout of
+        batch element 0 for all, wrappers.py:385-396): the sequences then go through the engine one after the other."""
+        usable = (filled.is_cuda and caches is None and not banned
                   and is_greedy(filter_logits_fn, filter_kwargs) and getattr(self, "use_decode_engine", True) and bool(mask.all()))
+        if usable and filled.shape[0] > 1:
+            holes = filled == self.mask_token_id
+            usable = bool((holes == holes[:1]).all())
         if not usable:
             return None
         try:
@@ -298,6 +303,20 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
             return GreedyDecoder(self.model, filled.shape[1], reference_compat=bool(getattr(self, "reference_compat", False)))
         except NotImplementedError:
             return None
+
+    @staticmethod
+    def _stack_caches(per_seq):
+        """Caches of single-sequence engine runs -> one TupleTransformerCaches with the batch in front (the reference's layout)."""
+        from .transformer import TupleTransformerCaches
+        from ...modules.transformer.attend import AttentionIntermediates
+        from ...modules.transformer.transformer import TransformerIntermediates
+        first = per_seq[0]
+        hid = [torch.cat([c.transformer.hiddens[i] for c in per_seq], dim=0) for i in range(len(first.transformer.hiddens))]
+        att = [AttentionIntermediates(keys=torch.cat([c.transformer.attention[i].keys for c in per_seq], dim=0),
+                                      values=torch.cat([c.transformer.attention[i].values for c in per_seq], dim=0))
+               for i in range(len(first.transformer.attention))]
+        return TupleTransformerCaches(token_emb=torch.cat([c.token_emb for c in per_seq], dim=0),
+                                      transformer=TransformerIntermediates(hiddens=hid, attention=att))
 
     @torch.inference_mode()
     def unmask_tokens(self, tokens: Tensor, tokens_masked, temperature: float = 1., filter_logits_fn: Callable = top_k,
@@ -310,10 +329,24 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         with _decode_call(self, tokens, tokens_masked, mask=kwargs.pop("mask", None)) as call:
             filled, masked_view = call.arrays[0].clone().detach(), call.arrays[1]
             engine = self._engine_for(filled, call.mask, caches, banned, filter_logits_fn, filter_kwargs)
-            if engine is not None:
+            if engine is not None and filled.shape[0] == 1:
                 filled, _ = engine.run(filled, masked_view, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id,
                                        context_mask=kwargs.get("context_mask"))
                 caches = engine.caches() if return_caches else None
+            elif engine is not None:       # several sequences with one MASK layout: one engine run each
+                pick = lambda t, i: None if t is None else t[i:i + 1]   # noqa: E731
+                rows, per_seq = [], []
+                for i in range(filled.shape[0]):
+                    row, _ = engine.run(filled[i:i + 1], masked_view[i:i + 1], pick(kwargs.get("context"), i), pick(kwargs.get("style_embeddings"), i),
+                                        self.mask_token_id, context_mask=pick(kwargs.get("context_mask"), i))
+                    rows.append(row.clone())
+                    if return_caches:    # the engine's buffers are overwritten by the next sequence
+                        c = engine.caches()
+                        per_seq.append(type(c)(token_emb=c.token_emb.clone(), transformer=type(c.transformer)(
+                            hiddens=[h.clone() for h in c.transformer.hiddens],
+                            attention=[type(a)(keys=a.keys.clone(), values=a.values.clone()) for a in c.transformer.attention])))
+                filled = torch.cat(rows, dim=0)
+                caches = self._stack_caches(per_seq) if return_caches else None
             else:
                 holes = filled == self.mask_token_id
                 holes_host = holes[0].cpu()   # ONE host read of the mask layout per window (the reference reads it per note: :385-390)

@@ -567,3 +567,76 @@ def test_latent_dropout_own_draws(dev):
     with torch.no_grad():
         ev = model(**batch).perf_encoder
     assert ev.dropout_mask is None and ev.embeddings is ev.full_embeddings or bool((ev.embeddings == ev.full_embeddings).all())
+
+
+def test_decode_engine_serves_a_batch_of_sequences_with_one_mask_layout(dev):
+    """`unmask_tokens` with b > 1 (the reference's loop takes the MASK layout of batch element 0 for every sequence, wrappers.py:385-396):
+    un-padded sequences with one layout go through the fp32 decode engine one after the other.  Row 0 is the reference's own fixture and
+    must come out token for token; every row equals its own single-sequence engine call bit for bit (tokens AND caches, in the reference's
+    batch-first layouts); the CPU oracle's greedy loop confirms a perturbed row; padded batches, or rows with different layouts, still
+    take the module path."""
+    from oracle import ref_cpu
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd import decode
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.modules.sampling import top_k
+    from scoreperformer_amd.synthetic import model_config
+    fix = dict(np.load(os.path.join(GOLD, "tiny_greedy.npz"), allow_pickle=False))
+    cfg = model_config(preset="tiny", num_tokens=SMALL_VOCAB)
+    model = ScorePerformer.init(model_config(preset="tiny", num_tokens=SMALL_VOCAB))
+    sd = filled_state_dict(model, seed=3)
+    model.load_state_dict(sd)
+    ParamArena(model, dev)
+    model.eval()
+    tokens = torch.from_numpy(fix["in/tokens"])
+    masked = torch.from_numpy(fix["in/masked_perf"])
+    ctx = torch.from_numpy(fix["out/score_embeddings"])
+    sty = torch.from_numpy(fix["out/perf_embeddings"])
+    g = torch.Generator().manual_seed(9)
+    # rows 1 and 2: the same MASK layout, other un-masked sub-tokens (score side) and other encoder outputs
+    tok_b, msk_b = tokens.repeat(3, 1, 1), masked.repeat(3, 1, 1)
+    for r in (1, 2):
+        keep = tok_b[r] != 1
+        noise = torch.randint(4, 10, tok_b[r].shape, generator=g)
+        tok_b[r] = torch.where(keep & (tok_b[r] > 3), noise, tok_b[r])
+        msk_b[r] = torch.where(msk_b[r] != 1, tok_b[r], msk_b[r])
+    ctx_b = torch.cat([ctx, ctx + 0.05 * torch.randn(ctx.shape, generator=g), ctx.flip(1)], 0)
+    sty_b = torch.cat([sty, sty * 0.9, sty + 0.05 * torch.randn(sty.shape, generator=g)], 0)
+    dec = model.perf_decoder
+    runs = []
+    real_run = decode.GreedyDecoder.run
+
+    def counting_run(self, *a, **k):
+        runs.append(1)
+        return real_run(self, *a, **k)
+
+    decode.GreedyDecoder.run = counting_run
+    try:
+        kw = dict(filter_logits_fn=top_k, filter_kwargs={"k": 1}, return_caches=True, disable_tqdm=True)
+        out_b, caches_b = dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), **kw)
+        assert len(runs) == 3                                             # three engine runs, no module path
+        assert int((out_b[0].cpu().numpy() != fix["out/tokens"][0]).sum()) == 0
+        assert tuple(caches_b.token_emb.shape) == (3,) + tuple(fix["cache/token_emb_shape"])[1:]
+        assert tuple(caches_b.transformer.attention[0].keys.shape) == (3,) + tuple(fix["cache/keys0_shape"])[1:]
+        for r in range(3):
+            out_r, caches_r = dec.unmask_tokens(tok_b[r:r + 1].to(dev), msk_b[r:r + 1].to(dev), context=ctx_b[r:r + 1].to(dev),
+                                                style_embeddings=sty_b[r:r + 1].to(dev), **kw)
+            assert torch.equal(out_r[0], out_b[r])
+            assert torch.equal(caches_r.token_emb[0], caches_b.token_emb[r])
+            for a, b_ in zip(caches_r.transformer.hiddens, caches_b.transformer.hiddens):
+                assert torch.equal(a[0], b_[r])
+            assert torch.equal(caches_r.transformer.attention[-1].values[0], caches_b.transformer.attention[-1].values[r])
+        # the oracle's greedy loop on the perturbed row 1
+        want = ref_cpu.greedy_unmask(sd, cfg, tok_b[1:2], msk_b[1:2], ctx_b[1:2], sty_b[1:2]).numpy()
+        got = out_b[1:2].cpu().numpy()
+        assert (got != want).sum() <= 0.03 * (want != tok_b[1:2].numpy()).sum()
+        # a padded batch keeps the module path (the engine has no key mask for its own sequence)
+        n_before = len(runs)
+        pad_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
+        pad_mask[2, -5:] = False
+        out_p = dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=pad_mask.to(dev),
+                                  filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        assert len(runs) == n_before and tuple(out_p.shape) == tuple(tok_b.shape)
+    finally:
+        decode.GreedyDecoder.run = real_run
