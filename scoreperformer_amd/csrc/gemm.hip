@@ -939,6 +939,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     constexpr int NS = sizeof(OutT) == 2 ? 16 : 32;   // store instructions per wave of one interior-tile epilogue
     constexpr int NSX = GLUF ? 24 : NS;               // (gated: 16 stores of u + 8 of g)
 #define PP_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n_) : "memory")
+// wave priority in the MFMA part / in the read part of a phase (tuning aid of round 5: PP_PRIO_MFMA=0 PP_PRIO_READ=1 swaps them)
+#ifndef PP_PRIO_MFMA
+#define PP_PRIO_MFMA 1
+#endif
+#ifndef PP_PRIO_READ
+#define PP_PRIO_READ 0
+#endif
 #define PP_SYNC_MFMA_BEGIN()                                   \
     TSTAMP(2);                                                  \
     __builtin_amdgcn_sched_barrier(0);                          \
@@ -947,9 +954,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
     TSTAMP(4);                                                  \
     __builtin_amdgcn_sched_barrier(0);                          \
-    __builtin_amdgcn_s_setprio(1)
+    __builtin_amdgcn_s_setprio(PP_PRIO_MFMA)
 #define PP_SYNC_MFMA_END()                                     \
-    __builtin_amdgcn_s_setprio(0);                              \
+    __builtin_amdgcn_s_setprio(PP_PRIO_READ);                   \
     __builtin_amdgcn_sched_barrier(0);                          \
     TSTAMP(5);                                                  \
     __builtin_amdgcn_s_barrier();                               \
