@@ -53,8 +53,10 @@ class GradSync:
             self._knob_before = lib.get_tuning("gemm_persist_bwd")
             self._knob_set = 1.0 if (persistent_backward and not self.active) else 0.0
             lib.set_tuning("gemm_persist_bwd", self._knob_set)
-        if self.active and self.world > 1 and not dry_run:
-            arena.all_trainable_active = True    # see ParamArena.active_params: replicas must agree on the set of parameters they step
+        self._counts_as_dp = bool(self.active and self.world > 1 and not dry_run)
+        if self._counts_as_dp:   # see ParamArena.active_params: replicas must agree on the set of parameters they step
+            arena._dp_syncs = getattr(arena, "_dp_syncs", 0) + 1     # (a count: two objects on one arena may overlap in time)
+            arena.all_trainable_active = True
         self.handles: List = []
         self.buckets: List[tuple] = []   # (start, end) element ranges of arena.grads
         self.bucket_of = {}
@@ -185,8 +187,10 @@ class GradSync:
                     if attr in getattr(h, "__dict__", {}):
                         delattr(h, attr)
         self._hooked = []
-        if self.active and self.world > 1 and not self.dry_run and getattr(self.arena, "all_trainable_active", False):
-            self.arena.all_trainable_active = False
+        if self._counts_as_dp:
+            self._counts_as_dp = False
+            self.arena._dp_syncs = max(0, getattr(self.arena, "_dp_syncs", 1) - 1)
+            self.arena.all_trainable_active = self.arena._dp_syncs > 0
         self.active = False
         if self.native is not None:
             self.native.close()
