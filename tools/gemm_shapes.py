@@ -8,7 +8,7 @@ from scoreperformer_amd.models import ScorePerformer
 from scoreperformer_amd.synthetic import model_config, synthetic_batch
 dev = torch.device("cuda")
 b, n = int(os.environ.get("B", 64)), int(os.environ.get("N", 2048))
-model = ScorePerformer.init(model_config("c3")); arena = ParamArena(model, dev); model.train(); model.sync_free = True
+model = ScorePerformer.init(model_config("c3", dropout=float(os.environ.get("DROPOUT", 0.1)), latent_dropout=[0.0, 0.1, 0.2, 0.4])); arena = ParamArena(model, dev); model.train(); model.sync_free = True
 batch = synthetic_batch(b, n, seed=1, device=dev)
 model.perf_encoder.segment_bounds = {m: int(batch[k].max()) + 1 for m, k in (("bar_mean", "bars"), ("beat_mean", "beats"), ("onset_mean", "onsets"))}
 opt = FusedAdamW(arena)
