@@ -100,6 +100,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Dot-product arithmetic of the decode kernels (round 5; decode.hip, decode_layer.hip, decode_attn.h -- every GEMV and score of both
+// decode paths goes through these two, which is what keeps them bit-identical to each other): a lane accumulates TWO partial sums, the
+// even and the odd elements of its k range, by packed FMA (v_pk_fma_f32: two fp32 FMAs per instruction at the issue cost of one --
+// tools/pk_probe.hip), chunks ascending, and folds them lo + hi before the wave reduction.  A decode step is bound by the instruction
+// count of its single-wave chains (4 multiplies + 4 adds per chunk became 2 instructions), not by bytes or flops.
+__device__ __forceinline__ void dec_dot4(f32x2& a, const f32x4 w, const f32x4 x) {
+    a = __builtin_elementwise_fma(f32x2{w[0], w[1]}, f32x2{x[0], x[1]}, a);
+    a = __builtin_elementwise_fma(f32x2{w[2], w[3]}, f32x2{x[2], x[3]}, a);
+}
+__device__ __forceinline__ float dec_fold(const f32x2 a) { return a[0] + a[1]; }
+
 // sum over each aligned group of 16 lanes (one DPP row), result in all 16 lanes
 __device__ __forceinline__ float row16_sum(float v) {
     v += spn_dpp<0xB1, 0xf>(v, v);

@@ -36,11 +36,13 @@ __global__ __launch_bounds__(256) void gemv_nk_kernel(const float* __restrict__ 
     const float* w = W + (long)n * ldw;
     float acc = 0.f;
     if ((K & 3) == 0 && (ldw & 3) == 0) {
+        f32x2 a2 = f32x2{0.f, 0.f};
         for (int k = lane * 4; k < K; k += 256) {
             const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
-            acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+            dec_dot4(a2, wv, xv);
         }
+        acc = dec_fold(a2);
     } else {
         for (int k = lane; k < K; k += 64) acc = fmaf(w[k], x[k], acc);
     }
@@ -132,11 +134,13 @@ __global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, con
         const float* x = r.x + (long)(*pos + r.x_off) * r.x_ld;
         float acc = 0.f;
         if (vec) {
+            f32x2 a2 = f32x2{0.f, 0.f};
             for (int k = lane * 4; k < r.K; k += 256) {
                 const f32x4 wv = k == lane * 4 ? w0 : *reinterpret_cast<const f32x4*>(w + k);
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(x + k);
-                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                dec_dot4(a2, wv, xv);
             }
+            acc = dec_fold(a2);
         } else {
             for (int k = lane; k < r.K; k += 64) acc = fmaf(w[k], x[k], acc);
         }
@@ -189,16 +193,18 @@ __global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, con
     const float* w = W + (long)n * ldw;
     const int K = d.D;
     float acc = 0.f;
-    if (vec_) {   // same expression order as the loop it replaces (k ascending, four products summed left to right)
+    if (vec_) {   // chunks ascending, common.h dec_dot4
+        f32x2 a2 = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k = lane * 4 + c * 256;
             if (k < K) {
                 const f32x4 wv = wreg[c];
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(buf + k);
-                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+                dec_dot4(a2, wv, xv);
             }
         }
+        acc = dec_fold(a2);
     } else {
         for (int k = lane; k < K; k += 64) acc = fmaf(w[k], buf[k], acc);
     }
@@ -511,20 +517,18 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
     __syncthreads();
     if (n >= a.N) return;
     float acc = 0.f, accg = 0.f;
-    if (vec) {   // same expression order as before the preload (k ascending, four products summed left to right): bit-identical outputs
+    if (vec) {   // chunks ascending, common.h dec_dot4 (the arithmetic of decode_layer.hip's dot_rows)
+        f32x2 a2 = f32x2{0.f, 0.f}, g2 = f32x2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int k = lane * 4 + c * 256;
             if (k < a.K) {
                 const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + k);
-                const f32x4 wv = wreg[c];
-                acc += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
-                if (gated) {
-                    const f32x4 wg = greg[c];
-                    accg += wg[0] * xv[0] + wg[1] * xv[1] + wg[2] * xv[2] + wg[3] * xv[3];
-                }
+                dec_dot4(a2, wreg[c], xv);
+                if (gated) dec_dot4(g2, greg[c], xv);
             }
         }
+        acc = dec_fold(a2); accg = dec_fold(g2);
     } else {
         for (int k = lane; k < a.K; k += 64) { acc = fmaf(wv_[k], xs[k], acc); if (gated) accg = fmaf(wg_[k], xs[k], accg); }
     }
@@ -571,12 +575,14 @@ __global__ __launch_bounds__(256) void dec_cat_kernel(const float* __restrict__ 
 // lane group, partials merged by the last block of each head.  ALiBi reach: with B = scale*|q|*max|k| every weight further than
 // D = (104 + 2B)/slope from the query is below exp(-104) of the largest one -- exactly 0 or one denormal ulp in the fp32 reference
 // as well -- so those keys are not read.  kmax2[0] = running max |k|^2 of this layer's cache (MQA: one kv head; else per kv head).
-__global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict__ qkv, float* __restrict__ kcache, float* __restrict__ vcache,
+__global__ __launch_bounds__(512) void dec_attn2_kernel(const float* __restrict__ qkv, float* __restrict__ kcache, float* __restrict__ vcache,
                                                         const float* __restrict__ slopes, const int* __restrict__ pos, float* __restrict__ o,
                                                         float* __restrict__ part, int* __restrict__ counter, float* __restrict__ kmax2,
                                                         int h, int kvh, float scale, int merge) {
-    __shared__ float sm[16], sl[16];
-    __shared__ __attribute__((aligned(16))) float so[16][64];
+    __shared__ float sm[DEC_G], sl[DEC_G];
+    __shared__ __attribute__((aligned(16))) float so[DEC_G][64];
+    __shared__ float sm2[8], sl2[8];
+    __shared__ float so2[8][64];
     __shared__ int is_last;
     const int hi = blockIdx.x, sp = blockIdx.y, S = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, l16 = lane & 15;
@@ -608,35 +614,29 @@ __global__ __launch_bounds__(256) void dec_attn2_kernel(const float* __restrict_
     const f32x4 q4 = *reinterpret_cast<const f32x4*>(qkv + hi * 64 + l16 * 4) * scale;
     float m = -INFINITY, l = 0.f;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the keys of a lane group, sixteen at a time (256 keys per block: the whole split at L <= 4096): all row loads of a batch are in flight
+    // the keys of a lane group, DEC_NU at a time (256 keys per block and batch: the whole split at L <= 4096): all row loads of a batch are in flight
     // together (a cache row read costs a trip to the Infinity Cache; one key per trip made this loop the longest part of a note)
     const f32x4 knew4 = *reinterpret_cast<const f32x4*>(knew + l16 * 4), vnew4 = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
     for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
-        f32x4 k4[16], v4[16];
+        f32x4 k4[DEC_NU], v4[DEC_NU];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = max(min(min(jb0 + 16 * u, j1 - 1), t - 1), 0);   // row t is knew / vnew
+        for (int u = 0; u < DEC_NU; ++u) {
+            const int j = max(min(min(jb0 + DEC_G * u, j1 - 1), t - 1), 0);   // row t is knew / vnew
             k4[u] = *reinterpret_cast<const f32x4*>(kcache + (long)j * cw + kh * 64 + l16 * 4);
             v4[u] = *reinterpret_cast<const f32x4*>(vcache + (long)j * cw + kh * 64 + l16 * 4);
         }
-        dec_attn_batch16(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, l, acc);
+        dec_attn_batch<DEC_NU>(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, l, acc);
     }
     const int gi = w * 4 + grp;
     if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
     *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+    dec_attn_merge_wave(sm, sl, so, sm2, sl2, so2, w, lane);
     __syncthreads();
     // block result -> partial (m, l, o[64]) of (head, split)
     float* mine = part + ((long)hi * S + sp) * 66;
     if (tid < 64) {
-        float mm = -INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
-            num += so[q][tid] * f; den += sl[q] * f;
-        }
+        float mm, num, den;
+        dec_attn_merge_block(sm2, sl2, so2, tid, lane, mm, num, den);
         mine[2 + tid] = num;
         if (tid == 0) { mine[0] = mm; mine[1] = den; }
     }
@@ -1082,7 +1082,7 @@ extern "C" int spn_dec_attn2(const float* qkv, float* kcache, float* vcache, con
                              int* counter, float* kmax2, int h, int kvh, float scale, int splits, hipStream_t s) {
     SPN_REQUIRE(qkv && kcache && vcache && pos && part && counter && kmax2 && h > 0 && (kvh == 1 || kvh == h) && splits > 0 && splits <= 64,
                 "spn_dec_attn2: bad arguments");
-    hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(256), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale,
+    hipLaunchKernelGGL(dec_attn2_kernel, dim3(h, splits), dim3(512), 0, s, qkv, kcache, vcache, slopes, pos, o, part, counter, kmax2, h, kvh, scale,
                        o ? 1 : 0);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

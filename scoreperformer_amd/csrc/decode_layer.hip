@@ -129,6 +129,64 @@ __device__ __forceinline__ void block_norm(float* xs, float* red, int K, bool af
     __syncthreads();
 }
 
+// The same LayerNorm WITHOUT barriers and LDS round trips (round 5: block_norm took ~0.76 us per call, twice per layer pair on a note's
+// critical path; this form 0.64).  Every wave recomputes what block_norm's waves 0-3 exchange through LDS: partial w' of a statistic is
+// lane l's (xs[l + 64 w'] (+) xs[l + 64 w' + 256]) pushed through the DPP ladder of wave_sum, and the four partials are added
+// ((r0 + r1) + r2) + r3 -- the same operations on the same values in the same order, so mean and variance carry the same bits.  (The
+// two waves of a SIMD share its issue slots, so the redundant statistics are not free; computing them on waves 0-3 only and handing the
+// two numbers to waves 4-7 through LDS behind ONE barrier measured 0.76 again.)
+// The normalised vector is returned in the dot_rows layout (lane owns k = 4 lane + 256 c, c < 2), with the affine parameters held in
+// that layout (NormRegs4); xs itself is left as gathered.  K <= 512.
+struct NormRegs4 { f32x4 g[2], b[2]; };
+__device__ __forceinline__ NormRegs4 norm_regs4(int K, int mode, const float* gam, const float* bet, int lane) {
+    NormRegs4 r;
+    const float* be = mode == 2 ? gam + K : bet;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int k = lane * 4 + c * 256;
+        const bool in = k < K && gam != nullptr;
+        r.g[c] = in ? *reinterpret_cast<const f32x4*>(gam + k) : f32x4{1.f, 1.f, 1.f, 1.f};
+        r.b[c] = in ? *reinterpret_cast<const f32x4*>(be + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return r;
+}
+__device__ __forceinline__ void wave_norm(const float* xs, int K, bool affine, const NormRegs4& nr, float eps, int lane, f32x4 (&xv)[2]) {
+    float xa[4], xb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xa[q] = xs[lane + 64 * q]; xb[q] = xs[lane + 64 * q + 256]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xs + lane * 4 + c * 256);
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        float s = 0.f;
+        s = k < K ? s + xa[q] : s;
+        s = k + 256 < K ? s + xb[q] : s;
+        r[q] = wave_sum(s);
+    }
+    const float mu = (r[0] + r[1] + r[2] + r[3]) / (float)K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = lane + 64 * q;
+        const float ta = xa[q] - mu, tb = xb[q] - mu;
+        float q2 = 0.f;
+        q2 = k < K ? q2 + ta * ta : q2;
+        q2 = k + 256 < K ? q2 + tb * tb : q2;
+        r[q] = wave_sum(q2);
+    }
+    const float rs = rsqrtf((r[0] + r[1] + r[2] + r[3]) / (float)K + eps);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = (xv[c][e] - mu) * rs;
+            if (affine) v = v * nr.g[c][e] + nr.b[c][e];
+            xv[c][e] = v;
+        }
+    }
+}
+
 // one weight row in registers: lane owns k = 4 lane + 256 c
 template <int C>
 __device__ __forceinline__ void load_row(f32x4 (&r)[C], const float* w, int K, int lane) {
@@ -139,8 +197,11 @@ __device__ __forceinline__ void load_row(f32x4 (&r)[C], const float* w, int K, i
     }
 }
 // R rows against the vector in LDS: the vector's chunks are read ONCE for all rows and every step is branch-free (a row-by-row loop with
-// an exec-masked branch per chunk cost ~190 ns per row: 3.1 us for the 16 products of a feed-forward wave).  Per row the expression is the
-// one of dec_fused_gemv_kernel: chunks ascending, ((p0 + p1) + p2) + p3 added to the running sum, then the DPP ladder of wave_sum.
+// an exec-masked branch per chunk cost ~190 ns per row: 3.1 us for the 16 products of a feed-forward wave).  Per row the arithmetic is
+// the one of dec_fused_gemv_kernel: chunks ascending through common.h dec_dot4 (two partial sums per lane by packed FMA), folded, then
+// the DPP ladder of wave_sum.
+template <int C, int R>
+__device__ __forceinline__ void dot_rows_x(const f32x4 (&r)[R][C], const f32x4 (&xv)[C], int K, int lane, float (&out)[R]);
 template <int C, int R>
 __device__ __forceinline__ void dot_rows(const f32x4 (&r)[R][C], const float* xs, int K, int lane, float (&out)[R]) {
     f32x4 xv[C];
@@ -149,19 +210,25 @@ __device__ __forceinline__ void dot_rows(const f32x4 (&r)[R][C], const float* xs
         const int k = lane * 4 + c * 256;
         xv[c] = *reinterpret_cast<const f32x4*>(xs + min(k, 2044));
     }
-    float acc[R];
+    dot_rows_x<C, R>(r, xv, K, lane, out);
+}
+// the same with the vector already in registers (lane owns k = 4 lane + 256 c): wave_norm's output
+template <int C, int R>
+__device__ __forceinline__ void dot_rows_x(const f32x4 (&r)[R][C], const f32x4 (&xv)[C], int K, int lane, float (&out)[R]) {
+    // entries past K: the rows are zero there (load_row), the vector may hold anything -- zeroed ONCE for all rows (fma(0, 0, a) = a,
+    // which is what the chunk-skipping loops of decode.hip compute)
+    f32x4 xz[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xz[c] = lane * 4 + c * 256 < K ? xv[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x2 acc[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        acc[i] = 0.f;
+        acc[i] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int k = lane * 4 + c * 256;
-            const float t = r[i][c][0] * xv[c][0] + r[i][c][1] * xv[c][1] + r[i][c][2] * xv[c][2] + r[i][c][3] * xv[c][3];
-            acc[i] = k < K ? acc[i] + t : acc[i];
-        }
+        for (int c = 0; c < C; ++c) dec_dot4(acc[i], r[i][c], xz[c]);
     }
 #pragma unroll
-    for (int i = 0; i < R; ++i) out[i] = wave_sum(acc[i]);
+    for (int i = 0; i < R; ++i) out[i] = wave_sum(dec_fold(acc[i]));
 }
 
 // Roles.  Workgroups 0 .. h S - 1 ("A") own the q|k|v rows (the first ceil(N1 / 16) of them, 16 rows each) and one (head, split) of the
@@ -179,8 +246,10 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                                                       const spn_dec_chain_ext* __restrict__ ext) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
-    __shared__ float sm[16], sl[16];
-    __shared__ __attribute__((aligned(16))) float so[16][64];
+    __shared__ float sm[DEC_G], sl[DEC_G];
+    __shared__ __attribute__((aligned(16))) float so[DEC_G][64];
+    __shared__ float sm2[8], sl2[8];
+    __shared__ float so2[8][64];
     __shared__ __attribute__((aligned(16))) float qs[192];
     __shared__ float outv[16];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,6 +261,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const int err_in = *a0.err;
     int* const err = a0.err;
 #define STAMP(k_) do { if (a.stamps && tid == 0) a.stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_OF(rec_, k_) do { if ((rec_).stamps && tid == 0) (rec_).stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     const int t = *a0.pos;
     const unsigned ebase = (unsigned)(*a0.tick) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
@@ -205,7 +275,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const unsigned eemb = efront + 4u;    // the projected token embeddings (attention workgroups -> front)
     const bool emb = front && ext->en > 0;
     // adaptive norms read their (gamma | beta) rows from the buffer of this note's parity (spn_dec_chain_ext.ada_par)
-    const long apar = (ext && (t & 1)) ? ext->ada_par : 0;
+    // (wave-uniform by construction: through readfirstlane it lives in scalar registers -- as a per-lane value it was spilled to scratch)
+    const long apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
 #define ADA(mode_, ptr_) (((mode_) == 2 && (ptr_)) ? (ptr_) + apar : (ptr_))
 
     if (b < nA) {
@@ -216,26 +287,26 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         const int kh = kvh == 1 ? 0 : hi;
         const long cw = (long)kvh * 64;
         f32x4 wq[2][2];
-        NormRegs n1;
+        NormRegs4 n1;
         auto request = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 wq[i][0] = wq[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r0 + i < N1) load_row<2>(wq[i], a.Wqkv + (long)(r0 + i) * a.ld_qkv, d, lane);
             }
-            n1 = norm_regs(d, a.norm1, ADA(a.norm1, a.gam1), a.bet1, tid);
+            n1 = norm_regs4(d, a.norm1, ADA(a.norm1, a.gam1), a.bet1, lane);
         };
         // Key / value rows of this workgroup's split, requested BEFORE the query exists: the split's key range depends on the query only
         // through the first key inside the ALiBi reach (j_lo), which is rounded down to a multiple of 256 (more keys than necessary, never
         // fewer) and therefore almost always equals the previous note's (jlo[head], written below).  The rows are then in registers when
         // q arrives (one trip to the Infinity Cache, ~1.5-2 us, off the critical path); a wrong guess falls back to the loads behind q.
         const int grp = lane >> 4, l16 = lane & 15;
-        f32x4 k4[16], v4[16];
+        f32x4 k4[DEC_NU], v4[DEC_NU];
         bool pre = false;
         int jlo_guess = 0;
         auto prefetch = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
             pre = false;
-            if (tid < 256 && a.jlo) {
+            if (a.jlo) {
                 // jlo[] and kmax2[] are read and written by different workgroups of the SAME launch without ordering (relaxed agent-scope
                 // accesses, no hand-off): benign by construction -- jlo is only a GUESS of which rows to request early (a stale or a fresh
                 // value both work: a wrong guess reloads behind q, see `hit` below), and kmax2 is a running maximum into which every reader
@@ -248,8 +319,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 pre = true;
                 if (jb0 < j1) {
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int j = min(min(jb0 + 16 * u, j1 - 1), t - 1);   // row t does not exist yet: patched from q|k|v below
+                    for (int u = 0; u < DEC_NU; ++u) {
+                        const int j = min(min(jb0 + DEC_G * u, j1 - 1), t - 1);   // row t does not exist yet: patched from q|k|v below
                         k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
                         v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
                     }
@@ -326,9 +397,10 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 if (l > 0) gather(layers[l - 1].gxo, d, ebase + 8u * (unsigned)layers[l - 1].layer + 5u, xs, tid, err);
                 else if (front) gather(ext->gxf, d, efront + 1u, xs, tid, err);
                 __syncthreads();
-                block_norm(xs, red, d, a.gam1 != nullptr, n1, a.eps1, tid);
+                f32x4 xn[2];
+                wave_norm(xs, d, a.gam1 != nullptr, n1, a.eps1, lane, xn);
                 float y[2];
-                dot_rows<2, 2>(wq, xs, d, lane, y);
+                dot_rows_x<2, 2>(wq, xn, d, lane, y);
                 if (lane == 0) { outv[2 * w] = y[0]; outv[2 * w + 1] = y[1]; }
                 publish16(a.gq, b * 16, N1, e0, outv, tid);
             }
@@ -351,7 +423,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             }
             __syncthreads();
             STAMP(3);
-            if (tid < 256) {
+            {
                 const float* knew = qs + 64;
                 const float* vnew = qs + 128;
                 float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
@@ -375,41 +447,36 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 float m = -INFINITY, lsum = 0.f;
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 const bool hit = pre && j_lo == jlo_guess;   // the rows requested before q are the rows of this range (first 256 keys of it)
-                // up to 16 keys per lane group and batch (= 256 keys per workgroup: the whole split at L <= 4096): decode_attn.h
+                // up to DEC_NU keys per lane group and batch (= 256 keys per workgroup: the whole split at L <= 4096): decode_attn.h
                 bool first = true;
                 const f32x4 knew4 = *reinterpret_cast<const f32x4*>(knew + l16 * 4), vnew4 = *reinterpret_cast<const f32x4*>(vnew + l16 * 4);
                 for (int jb0 = j0 + w * 4 + grp; jb0 < j1; jb0 += 256) {
                     if (!(hit && first)) {
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const int j = min(min(jb0 + 16 * u, j1 - 1), t - 1);
+                        for (int u = 0; u < DEC_NU; ++u) {
+                            const int j = min(min(jb0 + DEC_G * u, j1 - 1), t - 1);
                             k4[u] = *reinterpret_cast<const f32x4*>(a.kcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
                             v4[u] = *reinterpret_cast<const f32x4*>(a.vcache + (long)max(j, 0) * cw + kh * 64 + l16 * 4);
                         }
                     }
                     first = false;
-                    dec_attn_batch16(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, lsum, acc);
+                    dec_attn_batch<DEC_NU>(k4, v4, knew4, vnew4, q4, slope, t, jb0, j1, m, lsum, acc);
                 }
                 STAMP(4);
                 const int gi = w * 4 + grp;
                 if (l16 == 0) { sm[gi] = m; sl[gi] = lsum; }
                 *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+                dec_attn_merge_wave(sm, sl, so, sm2, sl2, so2, w, lane);
             }
             __syncthreads();
-            if (tid < 66) {
-                float mm = -INFINITY;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) mm = fmaxf(mm, sm[q]);
-                float num = 0.f, den = 0.f;
-                const int col = min(tid, 63);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float f = (sm[q] == -INFINITY) ? 0.f : __expf(sm[q] - mm);
-                    num += so[q][col] * f; den += sl[q] * f;
+            if (w < 2) {   // (the two waves that hold the 66 storing lanes, whole: the weights travel by readlane)
+                float mm, num, den;
+                dec_attn_merge_block(sm2, sl2, so2, min(tid, 63), lane, mm, num, den);
+                if (tid < 66) {
+                    // record (max, normaliser, 64 weighted value sums): lanes 0-63 of wave 0 store the sums, lanes 0-1 of wave 1 the two scalars
+                    unsigned long long* mine = a.gp + ((long)hi * S + sp) * 66;
+                    put(mine + (tid < 64 ? 2 + tid : tid - 64), e0 + 1, tid < 64 ? num : (tid == 64 ? mm : den));
                 }
-                // record (max, normaliser, 64 weighted value sums): lanes 0-63 of wave 0 store the sums, lanes 0-1 of wave 1 the two scalars
-                unsigned long long* mine = a.gp + ((long)hi * S + sp) * 66;
-                put(mine + (tid < 64 ? 2 + tid : tid - 64), e0 + 1, tid < 64 ? num : (tid == 64 ? mm : den));
             }
             STAMP(2);
             if (l + 1 < n_layers) request(layers[l + 1]);
@@ -424,21 +491,31 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 wh[i][0] = wh[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (r0 + i < Nh) load_row<2>(wh[i], ext->Wh + (long)(r0 + i) * ext->ld_h, d, lane);
             }
-            const NormRegs nh = norm_regs(d, ext->normh, ADA(ext->normh, ext->gamh), ext->beth, tid);
+            const NormRegs4 nh = norm_regs4(d, ext->normh, ADA(ext->normh, ext->gamh), ext->beth, lane);
             if (b * 16 < Nh) {
                 __syncthreads();
                 gather(al.gxo, d, ebase + 8u * (unsigned)al.layer + 5u, xs, tid, err);
                 __syncthreads();
-                block_norm(xs, red, d, ext->gamh != nullptr, nh, ext->epsh, tid);
-                if (b == 0 && ext->xn_out) for (int k = tid; k < d; k += NT) ext->xn_out[(long)t * ext->xn_ld + k] = xs[k];
+                f32x4 xn[2];
+                wave_norm(xs, d, ext->gamh != nullptr, nh, ext->epsh, lane, xn);
+                if (b == 0 && w == 0 && ext->xn_out) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = lane * 4 + c * 256 + e;
+                            if (k < d) ext->xn_out[(long)t * ext->xn_ld + k] = xn[c][e];
+                        }
+                }
                 float y[2];
-                dot_rows<2, 2>(wh, xs, d, lane, y);
+                dot_rows_x<2, 2>(wh, xn, d, lane, y);
                 if (lane == 0) {
                     if (r0 < Nh) ext->e_out[r0] = y[0];
                     if (r0 + 1 < Nh) ext->e_out[r0 + 1] = y[1];
                     outv[2 * w] = y[0]; outv[2 * w + 1] = y[1];
                 }
                 if (head) publish16(ext->ge, b * 16, Nh, ehead, outv, tid);
+                STAMP_OF(al, 5);   // e out
             }
         }
         return;
@@ -452,7 +529,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         const int r0 = bc * 32 + 4 * w;
         f32x4 w1v[4][2], w1g[4][2];
         float b1v[4], b1g[4];
-        NormRegs n2;
+        NormRegs4 n2;
         auto request = [&](const spn_dec_pair_args& a) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -464,7 +541,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     if (a.b1) { b1v[i] = a.b1[r0 + i]; b1g[i] = a.b1[r0 + i + inner]; }
                 }
             }
-            n2 = norm_regs(d, a.norm2, ADA(a.norm2, a.gam2), a.bet2, tid);
+            n2 = norm_regs4(d, a.norm2, ADA(a.norm2, a.gam2), a.bet2, lane);
         };
         request(a0);
         if (err_in) return;
@@ -489,9 +566,9 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int n = n0 + u * nCw;
-                    float acc = 0.f;
-                    if (in) acc += wv[u][0] * xv[0] + wv[u][1] * xv[1] + wv[u][2] * xv[2] + wv[u][3] * xv[3];
-                    acc = wave_sum(acc);
+                    f32x2 a2 = f32x2{0.f, 0.f};
+                    if (in) dec_dot4(a2, wv[u], xv);
+                    float acc = wave_sum(dec_fold(a2));
                     if (lane == 0 && n < rN) yo[n] = ext->rbias ? acc + bz[u] : acc;
                 }
             }
@@ -505,18 +582,23 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             gather(a.gx, d, e0 + 3, xs, tid, err);
             __syncthreads();
             STAMP(2);
-            block_norm(xs, red, d, a.gam2 != nullptr, n2, a.eps2, tid);
+            f32x4 xn[2];
+            wave_norm(xs, d, a.gam2 != nullptr, n2, a.eps2, lane, xn);
             STAMP(3);
             float* outc = &so[0][0];   // 32 results of the workgroup
             float accv[4], accg[4];
-            dot_rows<2, 4>(w1v, xs, d, lane, accv);
-            dot_rows<2, 4>(w1g, xs, d, lane, accg);
+            dot_rows_x<2, 4>(w1v, xn, d, lane, accv);
+            dot_rows_x<2, 4>(w1g, xn, d, lane, accg);
+            // lane i < 4 finishes row i (bias, activation, product): ONE evaluation of the activation per wave instead of four (erff is
+            // ~60 instructions, and a wave pays for an instruction whether one lane needs it or all)
+            float acc = accv[0], ag = accg[0], bv = b1v[0], bg = b1g[0];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float acc = accv[i], ag = accg[i];
-                if (a.b1) { acc += b1v[i]; ag += b1g[i]; }
-                if (lane == 0) outc[4 * w + i] = acc * pair_act(ag, a.act);
+            for (int i = 1; i < 4; ++i) {
+                const bool me = lane == i;
+                acc = me ? accv[i] : acc; ag = me ? accg[i] : ag; bv = me ? b1v[i] : bv; bg = me ? b1g[i] : bg;
             }
+            if (a.b1) { acc += bv; ag += bg; }
+            if (lane < 4) outc[4 * w + lane] = acc * pair_act(ag, a.act);
             STAMP(4);
             __syncthreads();
             if (tid < 32 && bc * 32 + tid < inner) put(a.gg + bc * 32 + tid, e0 + 4, outc[tid]);   // one store instruction: 2 whole lines
@@ -619,10 +701,15 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     __syncthreads();
                     if (tid < 2) put(ext->gh + (q * 16 + s0) * 2 + tid, ehead + 1u, outv[tid]);   // one store instruction, one line
                 }
+                STAMP_OF(layers[n_layers - 1], 6);   // this workgroup's slab maxima out
                 // the first slab's workgroup of a key picks the winner among the key's slabs and writes the token
                 for (int it = it0; it < items; it += nC) {
                     const int q = it / SL, s0 = it - q * SL;
                     if (s0 != 0) continue;
+                    // the cell of this key at the next position (MASK or a given token: nobody else writes it during this launch) is
+                    // requested BEFORE the poll -- read behind the winner it was one more trip to memory at the end of every note
+                    long* cell = ext->tokens + (long)(t + 1) * ext->tok_ld + ext->hdim[q];
+                    const long cur = tid == 0 ? *cell : 0;
                     __syncthreads();
                     gather(ext->gh + q * 32, 2 * SL, ehead + 1u, xs, tid, err);
                     __syncthreads();
@@ -634,9 +721,9 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                             const int bii = __float_as_int(xs[2 * r + 1]);
                             if (r == 0 || bvv > best || (bvv == best && bii < idx)) { best = bvv; idx = bii; }
                         }
-                        long* cell = ext->tokens + (long)(t + 1) * ext->tok_ld + ext->hdim[q];
-                        if (*cell == ext->mask_id) *cell = idx;
+                        if (cur == ext->mask_id) *cell = idx;
                     }
+                    STAMP_OF(layers[n_layers - 1], 7);   // token written
                 }
             }
             if (bc == 0 && tid == 0 && ext->pos_next) *ext->pos_next = t + 1;
@@ -723,6 +810,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (lane == 0 && r0 + i < d && ext->y2p) ext->y2p[(long)t * ext->y2p_ld + r0 + i] = y[i];
         }
         publish16(ext->gxf, bb * 16, d, efront + 1u, outv, tid);
+        STAMP_OF(a0, 7);   // the note's input vector out
     } else {
         request(a0);
 #pragma unroll
@@ -752,10 +840,14 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
 #pragma unroll
                 for (int q = 0; q < 16; ++q) mm = fmaxf(mm, mv[q]);
                 float num = 0.f, den = 0.f;
+                // split q's factor: computed by lane q, broadcast through a scalar register (as in the attention workgroups' own merge)
+                const int ql = lane & 15;
+                const float mq = ql < S ? xs[ql * 66] : -INFINITY;
+                const float fl = (mq == -INFINITY) ? 0.f : __expf(mq - mm);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     if (q < S) {
-                        const float f = (mv[q] == -INFINITY) ? 0.f : __expf(mv[q] - mm);
+                        const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fl), q));
                         num += nv[q] * f; den += lv[q] * f;
                     }
                 }

@@ -41,14 +41,17 @@ def timeline(L, groups, dev, model, batch, enc):
     groups = eng.pair_groups
     nA = eng.heads * eng.attn_splits
     nB = (eng.dim + 15) // 16
-    roles = {"A (q|k|v rows, attention)": (slice(0, nA), {1: "qkv out", 3: "q gathered", 4: "keys done", 2: "partials out"}),
-             "B (merge, projections)": (slice(nA, nA + nB), {3: "merged o out", 4: "x1 out", 6: "x out"}),
-             "C (gated rows)": (slice(nA + nB, groups), {1: "weights requested", 2: "x1 gathered", 3: "norm done", 4: "rows done", 5: "g out"})}
+    roles = {"A (q|k|v rows, attention)": (slice(0, nA), {1: "qkv out", 3: "q gathered", 4: "keys done", 2: "partials out", 5: "tail: e out"}),
+             "B (merge, projections)": (slice(nA, nA + nB), {7: "front: x in out", 3: "merged o out", 4: "x1 out", 6: "x out"}),
+             "C (gated rows)": (slice(nA + nB, groups), {1: "weights requested", 2: "x1 gathered", 3: "norm done", 4: "rows done", 5: "g out",
+                                                         6: "head: slab maxima out", 7: "head: token written"})}
     t_prev_end = None
+    t_launch = None
     for pi, st in enumerate(eng.pair_stamps):
         st = st.view(groups, 8).cpu().double() * 0.01          # us
         t0 = float(st[:, 0].min())
-        head = f"pair {pi}: workgroups start within {float(st[:, 0].max()) - t0:4.2f} us"
+        t_launch = t0 if t_launch is None else t_launch
+        head = f"pair {pi} (t0 = {t0 - t_launch:6.2f} us after the launch's first stamp): workgroups start within {float(st[:, 0].max()) - t0:4.2f} us"
         if t_prev_end is not None:
             head += f", {t0 - t_prev_end:4.2f} us after the previous pair's last store"
         print(head)
@@ -89,7 +92,8 @@ def main():
               f"  (max |dh| {float((hid - hid0).abs().max()):.3g})", flush=True)
         us0b, _, _ = run(L, 0, dev, model, batch, enc)
         print(f"L={L}  five launches per pair (again): {us0b:.1f} us per note", flush=True)
-    timeline(L, groups[0], dev, model, batch, enc)
+    if os.environ.get("TIMELINE", "1") != "0":
+        timeline(L, groups[0], dev, model, batch, enc)
 
 
 if __name__ == "__main__":
