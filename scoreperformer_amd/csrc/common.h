@@ -111,6 +111,31 @@ __device__ __forceinline__ void dec_dot4(f32x2& a, const f32x4 w, const f32x4 x)
 }
 __device__ __forceinline__ float dec_fold(const f32x2 a) { return a[0] + a[1]; }
 
+// LayerNorm statistics of the decode kernels (round 5), by ONE wave over the vector in the dot-product layout (lane owns the chunks
+// k = 4 lane + 256 c .. + 3, c < C; K a multiple of 4, entries past K ignored): two-pass, every lane folds its own entries first (packed
+// adds / FMAs, chunks ascending), then ONE wave_sum per pass.  Every wave that needs the normalised vector computes the statistics itself:
+// no barrier, no partial sums through LDS (the 256-thread form -- four wave partials per pass exchanged through LDS, three barriers --
+// cost 0.76 us per call on the critical path of a note, twice per layer pair; recomputing those four partials in every wave 0.64).
+template <int C>
+__device__ __forceinline__ void dec_ln_stats(const f32x4 (&xv)[C], int K, float eps, int lane, float& mu, float& rs) {
+    f32x2 s2 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (lane * 4 + c * 256 < K) { s2 += f32x2{xv[c][0], xv[c][1]}; s2 += f32x2{xv[c][2], xv[c][3]}; }
+    }
+    mu = wave_sum(dec_fold(s2)) / (float)K;
+    f32x2 q2 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (lane * 4 + c * 256 < K) {
+            const f32x2 ta = f32x2{xv[c][0], xv[c][1]} - mu, tb = f32x2{xv[c][2], xv[c][3]} - mu;
+            q2 = __builtin_elementwise_fma(ta, ta, q2);
+            q2 = __builtin_elementwise_fma(tb, tb, q2);
+        }
+    }
+    rs = rsqrtf(wave_sum(dec_fold(q2)) / (float)K + eps);
+}
+
 // sum over each aligned group of 16 lanes (one DPP row), result in all 16 lanes
 __device__ __forceinline__ float row16_sum(float v) {
     v += spn_dpp<0xB1, 0xf>(v, v);

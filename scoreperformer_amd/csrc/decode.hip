@@ -495,16 +495,30 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
         for (int k = threadIdx.x; k < a.K; k += 256) { const float v = x[k]; xs[k] = v; s += v; }
     }
     if (a.norm) {
-        s = wave_sum(s);
-        if (lane == 0) red[w] = s;
-        __syncthreads();
-        const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.K;
-        float q2 = 0.f;
-        for (int k = threadIdx.x; k < a.K; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
-        q2 = wave_sum(q2);
-        if (lane == 0) red[4 + w] = q2;
-        __syncthreads();
-        const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.K + a.eps);
+        float mu, rs;
+        if ((a.K & 3) == 0) {
+            // statistics per wave over the dot-product layout (common.h dec_ln_stats: the arithmetic of decode_layer.hip's wave_norm)
+            __syncthreads();
+            f32x4 xv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = lane * 4 + c * 256;
+                xv[c] = k < a.K ? *reinterpret_cast<const f32x4*>(xs + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            dec_ln_stats<8>(xv, a.K, a.eps, lane, mu, rs);
+            __syncthreads();   // every wave has read xs before the loop below overwrites it
+        } else {
+            s = wave_sum(s);
+            if (lane == 0) red[w] = s;
+            __syncthreads();
+            mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.K;
+            float q2 = 0.f;
+            for (int k = threadIdx.x; k < a.K; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+            q2 = wave_sum(q2);
+            if (lane == 0) red[4 + w] = q2;
+            __syncthreads();
+            rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.K + a.eps);
+        }
         const float* gam = a.gamma;
         const float* bet = a.norm == 2 ? a.gamma + a.K : a.beta;
         for (int k = threadIdx.x; k < a.K; k += 256) {

@@ -129,14 +129,9 @@ __device__ __forceinline__ void block_norm(float* xs, float* red, int K, bool af
     __syncthreads();
 }
 
-// The same LayerNorm WITHOUT barriers and LDS round trips (round 5: block_norm took ~0.76 us per call, twice per layer pair on a note's
-// critical path; this form 0.64).  Every wave recomputes what block_norm's waves 0-3 exchange through LDS: partial w' of a statistic is
-// lane l's (xs[l + 64 w'] (+) xs[l + 64 w' + 256]) pushed through the DPP ladder of wave_sum, and the four partials are added
-// ((r0 + r1) + r2) + r3 -- the same operations on the same values in the same order, so mean and variance carry the same bits.  (The
-// two waves of a SIMD share its issue slots, so the redundant statistics are not free; computing them on waves 0-3 only and handing the
-// two numbers to waves 4-7 through LDS behind ONE barrier measured 0.76 again.)
-// The normalised vector is returned in the dot_rows layout (lane owns k = 4 lane + 256 c, c < 2), with the affine parameters held in
-// that layout (NormRegs4); xs itself is left as gathered.  K <= 512.
+// LayerNorm of xs[0 .. K), K <= 512, per WAVE and without a barrier: statistics by common.h dec_ln_stats (the arithmetic of
+// dec_fused_gemv_kernel's norm), the normalised vector returned in the dot_rows layout (lane owns k = 4 lane + 256 c, c < 2) with the
+// affine parameters held in that layout (NormRegs4); xs itself is left as gathered.
 struct NormRegs4 { f32x4 g[2], b[2]; };
 __device__ __forceinline__ NormRegs4 norm_regs4(int K, int mode, const float* gam, const float* bet, int lane) {
     NormRegs4 r;
@@ -151,31 +146,10 @@ __device__ __forceinline__ NormRegs4 norm_regs4(int K, int mode, const float* ga
     return r;
 }
 __device__ __forceinline__ void wave_norm(const float* xs, int K, bool affine, const NormRegs4& nr, float eps, int lane, f32x4 (&xv)[2]) {
-    float xa[4], xb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { xa[q] = xs[lane + 64 * q]; xb[q] = xs[lane + 64 * q + 256]; }
 #pragma unroll
     for (int c = 0; c < 2; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xs + lane * 4 + c * 256);
-    float r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = lane + 64 * q;
-        float s = 0.f;
-        s = k < K ? s + xa[q] : s;
-        s = k + 256 < K ? s + xb[q] : s;
-        r[q] = wave_sum(s);
-    }
-    const float mu = (r[0] + r[1] + r[2] + r[3]) / (float)K;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = lane + 64 * q;
-        const float ta = xa[q] - mu, tb = xb[q] - mu;
-        float q2 = 0.f;
-        q2 = k < K ? q2 + ta * ta : q2;
-        q2 = k + 256 < K ? q2 + tb * tb : q2;
-        r[q] = wave_sum(q2);
-    }
-    const float rs = rsqrtf((r[0] + r[1] + r[2] + r[3]) / (float)K + eps);
+    float mu, rs;
+    dec_ln_stats<2>(xv, K, eps, lane, mu, rs);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
