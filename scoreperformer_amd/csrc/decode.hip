@@ -174,16 +174,30 @@ __global__ __launch_bounds__(256) void dec_embed_proj_kernel(DecEmbedDesc d, con
         s += v;
     }
     if (gamma) {
-        s = wave_sum(s);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
-        float q2 = 0.f;
-        for (int c = threadIdx.x; c < d.D; c += 256) { const float t = buf[c] - mu; q2 += t * t; }
-        q2 = wave_sum(q2);
-        if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q2;
-        __syncthreads();
-        const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+        float mu, rs;
+        if ((d.D & 3) == 0) {
+            // statistics per wave over the dot-product layout (common.h dec_ln_stats: what the embed phase of decode_layer.hip computes)
+            __syncthreads();
+            f32x4 xv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int k = lane_ * 4 + c * 256;
+                xv[c] = k < d.D ? *reinterpret_cast<const f32x4*>(buf + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            dec_ln_stats<8>(xv, d.D, eps, lane_, mu, rs);
+            __syncthreads();   // every wave has read buf before the loop below overwrites it
+        } else {
+            s = wave_sum(s);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+            __syncthreads();
+            mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
+            float q2 = 0.f;
+            for (int c = threadIdx.x; c < d.D; c += 256) { const float t = buf[c] - mu; q2 += t * t; }
+            q2 = wave_sum(q2);
+            if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q2;
+            __syncthreads();
+            rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+        }
         for (int c = threadIdx.x; c < d.D; c += 256) buf[c] = (buf[c] - mu) * rs * gamma[c] + beta[c];
     }
     __syncthreads();

@@ -216,8 +216,11 @@ __device__ __forceinline__ void dot_rows_x(const f32x4 (&r)[R][C], const f32x4 (
 // A CHAIN of n consecutive layer pairs runs in one launch (`layers`: device array): the residual stream goes from a pair's last phase to
 // the next pair's first one as granules too (gxo; the projection workgroups keep their own rows as the next residual in registers), so
 // the ~1.6 us between two launches and the first weight trip of every pair but the first leave the critical path.
+// pos_p / tick_p / err_p: the chain's position, tick and error word (= layers[0].pos / .tick / .err) as kernel arguments: read through the
+// argument record in device memory they were a dependent second trip to memory at the start of every note.
 __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers, int n_layers,
-                                                      const spn_dec_chain_ext* __restrict__ ext) {
+                                                      const spn_dec_chain_ext* __restrict__ ext, const int* __restrict__ pos_p,
+                                                      const int* __restrict__ tick_p, int* __restrict__ err_p) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float sm[DEC_G], sl[DEC_G];
@@ -232,12 +235,18 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const int d = a0.d, h = a0.h, kvh = a0.kvh, S = a0.S, inner = a0.inner;   // the same in every pair of a chain (checked by the host)
     // (position, tick and error word are requested here and first USED behind the weight requests of the role: read up front, the error
     // check alone held every workgroup's first weight load back by a trip to memory)
-    const int err_in = *a0.err;
-    int* const err = a0.err;
+    const int err_in = *err_p;
+    int* const err = err_p;
 #define STAMP(k_) do { if (a.stamps && tid == 0) a.stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP_OF(rec_, k_) do { if ((rec_).stamps && tid == 0) (rec_).stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-    const int t = *a0.pos;
-    const unsigned ebase = (unsigned)(*a0.tick) * 256u + 1u;
+    if (a0.stamps && tid == 0) a0.stamps[(long)b * 8 + (b < a0.h * a0.S ? 6 : (b < a0.h * a0.S + (a0.d + 15) / 16 ? 5 : 7))] = (long long)__builtin_amdgcn_s_memrealtime();   // kernel entry
+    // embed phase: key q's first column, row width and table in lane q.  Requested HERE, by every workgroup, before the record's scalar
+    // fields (which decide who runs the phase) have arrived: behind them these loads were a third dependent trip at the start of a note.
+    const int kq_ = min(lane, 15);
+    const int l_c0 = ext ? ext->ecol0[kq_] : 0, l_w = ext ? ext->ewidth[kq_] : 0;
+    const unsigned long long l_tb = ext ? reinterpret_cast<unsigned long long>(ext->etable[kq_]) : 0ull;
+    const int t = *pos_p;
+    const unsigned ebase = (unsigned)(*tick_p) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
     const int nA = h * S, nB = (d + 15) / 16;
     // Optional phases around the chain (spn_dec_chain_ext): in FRONT of the first pair the two input projections of the note (B
@@ -301,9 +310,13 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 }
             }
         };
-        if (emb && !err_in && b * 8 * ext->eR < 2 * ext->eN) {
+        if (emb && b * 8 * ext->eR < 2 * ext->eN) {
             // ---- embed: xin = We . LN(concat_k table_k[token_k]) + be for both sequences (dec_embed_proj_kernel, decode.hip): this workgroup's
-            //      8 eR rows of ONE sequence; every workgroup rebuilds that sequence's embedding in LDS with the statistics of the 256-thread kernel ----
+            //      8 eR rows of ONE sequence; every workgroup rebuilds that sequence's embedding in LDS ----
+            // The start of a note is a chain of dependent trips to memory (position -> tokens -> table rows): everything that does not depend
+            // on the position is requested first -- weight rows, the norm's affine rows in the dot-product layout, and per column of this
+            // thread (c = tid + 512 i) the table base, row width and key -- so that exactly those three trips remain (round 5: the
+            // column -> key search and the table pointer sat inside the gather loop, behind the tokens: 5 us from the position to the rows).
             const int N = ext->eN, R = ext->eR, D = ext->eD, gr0 = (b * 8 + w) * R;
             const int seq = (b * 8 * R) / N;
             f32x4 we[2][8];
@@ -318,38 +331,78 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     if (ext->be) bev[i] = ext->be[n];
                 }
             }
-            const long* tok = (seq ? ext->tok_b : ext->tok_a) + (long)(t + seq) * ext->etok_ld;
-            float s = 0.f;
-            if (tid < 256) for (int c = tid; c < D; c += 256) {
-                int kk = 0;
-                for (int q = 1; q < ext->en; ++q) if (c >= ext->ecol0[q]) kk = q;
-                const float v = ext->etable[kk][tok[kk] * ext->ewidth[kk] + (c - ext->ecol0[kk])];
-                xs[c] = v;
-                s += v;
-            }
-            if (ext->egamma) {
-                s = wave_sum(s);
-                if (tid < 256 && lane == 0) red[w] = s;
-                __syncthreads();
-                const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)D;
-                float q2 = 0.f;
-                if (tid < 256) for (int c = tid; c < D; c += 256) { const float t_ = xs[c] - mu; q2 += t_ * t_; }
-                q2 = wave_sum(q2);
-                if (tid < 256 && lane == 0) red[4 + w] = q2;
-                __syncthreads();
-                const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + ext->eeps);
-                if (tid < 256) for (int c = tid; c < D; c += 256) xs[c] = (xs[c] - mu) * rs * ext->egamma[c] + ext->ebeta[c];
-            }
-            __syncthreads();
-            float y[2];
-            dot_rows<8, 2>(we, xs, D, lane, y);
-            if (lane == 0) {
+            f32x4 eg[8], eb[8];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) if (i < R) outv[w * R + i] = ext->be ? y[i] + bev[i] : y[i];
+            for (int c = 0; c < 8; ++c) {
+                const int k = lane * 4 + c * 256;
+                const bool in = k < D && ext->egamma != nullptr;
+                eg[c] = in ? *reinterpret_cast<const f32x4*>(ext->egamma + k) : f32x4{1.f, 1.f, 1.f, 1.f};
+                eb[c] = in ? *reinterpret_cast<const f32x4*>(ext->ebeta + k) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            __syncthreads();
-            if (tid < 8 * R && b * 8 * R + tid < 2 * N) put(ext->gin + b * 8 * R + tid, eemb, outv[tid]);
-            __syncthreads();   // xs / outv are reused below
+            // (key of every column from the keys' first columns -- lane q holds key q's fields, handed round by readlane / bpermute: indexing
+            // the record with a per-lane key was one more trip to memory behind the weight rows, a scalar loop over the keys one trip per key)
+            const float* cbase[4];
+            int cwid[4], ckey[4];
+            {
+                const int en = ext->en;
+                int cc[4], kk[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cc[i] = min(tid + NT * i, D - 1);
+#pragma unroll
+                for (int q = 1; q < 16; ++q) {
+                    const int cq = q < en ? __builtin_amdgcn_readlane(l_c0, q) : 0x7fffffff;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) kk[i] = cc[i] >= cq ? q : kk[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c0 = __builtin_amdgcn_ds_bpermute(kk[i] << 2, l_c0);
+                    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(kk[i] << 2, (int)(unsigned)l_tb);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(kk[i] << 2, (int)(unsigned)(l_tb >> 32));
+                    ckey[i] = kk[i];
+                    cwid[i] = __builtin_amdgcn_ds_bpermute(kk[i] << 2, l_w);
+                    cbase[i] = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo) + (cc[i] - c0);
+                }
+            }
+            if (!err_in) {
+                const long* tok = (seq ? ext->tok_b : ext->tok_a) + (long)(t + seq) * ext->etok_ld;
+                if (n_layers > 1 && t >= 0) STAMP_OF(layers[1], 5);   // embed: position known
+                const int tq = lane < ext->en ? (int)tok[lane] : 0;   // the tuple's ids: one load per wave, handed to the columns by bpermute
+                float val[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tk = __builtin_amdgcn_ds_bpermute(ckey[i] << 2, tq);
+                    val[i] = cbase[i][(long)tk * cwid[i]];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (tid + NT * i < D) xs[tid + NT * i] = val[i];
+                __syncthreads();
+                if (n_layers > 1) STAMP_OF(layers[1], 6);   // embed: table rows gathered
+                f32x4 xv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = lane * 4 + c * 256;
+                    xv[c] = k < D ? *reinterpret_cast<const f32x4*>(xs + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (ext->egamma) {   // statistics per wave (common.h dec_ln_stats), the normalisation of dec_embed_proj_kernel in registers
+                    float mu, rs;
+                    dec_ln_stats<8>(xv, D, ext->eeps, lane, mu, rs);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) xv[c][e] = (xv[c][e] - mu) * rs * eg[c][e] + eb[c][e];
+                }
+                float y[2];
+                dot_rows_x<8, 2>(we, xv, D, lane, y);
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) if (i < R) outv[w * R + i] = ext->be ? y[i] + bev[i] : y[i];
+                }
+                __syncthreads();
+                if (tid < 8 * R && b * 8 * R + tid < 2 * N) put(ext->gin + b * 8 * R + tid, eemb, outv[tid]);
+                if (n_layers > 1) STAMP_OF(layers[1], 7);   // embed: rows out
+                __syncthreads();   // xs / outv are reused below
+            }
         }
         request(a0);
         if (own1 && !front) for (int k = tid; k < d; k += NT) xs[k] = a0.x[k];
@@ -755,6 +808,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         request(a0);
         if (err_in) return;
         if (emb) gather(ext->gin, Km, eemb, xs, tid, err);   // the embed phase of the attention workgroups
+        if (n_layers > 1) STAMP_OF(layers[1], 5);   // front: embedded tokens gathered
         __syncthreads();
         float y[2];
         dot_rows<4, 2>(wm, xs, Km, lane, y);
@@ -765,6 +819,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (lane == 0 && r0 + i < d && ext->y2m) ext->y2m[(long)t * ext->y2m_ld + r0 + i] = y[i];
         }
         publish16(ext->gf, bb * 16, d, efront, outv, tid);
+        if (n_layers > 1) STAMP_OF(layers[1], 7);   // front: x0 out
         __syncthreads();
         gather(ext->gf, d, efront, xs, tid, err);
 #pragma unroll
@@ -892,6 +947,11 @@ extern "C" int spn_dec_struct_size(int which) { return which == 0 ? (int)sizeof(
 
 // `host`: the n argument records (validated here); `dev`: the same n records in DEVICE memory (the launch reads them there: a chain of
 // pairs does not fit the kernel-argument segment).  The caller keeps both alive and identical; nothing is copied or allocated here.
+// the kernel reads the norms' affine rows (and the adaptive (gamma | beta) rows) with 16-byte loads in the dot-product layout
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool norm_rows_aligned(const spn_dec_pair_args& a) {
+    return al16(a.gam1) && al16(a.bet1) && al16(a.gam2) && al16(a.bet2) && (a.d % 4) == 0;
+}
 // every workgroup of the launch polls results of the others: all of them must be resident at once, one per CU
 static bool device_holds(int groups) {
     int dev = 0, cus = 0;
@@ -916,8 +976,9 @@ extern "C" int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_a
                     a.gx && a.gg && (a.gxo || l == n - 1), "spn_dec_pairs: null operand");
         SPN_REQUIRE(a.x == f.x, "spn_dec_pairs: one residual stream per chain");
         SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs: weight rows must be 16-byte aligned");
+        SPN_REQUIRE(norm_rows_aligned(a), "spn_dec_pairs: the norms' affine rows must be 16-byte aligned");
     }
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, (const spn_dec_chain_ext*)nullptr);
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, (const spn_dec_chain_ext*)nullptr, f.pos, (const int*)f.tick, f.err);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -941,6 +1002,7 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
         SPN_REQUIRE(a.Wqkv && a.Wo && a.W1 && a.W2 && a.x && a.kcache && a.vcache && a.kmax2 && a.gq && a.gp && a.go && a.gx && a.gg &&
                     (a.gxo || (l == n - 1 && !e.Wh)), "spn_dec_pairs_ext: null operand");
         SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs_ext: weight rows must be 16-byte aligned");
+        SPN_REQUIRE(norm_rows_aligned(a), "spn_dec_pairs_ext: the norms' affine rows must be 16-byte aligned");
     }
     if (e.Wm) {
         const int Kc = f.d + (e.ctx ? e.ctx_w : 0) + (e.style ? e.style_w : 0);
@@ -948,6 +1010,8 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
                     (e.ld_m % 4) == 0 && (e.ld_p % 4) == 0 && (!e.ctx || e.ctx_w <= 2048) && (!e.style || e.style_w <= 2048),
                     "spn_dec_pairs_ext: front projections: Km <= 1024, d + context + style <= 2048, 16-byte aligned rows");
     }
+    SPN_REQUIRE(al16(e.gamh) && al16(e.beth) && al16(e.egamma) && al16(e.ebeta) && (e.ada_par % 4) == 0,
+                "spn_dec_pairs_ext: affine rows (tail norm, embedding norm) must be 16-byte aligned, ada_par a multiple of 4");
     if (e.Wh) SPN_REQUIRE(e.e_out && e.Nh >= 1 && e.Nh <= 16 * f.h * f.S && (e.ld_h % 4) == 0, "spn_dec_pairs_ext: tail projection: at most 16 h S rows");
     if (e.en) {
         SPN_REQUIRE(e.Wm && e.en >= 1 && e.en <= 16 && e.eD >= 4 && e.eD <= 2048 && e.eD % 4 == 0 && e.eN >= 1 && 2 * e.eN == e.Km && (e.eR == 1 || e.eR == 2) &&
@@ -970,7 +1034,7 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
             SPN_REQUIRE(e.htable[q] && e.hV[q] >= 1 && e.hwidth[q] >= 1 && e.hcol0[q] >= 0 && e.hcol0[q] + e.hwidth[q] <= e.hD && e.hdim[q] >= 0,
                         "spn_dec_pairs_ext: head phase: bad key record");
     }
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev);
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev, f.pos, (const int*)f.tick, f.err);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

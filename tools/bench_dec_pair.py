@@ -47,6 +47,18 @@ def timeline(L, groups, dev, model, batch, enc):
                                                          6: "head: slab maxima out", 7: "head: token written"})}
     t_prev_end = None
     t_launch = None
+    st0 = eng.pair_stamps[0].view(groups, 8).cpu().double() * 0.01
+    entry = torch.cat([st0[:nA, 6], st0[nA:nA + nB, 5], st0[nA + nB:, 7]])
+    first = float(st0[:, 0].min())
+    print(f"kernel entry of the workgroups: {float(entry.min()) - first:6.2f} .. {float(entry.max()) - first:6.2f} us relative to the launch's first phase stamp")
+    if len(eng.pair_stamps) > 1:   # the note's first phases (embed on the attention workgroups, front on the projection workgroups) stamp pair 1's record
+        st1 = eng.pair_stamps[1].view(groups, 8).cpu().double() * 0.01
+        for name, sl, k in (("embed: position known", slice(0, nA), 5), ("embed: table rows gathered", slice(0, nA), 6), ("embed: rows out", slice(0, nA), 7),
+                            ("front: embedded tokens gathered", slice(nA, nA + nB), 5), ("front: x0 out", slice(nA, nA + nB), 7)):
+            col = st1[sl, k]
+            col = col[col > 0]
+            if len(col):
+                print(f"    {name}: {float(col.min()) - first:6.2f} .. {float(col.max()) - first:6.2f}")
     for pi, st in enumerate(eng.pair_stamps):
         st = st.view(groups, 8).cpu().double() * 0.01          # us
         t0 = float(st[:, 0].min())
@@ -58,6 +70,10 @@ def timeline(L, groups, dev, model, batch, enc):
         for role, (sl, cols) in roles.items():
             line = [f"    {role}:"]
             for k, name in cols.items():
+                if pi == 1 and len(eng.pair_stamps) > 2 and ((role.startswith("A") and k in (5, 6, 7)) or (role.startswith("B") and k in (5, 7))):
+                    continue   # the note's first phases (printed above)
+                if pi == 0 and ((role.startswith("C") and k == 7) or (role.startswith("A") and k == 6) or (role.startswith("B") and k == 5)):
+                    continue   # kernel-entry stamps (printed above)
                 col = st[sl, k]
                 col = col[col > 0]
                 if len(col):
