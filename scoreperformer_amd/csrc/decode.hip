@@ -92,16 +92,29 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(DecEmbedDesc d, const lo
         for (int c = threadIdx.x; c < d.D; c += 256) y[c] = buf[c];
         return;
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
-    float q2 = 0.f;
-    for (int c = threadIdx.x; c < d.D; c += 256) { const float t = buf[c] - mu; q2 += t * t; }
-    q2 = wave_sum(q2);
-    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q2;
-    __syncthreads();
-    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+    float mu, rs;
+    if ((d.D & 3) == 0) {   // per wave, common.h dec_ln_stats: as dec_embed_proj_kernel
+        __syncthreads();
+        const int lane = threadIdx.x & 63;
+        f32x4 xv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            xv[c] = k < d.D ? *reinterpret_cast<const f32x4*>(buf + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        dec_ln_stats<8>(xv, d.D, eps, lane, mu, rs);
+    } else {
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
+        float q2 = 0.f;
+        for (int c = threadIdx.x; c < d.D; c += 256) { const float t = buf[c] - mu; q2 += t * t; }
+        q2 = wave_sum(q2);
+        if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q2;
+        __syncthreads();
+        rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+    }
     for (int c = threadIdx.x; c < d.D; c += 256) y[c] = (buf[c] - mu) * rs * gamma[c] + beta[c];
 }
 
@@ -492,16 +505,29 @@ __global__ __launch_bounds__(256) void dec_fused_gemv_kernel(DecGemvArgs a) {
             for (int k = threadIdx.x; k < a.cat_style_w; k += 256)
                 xs[a.cat_d + (a.cat_ctx ? a.cat_ctx_w : 0) + k] = a.cat_style[(long)(p + 1) * a.cat_style_ld + k];
         if (a.gamma) {
-            s = wave_sum(s);
-            if (lane == 0) red[w] = s;
-            __syncthreads();
-            const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.cat_d;
-            float q2 = 0.f;
-            for (int k = threadIdx.x; k < a.cat_d; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
-            q2 = wave_sum(q2);
-            if (lane == 0) red[4 + w] = q2;
-            __syncthreads();
-            const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.cat_d + a.eps);
+            float mu, rs;
+            if ((a.cat_d & 3) == 0) {   // per wave, common.h dec_ln_stats (the front phase of decode_layer.hip)
+                __syncthreads();
+                f32x4 xv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int k = lane * 4 + c * 256;
+                    xv[c] = k < a.cat_d ? *reinterpret_cast<const f32x4*>(xs + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                dec_ln_stats<8>(xv, a.cat_d, a.eps, lane, mu, rs);
+                __syncthreads();
+            } else {
+                s = wave_sum(s);
+                if (lane == 0) red[w] = s;
+                __syncthreads();
+                mu = (red[0] + red[1] + red[2] + red[3]) / (float)a.cat_d;
+                float q2 = 0.f;
+                for (int k = threadIdx.x; k < a.cat_d; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+                q2 = wave_sum(q2);
+                if (lane == 0) red[4 + w] = q2;
+                __syncthreads();
+                rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)a.cat_d + a.eps);
+            }
             for (int k = threadIdx.x; k < a.cat_d; k += 256) xs[k] = (xs[k] - mu) * rs * a.gamma[k] + a.beta[k];
         }
     } else {
@@ -582,7 +608,15 @@ __global__ __launch_bounds__(256) void dec_cat_kernel(const float* __restrict__ 
     float s = 0.f;
     for (int k = threadIdx.x; k < d; k += 256) s += x[k];
     float mu = 0.f, rs = 1.f;
-    if (gamma) {
+    if (gamma && (d & 3) == 0 && d <= 2048 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // per wave, common.h dec_ln_stats: as the fused prologue
+        f32x4 xv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            xv[c] = k < d ? *reinterpret_cast<const f32x4*>(x + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        dec_ln_stats<8>(xv, d, eps, lane, mu, rs);
+    } else if (gamma) {
         s = wave_sum(s);
         if (lane == 0) red[w] = s;
         __syncthreads();
@@ -825,16 +859,29 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
     if (batched && vb < V) load_rows(rw, vb);
     float s = 0.f;
     for (int k = threadIdx.x; k < d.D; k += 256) { const float v = e[k]; xs[k] = v; s += v; }
-    s = wave_sum(s);
-    if (lane == 0) red[w] = s;
-    __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
-    float q2 = 0.f;
-    for (int k = threadIdx.x; k < d.D; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
-    q2 = wave_sum(q2);
-    if (lane == 0) red[4 + w] = q2;
-    __syncthreads();
-    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+    float mu, rs;
+    if ((d.D & 3) == 0) {   // statistics per wave over the dot-product layout (common.h dec_ln_stats: the head phase of decode_layer.hip)
+        __syncthreads();
+        f32x4 xv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = lane * 4 + c * 256;
+            xv[c] = k < d.D ? *reinterpret_cast<const f32x4*>(xs + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        dec_ln_stats<8>(xv, d.D, eps, lane, mu, rs);
+        __syncthreads();   // every wave has read xs before the slice below is overwritten
+    } else {
+        s = wave_sum(s);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        mu = (red[0] + red[1] + red[2] + red[3]) / (float)d.D;
+        float q2 = 0.f;
+        for (int k = threadIdx.x; k < d.D; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
+        q2 = wave_sum(q2);
+        if (lane == 0) red[4 + w] = q2;
+        __syncthreads();
+        rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)d.D + eps);
+    }
     for (int k = threadIdx.x; k < W; k += 256) xs[c0 + k] = (xs[c0 + k] - mu) * rs * gamma[c0 + k] + beta[c0 + k];
     __syncthreads();
     float best = -INFINITY;

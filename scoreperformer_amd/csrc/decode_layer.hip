@@ -100,35 +100,6 @@ __device__ __forceinline__ NormRegs norm_regs(int K, int mode, const float* gam,
     return r;
 }
 
-// LayerNorm of xs[0 .. K) in place, the arithmetic of dec_fused_gemv_kernel (256 threads own k = tid, tid + 256)
-__device__ __forceinline__ void block_norm(float* xs, float* red, int K, bool affine, const NormRegs& nr, float eps, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
-    float s = 0.f;
-    if (tid < 256) for (int k = tid; k < K; k += 256) s += xs[k];
-    s = wave_sum(s);
-    if (tid < 256 && lane == 0) red[w] = s;
-    __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)K;
-    float q2 = 0.f;
-    if (tid < 256) for (int k = tid; k < K; k += 256) { const float t = xs[k] - mu; q2 += t * t; }
-    q2 = wave_sum(q2);
-    if (tid < 256 && lane == 0) red[4 + w] = q2;
-    __syncthreads();
-    const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)K + eps);
-    if (tid < 256) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = tid + 256 * i;
-            if (k < K) {
-                float v = (xs[k] - mu) * rs;
-                if (affine) v = v * nr.g[i] + nr.b[i];
-                xs[k] = v;
-            }
-        }
-    }
-    __syncthreads();
-}
-
 // LayerNorm of xs[0 .. K), K <= 512, per WAVE and without a barrier: statistics by common.h dec_ln_stats (the arithmetic of
 // dec_fused_gemv_kernel's norm), the normalised vector returned in the dot_rows layout (lane owns k = 4 lane + 256 c, c < 2) with the
 // affine parameters held in that layout (NormRegs4); xs itself is left as gathered.
@@ -660,19 +631,18 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 __syncthreads();
                 gather(ext->ge, D, ehead, xs, tid, err);
                 __syncthreads();
-                // LayerNorm statistics of e, the arithmetic of dec_head_kernel (256 threads own k = tid, tid + 256, ...)
-                float s = 0.f;
-                if (tid < 256) for (int k = tid; k < D; k += 256) s += xs[k];
-                s = wave_sum(s);
-                if (tid < 256 && lane == 0) red[w] = s;
-                __syncthreads();
-                const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)D;
-                float q2 = 0.f;
-                if (tid < 256) for (int k = tid; k < D; k += 256) { const float t_ = xs[k] - mu; q2 += t_ * t_; }
-                q2 = wave_sum(q2);
-                if (tid < 256 && lane == 0) red[4 + w] = q2;
-                __syncthreads();
-                const float rs = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)D + ext->heps);
+                // LayerNorm statistics of e, the arithmetic of dec_head_kernel: per wave over the dot-product layout (common.h dec_ln_stats)
+                float mu, rs;
+                {
+                    f32x4 xv[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int k = lane * 4 + c * 256;
+                        xv[c] = k < D ? *reinterpret_cast<const f32x4*>(xs + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    dec_ln_stats<8>(xv, D, ext->heps, lane, mu, rs);
+                }
+                __syncthreads();   // every wave has read xs before the slices below are overwritten
                 for (int it = it0; it < items; it += nC) {
                     const int q = it / SL, s0 = it - q * SL;
                     const int c0 = ext->hcol0[q], W = ext->hwidth[q], V = ext->hV[q];
@@ -829,7 +799,22 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (k < sw_) xs[d + cw_ + k] = sx[q];
         }
         __syncthreads();
-        if (ext->cat_gamma) block_norm(xs, red, d, true, nc, ext->cat_eps, tid);
+        if (ext->cat_gamma) {   // dec_fused_gemv_kernel's cat prologue: statistics per wave (common.h dec_ln_stats), normalised in place
+            f32x4 xv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) xv[c] = lane * 4 + c * 256 < d ? *reinterpret_cast<const f32x4*>(xs + lane * 4 + c * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+            float mu, rs;
+            dec_ln_stats<2>(xv, d, ext->cat_eps, lane, mu, rs);
+            __syncthreads();
+            if (tid < 256) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int k = tid + 256 * i;
+                    if (k < d) xs[k] = (xs[k] - mu) * rs * nc.g[i] + nc.b[i];
+                }
+            }
+            __syncthreads();
+        }
         dot_rows<8, 2>(wp, xs, Kc, lane, y);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1028,8 +1013,8 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
     if (e.rW) SPN_REQUIRE(e.rN >= 1 && e.rK >= 4 && e.rK <= 256 && e.rK % 4 == 0 && (e.r_ldw % 4) == 0 && e.rx && (e.rx_ld % 4) == 0 && e.rx_rows >= 1 && e.ry && e.ada_par >= e.rN,
                           "spn_dec_pairs_ext: rider: K <= 256 in whole float4, two row buffers ada_par >= rN floats apart");
     if (e.hn) {
-        SPN_REQUIRE(e.Wh && e.hn >= 1 && e.hn <= 16 && e.hD == e.Nh && e.hD <= 2048 && e.hD % 2 == 0 && e.hgamma && e.hbeta && e.tokens && e.ge && e.gh,
-                    "spn_dec_pairs_ext: head phase: needs the tail, 1 to 16 keys, e of even width <= 2048, norm, tokens and granule buffers");
+        SPN_REQUIRE(e.Wh && e.hn >= 1 && e.hn <= 16 && e.hD == e.Nh && e.hD <= 2048 && e.hD % 4 == 0 && e.hgamma && e.hbeta && e.tokens && e.ge && e.gh,
+                    "spn_dec_pairs_ext: head phase: needs the tail, 1 to 16 keys, e of a width in whole float4 <= 2048, norm, tokens and granule buffers");
         for (int q = 0; q < e.hn; ++q)
             SPN_REQUIRE(e.htable[q] && e.hV[q] >= 1 && e.hwidth[q] >= 1 && e.hcol0[q] >= 0 && e.hcol0[q] + e.hwidth[q] <= e.hD && e.hdim[q] >= 0,
                         "spn_dec_pairs_ext: head phase: bad key record");

@@ -503,7 +503,7 @@ class GreedyDecoder:
                     self.pair_tail = True
                     # ... and the arg-max LM head itself (greedy decoding: sampling keeps its own launch), so that a note is TWO launches
                     if (head_ok and self.sampling is None and te.total_emb_dim == self.head_Wt.shape[0] and te.total_emb_dim <= 2048
-                            and te.total_emb_dim % 2 == 0 and os.environ.get("SPN_DEC_PAIR_HEAD", "1") != "0"):
+                            and te.total_emb_dim % 4 == 0 and os.environ.get("SPN_DEC_PAIR_HEAD", "1") != "0"):
                         ext.update(self._head_ext(), ge=self.pair_g2["ge"], gh=self.pair_g2["gh"])
                         self.pair_head = True
                 # ... and, in front, the two token-tuple embeddings with their projection (+ the NEXT note's AdaLN rows): ONE launch per note
