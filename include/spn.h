@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -331,9 +331,17 @@ typedef struct spn_dec_chain_ext {
      * rx[min(*pos + 2, rx_rows - 1), :] + rbias[n] with par = ada_par on even *pos, 0 on odd *pos; the adaptive norms (mode 2) of THIS
      * note read their (gamma | beta) rows at + ada_par when *pos is odd.  The caller computes the first note's rows (spn_dec_gemv). */
     const float* rW; long r_ldw; int rN; int rK; const float* rx; long rx_ld; int rx_rows; const float* rbias; float* ry; long ada_par;
+    /* several notes per launch (spn_dec_pairs_notes): granules [16] (zeroed once per render) through which the head's winners hand the
+     * final value of their token cells to the next note's embed phase; null: one note per launch only */
+    unsigned long long* gt;
 } spn_dec_chain_ext;
 int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
                       const spn_dec_chain_ext* ext_dev, spn_stream_t s);
+/* `notes` consecutive notes (positions *pos .. *pos + notes - 1, all of them to be decoded) in ONE launch: needs the embed, front, tail and
+ * head phases and ext.gt; position and tick advance by `notes`.  Same tokens, hidden rows and cache rows as `notes` launches of
+ * spn_dec_pairs_ext. */
+int spn_dec_pairs_notes(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                        const spn_dec_chain_ext* ext_dev, int notes, spn_stream_t s);
 int spn_dec_struct_size(int which); /* sizeof(spn_dec_pair_args) (0) / sizeof(spn_dec_chain_ext) (1): lets a binding check its record layout */
 int spn_dec_head(int n, const float* const* tables, const int* V, const int* width, const int* col0, const int* dim, int D, const float* e,
                  const float* gamma, const float* beta, float eps, unsigned ban_mask, long* tokens, long tok_ld, int mask_id,

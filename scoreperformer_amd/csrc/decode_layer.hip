@@ -106,7 +106,23 @@ __device__ __forceinline__ NormRegs norm_regs(int K, int mode, const float* gam,
 struct NormRegs4 { f32x4 g[2], b[2]; };
 __device__ __forceinline__ NormRegs4 norm_regs4(int K, int mode, const float* gam, const float* bet, int lane) {
     NormRegs4 r;
-    const float* be = mode == 2 ? gam + K : bet;
+    if (mode == 2 && gam != nullptr) {
+        // adaptive (gamma | beta) row: written by OTHER workgroups -- one note earlier, possibly in this very launch -- into a buffer that
+        // is reused every second note: read past the L2 (agent scope, aux 16 = sc1), or a later note of the launch finds the lines its
+        // XCD's L2 kept from two notes ago
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)gam, 0, 2 * K * 4, 0x00020000);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int k = lane * 4 + c * 256;
+            const bool in = k < K;
+            const pair_u32x4 g = __builtin_amdgcn_raw_buffer_load_b128(rs, min(k, K - 4) * 4, 0, 16);
+            const pair_u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (K + min(k, K - 4)) * 4, 0, 16);
+            r.g[c] = in ? __builtin_bit_cast(f32x4, g) : f32x4{1.f, 1.f, 1.f, 1.f};
+            r.b[c] = in ? __builtin_bit_cast(f32x4, b) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return r;
+    }
+    const float* be = bet;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int k = lane * 4 + c * 256;
@@ -187,11 +203,18 @@ __device__ __forceinline__ void dot_rows_x(const f32x4 (&r)[R][C], const f32x4 (
 // A CHAIN of n consecutive layer pairs runs in one launch (`layers`: device array): the residual stream goes from a pair's last phase to
 // the next pair's first one as granules too (gxo; the projection workgroups keep their own rows as the next residual in registers), so
 // the ~1.6 us between two launches and the first weight trip of every pair but the first leave the critical path.
+// n_notes consecutive notes in ONE launch (round 5; needs the embed, front, tail and head phases): every role loops over the notes, position
+// and tick advance in registers, and the one thing a note needs from its predecessor that used to cross a kernel boundary -- the chosen
+// tokens -- travels as granules from the head's winners to the embed workgroups (spn_dec_chain_ext.gt).  Everything else one note writes
+// and a later note reads from another workgroup is written through and read past the L2 (agent scope): the XCDs' L2s are only made
+// coherent at kernel boundaries.  Key / value rows: written through by their one writer, and no workgroup touches the lines of row t
+// before note t + 1 (at note t the row comes from the q | k | v granules).  AdaLN rows: two buffers by note parity, written through,
+// read with agent-scope loads.  Saves the graph edge and the first trips of a launch (position, argument records) per note.
 // pos_p / tick_p / err_p: the chain's position, tick and error word (= layers[0].pos / .tick / .err) as kernel arguments: read through the
 // argument record in device memory they were a dependent second trip to memory at the start of every note.
-__global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers, int n_layers,
-                                                      const spn_dec_chain_ext* __restrict__ ext, const int* __restrict__ pos_p,
-                                                      const int* __restrict__ tick_p, int* __restrict__ err_p) {
+__global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* __restrict__ layers0, int n_layers,
+                                                      const spn_dec_chain_ext* __restrict__ ext0, const int* __restrict__ pos_p,
+                                                      const int* __restrict__ tick_p, int* __restrict__ err_p, int n_notes) {
     __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float red[8];
     __shared__ float sm[DEC_G], sl[DEC_G];
@@ -202,7 +225,18 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     __shared__ float outv[16];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    const spn_dec_pair_args& a0 = layers[0];
+    // The record pointers as the loop over the notes sees them: re-derived at the top of every note through an offset the compiler cannot
+    // see through (always 0).  Without it everything that only depends on the records -- every weight address of every pair, every
+    // per-key field -- is loop-invariant, gets hoisted in front of the note loop and stays live across it: 106 spilled VGPRs.
+    const spn_dec_pair_args* layers = layers0;
+    const spn_dec_chain_ext* ext = ext0;
+    long nz = 0;
+    auto rebase = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+s"(nz));
+        layers = layers0 + nz;
+        ext = ext0 ? ext0 + nz : nullptr;
+    };
+#define a0 (layers[0])
     const int d = a0.d, h = a0.h, kvh = a0.kvh, S = a0.S, inner = a0.inner;   // the same in every pair of a chain (checked by the host)
     // (position, tick and error word are requested here and first USED behind the weight requests of the role: read up front, the error
     // check alone held every workgroup's first weight load back by a trip to memory)
@@ -216,22 +250,27 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const int kq_ = min(lane, 15);
     const int l_c0 = ext ? ext->ecol0[kq_] : 0, l_w = ext ? ext->ewidth[kq_] : 0;
     const unsigned long long l_tb = ext ? reinterpret_cast<unsigned long long>(ext->etable[kq_]) : 0ull;
-    const int t = *pos_p;
-    const unsigned ebase = (unsigned)(*tick_p) * 256u + 1u;
+    int t = *pos_p;
+    unsigned ebase = (unsigned)(*tick_p) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
     const int nA = h * S, nB = (d + 15) / 16;
     // Optional phases around the chain (spn_dec_chain_ext): in FRONT of the first pair the two input projections of the note (B
     // workgroups: x0 = Wm . xin + bm, then x = Wp . (LN?(x0) | context row | style row) + bp), BEHIND the last pair the LM head's input
     // projection e = Wh . LN(x) (A workgroups).  Their epochs use pair number 31.
     const bool front = ext && ext->Wm, tail = ext && ext->Wh, head = tail && ext->hn > 0;
-    const unsigned efront = ebase + 8u * 31u;
-    const unsigned ehead = efront + 2u;   // e (tail -> head workgroups); + 1: the per-key partial maxima
-    const unsigned eemb = efront + 4u;    // the projected token embeddings (attention workgroups -> front)
+    unsigned efront = ebase + 8u * 31u;
+    unsigned ehead = efront + 2u;   // e (tail -> head workgroups); + 1: the per-key partial maxima
+    unsigned eemb = efront + 4u;    // the projected token embeddings (attention workgroups -> front); + 1: the chosen tokens (winners -> embed)
     const bool emb = front && ext->en > 0;
     // adaptive norms read their (gamma | beta) rows from the buffer of this note's parity (spn_dec_chain_ext.ada_par)
     // (wave-uniform by construction: through readfirstlane it lives in scalar registers -- as a per-lane value it was spilled to scratch)
-    const long apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
+    long apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
 #define ADA(mode_, ptr_) (((mode_) == 2 && (ptr_)) ? (ptr_) + apar : (ptr_))
+    // the next note of this launch: position + 1, a fresh epoch block (tick + 1), the other set of AdaLN rows
+    auto next_note = [&]() __attribute__((always_inline)) {
+        t += 1; ebase += 256u; efront += 256u; ehead += 256u; eemb += 256u;
+        apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
+    };
 
     if (b < nA) {
         // ================================================ A: q|k|v rows, attention split ==================================================
@@ -281,6 +320,13 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 }
             }
         };
+        for (int note = 0; note < n_notes; ++note) {
+        rebase();
+        // (the early key / value rows are only conditionally reloaded below: without this the previous note's values count as live across
+        // the embed phase -- 64 registers on top of its weight rows)
+#pragma unroll
+        for (int u = 0; u < DEC_NU; ++u) k4[u] = v4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pre = false;
         if (emb && b * 8 * ext->eR < 2 * ext->eN) {
             // ---- embed: xin = We . LN(concat_k table_k[token_k]) + be for both sequences (dec_embed_proj_kernel, decode.hip): this workgroup's
             //      8 eR rows of ONE sequence; every workgroup rebuilds that sequence's embedding in LDS ----
@@ -338,7 +384,26 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (!err_in) {
                 const long* tok = (seq ? ext->tok_b : ext->tok_a) + (long)(t + seq) * ext->etok_ld;
                 if (n_layers > 1 && t >= 0) STAMP_OF(layers[1], 5);   // embed: position known
-                const int tq = lane < ext->en ? (int)tok[lane] : 0;   // the tuple's ids: one load per wave, handed to the columns by bpermute
+                int tq = 0;   // the tuple's ids: lane c holds column c, handed to the table columns by bpermute
+                if (note > 0 && seq == 0) {
+                    // a later note of the launch: the cells the head decodes come from its winners as granules (the PREVIOUS note's epoch
+                    // block), the other columns of the row are given input
+                    int qsel = -1;
+                    for (int q = 0; q < ext->hn; ++q) if (ext->hdim[q] == lane) qsel = q;
+                    if (lane < ext->en) {
+                        if (qsel < 0) tq = (int)tok[lane];
+                        else {
+                            unsigned spins = 0;
+                            for (;;) {
+                                const unsigned long long x = __hip_atomic_load(as_global(ext->gt + qsel), RLX_AGENT);
+                                tq = (int)(unsigned)x;
+                                if ((unsigned)(x >> 32) == eemb - 256u + 1u) break;
+                                if (++spins > SPIN_LIMIT) { *err = 3; break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                        }
+                    }
+                } else if (lane < ext->en) tq = (int)tok[lane];
                 float val[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -427,8 +492,9 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 float kn2 = knew[lane] * knew[lane], qn2 = qs[lane] * qs[lane];
                 kn2 = wave_sum(kn2); qn2 = wave_sum(qn2);
                 if (sp == 0 && w == 0) {
-                    a.kcache[t * cw + kh * 64 + lane] = knew[lane];
-                    a.vcache[t * cw + kh * 64 + lane] = vnew[lane];
+                    // (written through: a later note of the same launch reads the row from another XCD)
+                    __hip_atomic_store(a.kcache + t * cw + kh * 64 + lane, knew[lane], RLX_AGENT);
+                    __hip_atomic_store(a.vcache + t * cw + kh * 64 + lane, vnew[lane], RLX_AGENT);
                     if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(a.kmax2 + kh), __float_as_uint(kn2));
                 }
                 int j_lo = 0;
@@ -516,6 +582,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                 STAMP_OF(al, 5);   // e out
             }
         }
+        next_note();
+        }   // notes
         return;
     }
     if (b >= nA + nB) {
@@ -541,6 +609,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             }
             n2 = norm_regs4(d, a.norm2, ADA(a.norm2, a.gam2), a.bet2, lane);
         };
+        for (int note = 0; note < n_notes; ++note) {
+        rebase();
         request(a0);
         if (err_in) return;
         if (ext && ext->rW) {
@@ -567,7 +637,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     f32x2 a2 = f32x2{0.f, 0.f};
                     if (in) dec_dot4(a2, wv[u], xv);
                     float acc = wave_sum(dec_fold(a2));
-                    if (lane == 0 && n < rN) yo[n] = ext->rbias ? acc + bz[u] : acc;
+                    if (lane == 0 && n < rN) __hip_atomic_store(yo + n, ext->rbias ? acc + bz[u] : acc, RLX_AGENT);   // read by other workgroups, maybe in this launch
                 }
             }
         }
@@ -718,13 +788,18 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                             const int bii = __float_as_int(xs[2 * r + 1]);
                             if (r == 0 || bvv > best || (bvv == best && bii < idx)) { best = bvv; idx = bii; }
                         }
-                        if (cur == ext->mask_id) *cell = idx;
+                        const long chosen = cur == ext->mask_id ? (long)idx : cur;
+                        if (cur == ext->mask_id) __hip_atomic_store(cell, chosen, RLX_AGENT);
+                        // the cell's final value for the next note's embed phase (same launch: spn_dec_chain_ext.gt)
+                        if (ext->gt) __hip_atomic_store(as_global(ext->gt + q), ((unsigned long long)(eemb + 1u) << 32) | (unsigned)chosen, RLX_AGENT);
                     }
                     STAMP_OF(layers[n_layers - 1], 7);   // token written
                 }
             }
-            if (bc == 0 && tid == 0 && ext->pos_next) *ext->pos_next = t + 1;
+            if (note == n_notes - 1 && bc == 0 && tid == 0 && ext->pos_next) *ext->pos_next = t + 1;
         }
+        next_note();
+        }   // notes
         return;
     }
     // ==================================================== B: merge, output projections ====================================================
@@ -746,6 +821,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             if (r0 + i < d) { load_row<8>(w2[i], a.W2 + (long)(r0 + i) * a.ld_2, inner, lane); if (a.b2) b2v[i] = a.b2[r0 + i]; }
         }
     };
+    for (int note = 0; note < n_notes; ++note) {
+    rebase();
     if (front) {
         // ---- front: x0 = Wm . xin + bm (K = Km <= 1024), then x = Wp . (LN?(x0) | ctx[t + 1] | style[t + 1]) + bp (K <= 2048) ----
         const int Km = ext->Km, cw_ = ext->ctx ? ext->ctx_w : 0, sw_ = ext->style ? ext->style_w : 0, Kc = d + cw_ + sw_;
@@ -910,9 +987,12 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             STAMP(6);
             // Everybody has read the tick by now: this workgroup's inputs needed every C workgroup's gated rows, those needed every B
             // workgroup's x1 rows, those every A workgroup's partials, and every workgroup reads the tick before its first phase.
-            if (a.bump && bb == 0 && tid == 0) *a.tick = *a.tick + 1;
+            if (a.bump && note == n_notes - 1 && bb == 0 && tid == 0) *a.tick = *a.tick + n_notes;
         }
     }
+    next_note();
+    }   // notes
+#undef a0
 }
 
 }  // namespace
@@ -963,16 +1043,16 @@ extern "C" int spn_dec_pairs(const spn_dec_pair_args* host, const spn_dec_pair_a
         SPN_REQUIRE((a.ld_qkv % 4) == 0 && (a.ld_o % 4) == 0 && (a.ld_1 % 4) == 0 && (a.ld_2 % 4) == 0, "spn_dec_pairs: weight rows must be 16-byte aligned");
         SPN_REQUIRE(norm_rows_aligned(a), "spn_dec_pairs: the norms' affine rows must be 16-byte aligned");
     }
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, (const spn_dec_chain_ext*)nullptr, f.pos, (const int*)f.tick, f.err);
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, (const spn_dec_chain_ext*)nullptr, f.pos, (const int*)f.tick, f.err, 1);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
 
 // The same with the note's input projections in front of the first pair and / or the LM head's input projection behind the last one
 // (spn_dec_chain_ext: either part may be absent).  ext_host / ext_dev: the record on the host (validated) and in device memory.
-extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
-                                 const spn_dec_chain_ext* ext_dev, hipStream_t s) {
-    SPN_REQUIRE(host && dev && ext_host && ext_dev && n >= 1 && n <= 31, "spn_dec_pairs_ext: 1 to 31 argument records and the extension record, on the host and on the device");
+static int dec_pairs_ext_notes(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                               const spn_dec_chain_ext* ext_dev, int notes, hipStream_t s) {
+    SPN_REQUIRE(host && dev && ext_host && ext_dev && n >= 1 && n <= 31, "spn_dec_pairs_ext / _notes: 1 to 31 argument records and the extension record, on the host and on the device");
     const spn_dec_pair_args& f = host[0];
     const spn_dec_chain_ext& e = *ext_host;
     const int G = spn_dec_pair_groups(f.d, f.h, f.kvh, f.inner, f.S);
@@ -1019,7 +1099,25 @@ extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pa
             SPN_REQUIRE(e.htable[q] && e.hV[q] >= 1 && e.hwidth[q] >= 1 && e.hcol0[q] >= 0 && e.hcol0[q] + e.hwidth[q] <= e.hD && e.hdim[q] >= 0,
                         "spn_dec_pairs_ext: head phase: bad key record");
     }
-    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev, f.pos, (const int*)f.tick, f.err);
+    SPN_REQUIRE(notes >= 1 && notes <= 64, "spn_dec_pairs_notes: 1 to 64 notes per launch");
+    if (notes > 1)
+        SPN_REQUIRE(e.Wm && e.Wh && e.hn > 0 && e.en > 0 && e.gt && e.pos_next && host[n - 1].bump,
+                    "spn_dec_pairs_notes: several notes per launch need the whole note in the launch (embed, front, tail, head phases, the "
+                    "token granules gt, pos_next, and the last pair advancing the tick)");
+    hipLaunchKernelGGL(dec_pair_kernel, dim3(G), dim3(NT), 0, s, dev, n, ext_dev, f.pos, (const int*)f.tick, f.err, notes);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
+}
+
+extern "C" int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                                 const spn_dec_chain_ext* ext_dev, hipStream_t s) {
+    return dec_pairs_ext_notes(host, dev, n, ext_host, ext_dev, 1, s);
+}
+
+// `notes` consecutive notes (positions *pos .. *pos + notes - 1) in ONE launch: the note's phases repeat inside the kernel, the chosen
+// tokens reach the next note's embed phase as granules (ext.gt), *pos_next = *pos + notes and the tick advances by notes at the end.
+// The caller guarantees that all those positions are to be decoded (the launch does not look at a length).
+extern "C" int spn_dec_pairs_notes(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
+                                   const spn_dec_chain_ext* ext_dev, int notes, hipStream_t s) {
+    return dec_pairs_ext_notes(host, dev, n, ext_host, ext_dev, notes, s);
 }

@@ -64,6 +64,8 @@ class GreedyDecoder:
         self.graph = None
         self.graph_multi = None
         self.graph_notes = max(1, int(os.environ.get("SPN_DEC_GRAPH_NOTES", "16")))   # notes per graph replay (1: one note per replay)
+        # several notes per LAUNCH when the whole note is one persistent launch (spn_dec_pairs_notes); 0: one launch per note
+        self.multi_note = os.environ.get("SPN_DEC_MULTI_NOTE", "1") != "0"
         self.sampling = None       # None = arg-max; dict(topk=int32 device tensor [n dims], temperature=float) = top-k sampling
 
     # -- buffers -------------------------------------------------------------------------------------------
@@ -125,7 +127,7 @@ class GreedyDecoder:
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
             self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
-            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2), gin=zg(2048))
+            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2), gin=zg(2048), gt=zg(16))
             self.pair_front = self.pair_tail = self.pair_head = self.pair_embed = False
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -314,6 +316,19 @@ class GreedyDecoder:
         self.cur_dims = list(dims)
         chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail, latched and len(dims) <= 16) if self.pair_groups else {}
         return fused_tail, latched, fold_cat, chains
+
+    def _steps(self, dims: List[int], U: int):
+        """U consecutive notes (all of them to be decoded).  When a note is ONE persistent launch (embed .. head phases in it) the U notes are
+        one launch too -- csrc/decode_layer.hip loops over them, the chosen tokens go from the head's winners to the next note's embed phase
+        as granules -- else U steps."""
+        if U > 1 and self.fused and self.multi_note and self.pair_groups:
+            chains = self._step_plan(dims)[3]
+            if self.pair_embed and self.pair_head and U <= 64:
+                chains[0].launch(U)
+                return
+        step = self._step_fused if self.fused else self._step
+        for _ in range(U):
+            step(dims)
 
     def _step_fused(self, dims: List[int]):
         m, d, pos = self.m, self.dim, self.pos
@@ -518,7 +533,7 @@ class GreedyDecoder:
                         has_norm = isinstance(te.norm, nn.LayerNorm)
                         ext.update(self._embed_ext(), eD=D, eN=N, eR=R, egamma=te.norm.weight.data if has_norm else None,
                                    ebeta=te.norm.bias.data if has_norm else None, eeps=te.norm.eps if has_norm else 1e-5,
-                                   We=We, ld_e=We.stride(0), be=te.project_emb.bias.data, gin=self.pair_g2["gin"])
+                                   We=We, ld_e=We.stride(0), be=te.project_emb.bias.data, gin=self.pair_g2["gin"], gt=self.pair_g2["gt"])
                         if self.ada_rows:
                             ext.update(rW=self.ada_W, r_ldw=self.ada_W.stride(0), rN=self.ada_W.shape[0], rK=K_r, rbias=self.ada_b,
                                        ry=self.gb_both, ada_par=self.gb_both.stride(0))
@@ -660,8 +675,7 @@ class GreedyDecoder:
             if U > 1 and rest >= 2 * U:
                 gU = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gU):
-                    for _ in range(U):
-                        step(dims)
+                    self._steps(dims, U)
                 for _ in range(rest // U):
                     gU.replay()
                 rest -= (rest // U) * U
@@ -921,8 +935,7 @@ class RenderSession(GreedyDecoder):
                     torch.cuda.synchronize()
                     gU = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gU):
-                        for _ in range(U):
-                            self._step_fn(self.dims)
+                        self._steps(self.dims, U)
                     self.graph_multi = gU
                 for _ in range(rest // U):
                     self.graph_multi.replay()

@@ -1105,7 +1105,7 @@ class DecChainExt(ctypes.Structure):
                 ("tok_a", _P), ("tok_b", _P), ("etok_ld", _L), ("egamma", _P), ("ebeta", _P), ("eeps", _F), ("We", _P), ("ld_e", _L), ("be", _P),
                 ("gin", _P),
                 ("rW", _P), ("r_ldw", _L), ("rN", _I), ("rK", _I), ("rx", _P), ("rx_ld", _L), ("rx_rows", _I), ("rbias", _P), ("ry", _P),
-                ("ada_par", _L)]
+                ("ada_par", _L), ("gt", _P)]
 
 
 def _fill_struct(a, kw, keep, what):
@@ -1168,8 +1168,12 @@ class DecPairChain:
         self.keep_ext = keep
         self.ext_dev.copy_(torch.frombuffer(bytearray(bytes(self.ext)), dtype=torch.uint8))
 
-    def launch(self):
-        if self.ext is not None:
+    def launch(self, notes: int = 1):
+        """`notes` > 1: that many consecutive notes in one launch (spn_dec_pairs_notes; needs the whole note in the launch and ext.gt)."""
+        if self.ext is not None and notes > 1:
+            call("spn_dec_pairs_notes", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), ctypes.byref(self.ext),
+                 ctypes.c_void_p(self.ext_dev.data_ptr()), c_int(notes), stream_ptr())
+        elif self.ext is not None:
             call("spn_dec_pairs_ext", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), ctypes.byref(self.ext),
                  ctypes.c_void_p(self.ext_dev.data_ptr()), stream_ptr())
         else:
