@@ -1151,6 +1151,7 @@ class DecPairChain:
             _fill_struct(a, kw, self.keep, "dec_pairs")
         self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8).to(device)
         self.ext = self.ext_dev = None
+        self.max_notes = 0                               # most notes any launch of this chain ran (tests)
         if ext:                                          # front / tail phases of the same launch: spn_dec_chain_ext
             self.ext = DecChainExt()
             self._ext_kw = dict(ext)
@@ -1170,6 +1171,7 @@ class DecPairChain:
 
     def launch(self, notes: int = 1):
         """`notes` > 1: that many consecutive notes in one launch (spn_dec_pairs_notes; needs the whole note in the launch and ext.gt)."""
+        self.max_notes = max(self.max_notes, notes)
         if self.ext is not None and notes > 1:
             call("spn_dec_pairs_notes", self.host, ctypes.c_void_p(self.dev.data_ptr()), c_int(self.n), ctypes.byref(self.ext),
                  ctypes.c_void_p(self.ext_dev.data_ptr()), c_int(notes), stream_ptr())

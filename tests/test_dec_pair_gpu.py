@@ -260,3 +260,44 @@ def test_one_launch_note_with_two_embedding_rows_per_wave_and_with_more_keys_tha
     assert n0 == n1 and torch.equal(t0, t1) and not (t1[0, 1:] == 1).any()
     for a, b in zip(e0.hid + e0.kc + e0.vc, e1.hid + e1.kc + e1.vc):
         assert torch.equal(a[:n1], b[:n1])
+
+
+@pytest.mark.parametrize("kw,U", [({}, 16), ({"style_emb_mode": "cat"}, 5), ({}, 3)])
+def test_several_notes_per_launch_equal_one_note_per_launch(dev, monkeypatch, kw, U):
+    """spn_dec_pairs_notes: U consecutive notes inside ONE launch (the roles loop over the notes; the chosen tokens reach the next note's embed
+    phase as granules, key / value rows and the AdaLN rows of the next note cross notes at agent scope) against the same engine with one launch
+    per note: same tokens, hidden rows, key / value rows and token embeddings, also on a second run of the same engine."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import GreedyDecoder
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import model_config, synthetic_batch
+    L = 150
+    torch.manual_seed(11)
+    model = ScorePerformer.init(model_config("tiny", max_seq_len=L, **kw))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=23, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    tokens = batch["masked_perf"].clone()
+    tokens[:, 0] = batch["perf"][:, 0]
+    monkeypatch.setenv("SPN_DEC_PAIR", "1")
+    monkeypatch.setenv("SPN_DEC_GRAPH_NOTES", str(U))
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPN_DEC_MULTI_NOTE", flag)
+        eng = GreedyDecoder(model.perf_decoder.model, L)
+        toks, n = eng.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
+        torch.cuda.synchronize()
+        assert eng.pair_head and eng.pair_embed and int(eng.pair_err.item()) == 0
+        assert eng.pair_chains[0].max_notes == (U if flag == "1" else 1)
+        res.append((eng, toks.clone(), n))
+    (e0, t0, n0), (e1, t1, n1) = res
+    assert n0 == n1 == L - 1 and torch.equal(t0, t1)
+    for a, b in zip(e0.hid + e0.kc + e0.vc + [e0.tok_emb], e1.hid + e1.kc + e1.vc + [e1.tok_emb]):
+        assert torch.equal(a[:n1], b[:n1])
+    toks2, n2 = e1.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
+    torch.cuda.synchronize()
+    assert n2 == n1 and torch.equal(toks2, t1) and int(e1.pair_err.item()) == 0

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05d
 mkdir -p $O
 cd $R
-SPN_PROFILE_DIR=$O timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 > $O/pytest_gpu.txt
+SPN_PROFILE_DIR=$O timeout 2400 python -m pytest tests -q -m gpu -x 2>&1 | grep -E "passed|failed|rror" | tail -5 > $O/pytest_gpu.txt
 cat $O/pytest_gpu.txt
 timeout 120 tools/_bin/hop_probe > $O/hop_probe.txt 2>&1
 timeout 60 tools/_bin/pk_probe > $O/pk_probe.txt 2>&1
