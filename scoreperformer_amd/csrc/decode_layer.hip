@@ -12,9 +12,12 @@
 //     weight stream runs under the hop instead of behind it;
 //   * epoch = tick * 256 + 8 * layer + phase + 1 with `tick` a device counter that the last pair launch of a note advances: tags never
 //     repeat within a render (the host zeroes the granule buffers when a render starts), also when a session re-decodes a position.
-// Arithmetic, association order and rounding are those of the five kernels it replaces (one wave per output row, lanes own
-// k = 4 lane + 256 c; LayerNorm partial sums per thread of the first four waves; the split-key online softmax of dec_attn2_kernel with
-// 16 lane groups per split; the 16-record merge of dec_fused_gemv_kernel's prologue): the residual stream leaves bit-identical.
+// Arithmetic, association order and rounding are those of the five kernels it replaces, through helpers both files share: one wave per
+// output row, lanes own k = 4 lane + 256 c, two partial sums per lane by packed FMA (common.h dec_dot4); LayerNorm statistics per wave
+// over that layout (common.h dec_ln_stats); the split-key batches of dec_attn2_kernel (decode_attn.h: 8 keys per lane group, 32 lane
+// groups, two-level group merge); the 16-record split merge of dec_fused_gemv_kernel's prologue: the residual stream leaves bit-identical.
+// A decode step is bound by the INSTRUCTION COUNT of these single-wave chains between the hand-offs (tools/pk_probe.hip: a wave issues
+// ~one VALU instruction per 5 clocks whatever its neighbour on the SIMD does; packed fp32 issues at full rate), not by bytes or flops.
 // Every poll loop is bounded: a workgroup that never sees its tags sets *err and stops polling (the launch completes with garbage and
 // the host raises), it never hangs the device.
 //
