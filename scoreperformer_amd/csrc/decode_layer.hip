@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const int kq_ = min(lane, 15);
     const int l_c0 = ext ? ext->ecol0[kq_] : 0, l_w = ext ? ext->ewidth[kq_] : 0;
     const unsigned long long l_tb = ext ? reinterpret_cast<unsigned long long>(ext->etable[kq_]) : 0ull;
-    int t = *pos_p;
+    const int t_in = *pos_p;   // (requested here; made wave-uniform below, where the first user -- the AdaLN row set -- needs it anyway)
     unsigned ebase = (unsigned)(*tick_p) * 256u + 1u;
     const int N1 = (h + 2 * kvh) * 64;
     const int nA = h * S, nB = (d + 15) / 16;
@@ -267,12 +267,13 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     const bool emb = front && ext->en > 0;
     // adaptive norms read their (gamma | beta) rows from the buffer of this note's parity (spn_dec_chain_ext.ada_par)
     // (wave-uniform by construction: through readfirstlane it lives in scalar registers -- as a per-lane value it was spilled to scratch)
-    long apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
+    int t = __builtin_amdgcn_readfirstlane(t_in);   // scalar: every address derived from the position is scalar arithmetic
+    long apar = (ext && (t & 1)) ? ext->ada_par : 0;
 #define ADA(mode_, ptr_) (((mode_) == 2 && (ptr_)) ? (ptr_) + apar : (ptr_))
     // the next note of this launch: position + 1, a fresh epoch block (tick + 1), the other set of AdaLN rows
     auto next_note = [&]() __attribute__((always_inline)) {
         t += 1; ebase += 256u; efront += 256u; ehead += 256u; eemb += 256u;
-        apar = (ext && (__builtin_amdgcn_readfirstlane(t) & 1)) ? ext->ada_par : 0;
+        apar = (ext && (t & 1)) ? ext->ada_par : 0;
     };
 
     if (b < nA) {
