@@ -643,6 +643,7 @@ class GreedyDecoder:
         unmask = (self.seq2d == mask_token_id)
         rows = unmask.any(dim=1).nonzero().flatten()
         if rows.numel() == 0:
+            self.n_steps = 0
             return self.seq2d[None], 0
         dims = unmask.any(dim=0).nonzero().flatten().tolist()
         last = int(rows.max())                      # one host read for the whole window

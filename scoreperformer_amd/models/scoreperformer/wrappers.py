@@ -286,36 +286,58 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         self.pad_token_id, self.mask_token_id, self.num_special_tokens = pad_token_id, mask_token_id, num_special_tokens
 
     def _engine_for(self, filled: Tensor, mask: Tensor, caches, banned, filter_logits_fn, filter_kwargs):
-        """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, fresh caches, no padding -- one sequence, or
-        (round 5) several with the SAME layout of MASK sub-tokens, which is what the reference's loop assumes anyway (it takes the layout of
-        batch element 0 for all, wrappers.py:385-396): the sequences then go through the engine one after the other."""
+        """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, fresh caches -- one sequence, or (round 5)
+        several with the SAME layout of MASK sub-tokens, which is what the reference's loop assumes anyway (it takes the layout of batch
+        element 0 for all, wrappers.py:385-396): the sequences then go through the engine one after the other.  RIGHT-padded batches too: a
+        causal decoder's valid positions never see the padded keys behind them, so every sequence runs over its own valid prefix and its
+        padded tail is left as given (the reference writes draws from padded rows there: don't-care values).  Returns (engine, valid
+        lengths or None); (None, None) = module path."""
         usable = (filled.is_cuda and caches is None and not banned
-                  and is_greedy(filter_logits_fn, filter_kwargs) and getattr(self, "use_decode_engine", True) and bool(mask.all()))
-        if usable and filled.shape[0] > 1:
+                  and is_greedy(filter_logits_fn, filter_kwargs) and getattr(self, "use_decode_engine", True))
+        lens = None
+        if usable and not bool(mask.all()):
+            m = mask.bool()
+            usable = bool(m[:, 0].all()) and bool((m[:, 1:] <= m[:, :-1]).all())     # padding only BEHIND the notes
+            if usable:
+                holes = (filled == self.mask_token_id) & m[..., None]
+                # one MASK layout on every valid position (and nothing to decode where element 0, whose layout the reference uses, is padded)
+                usable = bool(((holes == holes[:1]) | ~m[..., None]).all()) and not bool((holes & ~m[:1, :, None]).any())
+                lens = [int(n) for n in m.sum(dim=1).tolist()]
+        elif usable and filled.shape[0] > 1:
             holes = filled == self.mask_token_id
             usable = bool((holes == holes[:1]).all())
         if not usable:
-            return None
+            return None, None
         try:
             from ...decode import GreedyDecoder
             # `reference_compat` (attribute, default False): cross-attending decoders reproduce the reference's stale-hidden-row behaviour
             # token for token (decode.GreedyDecoder; wrappers.py:364 with modules/transformer/transformer.py:201)
-            return GreedyDecoder(self.model, filled.shape[1], reference_compat=bool(getattr(self, "reference_compat", False)))
+            return GreedyDecoder(self.model, filled.shape[1], reference_compat=bool(getattr(self, "reference_compat", False))), lens
         except NotImplementedError:
-            return None
+            return None, None
 
     @staticmethod
     def _stack_caches(per_seq):
-        """Caches of single-sequence engine runs -> one TupleTransformerCaches with the batch in front (the reference's layout)."""
+        """Caches of single-sequence engine runs -> one TupleTransformerCaches with the batch in front (the reference's layout).  Runs over
+        prefixes of different lengths (a right-padded batch) are zero-padded to the longest along the position axis."""
         from .transformer import TupleTransformerCaches
         from ...modules.transformer.attend import AttentionIntermediates
         from ...modules.transformer.transformer import TransformerIntermediates
+
+        def cat(ts, pos_dim):
+            n = max(t.shape[pos_dim] for t in ts)
+            ts = [t if t.shape[pos_dim] == n else F.pad(t, (0, 0) * (t.ndim - 1 - pos_dim) + (0, n - t.shape[pos_dim])) for t in ts]
+            return torch.cat(ts, dim=0)
+
         first = per_seq[0]
-        hid = [torch.cat([c.transformer.hiddens[i] for c in per_seq], dim=0) for i in range(len(first.transformer.hiddens))]
-        att = [AttentionIntermediates(keys=torch.cat([c.transformer.attention[i].keys for c in per_seq], dim=0),
-                                      values=torch.cat([c.transformer.attention[i].values for c in per_seq], dim=0))
-               for i in range(len(first.transformer.attention))]
-        return TupleTransformerCaches(token_emb=torch.cat([c.token_emb for c in per_seq], dim=0),
+        hid = [cat([c.transformer.hiddens[i] for c in per_seq], 1) for i in range(len(first.transformer.hiddens))]
+        att = []
+        for i in range(len(first.transformer.attention)):
+            k0 = first.transformer.attention[i].keys
+            pd = 1 if k0.ndim == 3 else 2            # [1, n, 64] multi-query, [1, h, n, 64] otherwise
+            att.append(AttentionIntermediates(keys=cat([c.transformer.attention[i].keys for c in per_seq], pd),
+                                              values=cat([c.transformer.attention[i].values for c in per_seq], pd)))
+        return TupleTransformerCaches(token_emb=cat([c.token_emb for c in per_seq], 1),
                                       transformer=TransformerIntermediates(hiddens=hid, attention=att))
 
     @torch.inference_mode()
@@ -328,18 +350,25 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         banned = filter_key_ids or {}
         with _decode_call(self, tokens, tokens_masked, mask=kwargs.pop("mask", None)) as call:
             filled, masked_view = call.arrays[0].clone().detach(), call.arrays[1]
-            engine = self._engine_for(filled, call.mask, caches, banned, filter_logits_fn, filter_kwargs)
-            if engine is not None and filled.shape[0] == 1:
+            engine, lens = self._engine_for(filled, call.mask, caches, banned, filter_logits_fn, filter_kwargs)
+            if engine is not None and filled.shape[0] == 1 and lens is None:
                 filled, _ = engine.run(filled, masked_view, kwargs.get("context"), kwargs.get("style_embeddings"), self.mask_token_id,
                                        context_mask=kwargs.get("context_mask"))
                 caches = engine.caches() if return_caches else None
-            elif engine is not None:       # several sequences with one MASK layout: one engine run each
-                pick = lambda t, i: None if t is None else t[i:i + 1]   # noqa: E731
+            elif engine is not None:       # several sequences with one MASK layout (each over its valid prefix): one engine run each
+                L = filled.shape[1]
+                per_note_ctx = self.model.context_emb_mode == "cat"      # else: a whole cross-attended sequence with its own mask
+
+                def pick(t, i, n, per_note=True):
+                    return None if t is None else (t[i:i + 1, :n] if per_note else t[i:i + 1])
+
                 rows, per_seq = [], []
                 for i in range(filled.shape[0]):
-                    row, _ = engine.run(filled[i:i + 1], masked_view[i:i + 1], pick(kwargs.get("context"), i), pick(kwargs.get("style_embeddings"), i),
-                                        self.mask_token_id, context_mask=pick(kwargs.get("context_mask"), i))
-                    rows.append(row.clone())
+                    n = L if lens is None else lens[i]
+                    row, _ = engine.run(filled[i:i + 1, :n], masked_view[i:i + 1, :n], pick(kwargs.get("context"), i, n, per_note_ctx),
+                                        pick(kwargs.get("style_embeddings"), i, n), self.mask_token_id,
+                                        context_mask=pick(kwargs.get("context_mask"), i, n, False))
+                    rows.append(row.clone() if n == L else torch.cat([row, filled[i:i + 1, n:]], dim=1))
                     if return_caches:    # the engine's buffers are overwritten by the next sequence
                         c = engine.caches()
                         per_seq.append(type(c)(token_emb=c.token_emb.clone(), transformer=type(c.transformer)(

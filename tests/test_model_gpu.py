@@ -573,8 +573,8 @@ def test_decode_engine_serves_a_batch_of_sequences_with_one_mask_layout(dev):
     """`unmask_tokens` with b > 1 (the reference's loop takes the MASK layout of batch element 0 for every sequence, wrappers.py:385-396):
     un-padded sequences with one layout go through the fp32 decode engine one after the other.  Row 0 is the reference's own fixture and
     must come out token for token; every row equals its own single-sequence engine call bit for bit (tokens AND caches, in the reference's
-    batch-first layouts); the CPU oracle's greedy loop confirms a perturbed row; padded batches, or rows with different layouts, still
-    take the module path."""
+    batch-first layouts); the CPU oracle's greedy loop confirms a perturbed row; a RIGHT-padded batch takes the engine too (every sequence over
+    its valid prefix); padding in front of the notes, holes in the mask, or rows with different layouts still take the module path."""
     from oracle import ref_cpu
     from oracle.weights import filled_state_dict
     from scoreperformer_amd.arena import ParamArena
@@ -631,12 +631,34 @@ def test_decode_engine_serves_a_batch_of_sequences_with_one_mask_layout(dev):
         want = ref_cpu.greedy_unmask(sd, cfg, tok_b[1:2], msk_b[1:2], ctx_b[1:2], sty_b[1:2]).numpy()
         got = out_b[1:2].cpu().numpy()
         assert (got != want).sum() <= 0.03 * (want != tok_b[1:2].numpy()).sum()
-        # a padded batch keeps the module path (the engine has no key mask for its own sequence)
+        # a RIGHT-padded batch goes through the engine too, every sequence over its own valid prefix (a causal decoder's valid positions
+        # never see the padded keys behind them); the padded tail comes back as it was given, caches zero-padded to the longest prefix
         n_before = len(runs)
+        Lb = tok_b.shape[1]
+        cut = Lb - 5
         pad_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
-        pad_mask[2, -5:] = False
-        out_p = dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=pad_mask.to(dev),
+        pad_mask[2, cut:] = False
+        tok_p, msk_p = tok_b.clone(), msk_b.clone()
+        tok_p[2, cut:], msk_p[2, cut:] = 0, 0                      # pad tokens behind the notes of row 2
+        out_p, caches_p = dec.unmask_tokens(tok_p.to(dev), msk_p.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev),
+                                            mask=pad_mask.to(dev), **kw)
+        assert len(runs) == n_before + 3 and tuple(out_p.shape) == tuple(tok_b.shape)
+        assert torch.equal(out_p[:2], out_b[:2])                     # the full rows: as without padding
+        assert int((out_p[2, cut:].cpu() != 0).sum()) == 0           # the padded tail is left alone
+        out_t, caches_t = dec.unmask_tokens(tok_p[2:3, :cut].to(dev), msk_p[2:3, :cut].to(dev), context=ctx_b[2:3, :cut].to(dev),
+                                            style_embeddings=sty_b[2:3, :cut].to(dev), **kw)
+        assert torch.equal(out_t[0], out_p[2, :cut])                 # row 2 = its own trimmed single-sequence call, bit for bit
+        nt = caches_t.token_emb.shape[1]
+        assert torch.equal(caches_t.token_emb[0], caches_p.token_emb[2, :nt]) and not caches_p.token_emb[2, nt:].any()
+        assert torch.equal(caches_t.transformer.hiddens[-1][0], caches_p.transformer.hiddens[-1][2, :nt])
+        kt, kp = caches_t.transformer.attention[0].keys, caches_p.transformer.attention[0].keys
+        assert torch.equal(kt[0], kp[2, :nt] if kp.ndim == 3 else kp[2, :, :nt])
+        # padding in FRONT of the notes, or holes in the mask, keep the module path
+        n_before = len(runs)
+        odd_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
+        odd_mask[1, :3] = False
+        out_o = dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=odd_mask.to(dev),
                                   filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
-        assert len(runs) == n_before and tuple(out_p.shape) == tuple(tok_b.shape)
+        assert len(runs) == n_before and tuple(out_o.shape) == tuple(tok_b.shape)
     finally:
         decode.GreedyDecoder.run = real_run
