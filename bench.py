@@ -582,7 +582,7 @@ def decode_leg(args, dev):
                        "counter_bytes_per_launch": v["counter_bytes_per_launch"], "algorithmic_bytes_per_launch": v["algorithmic_bytes_per_launch"],
                        "counter_over_algorithmic": v["counter_over_algorithmic"]}
     return {"traffic": traffic,
-            "workload": f"C5 greedy render, seq {L}, batch 1, hipGraph-replayed decode engine (fp32; one persistent launch per note, 16 notes per replay), tokens bit-exact vs the fp32 reference on the fixtures",
+            "workload": f"C5 greedy render, seq {L}, batch 1, hipGraph-replayed decode engine (fp32; one persistent launch per 16 notes: embed .. LM head of every note inside it), tokens bit-exact vs the fp32 reference on the fixtures",
             "notes": notes, "us_per_note": best / notes * 1e6, "notes_per_s": notes / best, "masks_left": int((out == 1).sum()),
             "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": per_note / (best / notes) / 1e9,
                          "frac": per_note / (best / notes) / 1e9 / 8000.0, "algorithmic_bytes_per_note": per_note,
