@@ -7,6 +7,7 @@
 // Weight-gradient shapes (a handful of output tiles, contraction over every segment of the batch) are split along K
 // over blockIdx.z and reduced with fp32 atomics, otherwise 9 workgroups would walk 60k rows serially.
 #include "common.h"
+#include "tuning.h"
 
 namespace {
 
@@ -77,12 +78,168 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+
+// ---- fp32 MFMA kernel (round 5) for the products with BOTH operands contiguous along K: A [M, K] rows, B as nn.Linear keeps its weight,
+// [N, K] -- the batched re-priming of a render window (decode.py RenderSession.prefill: 280 - 512 rows through every projection of the
+// decoder, 884 ms of gemm_f32_kernel per 12 renders in tools/bench_render.py against 960 ms for all decode steps) and the wide VAE /
+// embedding-MLP layers of the train step.  v_mfma_f32_32x32x2_f32 multiplies and accumulates in fp32 (no reduced-precision inputs):
+// 256 flop per clock and CU, where the VALU tile above issues 4x4 FMAs per thread and 2 LDS reads per 16 of them.
+// Tile 128 x 128 x 16, four waves with 64 x 64 each (2 x 2 MFMA blocks, 64 accumulator registers), operands k-major in LDS (a lane of the
+// MFMA owns one row / column and ONE k: consecutive lanes read consecutive words), two LDS stages, one barrier per K tile.
+// Needs K, lda, ldb multiples of 4 and 16-byte aligned bases (float4 loads along K); everything else goes to gemm_f32_kernel.
+typedef float f32x16m __attribute__((ext_vector_type(16)));
+
+// TT x TT output tile (128: four waves of 64 x 64 = 2 x 2 MFMA blocks; 64: four waves of one 32 x 32 block), K tile TK_ in two LDS stages
+// (dynamic LDS: 2 stages x 2 operands x TK_ x (TT + 1) floats), the next K tile in registers while the current one is multiplied.
+// The 64-tile / K-tile-64 form is for the few-hundred-row products of a render window's re-priming: those are LATENCY-bound (80 - 512
+// workgroups, each alone on its CU, walking K through dependent trips to memory), so it keeps 8 float4 loads per thread in flight per
+// trip and gives every wave of the CU one MFMA block; the 128-tile form is the throughput kernel (94 TF/s at 2048 x 4096 x 512).
+// SP > 1 (64-tiles only): SP groups of four waves share one output tile and walk every SP-th K tile each -- the serial chain of trips to
+// memory is what these few-workgroup products wait for, and a second / fourth group halves / quarters it; the partial tiles are added
+// in group order through LDS at the end (a fixed order: the result does not depend on timing).
+template <int TT, int TK_, int SP>
+__global__ __launch_bounds__(256 * SP) void gemm_f32_mfma_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                            float* __restrict__ c, long ldc, const float* __restrict__ bias, int M, int N,
+                                                            int K, float alpha, int accumulate, const uint8_t* __restrict__ rowmask) {
+    constexpr int LD = TT + 1, NB = TT / 64;            // LDS row stride (k-major; ODD: the transposing stores of a wave -- 16 k quads x 4 rows --
+                                                        // then spread over all banks, 2-way; + 4 was 8-way), MFMA blocks per wave and dimension
+    constexpr int RW = TT * TK_ / 1024;                 // float4 loads per thread and operand per K tile
+    constexpr int QK = TK_ / 4;                         // float4 per row of a K tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int grp = threadIdx.x >> 8;                   // K group of this wave (SP > 1)
+    float* As = smem + grp * (4 * TK_ * LD);            // [2][TK_][LD] per group
+    float* Bs = As + 2 * TK_ * LD;
+    const int tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.y * TT, n0 = blockIdx.x * TT;
+    // global -> registers: load i of thread t is float4 number e = t + 256 i of the tile: row e / QK, k quad e % QK.  TWO register sets:
+    // the K tile after next is requested while the current one is multiplied (one tile ahead left ~0.7 us of every trip exposed)
+    f32x4 ra0[RW], rb0[RW], ra1[RW], rb1[RW];
+    auto gload = [&](f32x4 (&ra)[RW], f32x4 (&rb)[RW], int k0) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int e = tid + 256 * i, r = e / QK, gk = k0 + (e % QK) * 4;
+            const int gm = m0 + r, gn = n0 + r;
+            ra[i] = (gm < M && gk < K) ? *reinterpret_cast<const f32x4*>(a + (long)gm * lda + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = (gn < N && gk < K) ? *reinterpret_cast<const f32x4*>(b + (long)gn * ldb + gk) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&](const f32x4 (&ra)[RW], const f32x4 (&rb)[RW], int st) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const int e = tid + 256 * i, r = e / QK, kq = (e % QK) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                As[(st * TK_ + kq + j) * LD + r] = ra[i][j];
+                Bs[(st * TK_ + kq + j) * LD + r] = rb[i][j];
+            }
+        }
+    };
+    f32x16m acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int T = ((K + TK_ - 1) / TK_ + SP - 1) / SP;   // K tiles per group (tile number u of group g is K tile u SP + g; past K: zeros)
+    const int l32 = lane & 31, lk = lane >> 5;
+    auto multiply = [&](int st) {
+#pragma unroll
+        for (int kk = 0; kk < TK_; kk += 2) {
+            float av[NB], bv[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                av[i] = As[(st * TK_ + kk + lk) * LD + wm * (TT / 2) + i * 32 + l32];
+                bv[i] = Bs[(st * TK_ + kk + lk) * LD + wn * (TT / 2) + i * 32 + l32];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto ktile = [&](int u) { return (u * SP + grp) * TK_; };
+    gload(ra0, rb0, ktile(0));
+    if (T > 1) gload(ra1, rb1, ktile(1));
+    lstore(ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < T; t += 2) {
+        // stage 0 holds tile t, set 1 tile t + 1, set 0 is free
+        if (t + 2 < T) gload(ra0, rb0, ktile(t + 2));
+        multiply(0);
+        if (t + 1 < T) lstore(ra1, rb1, 1);
+        __syncthreads();
+        if (t + 1 >= T) break;
+        // stage 1 holds tile t + 1, set 0 tile t + 2, set 1 is free
+        if (t + 3 < T) gload(ra1, rb1, ktile(t + 3));
+        multiply(1);
+        if (t + 2 < T) lstore(ra0, rb0, 0);
+        __syncthreads();
+    }
+    if constexpr (SP > 1) {   // partial tiles of groups 1 .. SP - 1 through LDS (every operand stage is dead by now), added in group order
+        static_assert(SP == 1 || NB == 1, "K groups: 64-tiles only");
+        float* part = smem;   // [SP - 1][256 threads][16]
+        if (grp > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[((grp - 1) * 256 + tid) * 16 + e] = acc[0][0][e];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < SP; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][0][e] += part[((g - 1) * 256 + tid) * 16 + e];
+    }
+    // accumulator layout of the 32x32 MFMA: lane = column (l32), element e = row 8 (e / 4) + 4 (lane / 32) + e % 4
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int n = n0 + wn * (TT / 2) + j * 32 + l32;
+            const float bn = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * (TT / 2) + i * 32 + 8 * (e >> 2) + 4 * lk + (e & 3);
+                if (m < M && n < N) {
+                    float v = acc[i][j][e] * alpha + bn;
+                    if (rowmask) v *= rowmask[m] ? 1.f : 0.f;
+                    if (accumulate) v += c[(long)m * ldc + n];
+                    c[(long)m * ldc + n] = v;
+                }
+            }
+        }
+}
+
+template <int TT, int TK_, int SP>
+static void launch_mfma(const float* a, long lda, const float* b, long ldb, float* c, long ldc, const float* bias, int M, int N, int K, float alpha,
+                        int accumulate, const uint8_t* rowmask, hipStream_t stream) {
+    static std::atomic<unsigned> optin{0};
+    constexpr int bytes = SP * 2 * 2 * TK_ * (TT + 1) * 4;
+    static_assert(bytes <= 160 * 1024 && (SP - 1) * 256 * 16 * 4 <= bytes, "LDS budget");
+    spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<TT, TK_, SP>), bytes);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<TT, TK_, SP>), dim3(cdiv(N, TT), cdiv(M, TT)), dim3(256 * SP), bytes, stream, a, lda, b, ldb, c, ldc, bias,
+                       M, N, K, alpha, accumulate, rowmask);
+}
+
 }  // namespace
 
 extern "C" int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, long sbn, float* c, long ldc,
                             const float* bias, const uint8_t* rowmask, int M, int N, int K, float alpha, int accumulate,
                             hipStream_t stream) {
     SPN_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "spn_gemm_f32: bad arguments");
+    // both operands contiguous along K, float4-loadable: the fp32 MFMA kernels -- 128-tiles when they fill the chip twice over, else 64-tiles
+    if (sak == 1 && sbk == 1 && (K & 3) == 0 && (sam & 3) == 0 && (sbn & 3) == 0 && M >= 48 && N >= 64 &&
+        ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && spn_tune_i(SPN_TUNE_GEMM_F32_MFMA) != 0) {
+        const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64);
+#define MF(TT_, TK__, SP_) launch_mfma<TT_, TK__, SP_>(a, sam, b, sbn, c, ldc, bias, M, N, K, alpha, accumulate, rowmask, stream)
+        if ((long)cdiv(M, 128) * cdiv(N, 128) >= 512) MF(128, 16, 1);
+        else if (wg64 >= 384 || K < 256) MF(64, 64, 1);      // every CU has its workgroup(s) already, or there is hardly a K loop
+        else if (K >= 2048) MF(64, 32, 4);                   // few workgroups, long K: four K groups per tile
+        else MF(64, 64, 2);
+#undef MF
+        SPN_LAUNCH_CHECK();
+        return SPN_OK;
+    }
     const int TN = N <= 32 ? 16 : 64;
     const int TM = (M <= 32 && TN == 64) ? 16 : 64;
     const int tiles = cdiv(N, TN) * cdiv(M, TM);

@@ -518,3 +518,36 @@ def test_gradient_norm_has_a_fixed_summation_order():
     out = torch.zeros(1, device="cuda")
     ops.sumsq(g[: 1000000], out=out, ws=ws)           # fixed-order version on a short, 16-byte aligned slice
     assert abs(out.item() - float(g[: 1000000].double().pow(2).sum())) <= 1e-6 * float(g[: 1000000].double().pow(2).sum())
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 4096, 512), (280, 640, 512), (333, 512, 2048), (48, 64, 16), (130, 200, 572), (1, 64, 64)])
+def test_exact_fp32_gemm_on_the_fp32_matrix_cores(dev, M, N, K):
+    """spn_gemm_f32 with both operands contiguous along K (x [M, K], nn.Linear weight [N, K]) runs on v_mfma_f32_32x32x2_f32 tiles
+    (csrc/gemm_f32.hip gemm_f32_mfma_kernel; M >= 48, N >= 64, K in whole float4): fp32 products and sums -- against the fp64 product at
+    fp32 rounding, with bias, row mask, alpha and accumulation, tile edges in M, N and K, and against the VALU tile kernel (knob off)."""
+    from scoreperformer_amd import lib, ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    mask = (torch.rand(M, generator=g) > 0.2).to(dev)
+    c0 = torch.randn(M, N, generator=g).to(dev)
+    want = (0.5 * (a.double() @ w.double().t()) + bias.double()) * mask.double()[:, None] + c0.double()
+    before = lib.get_tuning("gemm_f32_mfma")
+    try:
+        outs = []
+        for knob in (1, 0):
+            lib.set_tuning("gemm_f32_mfma", knob)
+            out = c0.clone()
+            ops.gemm_f32(a, w, bias=bias, rowmask=mask, out=out, alpha=0.5, accumulate=True)
+            outs.append(out)
+            assert (out.double() - want).abs().max() <= 2e-6 * K ** 0.5 + 1e-6 * want.abs().max()
+        # the two kernels round differently (summation order), by no more than fp32 accumulation allows
+        assert (outs[0] - outs[1]).abs().max() <= 4e-6 * max(1.0, float(want.abs().max()))
+        # a strided view of A (rows of a wider buffer) and a plain product without the optional operands
+        wide = torch.randn(M, K + 8, generator=g).to(dev)
+        lib.set_tuning("gemm_f32_mfma", 1)
+        got = ops.gemm_f32(wide[:, :K], w)
+        assert (got.double() - wide[:, :K].double() @ w.double().t()).abs().max() <= 2e-6 * K ** 0.5
+    finally:
+        lib.set_tuning("gemm_f32_mfma", before)
