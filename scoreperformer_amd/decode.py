@@ -317,6 +317,10 @@ class GreedyDecoder:
         chains = self._pair_chains(fold_cat and (latched or not self.ada_rows), fused_tail, latched and len(dims) <= 16) if self.pair_groups else {}
         return fused_tail, latched, fold_cat, chains
 
+    def _one_launch_notes(self) -> bool:
+        """True when `_steps` runs several notes as one launch (the whole note lives in the persistent launch)."""
+        return bool(self.fused and self.multi_note and self.pair_groups and self.pair_embed and self.pair_head)
+
     def _steps(self, dims: List[int], U: int):
         """U consecutive notes (all of them to be decoded).  When a note is ONE persistent launch (embed .. head phases in it) the U notes are
         one launch too -- csrc/decode_layer.hip loops over them, the chosen tokens go from the head's winners to the next note's embed phase
@@ -941,6 +945,11 @@ class RenderSession(GreedyDecoder):
                 for _ in range(rest // U):
                     self.graph_multi.replay()
                 rest -= (rest // U) * U
+            if rest >= 2 and self.use_graph and self._one_launch_notes():
+                # a chord group's few notes: ONE launch for all of them (spn_dec_pairs_notes, issued directly: the count differs from
+                # call to call) instead of `rest` replays of the one-note graph
+                self._steps(self.dims, rest)
+                rest = 0
             for _ in range(rest):
                 self.graph.replay() if self.use_graph else self._step_fn(self.dims)
             if attempt or not self._pair_failed():
