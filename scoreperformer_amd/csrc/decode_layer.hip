@@ -245,9 +245,17 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     // check alone held every workgroup's first weight load back by a trip to memory)
     const int err_in = *err_p;
     int* const err = err_p;
+    // Per-phase time stamps (spn_dec_pair_args.stamps, tools/bench_dec_pair.py) are a tuning aid and compiled in with -DSPN_DEC_STAMPS only
+    // (tools/build_variant.py decode_layer.hip stamps_spn.so -DSPN_DEC_STAMPS): each of the ~45 stamp sites of a note is a scalar load of
+    // the record's pointer, a wait and a branch on the critical path, whether or not anybody asked for stamps.
+#ifdef SPN_DEC_STAMPS
 #define STAMP(k_) do { if (a.stamps && tid == 0) a.stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP_OF(rec_, k_) do { if ((rec_).stamps && tid == 0) (rec_).stamps[(long)b * 8 + (k_)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     if (a0.stamps && tid == 0) a0.stamps[(long)b * 8 + (b < a0.h * a0.S ? 6 : (b < a0.h * a0.S + (a0.d + 15) / 16 ? 5 : 7))] = (long long)__builtin_amdgcn_s_memrealtime();   // kernel entry
+#else
+#define STAMP(k_) ((void)0)
+#define STAMP_OF(rec_, k_) ((void)0)
+#endif
     // embed phase: key q's first column, row width and table in lane q.  Requested HERE, by every workgroup, before the record's scalar
     // fields (which decide who runs the phase) have arrived: behind them these loads were a third dependent trip at the start of a note.
     const int kq_ = min(lane, 15);

@@ -98,6 +98,9 @@ def main():
         enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
                                      bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
                                      compute_loss=False)
+    if os.environ.get("TIMELINE_ONLY") == "1":
+        timeline(L, groups[0], dev, model, batch, enc)
+        return
     us0, tok0, hid0 = run(L, 0, dev, model, batch, enc)
     print(f"L={L}  five launches per pair: {us0:.1f} us per note", flush=True)
     for g in groups:
@@ -109,6 +112,17 @@ def main():
         us0b, _, _ = run(L, 0, dev, model, batch, enc)
         print(f"L={L}  five launches per pair (again): {us0b:.1f} us per note", flush=True)
     if os.environ.get("TIMELINE", "1") != "0":
+        # the stamps are compiled into a variant library only (csrc/decode_layer.hip, -DSPN_DEC_STAMPS):
+        #   python tools/build_variant.py decode_layer.hip stamps_spn.so -DSPN_DEC_STAMPS
+        from scoreperformer_amd import lib as spn_lib
+        if os.path.basename(spn_lib.LIB_PATH) != "stamps_spn.so":
+            variant = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "stamps_spn.so")
+            if not os.path.exists(variant):
+                print("no tools/_bin/stamps_spn.so: build it with tools/build_variant.py (see the comment above) for the per-phase timeline")
+                return
+            import subprocess
+            env = dict(os.environ, SPN_LIB=variant, TIMELINE_ONLY="1")
+            sys.exit(subprocess.run([sys.executable, os.path.abspath(__file__), str(L)], env=env).returncode)
         timeline(L, groups[0], dev, model, batch, enc)
 
 
