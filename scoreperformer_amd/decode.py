@@ -135,7 +135,8 @@ class GreedyDecoder:
             if self._pair_fault_inject:
                 self.pair_err.fill_(9)
             self.pair_stamps = ([torch.zeros(self.pair_groups * 8, device=dev, dtype=torch.int64) for _ in range(n_self)]
-                                if os.environ.get("SPN_DEC_PAIR_STAMPS", "0") == "1" else None)   # tuning aid (tools/bench_dec_pair.py)
+                                if os.environ.get("SPN_DEC_PAIR_STAMPS", "0") == "1" else None)   # tuning aid (tools/bench_dec_pair.py; the
+            # kernel records them only in a library built with -DSPN_DEC_STAMPS: tools/build_variant.py decode_layer.hip stamps_spn.so -DSPN_DEC_STAMPS)
         tr = m.transformer
         self.norm_list = [norms[0] for norms, _, _ in tr.layers] + ([tr.final_norm] if not isinstance(tr.final_norm, nn.Identity) else [])
         self.ada_rows = {}
