@@ -228,17 +228,8 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
     __shared__ float outv[16];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    // The record pointers as the loop over the notes sees them: re-derived at the top of every note through an offset the compiler cannot
-    // see through (always 0).  Without it everything that only depends on the records -- every weight address of every pair, every
-    // per-key field -- is loop-invariant, gets hoisted in front of the note loop and stays live across it: 106 spilled VGPRs.
-    const spn_dec_pair_args* layers = layers0;
-    const spn_dec_chain_ext* ext = ext0;
-    long nz = 0;
-    auto rebase = [&]() __attribute__((always_inline)) {
-        asm volatile("" : "+s"(nz));
-        layers = layers0 + nz;
-        ext = ext0 ? ext0 + nz : nullptr;
-    };
+    const spn_dec_pair_args* const layers = layers0;
+    const spn_dec_chain_ext* const ext = ext0;
 #define a0 (layers[0])
     const int d = a0.d, h = a0.h, kvh = a0.kvh, S = a0.S, inner = a0.inner;   // the same in every pair of a chain (checked by the host)
     // (position, tick and error word are requested here and first USED behind the weight requests of the role: read up front, the error
@@ -333,7 +324,6 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             }
         };
         for (int note = 0; note < n_notes; ++note) {
-        rebase();
         // (the early key / value rows are only conditionally reloaded below: without this the previous note's values count as live across
         // the embed phase -- 64 registers on top of its weight rows)
 #pragma unroll
@@ -622,7 +612,6 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             n2 = norm_regs4(d, a.norm2, ADA(a.norm2, a.gam2), a.bet2, lane);
         };
         for (int note = 0; note < n_notes; ++note) {
-        rebase();
         request(a0);
         if (err_in) return;
         if (ext && ext->rW) {
@@ -834,7 +823,6 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
         }
     };
     for (int note = 0; note < n_notes; ++note) {
-    rebase();
     if (front) {
         // ---- front: x0 = Wm . xin + bm (K = Km <= 1024), then x = Wp . (LN?(x0) | ctx[t + 1] | style[t + 1]) + bp (K <= 2048) ----
         const int Km = ext->Km, cw_ = ext->ctx ? ext->ctx_w : 0, sw_ = ext->style ? ext->style_w : 0, Kc = d + cw_ + sw_;
