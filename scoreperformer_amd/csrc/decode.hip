@@ -306,41 +306,48 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 
 // ---- batched (prefill) variants: rows t0 .. t0+n-1 of a window whose tokens are all known, one launch per operator instead of one
 //      per position.  Same arithmetic as the single-position kernels above; K/V rows are already in the caches.
-// grid = (h, n): block (hi, r) is query t = t0 + r over keys j <= t.
-__global__ __launch_bounds__(256) void dec_attn_rows_kernel(const float* __restrict__ q, long q_ld, const float* __restrict__ kcache,
+// grid = (h, n): block (hi, r) is query t = t0 + r over keys j <= t, in the batched form of the decode step (decode_attn.h: 16 lanes per
+// key, DEC_NU keys per lane group scored together, 256 keys per workgroup and batch, the two-level group merge) -- round 5: the key-by-key
+// online softmax it replaces (one 64-lane reduction and a rescale per key) took 81 us per launch for a 500-row window, 163 ms per 12
+// renders of tools/bench_render.py.
+__global__ __launch_bounds__(512) void dec_attn_rows_kernel(const float* __restrict__ q, long q_ld, const float* __restrict__ kcache,
                                                             const float* __restrict__ vcache, const float* __restrict__ slopes, int t0,
                                                             float* __restrict__ o, long o_ld, int h, int kvh, float scale) {
-    __shared__ float m_s[4], l_s[4], o_s[4][64];
-    const int hi = blockIdx.x, r = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float sm[DEC_G], sl[DEC_G];
+    __shared__ __attribute__((aligned(16))) float so[DEC_G][64];
+    __shared__ float sm2[8], sl2[8];
+    __shared__ float so2[8][64];
+    const int hi = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, grp = lane >> 4, l16 = lane & 15;
     const int kh = kvh == 1 ? 0 : hi;
     const int t = t0 + r;
     const long cw = (long)kvh * 64;
-    const float qd = q[(long)r * q_ld + hi * 64 + lane] * scale;
     const float slope = slopes ? slopes[hi] : 0.f;
-    float m = -INFINITY, l = 0.f, acc = 0.f;
-    for (int j = w; j <= t; j += 4) {
-        const float kd = kcache[j * cw + kh * 64 + lane];
-        const float vd = vcache[j * cw + kh * 64 + lane];
-        const float s = wave_sum(qd * kd) - slope * (float)(t - j);
-        const float m_new = fmaxf(m, s);
-        const float alpha = __expf(m - m_new), p = __expf(s - m_new);
-        l = l * alpha + p;
-        acc = acc * alpha + p * vd;
-        m = m_new;
-    }
-    if (lane == 0) { m_s[w] = m; l_s[w] = l; }
-    o_s[w][lane] = acc;
-    __syncthreads();
-    if (w == 0) {
-        const float mm = fmaxf(fmaxf(m_s[0], m_s[1]), fmaxf(m_s[2], m_s[3]));
-        float num = 0.f, den = 0.f;
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(q + (long)r * q_ld + hi * 64 + l16 * 4) * scale;
+    // row t is in the cache like every other: the "new key" operands of the batch are that row itself
+    const f32x4 kt4 = *reinterpret_cast<const f32x4*>(kcache + (long)t * cw + kh * 64 + l16 * 4);
+    const f32x4 vt4 = *reinterpret_cast<const f32x4*>(vcache + (long)t * cw + kh * 64 + l16 * 4);
+    float m = -INFINITY, l = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int j1 = t + 1;
+    for (int jb0 = w * 4 + grp; jb0 < j1; jb0 += 256) {
+        f32x4 k4[DEC_NU], v4[DEC_NU];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const float f = (m_s[qq] == -INFINITY) ? 0.f : __expf(m_s[qq] - mm);
-            num += o_s[qq][lane] * f;
-            den += l_s[qq] * f;
+        for (int u = 0; u < DEC_NU; ++u) {
+            const int j = min(jb0 + DEC_G * u, t);
+            k4[u] = *reinterpret_cast<const f32x4*>(kcache + (long)j * cw + kh * 64 + l16 * 4);
+            v4[u] = *reinterpret_cast<const f32x4*>(vcache + (long)j * cw + kh * 64 + l16 * 4);
         }
-        o[(long)r * o_ld + hi * 64 + lane] = num / den;
+        dec_attn_batch<DEC_NU>(k4, v4, kt4, vt4, q4, slope, t, jb0, j1, m, l, acc);
+    }
+    const int gi = w * 4 + grp;
+    if (l16 == 0) { sm[gi] = m; sl[gi] = l; }
+    *reinterpret_cast<f32x4*>(&so[gi][l16 * 4]) = acc;
+    dec_attn_merge_wave(sm, sl, so, sm2, sl2, so2, w, lane);
+    __syncthreads();
+    if (tid < 64) {
+        float mm, num, den;
+        dec_attn_merge_block(sm2, sl2, so2, tid, lane, mm, num, den);
+        o[(long)r * o_ld + hi * 64 + tid] = num / den;
     }
 }
 
@@ -1233,7 +1240,8 @@ extern "C" int spn_dec_head_sample(int n, const float* const* tables, const int*
 extern "C" int spn_dec_attn_rows(const float* q, long q_ld, const float* kcache, const float* vcache, const float* slopes, int t0, int n,
                                  float* o, long o_ld, int h, int kvh, float scale, hipStream_t s) {
     SPN_REQUIRE(q && kcache && vcache && o && n > 0 && t0 >= 0 && h > 0 && (kvh == 1 || kvh == h), "spn_dec_attn_rows: bad arguments");
-    hipLaunchKernelGGL(dec_attn_rows_kernel, dim3(h, n), dim3(256), 0, s, q, q_ld, kcache, vcache, slopes, t0, o, o_ld, h, kvh, scale);
+    SPN_REQUIRE((q_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0, "spn_dec_attn_rows: query rows must be 16-byte aligned (float4 loads)");
+    hipLaunchKernelGGL(dec_attn_rows_kernel, dim3(h, n), dim3(512), 0, s, q, q_ld, kcache, vcache, slopes, t0, o, o_ld, h, kvh, scale);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
