@@ -551,3 +551,31 @@ def test_exact_fp32_gemm_on_the_fp32_matrix_cores(dev, M, N, K):
         assert (got.double() - wide[:, :K].double() @ w.double().t()).abs().max() <= 2e-6 * K ** 0.5
     finally:
         lib.set_tuning("gemm_f32_mfma", before)
+
+
+@pytest.mark.parametrize("n,t0,h,kvh,with_slopes", [(500, 0, 8, 1, True), (37, 300, 8, 1, True), (260, 5, 4, 4, True), (64, 0, 2, 1, False)])
+def test_window_attention_rows_against_fp64(dev, n, t0, h, kvh, with_slopes):
+    """spn_dec_attn_rows (the attention of a render window's batched re-priming: query rows t0 .. t0 + n - 1, each over the cached keys
+    j <= t, ALiBi distance t - j, multi-query or one K/V head per head) against an fp64 softmax: the batched form of the decode step
+    (8 keys per lane group scored together, two-level merge of the 32 groups) at fp32 accuracy."""
+    from scoreperformer_amd import ops
+    g = torch.Generator().manual_seed(n + 31 * t0)
+    L = t0 + n
+    q = torch.randn(n, (h + 2 * kvh) * 64, generator=g).to(dev)            # rows of a fused q | k | v buffer: only the q part is read
+    kc = torch.randn(L, kvh * 64, generator=g).to(dev)
+    vc = torch.randn(L, kvh * 64, generator=g).to(dev)
+    slopes = (2.0 ** -torch.arange(1, h + 1).float()).to(dev) if with_slopes else None
+    out = torch.zeros(n, h * 64, device=dev)
+    ops.dec_attn_rows(q, kc, vc, slopes, t0, out, h=h, kvh=kvh, scale=0.125)
+    qd = q[:, :h * 64].double().view(n, h, 64)
+    kd, vd = kc.double().view(L, kvh, 64), vc.double().view(L, kvh, 64)
+    if kvh == 1:
+        kd, vd = kd.expand(L, h, 64), vd.expand(L, h, 64)
+    s = torch.einsum("rhd,jhd->hrj", qd, kd) * 0.125
+    t = torch.arange(t0, t0 + n, device=dev)[:, None]
+    j = torch.arange(L, device=dev)[None, :]
+    if with_slopes:
+        s = s - slopes.double()[:, None, None] * (t - j).clamp_min(0).double()[None]
+    s = s.masked_fill((j > t)[None], float("-inf"))
+    want = torch.einsum("hrj,jhd->rhd", s.softmax(-1), vd).reshape(n, h * 64)
+    assert (out.double() - want).abs().max() <= 2e-5
