@@ -334,6 +334,10 @@ typedef struct spn_dec_chain_ext {
     /* several notes per launch (spn_dec_pairs_notes): granules [16] (zeroed once per render) through which the head's winners hand the
      * final value of their token cells to the next note's embed phase; null: one note per launch only */
     unsigned long long* gt;
+    /* sampling in the head phase (stopk = null: arg-max): the decision of spn_dec_head_sample -- keep the stopk[q] largest logits of key q,
+     * weights exp((l - max) * sinv_temp), one draw at the counter hash of (*sseed, position, key) -- inside the launch; gl: granules
+     * [16 * 1024] (zeroed once per render) through which the slabs hand their logits to the key's first workgroup */
+    unsigned long long* gl; const int* stopk; float sinv_temp; const unsigned* sseed;
 } spn_dec_chain_ext;
 int spn_dec_pairs_ext(const spn_dec_pair_args* host, const spn_dec_pair_args* dev, int n, const spn_dec_chain_ext* ext_host,
                       const spn_dec_chain_ext* ext_dev, spn_stream_t s);

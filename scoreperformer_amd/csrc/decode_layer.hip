@@ -23,6 +23,7 @@
 //
 // Replaces (per note) the layer body of `ScorePerformerMixedLMWrapper.unmask_tokens` (wrappers.py:325-407 ->
 // modules/transformer/transformer.py:159-221, attention.py:107-222, feedforward.py:13-64) for pre-norm ('a', 'f') decoders.
+#include <algorithm>
 #include "common.h"
 #include "decode_attn.h"
 #include "../../include/spn.h"   // spn_dec_pair_args
@@ -41,6 +42,9 @@ __device__ __forceinline__ gu64* as_global(unsigned long long* p) { return (gu64
 __device__ __forceinline__ void put(unsigned long long* g, unsigned epoch, float v) {
     __hip_atomic_store(as_global(g), ((unsigned long long)epoch << 32) | __float_as_uint(v), RLX_AGENT);
 }
+
+// the counter hash of dec_head_kernel<true>'s draw (decode.hip dec_mix)
+__device__ __forceinline__ unsigned dec_mix32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
 // Hand-off read: thread tid polls the granule PAIRS p = tid + 512 k (granules 2p, 2p + 1; k < 2, n even and <= 2048) with one 16-byte
 // agent-scope load each until both tags carry `epoch`, then leaves the values in xs.  One load per lane and pass at n <= 1024.  Measured
@@ -683,6 +687,11 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
             const int SL = min(16, max(1, nC / n)), items = n * SL;
             float* bvs = sm;                          // per-wave best value / id of the current item
             int* bis = reinterpret_cast<int*>(sl);
+            // Sampling (spn_dec_chain_ext.stopk): the slabs publish every LOGIT of their rows instead of their maxima, and the key's first
+            // workgroup ranks, filters, normalises and draws exactly as dec_head_kernel<true> does behind its last slab (same expressions,
+            // same 256-thread partial sums, same counter hash of (seed, position, key)): the token of spn_dec_head_sample, bit for bit.
+            const bool sampling = ext->stopk != nullptr;
+            float* slog = &so[0][0];                  // this workgroup's logits of the current item: [wave][row of the wave]
             float rw[4][4];
             auto load_rows = [&](float (&dst)[4][4], const float* tab, int V, int W, int vb, int vstep) __attribute__((always_inline)) {
 #pragma unroll
@@ -723,9 +732,11 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     __syncthreads();
                     float best = -INFINITY;
                     int idx = 0x7fffffff;
+                    const int UM = (V + vstep - 1) / vstep;   // rows per wave of a slab (rows v = 8 s0 + w + vstep u, u < UM)
                     auto take = [&](int v, float acc) __attribute__((always_inline)) {
                         acc = wave_sum(acc);
                         if (v < 32 && ((ext->hban >> v) & 1u)) acc = -INFINITY;
+                        if (sampling && lane == 0) slog[w * UM + (v - (s0 * 8 + w)) / vstep] = acc;
                         if (acc > best || (acc == best && v < idx)) { best = acc; idx = v; }
                     };
                     int vb = s0 * 8 + w;
@@ -762,6 +773,16 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     }
                     if (lane == 0) { bvs[w] = best; bis[w] = idx; }
                     __syncthreads();
+                    if (sampling) {
+                        // this slab's 8 UM logits as one contiguous run of the key's granules: entry (8 s0 + w) UM + u is row 8 s0 + w + vstep u
+                        if (tid < 8 * UM) {
+                            const int ww = tid / UM, u = tid - ww * UM;
+                            const float lv = (s0 * 8 + ww + vstep * u < V) ? slog[tid] : -INFINITY;
+                            put(ext->gl + q * 1024 + s0 * 8 * UM + tid, ehead + 1u, lv);
+                        }
+                        __syncthreads();   // slog is reused by this workgroup's next item
+                        continue;
+                    }
                     if (tid == 0) {
                         for (int r = 1; r < NW; ++r) if (bvs[r] > best || (bvs[r] == best && bis[r] < idx)) { best = bvs[r]; idx = bis[r]; }
                         outv[0] = best; outv[1] = __int_as_float(idx);
@@ -779,6 +800,52 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                     long* cell = ext->tokens + (long)(t + 1) * ext->tok_ld + ext->hdim[q];
                     const long cur = tid == 0 ? *cell : 0;
                     __syncthreads();
+                    if (sampling) {
+                        // ---- the key's logits from all its slabs, then dec_head_kernel<true>'s rank / filter / normalise / draw ----
+                        const int V = ext->hV[q], vstep = 8 * SL, UM = (V + vstep - 1) / vstep;
+                        gather(ext->gl + q * 1024, 8 * SL * UM, ehead + 1u, xs, tid, err);
+                        __syncthreads();
+                        float* lg = &so[0][0];          // [V] logits by id, [1024 + V] weights
+                        for (int v = tid; v < V; v += NT) lg[v] = xs[((v % vstep) / 8 * 8 + (v & 7)) * UM + v / vstep];
+                        __syncthreads();
+                        const int keep_n = ext->stopk[q];
+                        float mx = -INFINITY;
+                        if (tid < 256) for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+                        mx = wave_max(mx);
+                        if (tid < 256 && lane == 0) red[w] = mx;
+                        __syncthreads();
+                        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+                        __syncthreads();
+                        float mine_sum = 0.f;
+                        if (tid < 256) for (int v = tid; v < V; v += 256) {
+                            const float lv = lg[v];
+                            int rank = 0;
+                            for (int u = 0; u < V; ++u) { const float lu = lg[u]; rank += (lu > lv) || (lu == lv && u < v); }
+                            const float wgt = (rank < keep_n && lv > -INFINITY) ? __expf((lv - mx) * ext->sinv_temp) : 0.f;
+                            lg[1024 + v] = wgt;
+                            mine_sum += wgt;
+                        }
+                        mine_sum = wave_sum(mine_sum);
+                        if (tid < 256 && lane == 0) red[4 + w] = mine_sum;
+                        __syncthreads();
+                        if (tid == 0) {
+                            const float total = red[4] + red[5] + red[6] + red[7];
+                            const unsigned r = dec_mix32(dec_mix32(*ext->sseed ^ 0x9e3779b9u * (unsigned)(t + 1)) + 0x85ebca6bu * (unsigned)(q + 1));
+                            const float target = (float)(r >> 8) * (1.f / 16777216.f) * total;
+                            float cum = 0.f;
+                            int pick = -1, lastpos = 0;
+                            for (int v = 0; v < V; ++v) {
+                                const float wgt = lg[1024 + v];
+                                if (wgt > 0.f) { lastpos = v; cum += wgt; if (pick < 0 && cum > target) pick = v; }
+                            }
+                            if (pick < 0) pick = lastpos;
+                            const long chosen = cur == ext->mask_id ? (long)pick : cur;
+                            if (cur == ext->mask_id) __hip_atomic_store(cell, chosen, RLX_AGENT);
+                            if (ext->gt) __hip_atomic_store(as_global(ext->gt + q), ((unsigned long long)(eemb + 1u) << 32) | (unsigned)chosen, RLX_AGENT);
+                        }
+                        __syncthreads();   // lg / red are reused by this workgroup's next key
+                        continue;
+                    }
                     gather(ext->gh + q * 32, 2 * SL, ehead + 1u, xs, tid, err);
                     __syncthreads();
                     if (tid == 0) {
@@ -1092,6 +1159,15 @@ static int dec_pairs_ext_notes(const spn_dec_pair_args* host, const spn_dec_pair
     }
     if (e.rW) SPN_REQUIRE(e.rN >= 1 && e.rK >= 4 && e.rK <= 256 && e.rK % 4 == 0 && (e.r_ldw % 4) == 0 && e.rx && (e.rx_ld % 4) == 0 && e.rx_rows >= 1 && e.ry && e.ada_par >= e.rN,
                           "spn_dec_pairs_ext: rider: K <= 256 in whole float4, two row buffers ada_par >= rN floats apart");
+    if (e.stopk) {
+        SPN_REQUIRE(e.hn > 0 && e.gl && e.sseed && e.sinv_temp > 0.f, "spn_dec_pairs_ext: sampling needs the head phase, the logit granules gl and the seed");
+        const int nC = G - f.h * f.S - (f.d + 15) / 16, SL = std::min(16, std::max(1, nC / e.hn));
+        for (int q = 0; q < e.hn; ++q) {
+            const int UM = (e.hV[q] + 8 * SL - 1) / (8 * SL);
+            SPN_REQUIRE(e.hV[q] <= 1024 && 8 * UM <= 512 && 8 * SL * UM <= 1024,
+                        "spn_dec_pairs_ext: sampling: vocabularies up to 1024 ids, at most 64 rows per wave of a slab");
+        }
+    }
     if (e.hn) {
         SPN_REQUIRE(e.Wh && e.hn >= 1 && e.hn <= 16 && e.hD == e.Nh && e.hD <= 2048 && e.hD % 4 == 0 && e.hgamma && e.hbeta && e.tokens && e.ge && e.gh,
                     "spn_dec_pairs_ext: head phase: needs the tail, 1 to 16 keys, e of a width in whole float4 <= 2048, norm, tokens and granule buffers");

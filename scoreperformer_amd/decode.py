@@ -127,7 +127,7 @@ class GreedyDecoder:
             self.pair_g = dict(gq=zg(self.qkv.numel()), gp=zg(self.heads * S * 66), go=zg(self.heads * 64), gx=zg(d), gg=zg(self.g.numel()),
                                gxo=zg(d))
             self.pair_jlo = [torch.zeros(self.heads, device=dev, dtype=torch.int32) for _ in range(n_self)]
-            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2), gin=zg(2048), gt=zg(16))
+            self.pair_g2 = dict(gf=zg(d), gxf=zg(d), ge=zg(2048), gh=zg(16 * 16 * 2), gin=zg(2048), gt=zg(16), gl=zg(16 * 1024))
             self.pair_front = self.pair_tail = self.pair_head = self.pair_embed = False
             self.pair_chains = {}      # first layer index of a chain -> ops.DecPairChain (argument records, host + device copy)
             self.pair_tick = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -521,10 +521,14 @@ class GreedyDecoder:
                     ext.update(Wh=self.head_Wt, ld_h=self.head_Wt.stride(0), Nh=self.head_Wt.shape[0], normh=mode, gamh=g_, beth=b_, epsh=eps_,
                                e_out=self.e_head, xn_out=self.hid[-1], xn_ld=d)
                     self.pair_tail = True
-                    # ... and the arg-max LM head itself (greedy decoding: sampling keeps its own launch), so that a note is TWO launches
-                    if (head_ok and self.sampling is None and te.total_emb_dim == self.head_Wt.shape[0] and te.total_emb_dim <= 2048
+                    # ... and the LM head itself -- arg-max, or (round 5) top-k sampling with the decision of spn_dec_head_sample inside the
+                    # launch -- so that a note is TWO launches
+                    if (head_ok and self._sampling_fits_the_launch() and te.total_emb_dim == self.head_Wt.shape[0] and te.total_emb_dim <= 2048
                             and te.total_emb_dim % 4 == 0 and os.environ.get("SPN_DEC_PAIR_HEAD", "1") != "0"):
                         ext.update(self._head_ext(), ge=self.pair_g2["ge"], gh=self.pair_g2["gh"])
+                        if self.sampling is not None:
+                            ext.update(gl=self.pair_g2["gl"], stopk=self.sampling["topk"], sinv_temp=1.0 / self.sampling["temperature"],
+                                       sseed=self.seed_dev)
                         self.pair_head = True
                 # ... and, in front, the two token-tuple embeddings with their projection (+ the NEXT note's AdaLN rows): ONE launch per note
                 if self.pair_front and self.pair_head and os.environ.get("SPN_DEC_PAIR_EMBED", "1") != "0":
@@ -547,6 +551,23 @@ class GreedyDecoder:
                         self.pair_embed = True
             self.pair_chains = {k: ops.DecPairChain(v, self.dev, ext if (ext and k == 0) else None) for k, v in self.pair_chains.items()}
         return self.pair_chains
+
+    def _sampling_fits_the_launch(self) -> bool:
+        """Arg-max always; sampling when every decoded key's logits fit the head phase's hand-off (csrc/decode_layer.hip: vocabularies up to
+        1024 ids, at most 64 rows per wave of a slab) and SPN_DEC_PAIR_SAMPLE is not 0."""
+        if self.sampling is None:
+            return True
+        if os.environ.get("SPN_DEC_PAIR_SAMPLE", "1") == "0":
+            return False
+        dims = list(self.cur_dims)
+        n_c = self.g.numel() // 32
+        sl = min(16, max(1, n_c // max(1, len(dims))))
+        for dim in dims:
+            v = self.tables[dim].shape[0]
+            um = -(-v // (8 * sl))
+            if v > 1024 or 8 * um > 512 or 8 * sl * um > 1024:
+                return False
+        return True
 
     def _drop_chains(self):
         """Forget the argument records of the persistent launch (rebuilt by the next step): its set of phases is about to change."""
@@ -775,8 +796,7 @@ class RenderSession(GreedyDecoder):
         temperature = float(sampling.get("temperature", 1.0))
         if self.sampling is None or self.sampling["temperature"] != temperature:
             self.graph = self.graph_multi = None
-            if self.sampling is None:
-                self._drop_chains()              # sampling keeps the LM head in its own launch (spn_dec_head_sample)
+            self._drop_chains()                  # the head phase of the persistent launch changes (arg-max <-> sampling, or its temperature)
             self.sampling = {"topk": torch.tensor(ks, device=self.dev, dtype=torch.int32), "temperature": temperature, "ks": ks,
                              "calls": int(sampling.get("seed", 0))}
         elif self.sampling["ks"] != ks:

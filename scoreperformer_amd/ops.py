@@ -1105,7 +1105,7 @@ class DecChainExt(ctypes.Structure):
                 ("tok_a", _P), ("tok_b", _P), ("etok_ld", _L), ("egamma", _P), ("ebeta", _P), ("eeps", _F), ("We", _P), ("ld_e", _L), ("be", _P),
                 ("gin", _P),
                 ("rW", _P), ("r_ldw", _L), ("rN", _I), ("rK", _I), ("rx", _P), ("rx_ld", _L), ("rx_rows", _I), ("rbias", _P), ("ry", _P),
-                ("ada_par", _L), ("gt", _P)]
+                ("ada_par", _L), ("gt", _P), ("gl", _P), ("stopk", _P), ("sinv_temp", _F), ("sseed", _P)]
 
 
 def _fill_struct(a, kw, keep, what):

@@ -301,3 +301,47 @@ def test_several_notes_per_launch_equal_one_note_per_launch(dev, monkeypatch, kw
     toks2, n2 = e1.run(tokens.clone(), batch["masked_perf"], enc.score_embeddings, enc.perf_embeddings)
     torch.cuda.synchronize()
     assert n2 == n1 and torch.equal(toks2, t1) and int(e1.pair_err.item()) == 0
+
+
+@pytest.mark.parametrize("temperature,k", [(1.0, None), (0.7, 3)])
+def test_sampling_inside_the_launch_draws_what_the_sampling_head_launch_draws(dev, monkeypatch, temperature, k):
+    """Top-k sampling as the last phase of the persistent launch (spn_dec_chain_ext.stopk: the slabs hand every logit of their rows to the
+    key's first workgroup, which ranks, filters, normalises and draws with the expressions and the counter hash of spn_dec_head_sample)
+    against the same session with the sampling head in its own launch: the same tokens draw for draw, over windows that go back and
+    re-decode positions, with chord groups long enough for several notes per launch."""
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import RenderSession
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.synthetic import PREDICTED_DIMS, model_config, synthetic_batch
+    L = 120
+    torch.manual_seed(5)
+    model = ScorePerformer.init(model_config("tiny", max_seq_len=L))
+    ParamArena(model, dev)
+    model.eval()
+    batch = synthetic_batch(1, L, seed=13, device=dev)
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=batch["perf"], perf_mask=batch["perf_mask"], score=batch["score"], score_mask=batch["score_mask"],
+                                     bars=batch["bars"], beats=batch["beats"], onsets=batch["onsets"], deadpan_mask=batch["deadpan_mask"],
+                                     compute_loss=False)
+    truth, masked = batch["perf"][0], batch["masked_perf"][0]
+    ctx, sty = enc.score_embeddings[0], enc.perf_embeddings[0]
+    dims = list(PREDICTED_DIMS)
+    monkeypatch.setenv("SPN_DEC_PAIR", "1")
+    got = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SPN_DEC_PAIR_SAMPLE", flag)
+        sess = RenderSession(model.perf_decoder.model, L, dims)
+        sess.configure(dict(k=k, thres=0.9, temperature=temperature, seed=41))
+        rows = []
+        for kk, g in ((20, 8), (36, 8), (28, 20), (60, 3), (44, 8), (90, 24)):
+            win = truth[:kk + g].clone()
+            win[kk:kk + g, dims] = 1
+            sess.truncate(min(sess.length, kk - 1))
+            rows.append(sess.decode(win, masked[:kk + g], ctx[:kk + g], sty[:kk + g], g).clone())
+        torch.cuda.synchronize()
+        assert sess.pair_groups > 0 and sess.pair_head == (flag == "1") and int(sess.pair_err.item()) == 0
+        if flag == "1":
+            assert sess.pair_embed and sess.pair_chains[0].max_notes > 1       # whole notes, several per launch
+        got.append(torch.cat(rows))
+    assert torch.equal(got[0], got[1])
+    assert not (got[1][:, dims] == 1).any()                                     # every MASK cell was drawn
