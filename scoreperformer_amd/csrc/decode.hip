@@ -13,6 +13,7 @@
 // exact near-ties.
 #include "common.h"
 #include "decode_attn.h"
+#include "decode_sample.h"
 
 // No floating-point contraction in this file: whether `a * b + c` becomes one fused operation or two is otherwise the optimiser's choice per
 // call site (packed multiplies + adds in one loop, fused multiply-adds in its twin), and the persistent layer launch
@@ -960,23 +961,16 @@ __global__ __launch_bounds__(256) void dec_head_kernel(DecHeadDesc d, const floa
             xs[1024 + v] = wgt;
             mine_sum += wgt;
         }
-        mine_sum = wave_sum(mine_sum);
-        if (lane == 0) red[4 + w] = mine_sum;
+        (void)mine_sum;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const float total = red[4] + red[5] + red[6] + red[7];
+        if (w == 0) {   // the draw: decode_sample.h (one definition for this launch and the head phase of the persistent one)
             const unsigned r = dec_mix(dec_mix(*sa.seed ^ 0x9e3779b9u * (unsigned)(*pos + 1)) + 0x85ebca6bu * (unsigned)(q + 1));
-            const float target = (float)(r >> 8) * (1.f / 16777216.f) * total;
-            float cum = 0.f;
-            int pick = -1, lastpos = 0;
-            for (int v = 0; v < V; ++v) {
-                const float wgt = xs[1024 + v];
-                if (wgt > 0.f) { lastpos = v; cum += wgt; if (pick < 0 && cum > target) pick = v; }
+            const int pick = dec_sample_pick(xs + 1024, V, (float)(r >> 8) * (1.f / 16777216.f), lane);
+            if (lane == 0) {
+                long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
+                if (*cell == mask_id) *cell = pick;
+                counter[q] = 0;
             }
-            if (pick < 0) pick = lastpos;
-            long* cell = tokens + (long)(*pos + 1) * tok_ld + d.dim[q];
-            if (*cell == mask_id) *cell = pick;
-            counter[q] = 0;
         }
         return;
     }

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include "common.h"
 #include "decode_attn.h"
+#include "decode_sample.h"
 #include "../../include/spn.h"   // spn_dec_pair_args
 
 #pragma clang fp contract(off)   // as decode.hip: the same source expression must round the same way in both files
@@ -825,23 +826,16 @@ __global__ __launch_bounds__(NT) void dec_pair_kernel(const spn_dec_pair_args* _
                             lg[1024 + v] = wgt;
                             mine_sum += wgt;
                         }
-                        mine_sum = wave_sum(mine_sum);
-                        if (tid < 256 && lane == 0) red[4 + w] = mine_sum;
+                        (void)mine_sum;
                         __syncthreads();
-                        if (tid == 0) {
-                            const float total = red[4] + red[5] + red[6] + red[7];
+                        if (w == 0) {
                             const unsigned r = dec_mix32(dec_mix32(*ext->sseed ^ 0x9e3779b9u * (unsigned)(t + 1)) + 0x85ebca6bu * (unsigned)(q + 1));
-                            const float target = (float)(r >> 8) * (1.f / 16777216.f) * total;
-                            float cum = 0.f;
-                            int pick = -1, lastpos = 0;
-                            for (int v = 0; v < V; ++v) {
-                                const float wgt = lg[1024 + v];
-                                if (wgt > 0.f) { lastpos = v; cum += wgt; if (pick < 0 && cum > target) pick = v; }
+                            const int pick = dec_sample_pick(lg + 1024, V, (float)(r >> 8) * (1.f / 16777216.f), lane);   // decode_sample.h
+                            if (tid == 0) {
+                                const long chosen = cur == ext->mask_id ? (long)pick : cur;
+                                if (cur == ext->mask_id) __hip_atomic_store(cell, chosen, RLX_AGENT);
+                                if (ext->gt) __hip_atomic_store(as_global(ext->gt + q), ((unsigned long long)(eemb + 1u) << 32) | (unsigned)chosen, RLX_AGENT);
                             }
-                            if (pick < 0) pick = lastpos;
-                            const long chosen = cur == ext->mask_id ? (long)pick : cur;
-                            if (cur == ext->mask_id) __hip_atomic_store(cell, chosen, RLX_AGENT);
-                            if (ext->gt) __hip_atomic_store(as_global(ext->gt + q), ((unsigned long long)(eemb + 1u) << 32) | (unsigned)chosen, RLX_AGENT);
                         }
                         __syncthreads();   // lg / red are reused by this workgroup's next key
                         continue;
