@@ -849,7 +849,34 @@ class RenderSession(GreedyDecoder):
     def prefill(self, n: int):
         """Cache rows 0 .. n-1 from the tokens / embeddings already written to rows 0 .. n (by `decode`'s upload): the same fp32
         arithmetic as `_step`, but every operator runs ONCE over all n positions (exact-fp32 GEMMs instead of n GEMVs, causal
-        attention with the position in the grid) -- what the reference does when it recomputes a cropped window in one forward."""
+        attention with the position in the grid) -- what the reference does when it recomputes a cropped window in one forward.
+
+        The pass is ~150 launches whose enqueueing (2-3 ms of host time) takes longer than their execution (~1.2 ms): under
+        `use_graph` it is captured ONCE PER ROW COUNT and replayed afterwards -- every operand is a static buffer of the session, the
+        intermediates live in the graphs' shared memory pool, and a full context window re-primes with a handful of distinct row counts
+        (SPN_DEC_PREFILL_GRAPHS = 0: always eager; at most 64 counts are kept)."""
+        graphs = getattr(self, "_prefill_graphs", None)
+        if graphs is None:
+            graphs = self._prefill_graphs = {}
+            self._prefill_pool = None
+        if not self.use_graph or os.environ.get("SPN_DEC_PREFILL_GRAPHS", "1") == "0":
+            self._prefill_eager(n)
+        elif n in graphs:
+            graphs[n].replay()
+        else:
+            self._prefill_eager(n)                       # does the work this time (and warms every lazily built operand)
+            if len(graphs) < 64:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                if self._prefill_pool is None:
+                    self._prefill_pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=self._prefill_pool):
+                    self._prefill_eager(n)               # recorded, not executed
+                graphs[n] = g
+        self.length = n
+        self.prefilled_rows += n
+
+    def _prefill_eager(self, n: int):
         m, d = self.m, self.dim
         te, tr = m.token_emb, m.transformer
         cond = self.style2d[1:n + 1] if self.style2d is not None else None
@@ -890,7 +917,7 @@ class RenderSession(GreedyDecoder):
                 self.kc[ai][:n].copy_(qkv[:, H:H + KV])
                 self.vc[ai][:n].copy_(qkv[:, H + KV:H + 2 * KV])
                 self.kmax2[ai].copy_(torch.maximum(self.kmax2[ai], self.kc[ai][:n].view(n, self.kvh, 64).pow(2).sum(-1).amax(0)))
-                slopes = block.rel_pos.padded_slopes().detach().contiguous() if block.rel_pos is not None else None
+                slopes = self._slopes(block)
                 o = torch.empty(n, H, device=self.dev, dtype=F32)
                 ops.dec_attn_rows(qkv, self.kc[ai], self.vc[ai], slopes, 0, o, h=self.heads, kvh=self.kvh, scale=block.scale)
                 ops.gemm_f32(o, block.to_out.weight.data, out=x, accumulate=True)
@@ -906,8 +933,6 @@ class RenderSession(GreedyDecoder):
                 ops.gemm_f32(g, out.weight.data, bias=out.bias.data if out.bias is not None else None, out=x, accumulate=True)
         fn = tr.final_norm
         self.hid[-1][:n].copy_(ln(x, fn) if not isinstance(fn, nn.Identity) else x)
-        self.length = n
-        self.prefilled_rows += n
 
     @torch.no_grad()
     def decode(self, tokens: torch.Tensor, masked: torch.Tensor, context: Optional[torch.Tensor], style: Optional[torch.Tensor],
