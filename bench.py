@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the child command and exit")
     ap.add_argument("--no-decode", action="store_true", help="skip the C5 decode object (N = 1 only)")
     ap.add_argument("--decode-seq", type=int, default=4096)
+    ap.add_argument("--sustained-seconds", type=float, default=25.0,
+                    help="N = 1 only, after the timed region: keep stepping for this long (>= 50 steps) and report ms/step, its drift and the "
+                         "mean shader clock / socket power from rocm-smi -- the chip runs this step at its power limit and a 20-step line "
+                         "overstates the sustained rate by a few percent (0 = skip)")
     return ap.parse_args()
 
 
@@ -231,6 +235,9 @@ def main():
         roof = roofline_leg(ops, step, args)
         if rank == 0:
             result["roofline"] = roof
+    result["phases"] = phases_leg(model, batch, opt, holder, world)           # every rank runs it (it contains the all-reduce)
+    if rank == 0 and world == 1 and args.sustained_seconds > 0:
+        result["sustained"] = sustained_leg(step, args.sustained_seconds, local_rank, args.batch * args.seq)
     if rank == 0 and world == 1 and dist is None and not args.no_dp1_forced:
         result["dp1_forced"] = dp1_forced_leg(args, arena, dev, holder, step, lib_mod, GradSync)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 measurement
@@ -254,6 +261,81 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(result), flush=True)
+
+
+def phases_leg(model, batch, opt, holder, world, n=3):
+    """"also report fwd-only and fwd+bwd".  The same step as the timed region, `n` more of them with events on
+    the launch stream (torch's current stream: every kernel of the library is launched on it) after the forward, after the backward
+    (+ gradient all-reduce wait) and after clip + AdamW; outside the timed region."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+    for e in ev:
+        gs = holder["sync"]
+        gs.begin_step()
+        e[0].record()
+        out = model(**batch)
+        e[1].record()
+        out.loss.backward()
+        gs.finish()
+        e[2].record()
+        opt.step(grad_scale=1.0 / world)
+        e[3].record()
+    torch.cuda.synchronize()
+    mean = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in ev) / n   # noqa: E731
+    return {"steps": n, "fwd_ms": mean(0, 1), "fwd_bwd_ms": mean(0, 2), "step_ms": mean(0, 3), "bwd_ms": mean(1, 2), "optimizer_ms": mean(2, 3),
+            "note": "device time between events on the launch stream inside ordinary train steps: forward (loss included), forward + backward "
+                    "(incl. the wait for the gradient all-reduce when N > 1), full step (+ global-norm clip + AdamW)"}
+
+
+def _smi_sample(device_index):
+    """(sclk MHz, socket W) from `rocm-smi --showclocks --showpower` run as a CHILD process, or (None, None) when it is not readable."""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=15)
+    except Exception:  # noqa: BLE001
+        return None, None
+    sclk = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", r.stdout)
+    power = re.search(r"Power \(W\):\s*([\d.]+)", r.stdout)
+    return (float(sclk.group(1)) if sclk else None), (float(power.group(1)) if power else None)
+
+
+def sustained_leg(step, seconds, device_index, tokens_per_step, chunk=10):
+    """The same step for `seconds` (at least 50 steps) in chunks of `chunk` steps, device-synchronised per chunk; a sampler thread reads
+    the shader clock and the socket power once every ~2 s.  VERDICT r5: the 20-step line runs before the power limit has pulled the clock
+    down -- this object is the rate a training run sees."""
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(_smi_sample(device_index))
+            stop.wait(2.0)
+    th = threading.Thread(target=sampler, daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    chunks, t_start = [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(chunk):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        chunks.append((t1 - t0) / chunk * 1e3)
+        if t1 - t_start >= seconds and len(chunks) * chunk >= 50:
+            break
+    total = time.perf_counter() - t_start
+    stop.set()
+    th.join(timeout=20)
+    sclk = [a for a, _ in samples[1:] if a]          # the first sample may predate the ramp
+    power = [b for _, b in samples[1:] if b]
+    steps = len(chunks) * chunk
+    return {"steps": steps, "seconds": total, "ms_per_step": total / steps * 1e3, "note_tokens_per_s": tokens_per_step * steps / total,
+            "first_chunk_ms_per_step": chunks[0], "last_chunk_ms_per_step": chunks[-1], "chunk_steps": chunk,
+            "mean_sclk_mhz": (sum(sclk) / len(sclk)) if sclk else None, "min_sclk_mhz": min(sclk) if sclk else None,
+            "mean_socket_power_w": (sum(power) / len(power)) if power else None, "smi_samples": len(sclk),
+            "note": "after the timed region, same process: wall time over device-synchronised chunks; sclk / power from rocm-smi (child process, "
+                    "one sample per ~2 s; null when rocm-smi is not readable).  The headline `value` is the short timed region the contract "
+                    "asks for; this is the rate once the power limit has settled the clock"}
 
 
 class Deadline:

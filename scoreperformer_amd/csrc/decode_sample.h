@@ -9,9 +9,10 @@
 #pragma once
 #include "common.h"
 
-#pragma clang fp contract(off)
-
 __device__ __forceinline__ int dec_sample_pick(const float* wg, int V, float u01, int lane) {
+    // no FMA contraction in the sums below, whatever the including file's setting: both callers must add the same values in the same way
+    // (scoped to this function; decode.hip / decode_layer.hip set their own file-wide pragma explicitly)
+#pragma clang fp contract(off)
     const int C = (V + 63) >> 6;
     float s = 0.f;
     int last_pos = -1;                      // the last id with a positive weight in this lane's range

@@ -55,6 +55,12 @@ class GreedyDecoder:
             raise NotImplementedError("decode engine: pre-norm decoder with ('a','f') or ('a','c','f') layer blocks")
         if getattr(m.token_emb, "multiseq_mode", None) != "post-cat" or m.pos_emb is not None:
             raise NotImplementedError("decode engine: multi-seq post-cat token embeddings without absolute positions")
+        for kind, (_norms, blk, _res) in zip(types, tr.layers):
+            # the engine's q | k | v rows, caches and out-projection columns are laid out for 64-wide heads and it knows no learned memory
+            # rows; `Attention` serves both on the module path (zero-padded weights, memories in front of the keys), which the wrapper falls
+            # back to on this error
+            if kind in "ac" and (blk.dim_head != 64 or blk.num_mem_kv > 0):
+                raise NotImplementedError("decode engine: attention blocks with dim_head == 64 and num_mem_kv == 0")
         self.dev = next(m.parameters()).device
         self.dim = m.dim
         self.ada = tr.ada_norm

@@ -17,6 +17,7 @@ from ...modules.constructor import Constructor, Registry, VariableModuleConfig
 from ...modules.transformer.embeddings import DiscreteContinuousEmbedding, DiscreteDenseContinuousEmbedding
 from ...modules.layers import LayerNorm
 from ...utils.config import MISSING
+from ...utils.amp import no_autocast
 
 # ---------------------------------------------------------------------------------------------------------
 # table building (K1), shared per forward pass
@@ -169,6 +170,7 @@ class TupleTokenEmbeddings(nn.Module, Constructor):
             return e
         return F_.linear(e, self.project_emb.weight, self.project_emb.bias)
 
+    @no_autocast
     def forward(self, x: Tensor, values: Optional[Tensor] = None, cache: Optional[Tensor] = None,
                 return_embeddings: bool = False):
         if values is not None or return_embeddings:
@@ -201,6 +203,7 @@ class MultiSeqTupleTokenEmbeddings(TupleTokenEmbeddings):
         if self.multiseq_mode == "post-cat":
             self.project_multiemb = nn.Linear(num_sequences * project_emb_dim, project_emb_dim)
 
+    @no_autocast
     def forward(self, tokens: Union[Tensor, List[Tensor]], values=None, cache: Optional[Tensor] = None,
                 return_embeddings: bool = False):
         if isinstance(tokens, (list, tuple)) and len(tokens) == 1:
@@ -337,6 +340,7 @@ class TupleTokenLMHead(_HeadBase, Constructor):
         self.heads = nn.ModuleDict({key: nn.Linear(dim, num) for key, num in num_tokens.items()
                                     if not filter_keys or key in filter_keys})
 
+    @no_autocast
     def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
                 label_counts=None):
         xb = F_.cast(x, torch.bfloat16)
@@ -370,6 +374,7 @@ class TupleTokenTiedLMHead(_HeadBase, Constructor):
         self.norm = LayerNorm(self.total_emb_dim)
         self.reuse_projection = reuse_projection
 
+    @no_autocast
     def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
                 label_counts=None):
         # `x @ project_emb.weight` uses the weight UNtransposed (embeddings.py:346) -- the embeddings' [dim, total] projection when
@@ -401,6 +406,7 @@ class TupleTokenTiedSplitLMHead(_HeadBase, Constructor):
         self.to_embs = nn.ModuleDict(to_embs)
         self.embs = embeddings.embs
 
+    @no_autocast
     def forward(self, x: Tensor, keys=None, labels: Optional[Tensor] = None, ignore_index: int = -100, want_argmax=False,
                 label_counts=None):
         tables = build_tables(list(self.embs.values()))
@@ -425,6 +431,7 @@ class TupleTokenRegressionHead(nn.Module, Constructor):
         super().__init__()
         self.layers = nn.ModuleDict({key: nn.Linear(dim, 1) for key in regression_keys})
 
+    @no_autocast
     def forward(self, x: Tensor, keys=None):
         return {key: F_.linear_f32(F_.cast(x, torch.float32), layer.weight, layer.bias)
                 for i, (key, layer) in enumerate(self.layers.items()) if _wanted(i, key, keys)}
@@ -458,6 +465,7 @@ class TupleTokenEmbeddingHead(nn.Module, Constructor):
         self.layers = nn.Sequential(*stack)
         self.detach_inputs = detach_inputs
 
+    @no_autocast
     def forward(self, x: Tensor):
         keep = float(self.detach_inputs)
         x = F_.cast(x, torch.float32)

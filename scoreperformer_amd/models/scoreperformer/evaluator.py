@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from .wrappers import ScorePerformerLMModes
+from ...utils.amp import no_autocast
 
 
 class ScorePerformerEvaluator:
@@ -80,6 +81,7 @@ class ScorePerformerEvaluator:
         return (predictions[m] == labels[m]).float().mean()
 
     @torch.no_grad()
+    @no_autocast
     def __call__(self, inputs, outputs, ignore_keys: Optional[List[str]] = None):
         metrics = {}
         ignore_keys = ignore_keys or self.ignore_keys

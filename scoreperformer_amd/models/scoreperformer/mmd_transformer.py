@@ -22,6 +22,7 @@ from ...utils import ExplicitEnum
 from ...utils.config import DictConfig
 from .embeddings import TupleTokenEmbeddingsConfig, TupleTokenHeadsConfig, TupleTokenRegressionHeadConfig
 from .transformer import TupleTransformerOutput, TupleTransformerConfig, TupleTransformer
+from ...utils.amp import no_autocast
 
 
 class EmbeddingAggregateModes(ExplicitEnum):
@@ -66,6 +67,7 @@ class MMDVAE(nn.Module):
         self.latent_dim = latent_dim
         self.linear = nn.Linear(input_dim, latent_dim)
 
+    @no_autocast
     def forward(self, inputs: Tensor):
         return F_.linear_f32(F_.cast(inputs, torch.float32), self.linear.weight, self.linear.bias)
 
@@ -258,6 +260,7 @@ class MMDTupleTransformer(TupleTransformer):
         return int(bounds[{EmbeddingAggregateModes.BAR_MEAN: "bar", EmbeddingAggregateModes.ISOLATED_BAR_MEAN: "bar",
                            EmbeddingAggregateModes.BEAT_MEAN: "beat", EmbeddingAggregateModes.ONSET_MEAN: "onset"}[mode]])
 
+    @no_autocast
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, x_extra=None, latents=None, bars: Optional[Tensor] = None,
                 beats: Optional[Tensor] = None, onsets: Optional[Tensor] = None, deadpan_mask: Optional[Tensor] = None,
                 return_embeddings: bool = False, return_attn: bool = False, compute_loss: bool = True, segment_bounds=None, **kwargs):
@@ -397,6 +400,7 @@ class MMDLoss(nn.Module):
         self.num_samples = num_samples
         self.max_num_latents = max_num_latents
 
+    @no_autocast
     def forward(self, latents: Tensor, mask: Optional[Tensor] = None, z: Optional[Tensor] = None):
         D = latents.shape[-1]
         y = latents.reshape(-1, D)

@@ -13,6 +13,7 @@ from .embeddings import TupleTokenLMHeadConfig, shared_tables
 from .mmd_transformer import MMDTupleTransformer, MMDTupleTransformerOutput
 from .transformer import TupleTransformerConfig, TupleTransformerOutput, TupleTransformer
 from .wrappers import LMWrapper, ScorePerformerLMModes, ScorePerformerLMWrappers, finalize_lm_losses, mark_inputs_ready
+from ...utils.amp import no_autocast
 
 
 def _get(inputs, *path):
@@ -72,6 +73,7 @@ class Performer(_LMModeMixin, Model):
             transformer, lm_head=transformer.get("lm_head", TupleTokenLMHeadConfig(dim=transformer.dim)))
         self._init_mode(mode)
 
+    @no_autocast
     def forward(self, perf: Tensor, mask: Optional[Tensor] = None, labels: Optional[Tensor] = None,
                 masked_perf: Optional[Tensor] = None):
         with shared_tables():
@@ -151,6 +153,7 @@ class ScorePerformer(_LMModeMixin, Model):
         self.sync_free = False  # True: keep every loss key, never read flags back to the host inside forward
         self._init_mode(mode)
 
+    @no_autocast
     def forward_encoders(self, perf=None, perf_mask=None, score=None, score_mask=None, bars=None, beats=None, onsets=None,
                          deadpan_mask=None, compute_loss: bool = True, segment_bounds=None):
         score_emb = perf_emb = None
@@ -167,6 +170,7 @@ class ScorePerformer(_LMModeMixin, Model):
         return ScorePerformerEncoderOutputs(score_embeddings=score_emb, score_mask=score_mask, perf_embeddings=perf_emb,
                                             score_encoder=score_enc_out, perf_encoder=perf_enc_out)
 
+    @no_autocast
     def forward(self, perf: Tensor, perf_mask=None, score=None, score_mask=None, noisy_perf=None, noisy_perf_mask=None,
                 masked_perf=None, labels=None, bars=None, beats=None, onsets=None, directions=None, deadpan_mask=None,
                 segment_bounds=None):

@@ -18,6 +18,7 @@ from .embeddings import (
     TupleTokenEmbeddingsConfig, TupleTokenEmbeddingsRegistry, TupleTokenHeadsConfig, TupleTokenHeadsRegistry,
     TupleTokenRegressionHeadConfig, TupleTokenRegressionHead
 )
+from ...utils.amp import no_autocast
 
 
 class EmbeddingModes(ExplicitEnum):
@@ -100,6 +101,7 @@ class TupleTransformer(nn.Module, Constructor):
             assert self.token_emb.continuous, "TupleTokenRegressionHead depends on `continuous` token embeddings."
             self.regression_head = TupleTokenRegressionHead.init(config=regression_head, dim=dim)
 
+    @no_autocast
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, x_extra=None, style_embeddings: Optional[Tensor] = None,
                 context: Optional[Tensor] = None, context_mask: Optional[Tensor] = None,
                 caches: Optional[TupleTransformerCaches] = None, logits_keys: Optional[List] = None,

@@ -12,6 +12,7 @@ from ...modules.sampling import top_k, filter_logits_and_sample, is_greedy
 from ...utils import ExplicitEnum, exists
 from .embeddings import shared_tables
 from .transformer import TupleTransformer, TupleTransformerOutput, TupleTransformerCaches
+from ...utils.amp import no_autocast
 
 
 class LMWrapper(nn.Module):
@@ -20,6 +21,7 @@ class LMWrapper(nn.Module):
         self.model = model
         self.max_seq_len = self.model.max_seq_len
 
+    @no_autocast
     def forward(self, seq, labels=None, **kwargs):
         ...
 
@@ -84,6 +86,7 @@ class ScorePerformerLMWrapper(LMWrapper):
         super().__init__(model=model)
         self.ignore_index = ignore_index
 
+    @no_autocast
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, _defer_sync: bool = False, **kwargs):
         if exists(labels) and labels.is_cuda and labels.ndim == 3:
             kwargs["label_counts"] = _count_labels_async(labels, self.ignore_index)
@@ -192,6 +195,7 @@ class ScorePerformerMLMWrapper(ScorePerformerLMWrapper):
         self.num_special_tokens = num_special_tokens
 
     @torch.inference_mode()
+    @no_autocast
     def unmask_tokens(self, tokens: Tensor, single_run: bool = True, temperature: float = 1., filter_logits_fn: Callable = top_k,
                       filter_kwargs: Optional[Dict[str, object]] = None, filter_key_ids: Optional[Dict[str, list]] = None,
                       disable_tqdm: bool = False, **kwargs):
@@ -238,6 +242,7 @@ class ScorePerformerARWrapper(ScorePerformerLMWrapper):
         return None, logits_k
 
     @torch.inference_mode()
+    @no_autocast
     def generate(self, start_tokens: Tensor, seq_len: int, max_bar: Optional[int] = None, temperature: float = 1.,
                  filter_logits_fn: Callable = top_k, filter_kwargs: Optional[Dict[str, object]] = None,
                  caches: Optional[TupleTransformerCaches] = None, return_caches: bool = False, tokenizer=None,
@@ -274,6 +279,7 @@ class ScorePerformerARWrapper(ScorePerformerLMWrapper):
             continuation = call.result(notes[:, prompt_len:])
         return (continuation, caches) if return_caches else continuation
 
+    @no_autocast
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, **kwargs):
         inputs, targets = _teacher_forcing_views(self.model, seq, labels, kwargs)
         return super().forward(inputs, labels=targets, **kwargs)
@@ -341,6 +347,7 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
                                       transformer=TransformerIntermediates(hiddens=hid, attention=att))
 
     @torch.inference_mode()
+    @no_autocast
     def unmask_tokens(self, tokens: Tensor, tokens_masked, temperature: float = 1., filter_logits_fn: Callable = top_k,
                       filter_kwargs: Optional[Dict[str, object]] = None, filter_key_ids: Optional[Dict[str, list]] = None,
                       caches: Optional[TupleTransformerCaches] = None, return_caches: bool = False, disable_tqdm: bool = False,
@@ -393,6 +400,7 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
             filled = call.result(filled)
         return (filled, caches) if return_caches else filled
 
+    @no_autocast
     def forward(self, seq: Tensor, labels: Optional[Tensor] = None, **kwargs):
         masked_view = kwargs.pop("seq_masked", None)
         inputs, targets = _teacher_forcing_views(self.model, seq, labels, kwargs)

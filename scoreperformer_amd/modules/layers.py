@@ -6,6 +6,7 @@ import torch
 from torch import nn, Tensor
 
 from .. import functional as F_
+from ..utils.amp import no_autocast
 
 
 class Residual(nn.Module):
@@ -14,6 +15,7 @@ class Residual(nn.Module):
         self.residual_scale = nn.Parameter(torch.ones(dim)) if scale_residual else None
         self.scale_residual_constant = scale_residual_constant
 
+    @no_autocast
     def forward(self, x, residual):
         # the transformer stack fuses the plain residual add into the producing GEMM's epilogue; this eager path only
         # serves stand-alone use and the (unused in shipped recipes) scaled variants
@@ -31,6 +33,7 @@ class Residual(nn.Module):
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters (same state_dict keys), HIP forward/backward; returns bf16 unless `out_fp32`."""
 
+    @no_autocast
     def forward(self, x: Tensor, out_fp32: bool = False, fork: bool = False):
         """`fork=True` returns (norm(x), x): the pair a pre-norm residual block consumes, with one fused backward."""
         return F_.layer_norm(x, self.weight, self.bias, out_fp32=out_fp32, eps=self.eps, fork=fork)
@@ -46,6 +49,7 @@ class AdaptiveLayerNorm(nn.Module):
         with torch.no_grad():
             self.linear.bias.copy_(torch.cat([torch.ones(dim), torch.zeros(dim)]))
 
+    @no_autocast
     def forward(self, x: Tensor, condition: Optional[Tensor] = None, out_fp32: bool = False, fork: bool = False):
         if condition is None:  # gamma = 1, beta = 0
             return F_.layer_norm(x, None, None, out_fp32=out_fp32, eps=self.eps, fork=fork)

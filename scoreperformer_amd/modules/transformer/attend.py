@@ -6,6 +6,7 @@ import torch
 from torch import nn, Tensor
 
 from ... import functional as F_
+from ...utils.amp import no_autocast
 
 
 @dataclass
@@ -34,6 +35,7 @@ class Attend(nn.Module):
         self.attn_dropout = nn.Dropout(dropout)
         self.efficient = True
 
+    @no_autocast
     def forward(self, q, k, v, mask=None, attn_bias=None, prev_attn=None, slopes: Optional[Tensor] = None):
         assert prev_attn is None, 'residual attention not compatible with efficient attention'
         if attn_bias is not None:

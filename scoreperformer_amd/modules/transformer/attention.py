@@ -28,6 +28,7 @@ from ...utils import default
 from ..constructor import Constructor, ModuleConfig
 from .attend import AttentionIntermediates, Attend
 from .embeddings import ALiBiPositionalBias, LearnedALiBiPositionalBias
+from ...utils.amp import no_autocast
 
 
 @dataclass
@@ -113,6 +114,13 @@ class Attention(nn.Module, Constructor):
             return w
         return nn.functional.pad(w.view(w.shape[0], self.heads, self.dim_head), (0, 64 - self.dim_head)).reshape(w.shape[0], self.heads * 64)
 
+    def _cache_rows(self, t: Tensor) -> Tensor:
+        """Cached keys / values as this module hands them out ([b, n, dim_head] multi-query, [b, h, n, dim_head] otherwise) -> the kernels'
+        row layout [b, n, kv_heads * 64]: narrow heads get their zero columns back (the intermediates are sliced to dim_head)."""
+        if self.dim_head != 64:
+            t = nn.functional.pad(t, (0, 64 - self.dim_head))
+        return t if t.ndim == 3 else t.permute(0, 2, 1, 3).flatten(-2)
+
     def _memory_rows(self, b: int) -> Tensor:
         """[b, m, 2 * heads * 64] bf16: the learned memories in the fused (k | v) row layout of the sequence's own projections."""
         def rows(t):   # [h, m, d] -> [m, h * 64]
@@ -121,6 +129,7 @@ class Attention(nn.Module, Constructor):
         mem = F_.cast(torch.cat([rows(self.mem_k), rows(self.mem_v)], dim=-1), torch.bfloat16)
         return mem[None].expand(b, -1, -1)
 
+    @no_autocast
     def forward(self, x: Tensor, context: Optional[Tensor] = None, mask: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None, prev_attn: Optional[Tensor] = None,
                 mem: Optional[Tensor] = None, cache: Optional[AttentionIntermediates] = None,
@@ -149,8 +158,7 @@ class Attention(nn.Module, Constructor):
             if has_memkv:  # attention.py:146-150: memories in front of the sequence's own keys / values (and behind an older cache)
                 kv = torch.cat([self._memory_rows(b), kv], dim=1)
             if has_cache:  # attention.py:155-156 (K/V of earlier positions; layout b n (kvh d))
-                ck = cache.keys if cache.keys.ndim == 3 else cache.keys.permute(0, 2, 1, 3).flatten(-2)
-                cv = cache.values if cache.values.ndim == 3 else cache.values.permute(0, 2, 1, 3).flatten(-2)
+                ck, cv = self._cache_rows(cache.keys), self._cache_rows(cache.values)
                 kv = torch.cat([torch.cat([ck, kv[..., :kvh * 64]], dim=1), torch.cat([cv, kv[..., kvh * 64:]], dim=1)], dim=-1)
             o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop)
             k_view, v_view = kv[..., :kvh * 64], kv[..., kvh * 64:]

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from ... import functional as F_
+from ...utils.amp import no_autocast
 
 
 class DiscreteContinuousEmbedding(nn.Module):
@@ -112,6 +113,7 @@ class DiscreteContinuousEmbedding(nn.Module):
         from ...models.scoreperformer.embeddings import build_tables
         return build_tables([self])[0]
 
+    @no_autocast
     def forward(self, tokens: Optional[Tensor] = None, values: Optional[Tensor] = None) -> Tensor:
         if values is not None:
             raise NotImplementedError("explicit `values` are not used on the ScorePerformer hot path")
@@ -158,6 +160,7 @@ class AbsolutePositionalEmbedding(nn.Module):
         self.dim, self.scale, self.max_seq_len = dim, dim ** -0.5, max_seq_len
         self.emb = nn.Embedding(max_seq_len, dim)
 
+    @no_autocast
     def forward(self, x: Tensor, pos: Optional[Tensor] = None):
         seq_len = x.shape[1]
         assert seq_len <= self.max_seq_len
@@ -178,6 +181,7 @@ class FixedPositionalEmbedding(nn.Module):
         exponents = torch.arange(0, dim, 2, dtype=torch.float32) / dim
         self.register_buffer('inv_freq', torch.reciprocal(torch.pow(10000.0, exponents)))
 
+    @no_autocast
     def forward(self, x: Tensor, pos: Optional[Tensor] = None, seq_dim: int = 1, offset: int = 0):
         positions = torch.arange(x.shape[seq_dim], device=x.device) if pos is None else pos
         angles = torch.outer(positions.to(self.inv_freq.dtype).reshape(-1) + offset, self.inv_freq)
@@ -228,6 +232,7 @@ class ALiBiPositionalBias(nn.Module):
             s = F.pad(s, (0, self.total_heads - s.shape[0]))
         return s
 
+    @no_autocast
     def forward(self, i: int, j: int, k: int = 0, bias: Optional[Tensor] = None):
         if bias is not None and bias.shape[-2] >= i and bias.shape[-1] >= j - k:
             bias = bias[..., :i, :j]

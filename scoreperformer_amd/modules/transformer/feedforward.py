@@ -5,6 +5,7 @@ import torch.nn as nn
 
 from ... import functional as F_
 from ..constructor import Constructor, ModuleConfig
+from ...utils.amp import no_autocast
 
 
 class GLU(nn.Module):
@@ -13,6 +14,7 @@ class GLU(nn.Module):
         self.act = activation
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
+    @no_autocast
     def forward(self, x, p_drop: float = 0.0):
         return F_.linear_glu(x, self.proj.weight, self.proj.bias, act=F_.ACT_SILU if isinstance(self.act, nn.SiLU) else F_.ACT_GELU,
                             p_drop=p_drop)
@@ -41,6 +43,7 @@ class FeedForward(nn.Module, Constructor):
                                 nn.Linear(inner_dim, dim, bias=not no_bias))
         self.glu, self.act_code, self.dropout = glu, (F_.ACT_SILU if swish else F_.ACT_GELU), dropout
 
+    @no_autocast
     def forward(self, x, residual=None):
         p = self.dropout if self.training else 0.0
         has_ln = isinstance(self.ff[1], nn.LayerNorm)

@@ -17,6 +17,7 @@ from ..layers import Residual, AdaptiveLayerNorm, LayerNorm
 from .attend import AttentionIntermediates
 from .attention import Attention, AttentionConfig
 from .feedforward import FeedForward, FeedForwardConfig
+from ...utils.amp import no_autocast
 
 
 @dataclass
@@ -83,6 +84,7 @@ class Transformer(nn.Module, Constructor):
             return norm(x, condition=style, out_fp32=out_fp32, fork=fork)
         return norm(x, out_fp32=out_fp32, fork=fork)
 
+    @no_autocast
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attn_mask: Optional[Tensor] = None,
                 style_embeddings: Optional[Tensor] = None, mems: Optional[List[Tensor]] = None,

@@ -407,21 +407,24 @@ def act_bwd_can_fuse_colsum(width: int, glu: bool) -> bool:
 
 
 def dropout(x: torch.Tensor, p_drop: float, seed: int) -> torch.Tensor:
-    """Stand-alone dropout of [.., D] (fp32 or bf16, unit inner stride; D and the row stride multiples of 8 run in place of the rows, other
-    widths through a padded flat copy): kept entries scaled by 1 / (1 - p), mask a
+    """Stand-alone dropout of [.., D] (fp32 or bf16, unit inner stride; D a multiple of 8 runs row-wise -- a row stride off the 8-element grid is
+    packed first --, other widths through a padded flat copy): kept entries scaled by 1 / (1 - p), mask a
     function of (seed, row, column) -- calling it again on the gradient with the same seed is the backward."""
     require_gpu(x)
     x2 = _rows2d(x)
     if x2.dtype not in (F32, BF16):
         raise SpnError("dropout: fp32 / bf16 input")
-    if x2.shape[1] % 8 or x2.stride(0) % 8:
+    if x2.shape[1] % 8:
         # a width off the kernel's 8-element grid (the reference's nn.Dropout takes any): the same kernel over the tensor laid out as
         # zero-padded rows of 256 -- the mask is then a function of (seed, flat index), which the backward reproduces on a gradient of the
-        # same shape.  One pad copy and one slice; no shipped recipe comes here.
+        # same shape.  One pad copy and one slice; no shipped recipe comes here.  The choice depends on the WIDTH only, so the forward (on
+        # x) and the backward (on dy, whatever its strides) always agree on the mask's definition (ADVICE r5).
         n = x.numel()
         flat = torch.zeros(((n + 255) // 256) * 256, device=x.device, dtype=x.dtype)
         flat[:n] = x.reshape(-1)
         return dropout(flat.view(-1, 256), p_drop, seed).view(-1)[:n].view(x.shape)
+    if x2.stride(0) % 8 or x2.data_ptr() % 16:      # a narrowed view whose rows start off the grid: same (seed, row, column) mask over a packed copy
+        x2 = x2.contiguous()
     y = torch.empty(x2.shape, device=x.device, dtype=x2.dtype)
     call("spn_dropout", ptr(x2), c_long(x2.stride(0)), ptr(y), c_long(y.stride(0)), c_int(0 if x2.dtype == F32 else 1), c_long(x2.shape[0]),
          c_int(x2.shape[1]), c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), stream_ptr())

@@ -79,3 +79,116 @@ def test_attention_with_8_wide_heads_matches_the_reference(dev, c, m, l):
     with torch.no_grad():
         out = att(torch.from_numpy(U8["attn/x"]).to(dev), mask=torch.from_numpy(U8["attn/mask"]).to(dev))[0]
     assert rel(out, U8[f"attn/c{c}_m{m}_l{l}"]) <= 0.02
+
+
+@pytest.mark.parametrize("dh", [32, 8])
+@pytest.mark.parametrize("mqa", [0, 1])
+def test_cached_step_with_narrow_heads_matches_the_oracle_and_the_full_forward(dev, dh, mqa):
+    """The cache protocol of the module path with heads narrower than 64: the keys / values a call returns ([..., dim_head],
+    the reference's layout) go back in as `cache` for the next position (attention.py:155-156).  The one-row step must reproduce (a) the
+    last row of the cache-free causal forward over the whole prefix and (b) the fp32 oracle's cached step."""
+    from oracle import ref_cpu
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.modules.transformer import Attention
+    att = Attention(dim=DIM, dim_head=dh, heads=HEADS, causal=True, one_kv_head=bool(mqa), alibi_pos_bias=True, alibi_learned=True).eval()
+    sd = filled_state_dict(att, seed=21)
+    att.load_state_dict(sd)
+    att.to(dev)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 33, DIM, generator=g)
+    with torch.no_grad():
+        xg = x.to(dev)
+        full = att(xg)[0].float().cpu()
+        _, inter, _ = att(xg[:, :-1])
+        assert inter.keys.shape[-1] == dh
+        step, inter2, _ = att(xg[:, -1:], cache=inter)
+        assert inter2.keys.shape[-2] == 33 and inter2.keys.shape[-1] == dh
+        # oracle: prefix pass for its cache, then the cached step
+        _, (ck, cv) = ref_cpu.attention(sd, "", x[:, :-1], heads=HEADS, causal=True, return_kv=True)
+        want, _ = ref_cpu.attention(sd, "", x[:, -1:], heads=HEADS, causal=True, cache_k=ck, cache_v=cv, return_kv=True)
+    scale = float(want.abs().max())
+    assert float((step.float().cpu() - want).abs().max()) <= 0.02 * scale
+    assert float((step.float().cpu() - full[:, -1:]).abs().max()) <= 0.01 * scale
+    # a second step on the grown cache keeps working (the returned intermediates are valid caches themselves)
+    with torch.no_grad():
+        step2 = att(torch.randn(2, 1, DIM, generator=g).to(dev), cache=inter2)[0]
+    assert torch.isfinite(step2).all()
+
+
+def test_cached_step_with_memory_key_values_runs_like_the_reference(dev):
+    """num_mem_kv under the cache protocol, no padding mask (with one the reference's own mask length no longer matches its keys,
+    attention.py:151-156): the memories are concatenated again in front of the new position's keys, behind the cache -- the
+    reference's literal order; the step's key count is cache + m + 1."""
+    from oracle.weights import filled_state_dict
+    from scoreperformer_amd.modules.transformer import Attention
+    att = Attention(dim=DIM, dim_head=32, heads=HEADS, causal=True, num_mem_kv=MEM, alibi_pos_bias=True).eval()
+    att.load_state_dict(filled_state_dict(att, seed=22))
+    att.to(dev)
+    x = torch.randn(1, 12, DIM, generator=torch.Generator().manual_seed(6)).to(dev)
+    with torch.no_grad():
+        _, inter, _ = att(x[:, :-1])
+        assert tuple(inter.keys.shape) == (1, HEADS, MEM + 11, 32)
+        step, inter2, _ = att(x[:, -1:], cache=inter)
+    assert tuple(inter2.keys.shape) == (1, HEADS, MEM + 11 + MEM + 1, 32)
+    assert tuple(step.shape) == (1, 1, DIM) and torch.isfinite(step).all()
+
+
+@pytest.mark.parametrize("variant", ["narrow", "memkv"])
+def test_unmask_tokens_falls_back_to_the_module_path_for_heads_the_engine_does_not_serve(dev, variant):
+    """the decode engine is laid out for 64-wide heads without learned memories; a decoder configured otherwise must not be
+    served by it (silently wrong tokens) -- `GreedyDecoder` refuses, `unmask_tokens` takes the module path, and its greedy tokens are
+    the teacher-forced arg-max of the fp32 oracle at every decoded position (near-ties below bf16 resolution excepted, <= 3 %)."""
+    from oracle import ref_cpu
+    from scoreperformer_amd.arena import ParamArena
+    from scoreperformer_amd.decode import GreedyDecoder
+    from scoreperformer_amd.models import ScorePerformer
+    from scoreperformer_amd.modules.sampling import top_k
+    from scoreperformer_amd.synthetic import PREDICTED_DIMS, model_config, synthetic_batch
+    vocab = {"Bar": 40, "Position": 36, "Pitch": 28, "Velocity": 36, "Duration": 37, "Tempo": 29, "TimeSig": 10,
+             "PositionShift": 21, "NotesInOnset": 16, "PositionInOnset": 16, "RelOnsetDev": 45, "RelPerfDuration": 25}
+
+    def make():
+        cfg = model_config("tiny", num_tokens=vocab, one_kv_head=(variant == "narrow"))
+        if variant == "narrow":
+            cfg["perf_decoder"]["transformer"]["attention"]["dim_head"] = 32
+        else:
+            cfg["perf_decoder"]["transformer"]["attention"]["num_mem_kv"] = 3
+        return cfg
+    torch.manual_seed(4)
+    cfg = make()
+    model = ScorePerformer.init(make())
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ParamArena(model, dev)
+    model.eval()
+    with pytest.raises(NotImplementedError):
+        GreedyDecoder(model.perf_decoder.model, 64)
+    if variant == "memkv":
+        # cached decoding with learned memories is not defined by the reference: its loop always passes a mask (wrappers.py:350-353) and
+        # the padded mask no longer matches the keys once a cache holds the memories too (attention.py:151-156) -- refusing is the contract
+        return
+    L = 24
+    batch = synthetic_batch(1, L, seed=3, num_tokens=vocab)
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():
+        enc = model.forward_encoders(perf=gb["perf"], perf_mask=gb["perf_mask"], score=gb["score"], score_mask=gb["score_mask"],
+                                     bars=gb["bars"], beats=gb["beats"], onsets=gb["onsets"], deadpan_mask=gb["deadpan_mask"],
+                                     compute_loss=False)
+        tokens = gb["masked_perf"].clone()
+        tokens[:, 0] = gb["perf"][:, 0]
+        out = model.perf_decoder.unmask_tokens(tokens, gb["masked_perf"], context=enc.score_embeddings, style_embeddings=enc.perf_embeddings,
+                                               filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+    got = out.cpu()
+    assert int((got == 1).sum()) == 0
+    with torch.no_grad():
+        _, logits = ref_cpu.tuple_transformer(sd, "perf_decoder.model.", cfg["perf_decoder"], [got[:, :-1], batch["masked_perf"][:, 1:]],
+                                              causal=True, mask=torch.ones(1, L - 1, dtype=torch.bool),
+                                              context=enc.score_embeddings.float().cpu()[:, 1:], style=enc.perf_embeddings.float().cpu()[:, 1:],
+                                              with_logits=True)
+    keys = list(logits.keys())
+    total = wrong = 0
+    for d in PREDICTED_DIMS:
+        lg = logits[keys[d]][0].clone()
+        lg[:, :2] = -float("inf")
+        total += L - 1
+        wrong += int((lg.argmax(-1) != got[0, 1:, d]).sum())
+    assert wrong <= max(1, int(0.03 * total)), (wrong, total)

@@ -9,7 +9,13 @@
 
 against the fp32 CPU oracle running the same accumulation window (two backward passes into one gradient, torch-equivalent clip +
 AdamW), and against the fast binding (ParamArena + FusedAdamW) driven through the same window, which pins gradient ACCUMULATION across
-two backward calls on the arena path as well.  Dropout 0, the N(0, I) samples of the MMD term injected on both sides."""
+two backward calls on the arena path as well.  Dropout 0, the N(0, I) samples of the MMD term injected on both sides.
+
+Both loops also run in the reference's DEFAULT precision mode (`recipes/default.yaml:89` `mixed_precision: true`): the forward inside
+`torch.cuda.amp.autocast(enabled=True)` (`trainer.py:449`) and an enabled `GradScaler` (`optimizers.py:146`: loss x 65 536, `unscale_`,
+inf-skip).  On this path autocast decides nothing -- every public forward fences it off (`utils/amp.py`), bf16 operands regardless --
+so the bounds are those of the unscaled loop, plus: the scaler must not skip a step (its scale stays at 65 536: no inf / nan reached
+a gradient) and the unscaled gradients equal the ones of the plain loop to bf16 rounding of the scaled values."""
 import os
 
 import pytest
@@ -54,12 +60,16 @@ def _oracle_window(sdg, cfg, batches, zs, names, state, step):
     return losses, grads
 
 
-def _reference_window(model, opt, scaler, batches, zs, dev):
+def _reference_window(model, opt, scaler, batches, zs, dev, amp=False):
     """trainer.py:449-456 + optimizers.py:151-169, verbatim in shape: nothing here knows about the HIP path."""
+    from torch.cuda import amp as cuda_amp                       # trainer.py:19 / optimizers.py:7
     losses = []
     for batch, z in zip(batches, zs):
         model.perf_encoder._z_override = [t.to(dev) for t in z]
-        out = model(**batch)
+        with cuda_amp.autocast(enabled=amp):                     # trainer.py:449 (fp16 autocast, the CUDA default)
+            assert torch.is_autocast_enabled("cuda") == amp
+            out = model(**batch)
+        assert out.loss.dtype == torch.float32
         scaler.scale(out.loss / ACCUM).backward()
         losses.append(float(out.loss.detach()))
     scaler.unscale_(opt)
@@ -89,7 +99,8 @@ def _setup(preset, dev, seq, n_windows, seed, own_init=False):
     return cfg, model, sd0, batches, gb, zs
 
 
-def test_reference_trainer_loop_without_arena_matches_the_oracle_and_the_arena_binding(dev):
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32-loop", "mixed_precision"])
+def test_reference_trainer_loop_without_arena_matches_the_oracle_and_the_arena_binding(dev, amp):
     """Tiny model, three accumulation windows of two micro-batches.  (1) The zero-edit binding (model.to + torch.optim.AdamW +
     GradScaler(enabled=False)) follows the oracle: every micro-batch loss within 5e-3 relative (the bound of
     test_train_trajectory_matches_cpu_oracle), the ACCUMULATED gradient of the first window per tensor within 6 % + 2e-3 in norm.
@@ -107,15 +118,17 @@ def test_reference_trainer_loop_without_arena_matches_the_oracle_and_the_arena_b
     assert all(p.is_cuda and getattr(p, "_spn_main_grad", None) is None for p in model.parameters())     # no arena behind it
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=LR, betas=(0.9, 0.999), eps=1e-8, weight_decay=WD)
-    scaler = torch.cuda.amp.GradScaler(enabled=False)
+    scaler = torch.cuda.amp.GradScaler(enabled=amp)               # optimizers.py:146
     sdg = _oracle_leaves(sd0)
     state = {"m": [torch.zeros_like(sdg[n]) for n in names], "v": [torch.zeros_like(sdg[n]) for n in names]}
     named = dict(model.named_parameters())
     traj = []
     for w in range(n_windows):
         before = torch.cat([named[n].detach().float().reshape(-1) for n in names])
-        got, ggrads = _reference_window(model, opt, scaler, gb[w], zs[w], dev)
+        got, ggrads = _reference_window(model, opt, scaler, gb[w], zs[w], dev, amp)
         want, ograds = _oracle_window(sdg, cfg, batches[w], zs[w], names, state, w + 1)
+        if amp:
+            assert scaler.get_scale() == 65536.0, (w, scaler.get_scale())                                # no step was skipped
         for a, b in zip(got, want):
             assert abs(a - b) <= 5e-3 * abs(b), (w, got, want)
         if w == 0:
@@ -132,6 +145,7 @@ def test_reference_trainer_loop_without_arena_matches_the_oracle_and_the_arena_b
         traj.append(torch.cat([named[n].detach().float().reshape(-1) for n in names]) - before)
         assert all(p.grad is None for p in model.parameters())                                           # opt.zero_grad() (set_to_none)
     assert all(torch.isfinite(t).all() for t in traj)
+    assert all(float(t.abs().max()) > 0 for t in traj)                                                   # every window stepped
 
     # ---- (2) the fast binding through the same windows
     model2 = ScorePerformer.init(model_config("tiny", dropout=0.0))
@@ -195,7 +209,8 @@ def test_two_accumulating_backward_calls_equal_one_backward_of_the_mean_loss(dev
         assert rel <= 2e-3, (use_arena, rel)
 
 
-def test_reference_trainer_loop_at_c2_scale(dev):
+@pytest.mark.parametrize("amp", [False, True], ids=["fp32-loop", "mixed_precision"])
+def test_reference_trainer_loop_at_c2_scale(dev, amp):
     """The C2 model (d = 512, 6/6/6 layers, 71.9 M parameters at its own initialisation), one accumulation window of two micro-batches of
     1 x 1024 notes through the zero-edit binding: each micro-batch loss within 1e-3 of the oracle (north_star), the accumulated gradient
     as one vector within 5 % relative L2 and 1 % in norm (the bounds of test_c3_step_matches_oracle), and the AdamW update moves the
@@ -207,10 +222,12 @@ def test_reference_trainer_loop_at_c2_scale(dev):
     model.to(dev)
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=LR, weight_decay=WD)
-    scaler = torch.cuda.amp.GradScaler(enabled=False)
+    scaler = torch.cuda.amp.GradScaler(enabled=amp)
     named = dict(model.named_parameters())
     before = [named[n].detach().float().cpu().clone() for n in names]
-    got, ggrads = _reference_window(model, opt, scaler, gb[0], zs[0], dev)
+    got, ggrads = _reference_window(model, opt, scaler, gb[0], zs[0], dev, amp)
+    if amp:
+        assert scaler.get_scale() == 65536.0
     sdg = _oracle_leaves(sd0)
     state = {"m": [torch.zeros_like(sdg[n]) for n in names], "v": [torch.zeros_like(sdg[n]) for n in names]}
     o_before = [sdg[n].detach().clone() for n in names]
@@ -247,3 +264,22 @@ def test_dropout_of_a_width_off_the_8_element_grid(dev):
     out.sum().backward()
     assert torch.equal(xr.grad != 0, out != 0)
     assert F_.dropout(xr, 0.25, training=False) is xr
+
+
+def test_dropout_mask_does_not_depend_on_the_strides_of_its_argument(dev):
+    """the forward (on x) and the backward (on dy) pick the mask's definition independently, so it may depend on the WIDTH only.
+    A narrowed view whose row stride is off the kernel's 8-element grid, the same values packed, and a column slice starting off the
+    16-byte grid all drop the same entries; through autograd, a strided x with a contiguous dy gets the forward's mask."""
+    from scoreperformer_amd import functional as F_, ops
+    base = torch.randn(64, 44, device=dev)
+    view = base[:, :40]                                   # width 40 (on the grid), row stride 44 (off it)
+    assert view.stride(0) % 8 and view.shape[1] % 8 == 0
+    a, b = ops.dropout(view, 0.3, seed=77), ops.dropout(view.contiguous(), 0.3, seed=77)
+    assert torch.equal(a, b)
+    off = torch.randn(64, 52, device=dev)[:, 4:44]        # stride 52, first column 4: rows start off the 16-byte grid
+    assert torch.equal(ops.dropout(off, 0.3, seed=78), ops.dropout(off.contiguous(), 0.3, seed=78))
+    xr = base.clone().requires_grad_(True)
+    torch.manual_seed(9)
+    y = F_.dropout(xr[:, :40], 0.3, training=True)        # forward on the strided view
+    y.backward(torch.ones(64, 40, device=dev))            # backward on a packed gradient
+    assert torch.equal(xr.grad[:, :40] != 0, y != 0) and float(xr.grad[:, 40:].abs().max()) == 0.0
