@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 9: round 6 added spn_latent_{select,unselect,scalars,drop,drop_bwd}; 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -189,6 +189,30 @@ int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, in
 /* scalar tail of compute_mmd (mmd_transformer.py:529-534) in one launch; n = max(sums[3], 1).  g == null: out[0] = the MMD value from
  * spn_mmd_fwd's sums; g != null (device scalar dL/dmmd): out[0..1] = the two coefficients spn_mmd_bwd takes */
 int spn_mmd_scalars(const float* sums /* [4] */, int Z, const float* g, float* out, spn_stream_t s);
+
+/* ---- latent stage behind the VAE head projections (csrc/latent.hip), one launch each instead of ~60 tensor ops per level.
+ * spn_latent_select: MMDLoss.forward's `latents[mask]` + `randperm(N)[:max_num_latents]` (mmd_transformer.py:511-517) without a host
+ * read -- a uniform random subset of at most K of the valid latents of one level, packed into y [K, D] with 0/1 row weights w [K]
+ * (rows past the number of valid latents: weight 0, zeros); slot [N]: the row of y a latent went to or -1; and the deadpan sums of the
+ * level (mmd:232-237,268-273) dead[3] = (sum of lat^2 over valid latents of flagged batch elements, their count, any-non-zero flag).
+ * lat [N, D] fp32, valid [N] bytes, dead_b [N / S] bytes or null.  N <= 262144, K <= 4096, N / S <= 1024. */
+int spn_latent_select(const float* lat, const uint8_t* valid, const uint8_t* dead_b, int N, int S, int D, int K, unsigned seed,
+                      float* y, float* w, int* slot, float* dead, spn_stream_t s);
+/* backward of the above: dlat[i] = (slot[i] >= 0 ? dy[slot[i]] : 0) + 2 g_dead / max(dead[1] D, 1) * lat[i] on valid latents of flagged
+ * batch elements.  dy [K, D] or null; g_dead: device scalar dL/d(deadpan loss) or null */
+int spn_latent_unselect(const float* dy, const int* slot, const float* lat, const uint8_t* valid, const uint8_t* dead_b, const float* dead,
+                        const float* g_dead, int N, int S, int D, float* dlat, spn_stream_t s);
+/* out[3] = (weight * MMD from spn_mmd_fwd's sums (mmd:529-534, loss_weight mmd:266), deadpan loss dead[0] / max(dead[1] D, 1), dead[2]) */
+int spn_latent_scalars(const float* sums /* [4] */, int Z, const float* dead /* [3] */, int D, float weight, float* out, spn_stream_t s);
+/* latent dropout of all levels in one pass over the style embeddings [b, n, W] (mmd_transformer.py:249-253,275-283,351-354,537-542): one
+ * draw per valid latent (probability p[l]; 0: the level draws nothing), scattered to the latent's notes through seg[l] (int64 [b, n]; null:
+ * S[l] == 1 one latent per sequence, else one per note), OR-ed into the following levels when `inclusive`, never on padded notes or
+ * deadpan sequences.  out = emb with dropped columns zeroed, drop [b, n, W] bytes = the reference's dropout_mask.  Host arrays of nl <= 8
+ * entries; col0[l] = first column of level l; given[l] (or given == null): explicit uint8 [b, S[l]] drop masks instead of draws. */
+int spn_latent_drop(int nl, const long* const* seg, const uint8_t* const* lmask, const int* S, const int* col0, const float* p,
+                    const uint8_t* const* given, int inclusive, const float* emb, const uint8_t* mask, const uint8_t* deadpan, int b, int n,
+                    int W, unsigned seed, float* out, uint8_t* drop, spn_stream_t s);
+int spn_latent_drop_bwd(const float* g, const uint8_t* drop, long total, float* dx, spn_stream_t s);
 
 /* ---- optimizer (experiments/optimizers.py:151-169: clip_grad_norm_ + torch.optim.AdamW) over the flat arena */
 int spn_sumsq(const float* g, long n, float* out /* ACCUMULATED */, spn_stream_t s);

@@ -43,6 +43,10 @@ def bf16_weight(w: torch.Tensor) -> torch.Tensor:
         return w
     shadow = getattr(w, "_spn_shadow", None)
     parts = getattr(w, "_spn_parts", None)   # fused arena view (e.g. q|k|v): stale when any constituent parameter changed
+    if shadow is None and parts is None and w.is_inference():
+        # a temporary made under torch.inference_mode (zero-padded narrow-head weights in `unmask_tokens`): it has no version counter
+        # to cache against and does not outlive the call
+        return ops.cast(w if w.ndim > 1 else w.view(1, -1), BF16).view(w.shape)
     ver = w._version if parts is None else tuple(p._version for p in parts)
     if shadow is not None and shadow.device == w.device:
         if getattr(w, "_spn_shadow_version", None) != ver:
@@ -1172,3 +1176,61 @@ class MMDFn(Function):
         y, w, z, sums = ctx.saved_tensors
         coef = ops.mmd_scalars(sums, z.shape[0], g)      # (g / n^2, -2 g / (Z n)): one launch
         return ops.mmd_bwd(z, y, w, coef), None, None
+
+
+class LatentLossFn(Function):
+    """One latent level behind its head projection (mmd_transformer.py:232-237,266-273,505-534): (weight * MMD of a uniform random
+    subset of at most `K` valid latents against `z`, the deadpan MSE-to-zero of the level, its any-non-zero flag) in three launches
+    (ops.latent_select, ops.mmd_fwd, ops.latent_scalars) and three more in the backward; no host read, no boolean gather."""
+
+    @staticmethod
+    def forward(ctx, lat, lmask, deadpan, z, K: int, seed: int, weight: float):
+        lat = lat.contiguous()
+        y, w, slot, dead = ops.latent_select(lat, lmask, deadpan, K, seed)
+        sums = ops.mmd_fwd(z, y, w)
+        out = ops.latent_scalars(sums, z.shape[0], dead, lat.shape[-1], weight)
+        ctx.save_for_backward(lat, lmask, deadpan, z, y, w, slot, dead, sums)
+        ctx.weight = weight
+        ctx.mark_non_differentiable(out[2])
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_mmd, g_dead, _g_flag):
+        lat, lmask, deadpan, z, y, w, slot, dead, sums = ctx.saved_tensors
+        dy = None
+        if g_mmd is not None:
+            coef = ops.mmd_scalars(sums, z.shape[0], g_mmd if ctx.weight == 1.0 else g_mmd * ctx.weight)
+            dy = ops.mmd_bwd(z, y, w, coef)
+        dlat = ops.latent_unselect(dy, slot, lat, lmask, deadpan, dead, g_dead if deadpan is not None else None)
+        return dlat, None, None, None, None, None, None
+
+
+def latent_losses(lat, lmask, deadpan, z, *, max_num_latents: int, weight: float = 1.0):
+    """(weight * MMD, deadpan loss, deadpan flag) of one level; `deadpan` None: the two deadpan entries are zeros.  Levels larger than
+    the select kernel's limits are refused (`ops.LATENT_SELECT_MAX_*`): the caller keeps the tensor-op path for those."""
+    b, S, _ = lat.shape
+    K = min(b * S, int(max_num_latents))
+    return LatentLossFn.apply(lat, lmask, deadpan, z, K, next_seed(), float(weight))
+
+
+def latent_levels_fit(shapes, max_num_latents: int) -> bool:
+    return all(b * S <= ops.LATENT_SELECT_MAX_N and b <= ops.LATENT_SELECT_MAX_B for b, S in shapes) and max_num_latents <= ops.LATENT_SELECT_MAX_K
+
+
+class LatentDropFn(Function):
+    """Latent dropout of all levels + the masked style embeddings in one launch (mmd_transformer.py:249-253,275-283,537-542)."""
+
+    @staticmethod
+    def forward(ctx, emb, mask, deadpan, levels, inclusive: bool):
+        out, drop = ops.latent_drop(emb, mask, deadpan, levels, inclusive, next_seed())
+        ctx.save_for_backward(drop)
+        ctx.mark_non_differentiable(drop)
+        return out, drop
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _g_drop):
+        (drop,) = ctx.saved_tensors
+        return ops.latent_drop_bwd(g, drop), None, None, None, None
+

@@ -303,9 +303,28 @@ class MMDTupleTransformer(TupleTransformer):
 
         loss, losses = None, {}
         flags = {}
+        dev_ok = hidden.is_cuda and len(modes) <= 8
         if compute_loss:
+            # one fused launch chain per level (functional.LatentLossFn: subset selection, MMD, deadpan sums) when the level fits the select
+            # kernel; else the tensor-op path below (host-free as well, ~60 small launches per level)
+            fused = dev_ok and F_.latent_levels_fit([t.shape[:2] for t in lat_list], self.criterion.max_num_latents)
+            zs = self._z_override
+            if fused and zs is None:      # the N(0, I) samples of all levels in ONE draw (mmd_transformer.py:519: randn per level)
+                Z = self.criterion.num_samples
+                flat = torch.randn(Z * sum(Ls), device=hidden.device, dtype=torch.float32)
+                zs, o = [], 0
+                for L in Ls:
+                    zs.append(flat[o:o + Z * L].view(Z, L)); o += Z * L
             for i, mode in enumerate(modes):
-                z = self._z_override[i] if self._z_override is not None else None
+                if fused:
+                    mmd, dead, dflag = F_.latent_losses(lat_list[i], lmasks[i], deadpan_mask if self.deadpan_zero_latent else None, zs[i],
+                                                        max_num_latents=self.criterion.max_num_latents, weight=self.loss_weight)
+                    losses[f'MMD/{mode}'] = mmd
+                    if self.deadpan_zero_latent:  # mmd_transformer.py:232-237,268-273
+                        losses[f'MMD/{mode}/deadpan'] = dead
+                        flags[f'MMD/{mode}/deadpan'] = dflag
+                    continue
+                z = zs[i] if zs is not None else None
                 losses[f'MMD/{mode}'] = self.loss_weight * self.criterion(lat_list[i], mask=lmasks[i], z=z)
                 if self.deadpan_zero_latent:  # mmd_transformer.py:232-237,268-273
                     w = (deadpan_mask[:, None] & lmasks[i]).float()
@@ -316,8 +335,21 @@ class MMDTupleTransformer(TupleTransformer):
 
         # latent dropout (training): whole latent vectors dropped per segment, inclusive across levels (mmd:249-253)
         drop_mask = None
-        if self.training:
-            full_embeddings = embeddings
+        full_embeddings = embeddings
+        if self.training and dev_ok:
+            # all levels in one launch (functional.LatentDropFn): one counter-based draw per valid latent, scattered to its notes
+            draws = self._drop_override is None
+            levels = []
+            for i, mode in enumerate(modes):
+                given = None if draws else self._drop_override[i]
+                p = float(drops[i]) if draws and mode != EmbeddingAggregateModes.MEAN else 0.0
+                levels.append((segs[i], lmasks[i], lmasks[i].shape[1], Ls[i], p, given))
+            if any(lv[4] > 0. or lv[5] is not None for lv in levels):
+                embeddings, drop_mask = F_.LatentDropFn.apply(embeddings, mask.contiguous(), deadpan_mask, levels,
+                                                              bool(self.inclusive_latent_dropout))
+            else:
+                drop_mask = torch.zeros(embeddings.shape, dtype=torch.bool, device=hidden.device)
+        elif self.training:
             level_masks, prior = [], None
             for i, mode in enumerate(modes):
                 dm = None
@@ -340,11 +372,10 @@ class MMDTupleTransformer(TupleTransformer):
             drop_mask = torch.cat(level_masks, dim=-1) & mask[..., None] & (~deadpan_mask[:, None, None])
             if self._drop_override is not None or any(d > 0. for d in drops):
                 embeddings = embeddings * (~drop_mask)
-        else:
-            full_embeddings = embeddings
 
         if compute_loss:
-            loss = sum(losses.values())
+            vals = list(losses.values())
+            loss = torch.stack(vals).sum() if len(vals) > 2 else sum(vals)     # (one concat + one reduction instead of a chain of adds)
             losses['MMD'] = loss
         out_latents = lat_list if not isinstance(self.aggregate_mode, str) else lat_list[0]
         res = MMDTupleTransformerOutput(

@@ -784,6 +784,92 @@ def mmd_bwd(z: torch.Tensor, y: torch.Tensor, w: torch.Tensor, coef: torch.Tenso
 
 
 # ---------------------------------------------------------------------------------------------------------
+# latent stage behind the VAE heads (csrc/latent.hip)
+# ---------------------------------------------------------------------------------------------------------
+
+LATENT_SELECT_MAX_N, LATENT_SELECT_MAX_K, LATENT_SELECT_MAX_B = 262144, 4096, 1024
+
+
+def latent_select(lat: torch.Tensor, valid: torch.Tensor, deadpan: Optional[torch.Tensor], K: int, seed: int):
+    """lat [b, S, D] fp32, valid [b, S] bool, deadpan [b] bool or None -> (y [K, D], w [K], slot [b * S] int32, dead [3]): a uniform
+    random subset of at most K valid latents packed into y with 0 / 1 row weights, and the level's deadpan sums (see include/spn.h)."""
+    require_gpu(lat)
+    b, S, D = lat.shape
+    lat = lat.contiguous()
+    dev = lat.device
+    y = torch.empty((K, D), device=dev, dtype=F32)
+    w = torch.empty(K, device=dev, dtype=F32)
+    slot = torch.empty(b * S, device=dev, dtype=torch.int32)
+    dead = torch.empty(3, device=dev, dtype=F32)
+    call("spn_latent_select", ptr(lat), ptr(_mask_u8(valid)), ptr(_mask_u8(deadpan)), c_int(b * S), c_int(S), c_int(D), c_int(K),
+         ctypes.c_uint(seed & 0xFFFFFFFF), ptr(y), ptr(w), ptr(slot), ptr(dead), stream_ptr())
+    return y, w, slot, dead
+
+
+def latent_unselect(dy: Optional[torch.Tensor], slot: torch.Tensor, lat: torch.Tensor, valid: torch.Tensor,
+                    deadpan: Optional[torch.Tensor], dead: torch.Tensor, g_dead: Optional[torch.Tensor]) -> torch.Tensor:
+    b, S, D = lat.shape
+    lat = lat.contiguous()
+    dlat = torch.empty_like(lat)
+    if g_dead is not None:
+        g_dead = g_dead.reshape(1).float().contiguous()
+    call("spn_latent_unselect", ptr(None if dy is None else dy.contiguous()), ptr(slot), ptr(lat), ptr(_mask_u8(valid)), ptr(_mask_u8(deadpan)),
+         ptr(dead), ptr(g_dead), c_int(b * S), c_int(S), c_int(D), ptr(dlat), stream_ptr())
+    return dlat
+
+
+def latent_scalars(sums: torch.Tensor, Z: int, dead: torch.Tensor, D: int, weight: float) -> torch.Tensor:
+    out = torch.empty(3, device=sums.device, dtype=F32)
+    call("spn_latent_scalars", ptr(sums), c_int(int(Z)), ptr(dead), c_int(int(D)), c_float(float(weight)), ptr(out), stream_ptr())
+    return out
+
+
+def latent_drop(emb: torch.Tensor, mask: torch.Tensor, deadpan: Optional[torch.Tensor], levels, inclusive: bool, seed: int):
+    """emb [b, n, W] fp32; levels: per level (seg int64 [b, n] | None, lmask bool [b, S], S, width, p, given bool [b, S] | None) ->
+    (emb with dropped columns zeroed, drop mask bool [b, n, W])."""
+    require_gpu(emb)
+    b, n, W = emb.shape
+    emb = emb.contiguous()
+    nl = len(levels)
+    keep = []                                     # the contiguous / byte views must outlive the launch call
+
+    def u8(t):
+        t = _mask_u8(t)
+        keep.append(t)
+        return t
+    segs = (ctypes.c_void_p * nl)(); lms = (ctypes.c_void_p * nl)(); givs = (ctypes.c_void_p * nl)()
+    Ss = (ctypes.c_int * nl)(); cols = (ctypes.c_int * nl)(); ps = (ctypes.c_float * nl)()
+    col = 0
+    for i, (seg, lmask, S, width, p, given) in enumerate(levels):
+        if seg is not None:
+            seg = seg.contiguous(); keep.append(seg)
+            if seg.dtype != torch.int64:
+                raise SpnError("latent_drop: int64 segment ids")
+        segs[i] = 0 if seg is None else seg.data_ptr()
+        lms[i] = 0 if lmask is None else u8(lmask).data_ptr()
+        givs[i] = 0 if given is None else u8(given).data_ptr()
+        Ss[i], cols[i], ps[i] = int(S), col, float(p)
+        col += int(width)
+    if col != W:
+        raise SpnError("latent_drop: the level widths must add up to the embedding width")
+    out = torch.empty_like(emb)
+    drop = torch.empty((b, n, W), device=emb.device, dtype=torch.bool)
+    call("spn_latent_drop", c_int(nl), segs, lms, Ss, cols, ps, givs, c_int(int(bool(inclusive))), ptr(emb), ptr(u8(mask)),
+         ptr(None if deadpan is None else u8(deadpan)), c_int(b), c_int(n), c_int(W), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(out),
+         ptr(drop.view(torch.uint8)), stream_ptr())
+    return out, drop
+
+
+def latent_drop_bwd(g: torch.Tensor, drop: torch.Tensor) -> torch.Tensor:
+    g = g.contiguous()
+    if g.dtype != F32:
+        g = g.float()
+    dx = torch.empty_like(g)
+    call("spn_latent_drop_bwd", ptr(g), ptr(drop.view(torch.uint8)), c_long(g.numel()), ptr(dx), stream_ptr())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------------------------------------
 

@@ -1,9 +1,11 @@
 """GPU: `torch.cuda.amp.autocast` around the public entry points changes NOTHING (recipes/default.yaml:89 -> trainer.py:449).
 
 The precision of this path is fixed by its kernels; every public forward fences autocast off (`scoreperformer_amd/utils/amp.py`).  These
-tests run the same call with and without an enabled fp16 autocast context and require bit-identical results: the train forward /
-backward of both bindings, the module-level operators a user may call on their own, the evaluator, and the cached greedy decode on
-both the engine and the module path."""
+tests run the same call with and without an enabled fp16 autocast context and require the same results: the train forward / backward
+of both bindings, the module-level operators a user may call on their own, the evaluator, and the cached greedy decode on both the
+engine and the module path.  "The same" is bit-identical wherever the kernels are run-to-run deterministic (logits, tokens, module
+outputs) and 3e-6 relative where sums go through float atomics (loss entries, gradients: two plain runs differ by 1-3e-7 there,
+`tools/scratch/det_probe.py`) -- three orders of magnitude below what a recast to fp16 of any intermediate would leave."""
 import os
 
 import numpy as np
@@ -37,8 +39,8 @@ def _tiny(dev, arena, dropout=0.0):
 
 @pytest.mark.parametrize("arena", [False, True], ids=["zero-edit", "arena"])
 def test_train_forward_backward_is_bit_identical_under_autocast(dev, arena):
-    """Loss, every entry of `losses`, the decoder's logits and every parameter gradient: equal bit for bit with autocast on and off, on
-    both bindings.  The backward runs outside the context, as optimizers.py:152 does."""
+    """Loss, every entry of `losses`, the decoder's logits and every parameter gradient: the same with autocast on and off, on both
+    bindings (logits bit for bit; sums through float atomics to 3e-6).  The backward runs outside the context, as optimizers.py:152 does."""
     from scoreperformer_amd.synthetic import model_config, synthetic_batch
     cfg = model_config("tiny", dropout=0.0)
     model = _tiny(dev, arena)
@@ -60,11 +62,14 @@ def test_train_forward_backward_is_bit_identical_under_autocast(dev, arena):
         runs.append((out.loss.detach().clone(), {k: v.detach().clone() for k, v in out.losses.items()},
                      {k: v.detach().clone() for k, v in out.perf_decoder.logits.items()}, grads))
     (l0, ls0, lg0, g0), (l1, ls1, lg1, g1) = runs
-    assert l0.dtype == l1.dtype == torch.float32 and torch.equal(l0, l1)
-    assert ls0.keys() == ls1.keys() and all(torch.equal(ls0[k], ls1[k]) for k in ls0)
-    assert all(lg0[k].dtype == lg1[k].dtype and torch.equal(lg0[k], lg1[k]) for k in lg0)
+    assert l0.dtype == l1.dtype == torch.float32 and abs(float(l0) - float(l1)) <= 3e-6 * abs(float(l0))
+    assert ls0.keys() == ls1.keys()
+    assert all(ls0[k].dtype == ls1[k].dtype and abs(float(ls0[k]) - float(ls1[k])) <= 3e-6 * max(1.0, abs(float(ls0[k]))) for k in ls0)
+    assert all(lg0[k].dtype == lg1[k].dtype and torch.equal(lg0[k], lg1[k]) for k in lg0)          # deterministic kernels: bit for bit
     assert g0.keys() == g1.keys() and len(g0) > 50
-    assert all(g0[k].dtype == g1[k].dtype == torch.float32 and torch.equal(g0[k], g1[k]) for k in g0)
+    assert all(g0[k].dtype == g1[k].dtype == torch.float32 for k in g0)
+    worst = max(float((g0[k] - g1[k]).norm() / g0[k].norm().clamp_min(1e-30)) for k in g0)
+    assert worst <= 3e-6, worst
     assert all(torch.isfinite(v).all() for v in g0.values())
 
 
@@ -167,4 +172,5 @@ def test_greedy_decode_and_evaluator_under_autocast(dev):
                 metrics.append(evaluator(batch, out))
         evaluator.detach()
         assert metrics[0].keys() == metrics[1].keys() and len(metrics[0]) > 0
-        assert all(torch.equal(metrics[0][k], metrics[1][k]) for k in metrics[0]), attach
+        assert all(metrics[0][k].dtype == metrics[1][k].dtype and abs(float(metrics[0][k]) - float(metrics[1][k])) <= 1e-5 * max(1.0, abs(float(metrics[0][k])))
+                   for k in metrics[0]), attach          # (the fused metric sums go through float atomics)

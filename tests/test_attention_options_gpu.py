@@ -154,9 +154,10 @@ def test_unmask_tokens_falls_back_to_the_module_path_for_heads_the_engine_does_n
         else:
             cfg["perf_decoder"]["transformer"]["attention"]["num_mem_kv"] = 3
         return cfg
-    torch.manual_seed(4)
+    from oracle.weights import filled_state_dict
     cfg = make()
     model = ScorePerformer.init(make())
+    model.load_state_dict(filled_state_dict(model, seed=3))      # the fixtures' fill: logit margins well above bf16 noise
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     ParamArena(model, dev)
     model.eval()
@@ -177,8 +178,16 @@ def test_unmask_tokens_falls_back_to_the_module_path_for_heads_the_engine_does_n
         tokens[:, 0] = gb["perf"][:, 0]
         out = model.perf_decoder.unmask_tokens(tokens, gb["masked_perf"], context=enc.score_embeddings, style_embeddings=enc.perf_embeddings,
                                                filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        # the product's own cache-free forward, teacher-forced on the decoded tokens: the cached steps must reproduce its arg-max exactly
+        tf = model.perf_decoder(out, seq_masked=gb["masked_perf"], mask=gb["perf_mask"], context=enc.score_embeddings,
+                                style_embeddings=enc.perf_embeddings)
     got = out.cpu()
     assert int((got == 1).sum()) == 0
+    tf_keys = list(tf.logits.keys())
+    for d in PREDICTED_DIMS:
+        lg = tf.logits[tf_keys[d]][0].float().cpu().clone()
+        lg[:, :2] = -float("inf")
+        assert int((lg.argmax(-1) != got[0, 1:, d]).sum()) <= 1, d      # (<= 1: a bf16 near-tie between the cached and the full pass)
     with torch.no_grad():
         _, logits = ref_cpu.tuple_transformer(sd, "perf_decoder.model.", cfg["perf_decoder"], [got[:, :-1], batch["masked_perf"][:, 1:]],
                                               causal=True, mask=torch.ones(1, L - 1, dtype=torch.bool),
