@@ -263,7 +263,7 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def phases_leg(model, batch, opt, holder, world, n=3):
+def phases_leg(model, batch, opt, holder, world, n=5):
     """"also report fwd-only and fwd+bwd".  The same step as the timed region, `n` more of them with events on
     the launch stream (torch's current stream: every kernel of the library is launched on it) after the forward, after the backward
     (+ gradient all-reduce wait) and after clip + AdamW; outside the timed region."""
@@ -280,9 +280,10 @@ def phases_leg(model, batch, opt, holder, world, n=3):
         opt.step(grad_scale=1.0 / world)
         e[3].record()
     torch.cuda.synchronize()
-    mean = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in ev) / n   # noqa: E731
+    import statistics
+    mean = lambda a, b: statistics.median(e[a].elapsed_time(e[b]) for e in ev)   # noqa: E731  (median: one of these few steps may catch a clock dip)
     return {"steps": n, "fwd_ms": mean(0, 1), "fwd_bwd_ms": mean(0, 2), "step_ms": mean(0, 3), "bwd_ms": mean(1, 2), "optimizer_ms": mean(2, 3),
-            "note": "device time between events on the launch stream inside ordinary train steps: forward (loss included), forward + backward "
+            "note": "median device time between events on the launch stream inside ordinary train steps: forward (loss included), forward + backward "
                     "(incl. the wait for the gradient all-reduce when N > 1), full step (+ global-norm clip + AdamW)"}
 
 

@@ -12,6 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "tests", "golden")   # module-level, like the other generators: a checker may point it elsewhere
 sys.path.insert(0, ROOT)
 from oracle.refimport import stubs  # noqa: E402
 
@@ -72,7 +73,7 @@ def main():
             ref.update(noisy=data.noisy_performances.tokens, noisy_mask=data.noisy_performances.mask, noisy_len=data.noisy_performances.lengths)
         for k, v in ref.items():
             out[f"{name}/out/{k}"] = v.numpy()
-    path = os.path.join(ROOT, "tests", "golden", "collate_mixlm.npz")
+    path = os.path.join(OUT, "collate_mixlm.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "tests", "golden")   # module-level, like the other generators: a checker may point it elsewhere
 sys.path.insert(0, ROOT)
 from oracle.refimport import stubs  # noqa: E402
 
@@ -73,7 +74,7 @@ def main():
         for k, v in metrics.items():
             out[f"{name}/metric/{k}"] = np.float64(float(v))
         print(name, {k: round(float(v), 4) for k, v in metrics.items()})
-    path = os.path.join(ROOT, "tests", "golden", "evaluator.npz")
+    path = os.path.join(OUT, "evaluator.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

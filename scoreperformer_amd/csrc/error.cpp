@@ -17,7 +17,7 @@ const Knob kKnobs[SPN_TUNE_COUNT] = {
     {"gemm_slice_xcd", 1.0},     {"gemm_split_blocks", 0.0},   {"gemm_persist", 2.0},         {"glu_persist", 2.0},
     {"embed_stats_blocks", 2048.0}, {"embed_scatter_mfma", 1.0}, {"embed_scatter_blocks", 256.0}, {"ln_bwd_blocks", 2048.0},
     {"gemm_duo", 1.0},           {"gemm_duo_ngroup", 8.0},      {"gemm_stagger", 0.0},        {"glu_bwd_duo", 2.0},
-    {"gemm_persist_bwd", 0.0},   {"gemm_ow", 0.0},             {"gemm_f32_mfma", 1.0},
+    {"gemm_persist_bwd", 0.0},   {"gemm_f32_mfma", 1.0},
 };
 std::atomic<double> g_val[SPN_TUNE_COUNT];
 std::atomic<bool> g_set[SPN_TUNE_COUNT];

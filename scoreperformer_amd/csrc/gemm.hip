@@ -1139,378 +1139,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g) {
 #endif
 }
 
-// ---- 256x256 "one wave per SIMD" kernel (round 5) ------------------------------------------------------------------------------
-// What bounds the ping-pong kernel on long contractions is measured: not bytes in flight -- halving the
-// DMA depth (PP_STEADY_VM 8 -> 4) moves nothing, the vmcnt waits are ~9 cycles per phase -- but the READ part of a phase: ~250-310
-// cycles of fragment reads + ~145 of DMA issue + waits against 256 cycles of MFMA issue in the partner group, i.e. the group that
-// multiplies waits at the barrier for the group that reads.  A 128x64 wave tile reads 24 fragments per 32 MFMAs.  Here a workgroup is
-// FOUR waves (one per SIMD, 512 registers each) and a wave owns 128x128 of the 256x256 tile: 256 accumulator registers, 16 fragment
-// reads per 32 MFMAs (a third fewer LDS bytes per flop), no partner wave, no phase barriers -- ONE barrier per K tile.
-//   * K tile 32; half-tiles of 128 rows x 32 k = 8 KiB (A rows 0-127 / 128-255, B columns 0-127 / 128-255); four K tiles in a
-//     16-slot ring (128 KiB): tile t + 4 is requested right behind the barrier that publishes tile t + 1 (it overwrites tile t, whose
-//     reads every wave has retired by then), so three tiles = 96 KiB are in flight or landed ahead of the one being multiplied
-//   * a K tile = two MFMA blocks of 16 (k steps 0 / 1).  Block 0 of tile t runs beside the fragment reads of its own k step 1, block 1
-//     beside the reads of tile t + 1's k step 0 and the 8 DMA instructions of tile t + 4; `s_waitcnt vmcnt(16)` + the barrier sit
-//     between them.  Fragments are double-buffered in registers (2 x 8 x 4 VGPRs), groups of {2 MFMA, 1 read} are pinned with
-//     sched_barrier so that the reads and the DMA issue hide in the MFMAs' shadow (<= 5 issue slots per 32-cycle MFMA)
-//   * K-contiguous half-tile image [128 rows][32 k]: 64-byte rows, 16-byte chunk index XOR (row >> 2) & 3 (the duo kernel's key: the 16
-//     rows of a ds_read_b128 lane group cover all 16 slots of a 256-byte bank row); R-contiguous image [32 k][128 r] as in the
-//     ping-pong kernel (pp_rc_off, hardware transpose reads); both linear in LDS with the swizzle on the DMA source address
-//   * tile order, split-K plan and epilogue (pp_store_tile, called for the wave's two 64-column halves) are the ping-pong kernel's
-// K must be whole 64-tiles and >= 256 like there (the split plans are shared); M / N edges by clamped loads + guarded stores.
-constexpr int OW_BK = 32, OW_STAGES = 4, OW_HALF = 128 * OW_BK * 2;
-constexpr int OW_LDS_BYTES = OW_STAGES * 4 * OW_HALF + 4 * 8192;   // ring + 8 KiB of epilogue staging per wave
-
-__device__ __forceinline__ int ow_kc_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-template <bool T>
-__device__ __forceinline__ bf16x8 ow_read_frag(const char* lds, int r_base, int ks, int lane) {
-    if (!T) return *reinterpret_cast<const bf16x8*>(lds + ow_kc_off(r_base + (lane & 31), ks * 2 + (lane >> 5)));
-    else return pp_read_frag<true>(lds, r_base, ks, lane);
-}
-
-// one half-tile = 8 pieces of 1 KiB, 2 per wave: LDS chunk L = (wave * 2 + i) * 64 + lane <- source chunk (inverse swizzle)
-template <bool T>
-__device__ __forceinline__ uint32_t ow_voffset(int ld, int row0, int R, int wave, int lane, int i) {
-    const int L = (wave * 2 + i) * 64 + lane;
-    if (!T) {
-        const int x = L >> 2, kc = (L & 3) ^ ((x >> 2) & 3);
-        return (uint32_t)(((long)min(row0 + x, R - 1) * ld + kc * 8) * 2);
-    } else {
-        const int krow = L >> 4, rc = (L & 15) ^ pp_rc_swz(krow);
-        return (uint32_t)(((long)krow * ld + min(row0 + rc * 8, R - 8)) * 2);
-    }
-}
-
-template <bool TA, bool TB, typename OutT>
-__global__ __launch_bounds__(256, 1) void gemm_ow_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int nwg = g.tx * g.ty;
-    int first = blockIdx.y * gridDim.x + blockIdx.x, zid = blockIdx.z;
-    if (g.slice_xcd) {
-        const int L = first + nwg * (int)blockIdx.z;
-        zid = (L & 7) + 8 * (L / (8 * nwg));
-        first = (L >> 3) % nwg;
-    }
-    int m0, n0;
-    {   // tile id -> tile: the ping-pong kernel's order (XCD-contiguous, column groups of `ngroup` n-tiles)
-        const int q = nwg >> 3, r = nwg & 7, xcd = first & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (first >> 3);
-        const int G = g.ngroup, mt = g.ty, per = G * mt;
-        const int c = wg / per, within = wg - c * per;
-        const int gw = min(G, g.tx - c * G);
-        m0 = (within / gw) * PP_BM;
-        n0 = (c * G + within % gw) * PP_BN;
-    }
-    const bool split = g.splitk > 1;
-    const bf16_t* A = g.A + (split ? 0 : (long)zid * g.sA);
-    const bf16_t* B = g.B + (split ? 0 : (long)zid * g.sB);
-    const int nt_all = g.K / OW_BK;
-    const int t_begin = split ? zid * g.kt_per_split : 0;
-    const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
-    if (nt <= 0 || first >= nwg) return;
-    const int kbase = t_begin * OW_BK;
-    const u32x4 rsA = spn_buffer_rsrc(A, 0x7fffffffu), rsB = spn_buffer_rsrc(B, 0x7fffffffu);
-    const uint32_t ring = spn_lds_addr(smem) + (uint32_t)wave * 2048u;   // this wave's 2 KiB of every half-tile slot
-    uint32_t vo[4][2];   // [kind: A lo, A hi, B lo, B hi][piece]
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        vo[0][i] = ow_voffset<TA>(g.lda, m0, g.M, wave, lane, i);
-        vo[1][i] = ow_voffset<TA>(g.lda, m0 + 128, g.M, wave, lane, i);
-        vo[2][i] = ow_voffset<TB>(g.ldb, n0, g.N, wave, lane, i);
-        vo[3][i] = ow_voffset<TB>(g.ldb, n0 + 128, g.N, wave, lane, i);
-    }
-    const uint32_t kstepA = TA ? (uint32_t)OW_BK * g.lda * 2u : (uint32_t)OW_BK * 2u;
-    const uint32_t kstepB = TB ? (uint32_t)OW_BK * g.ldb * 2u : (uint32_t)OW_BK * 2u;
-    const uint32_t kbaseA = TA ? (uint32_t)kbase * g.lda * 2u : (uint32_t)kbase * 2u;
-    const uint32_t kbaseB = TB ? (uint32_t)kbase * g.ldb * 2u : (uint32_t)kbase * 2u;
-    auto issue_kind = [&](int c, int t) __attribute__((always_inline)) {   // c is a compile-time constant at every call site
-        const bool isA = c < 2;
-        const uint32_t soff = isA ? kbaseA + (uint32_t)t * kstepA : kbaseB + (uint32_t)t * kstepB;
-        spn_dma16x2(isA ? rsA : rsB, ring + (uint32_t)(((t & 3) * 4 + c) * OW_HALF), vo[c][0], vo[c][1], soff);
-    };
-    // one 1 KiB piece (kind c, piece i) of tile t: the in-loop form, ONE DMA instruction per MFMA group
-    auto issue_piece = [&](int c, int i, int t) __attribute__((always_inline)) {
-        const bool isA = c < 2;
-        const uint32_t soff = isA ? kbaseA + (uint32_t)t * kstepA : kbaseB + (uint32_t)t * kstepB;
-        spn_dma16_lean(isA ? rsA : rsB, ring + (uint32_t)(((t & 3) * 4 + c) * OW_HALF + i * 1024), vo[c][i], soff);
-    };
-#define OW_VMWAIT(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(n_) : "memory")
-#define OW_PIN() __builtin_amdgcn_sched_barrier(0)
-    // prologue: K tiles 0 .. 3 (nt >= 8: K >= 256)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { issue_kind(0, t); issue_kind(2, t); issue_kind(1, t); issue_kind(3, t); }
-
-    f32x16 accL[4][2], accR[4][2];   // columns 0-63 / 64-127 of the wave's 128: [32-row block][32-column block]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
-
-    // stage s: A rows of this wave's half at (s * 4 + wr), B columns at (s * 4 + 2 + wc)
-#define OW_A(t_) (smem + (((t_) & 3) * 4 + wr) * OW_HALF)
-#define OW_B(t_) (smem + (((t_) & 3) * 4 + 2 + wc) * OW_HALF)
-    bf16x8 fa[2][4], fb[2][4];
-    OW_VMWAIT(24);             // tile 0 has landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[0][i] = ow_read_frag<TA>(OW_A(0), 32 * i, 0, lane); fb[0][i] = ow_read_frag<TB>(OW_B(0), 32 * i, 0, lane); }
-
-    // 16 MFMAs of k step buffer `cur` with the 8 fragment reads of the next k step spread between them: {2 MFMA, 1 read} x 8.
-    // DMA: the four issue_kind calls of tile t + 4 ride in groups 1, 3, 5, 7 of block 1.
-    auto mfma_pair = [&](int cur, int idx) __attribute__((always_inline)) {   // MFMAs 2 idx, 2 idx + 1 of the 16: (i, j) = (m >> 2, m & 3)
-#pragma unroll
-        for (int m = 2 * idx; m < 2 * idx + 2; ++m) {
-            const int i = m >> 2, j = m & 3;
-            if (j < 2) accL[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accL[i][j], 0, 0, 0);
-            else accR[i][j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accR[i][j - 2], 0, 0, 0);
-        }
-    };
-    // one K tile; MODE 0: steady state (>= 4 tiles behind this one: tile t + 4 is requested), 1 / 2 / 3: three / two / one tile behind
-    // (nothing left to request, the wait shrinks with the tiles still in flight), 4: the last tile
-    auto ktile = [&](auto mode_c, const int t) __attribute__((always_inline)) {
-        constexpr int MODE = decltype(mode_c)::value;
-        constexpr bool MORE = MODE != 4, REFILL = MODE == 0;
-        const char* a_t = OW_A(t);
-        const char* b_t = OW_B(t);
-        // ---- block 0: k step 0 of tile t; reads k step 1 of tile t ----
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            mfma_pair(0, x);
-            // both reads of a group in the first four groups: they have returned when the barrier's lgkmcnt(0) asks for them
-            if (x < 4) { fb[1][x] = ow_read_frag<TB>(b_t, 32 * x, 1, lane); fa[1][x] = ow_read_frag<TA>(a_t, 32 * x, 1, lane); }
-            OW_PIN();
-        }
-        // ---- tile t + 1 published, tile t's slots free ----
-        if (MORE) {
-            if (MODE <= 1) OW_VMWAIT(16); else if (MODE == 2) OW_VMWAIT(8); else OW_VMWAIT(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile t have returned: its slots may be overwritten
-            __builtin_amdgcn_s_barrier();
-        }
-        OW_PIN();
-        const char* a_n = OW_A(t + 1);
-        const char* b_n = OW_B(t + 1);
-        // ---- block 1: k step 1 of tile t; reads k step 0 of tile t + 1; requests tile t + 4 ----
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            mfma_pair(1, x);
-            if (MORE && x < 4) { fb[0][x] = ow_read_frag<TB>(b_n, 32 * x, 0, lane); fa[0][x] = ow_read_frag<TA>(a_n, 32 * x, 0, lane); }
-            if (REFILL) issue_piece(x >> 1, x & 1, t + 4);   // kinds A lo, A hi, B lo, B hi: one piece per group
-            OW_PIN();
-        }
-    };
-    {
-        int t = 0;
-        for (; t < nt - 4; ++t) ktile(std::integral_constant<int, 0>{}, t);
-        ktile(std::integral_constant<int, 1>{}, nt - 4);
-        ktile(std::integral_constant<int, 2>{}, nt - 3);
-        ktile(std::integral_constant<int, 3>{}, nt - 2);
-        ktile(std::integral_constant<int, 4>{}, nt - 1);
-    }
-#undef OW_A
-#undef OW_B
-
-    // ---- epilogue: the ping-pong kernel's, once per 64-column half of the wave's block ----
-    GemmKernargPtr gk = (GemmKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(gk));
-    const GemmArgs ge = kernarg_copy(gk);
-    OutT* C = reinterpret_cast<OutT*>(ge.C) + (long)zid * ge.sC;
-    const bool lead = !split || zid == 0;
-    char* stg = smem + OW_STAGES * 4 * OW_HALF + wave * 8192;
-    __syncthreads();   // every wave is done with the operand ring
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int wcx = 2 * wc + half;   // 64-column group of the 256
-        f32x4 bv[8];
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-            const int bn = min(n0 + wcx * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, ge.N - 4);
-            bv[jq] = (ge.bias && lead) ? *reinterpret_cast<const f32x4*>(ge.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        pp_store_tile<OutT, 0>(ge, half ? accR : accL, bv, C, lead, m0, n0, wr, wcx, lane, stg, smem + wave * 32768);
-    }
-#undef OW_VMWAIT
-#undef OW_PIN
-}
-
-// ---- the same kernel with REGISTER-staged operands (round 5, second attempt) -------------------------------------------------------
-// gemm_ow_kernel loses to the ping-pong kernel because a lone wave issues in order and one LDS-DMA instruction holds its issue port for
-// ~60 cycles -- twice the shadow of an MFMA.  The vendor library's fastest kernel on 8192^3 has this very shape (four waves, 128x128 wave
-// tiles) and stages through REGISTERS: buffer_load_dwordx4 into VGPRs and ds_write_b128 later are both short instructions.  Same here:
-// per K tile of 32 a wave issues 8 global loads (tile t + 3, into the register set tile t + 1 has just left), 8 LDS writes (tile
-// t + 1, loaded one and a half K tiles earlier), 16 fragment reads and 32 MFMAs, one of each kind per {2 MFMA} group.  Two LDS stages
-// suffice (tile t + 1 is written while tile t's second k step is read; 64 KiB), the barrier of a K tile sits between its two MFMA
-// blocks as before, and every wait is the compiler's own (plain loads and stores: hipcc counts vmcnt / lgkmcnt itself).
-// Same LDS images as gemm_ow_kernel (a lane writes the 16 bytes the DMA would have written for it), same tile order / split plan / epilogue.
-constexpr int OWR_LDS_BYTES = 2 * 4 * OW_HALF + 4 * 8192;
-
-template <bool TA, bool TB, typename OutT>
-__global__ __launch_bounds__(256, 1) void gemm_owr_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int nwg = g.tx * g.ty;
-    int first = blockIdx.y * gridDim.x + blockIdx.x, zid = blockIdx.z;
-    if (g.slice_xcd) {
-        const int L = first + nwg * (int)blockIdx.z;
-        zid = (L & 7) + 8 * (L / (8 * nwg));
-        first = (L >> 3) % nwg;
-    }
-    int m0, n0;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = first & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (first >> 3);
-        const int G = g.ngroup, mt = g.ty, per = G * mt;
-        const int c = wg / per, within = wg - c * per;
-        const int gw = min(G, g.tx - c * G);
-        m0 = (within / gw) * PP_BM;
-        n0 = (c * G + within % gw) * PP_BN;
-    }
-    const bool split = g.splitk > 1;
-    const bf16_t* A = g.A + (split ? 0 : (long)zid * g.sA);
-    const bf16_t* B = g.B + (split ? 0 : (long)zid * g.sB);
-    const int nt_all = g.K / OW_BK;
-    const int t_begin = split ? zid * g.kt_per_split : 0;
-    const int nt = split ? min(nt_all - t_begin, g.kt_per_split) : nt_all;
-    if (nt <= 0 || first >= nwg) return;
-    const int kbase = t_begin * OW_BK;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
-    uint32_t vo[4][2];   // [kind: A lo, A hi, B lo, B hi][piece]
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        vo[0][i] = ow_voffset<TA>(g.lda, m0, g.M, wave, lane, i);
-        vo[1][i] = ow_voffset<TA>(g.lda, m0 + 128, g.M, wave, lane, i);
-        vo[2][i] = ow_voffset<TB>(g.ldb, n0, g.N, wave, lane, i);
-        vo[3][i] = ow_voffset<TB>(g.ldb, n0 + 128, g.N, wave, lane, i);
-    }
-    const uint32_t kstepA = TA ? (uint32_t)OW_BK * g.lda * 2u : (uint32_t)OW_BK * 2u;
-    const uint32_t kstepB = TB ? (uint32_t)OW_BK * g.ldb * 2u : (uint32_t)OW_BK * 2u;
-    const uint32_t kbaseA = TA ? (uint32_t)kbase * g.lda * 2u : (uint32_t)kbase * 2u;
-    const uint32_t kbaseB = TB ? (uint32_t)kbase * g.ldb * 2u : (uint32_t)kbase * 2u;
-    u32x4 R[2][8];   // [tile parity][2 * kind + piece]: this lane's 16 bytes of each of its 8 pieces of a K tile
-    auto gload = [&](int par, int x, int t) __attribute__((always_inline)) {   // par, x compile-time
-        const int c = x >> 1, i = x & 1;
-        const bool isA = c < 2;
-        const uint32_t soff = isA ? kbaseA + (uint32_t)t * kstepA : kbaseB + (uint32_t)t * kstepB;
-        R[par][x] = __builtin_amdgcn_raw_buffer_load_b128(isA ? rsA : rsB, (int)vo[c][i], (int)soff, 0);
-    };
-    char* wlane = smem + wave * 2048 + lane * 16;   // + (stage * 4 + kind) * OW_HALF + piece * 1024
-    auto lwrite = [&](int par, int x, int stage) __attribute__((always_inline)) {
-        *reinterpret_cast<u32x4*>(wlane + (stage * 4 + (x >> 1)) * OW_HALF + (x & 1) * 1024) = R[par][x];
-    };
-#define OW_PIN() __builtin_amdgcn_sched_barrier(0)
-#define OWR_A(t_) (smem + (((t_) & 1) * 4 + wr) * OW_HALF)
-#define OWR_B(t_) (smem + (((t_) & 1) * 4 + 2 + wc) * OW_HALF)
-    // prologue: tiles 0 and 1 into the two register sets, tile 0 into stage 0, tile 2 into the freed set (nt >= 8)
-#pragma unroll
-    for (int x = 0; x < 8; ++x) gload(0, x, 0);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) gload(1, x, 1);
-    f32x16 accL[4][2], accR[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accL[i][j][r] = 0.f; accR[i][j][r] = 0.f; }
-#pragma unroll
-    for (int x = 0; x < 8; ++x) lwrite(0, x, 0);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) gload(0, x, 2);
-    __syncthreads();
-    bf16x8 fa[2][4], fb[2][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[0][i] = ow_read_frag<TA>(OWR_A(0), 32 * i, 0, lane); fb[0][i] = ow_read_frag<TB>(OWR_B(0), 32 * i, 0, lane); }
-    auto mfma_pair = [&](int cur, int idx) __attribute__((always_inline)) {
-#pragma unroll
-        for (int m = 2 * idx; m < 2 * idx + 2; ++m) {
-            const int i = m >> 2, j = m & 3;
-            if (j < 2) accL[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accL[i][j], 0, 0, 0);
-            else accR[i][j - 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][j], fa[cur][i], accR[i][j - 2], 0, 0, 0);
-        }
-    };
-    // one K tile; PAR = its parity (register set and LDS stage are compile-time), MODE 0: steady (tile t + 3 exists), 1: tiles t + 1 .. exist
-    // but t + 3 does not, 2: the last tile
-#ifdef SPN_GEMM_TIMING
-    long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = __builtin_amdgcn_s_memtime();
-    const long long t_start = tprev;
+// (the one-wave-per-SIMD kernels of round 5 -- 128x128 wave tiles, LDS-DMA or register-staged operands, 0.85-0.99x of the ping-pong
+// kernel on every shape of the step -- live in tools/variants/ and are compiled into variant builds only)
+#ifdef SPN_GEMM_OW_VARIANT
+#include "../../tools/variants/gemm_ow_kernels.inc"
 #endif
-    auto ktile = [&](auto par_c, auto mode_c, const int t) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_c)::value, MODE = decltype(mode_c)::value;
-        constexpr bool MORE = MODE != 2, REFILL = MODE == 0;
-        const char* a_t = OWR_A(PAR);
-        const char* b_t = OWR_B(PAR);
-        TSTAMP(3);
-        // ---- block 0: k step 0 of tile t; reads its k step 1; writes tile t + 1 (register set PAR ^ 1) into stage PAR ^ 1 ----
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            mfma_pair(0, x);
-            if (x < 4) { fb[1][x] = ow_read_frag<TB>(b_t, 32 * x, 1, lane); fa[1][x] = ow_read_frag<TA>(a_t, 32 * x, 1, lane); }
-            if (MORE) lwrite(PAR ^ 1, x, PAR ^ 1);
-            if (REFILL) gload(PAR ^ 1, x, t + 3);   // into the register the write above has just read: two whole K tiles of lead
-            OW_PIN();
-        }
-        TSTAMP(0);
-        if (MORE) __syncthreads();   // tile t + 1 is in LDS for everybody; everybody's reads of tile t have returned
-        OW_PIN();
-        TSTAMP(1);
-        const char* a_n = OWR_A(PAR ^ 1);
-        const char* b_n = OWR_B(PAR ^ 1);
-        // ---- block 1: k step 1 of tile t; reads k step 0 of tile t + 1; requests tile t + 3 into the register set tile t + 1 has left ----
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            mfma_pair(1, x);
-            if (MORE && x < 4) { fb[0][x] = ow_read_frag<TB>(b_n, 32 * x, 0, lane); fa[0][x] = ow_read_frag<TA>(a_n, 32 * x, 0, lane); }
-            OW_PIN();
-        }
-        TSTAMP(2);
-    };
-    {
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        // nt = K / 32 is even (K is a multiple of 64) and >= 8: steady pairs up to tile nt - 5, then the fixed four-tile tail
-        int t = 0;
-        for (; t <= nt - 6; t += 2) { ktile(I0{}, I0{}, t); ktile(I1{}, I0{}, t + 1); }
-        ktile(I0{}, I0{}, nt - 4);    // requests the last tile
-        ktile(I1{}, I1{}, nt - 3);
-        ktile(I0{}, I1{}, nt - 2);
-        ktile(I1{}, I2{}, nt - 1);
-    }
-#undef OWR_A
-#undef OWR_B
-#ifdef SPN_GEMM_TIMING
-    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave == 0 || wave == 3) && lane == 0) {
-        for (int k = 0; k < 8; ++k) g.dbg[(wave ? 8 : 0) + k] = seg[k];
-        if (wave == 0) g.dbg[16] = __builtin_amdgcn_s_memtime() - t_start;
-    }
-#endif
-    GemmKernargPtr gk = (GemmKernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(gk));
-    const GemmArgs ge = kernarg_copy(gk);
-    OutT* C = reinterpret_cast<OutT*>(ge.C) + (long)zid * ge.sC;
-    const bool lead = !split || zid == 0;
-    char* stg = smem + 2 * 4 * OW_HALF + wave * 8192;
-    __syncthreads();
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int wcx = 2 * wc + half;
-        f32x4 bv[8];
-#pragma unroll
-        for (int jq = 0; jq < 8; ++jq) {
-            const int bn = min(n0 + wcx * 64 + 32 * (jq >> 2) + 8 * (jq & 3) + (lane >> 5) * 4, ge.N - 4);
-            bv[jq] = (ge.bias && lead) ? *reinterpret_cast<const f32x4*>(ge.bias + bn) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        pp_store_tile<OutT, 0>(ge, half ? accR : accL, bv, C, lead, m0, n0, wr, wcx, lane, stg, smem + wave * 16384);
-    }
-#undef OW_PIN
-}
 
 // ---- 256x128 "duo" kernel: TWO independent 4-wave workgroups per CU -----------------------------------------------------
 // The projections with d_model = 512 on the contraction side (K = 512: 8 K-tiles of 64) spend a third of a 256x256 tile's life in the
@@ -2008,40 +1641,9 @@ int launch_pp(GemmArgs g, hipStream_t stream) {
     return SPN_OK;
 }
 
-// the one-wave-per-SIMD kernel: the ping-pong kernel's shapes, tile grid and split plan (K tiles counted in 32s here)
-template <bool TA, bool TB, typename OutT>
-int launch_ow(GemmArgs g, hipStream_t stream) {
-    const int tiles = cdiv(g.N, PP_BN) * cdiv(g.M, PP_BM), nt = g.K / PP_BK;
-    SplitPlan plan;
-    if (sizeof(OutT) == 4) {
-        plan_split(g, tiles, nt, PP_SPLIT_MAX_TILES, pp_split_want(), PP_SPLIT_MIN_KT, plan);
-    } else {
-        g.splitk = 1; g.kt_per_split = nt; plan.ws = nullptr;
-    }
-    g.kt_per_split *= PP_BK / OW_BK;
-    dim3 grid(cdiv(g.N, PP_BN), cdiv(g.M, PP_BM), g.splitk > 1 ? g.splitk : g.batch);
-    g.ngroup = spn_tune_i(SPN_TUNE_GEMM_NGROUP) > 0 ? spn_tune_i(SPN_TUNE_GEMM_NGROUP) : 8;
-    if (g.ngroup > (int)grid.x) g.ngroup = grid.x;
-    g.tx = grid.x; g.ty = grid.y;
-    g.slice_xcd = (spn_tune_i(SPN_TUNE_GEMM_SLICE_XCD) && g.splitk > 1 && g.splitk % 8 == 0) ? 1 : 0;
-    g.stagger = 0;
-    if (spn_tune_i(SPN_TUNE_GEMM_OW) >= 3) {   // register-staged operands
-        static std::atomic<unsigned> optin_r{0};
-        spn_lds_optin(optin_r, reinterpret_cast<const void*>(&gemm_owr_kernel<TA, TB, OutT>), OWR_LDS_BYTES);
-        hipLaunchKernelGGL((gemm_owr_kernel<TA, TB, OutT>), grid, dim3(256), OWR_LDS_BYTES, stream, g);
-    } else {
-        static std::atomic<unsigned> optin{0};
-        spn_lds_optin(optin, reinterpret_cast<const void*>(&gemm_ow_kernel<TA, TB, OutT>), OW_LDS_BYTES);
-        hipLaunchKernelGGL((gemm_ow_kernel<TA, TB, OutT>), grid, dim3(256), OW_LDS_BYTES, stream, g);
-    }
-    SPN_LAUNCH_CHECK();
-    finish_split(g, plan, stream);
-    SPN_LAUNCH_CHECK();
-    return SPN_OK;
-}
-
-// measured policy of the one-wave-per-SIMD kernel (gemm_ow = 1): long contractions, where the main loop is the launch
-static bool ow_preferred(const GemmArgs& g) { return g.K >= 2048; }
+#ifdef SPN_GEMM_OW_VARIANT
+#include "../../tools/variants/gemm_ow_launch.inc"
+#endif
 
 template <bool TA, bool TB, typename OutT, int BK, int STAGES>
 int launch_bk(GemmArgs g, hipStream_t stream) {
@@ -2121,11 +1723,13 @@ int launch(const GemmArgs& g, hipStream_t stream) {
     if (variant == 5) return launch_bk<TA, TB, OutT, 64, 4>(g, stream);
     if (variant == 6) return launch_bk<TA, TB, OutT, 32, 3>(g, stream);
     if (variant == 9 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
+#ifdef SPN_GEMM_OW_VARIANT
     {
-        const int ow = spn_tune_i(SPN_TUNE_GEMM_OW);
+        constexpr int ow = SPN_GEMM_OW_VARIANT;
         // 1 / 2: LDS-DMA variant where preferred / everywhere; 3 / 4: register-staged variant where preferred / everywhere
-        if (variant == 0 && ow && pp_eligible(g) && (ow == 2 || ow == 4 || ow_preferred(g))) return launch_ow<TA, TB, OutT>(g, stream);
+        if (variant == 0 && pp_eligible(g) && (ow == 2 || ow == 4 || ow_preferred(g))) return launch_ow<TA, TB, OutT>(g, stream);
     }
+#endif
     // measured (tools/bench_gemm.py): with the LDS-staged epilogue the 256x256 ping-pong kernel wins on every shape it can take
     if (variant == 0 && pp_eligible(g)) return launch_pp<TA, TB, OutT>(g, stream);
     // measured on MI355X (tools/bench_gemm.py): residency beats in-block pipelining -- two 16 KiB-per-operand stages with

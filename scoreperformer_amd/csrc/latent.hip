@@ -55,7 +55,7 @@ __global__ __launch_bounds__(SEL_THREADS) void latent_select_kernel(const float*
                                                                     const uint8_t* __restrict__ dead_b, int N, int S, int D, int K,
                                                                     uint32_t seed, float* __restrict__ y, float* __restrict__ w,
                                                                     int* __restrict__ slot, float* __restrict__ dead) {
-    __shared__ uint32_t bits[SEL_MAX_N / 32];
+    __shared__ uint32_t bits[SEL_MAX_N / 32 + 2];
     __shared__ int inv[SEL_MAX_K];
     __shared__ int hist[256];
     __shared__ int scratch[32];
@@ -63,12 +63,36 @@ __global__ __launch_bounds__(SEL_THREADS) void latent_select_kernel(const float*
     __shared__ int sh_rem, sh_anydead;
     __shared__ float fred[3 * (SEL_THREADS / 64)];
     const int tid = threadIdx.x, lane = tid & 63;
-    // ---- the validity bytes -> a bitmask in LDS (coalesced: a wave takes 64 consecutive latents per trip)
+    // ---- the validity bytes -> a bitmask in LDS.  16 bytes per lane and load, every load of a thread requested before the first is
+    // packed (a byte per lane and trip was 68 dependent round trips to memory for the onset level: 60 of the kernel's 80 us)
     if (tid == 0) sh_anydead = 0;
-    for (int base = (tid >> 6) * 64; base < N; base += SEL_THREADS) {
-        const int i = base + lane;
-        const unsigned long long m = __ballot(i < N && valid[i] != 0);
-        if (lane == 0) { bits[base >> 5] = (uint32_t)m; bits[(base >> 5) + 1] = (uint32_t)(m >> 32); }
+    uint16_t* bits16 = reinterpret_cast<uint16_t*>(bits);
+    const int nvec = N >> 4;                                  // whole 16-latent groups (valid is 16-byte aligned: host wrapper)
+    for (int v0 = tid; v0 < nvec; v0 += 4 * SEL_THREADS) {
+        uint4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = v0 + k * SEL_THREADS;
+            u[k] = v < nvec ? reinterpret_cast<const uint4*>(valid)[v] : uint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = v0 + k * SEL_THREADS;
+            if (v >= nvec) continue;
+            const uint32_t w4[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+            uint32_t m = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m |= ((w4[q] >> (8 * e)) & 0xffu) ? 1u << (4 * q + e) : 0u;
+            bits16[v] = (uint16_t)m;
+        }
+    }
+    if (tid == 0) {                                          // the last, partial group
+        uint32_t m = 0u;
+        for (int i = nvec << 4; i < N; ++i) m |= valid[i] ? 1u << (i & 15) : 0u;
+        bits16[nvec] = (uint16_t)m;
+        if ((nvec & 1) == 0) bits16[nvec + 1] = 0;
     }
     __syncthreads();
     const int B = N / S;
@@ -117,17 +141,24 @@ __global__ __launch_bounds__(SEL_THREADS) void latent_select_kernel(const float*
                 if (k != 0u && (k & pmask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
             }
             __syncthreads();
-            // suffix sums over the 256 bins (Hillis-Steele in LDS, first 256 threads)
-            for (int o = 1; o < 256; o <<= 1) {
-                int v = 0;
-                if (tid < 256) v = hist[tid] + (tid + o < 256 ? hist[tid + o] : 0);
-                __syncthreads();
-                if (tid < 256) hist[tid] = v;
-                __syncthreads();
-            }
-            if (tid < 256) {
-                const int above = tid + 1 < 256 ? hist[tid + 1] : 0;      // keys in higher bins of this digit
-                if (hist[tid] >= rem && above < rem) { sh_prefix = prefix | ((uint32_t)tid << shift); sh_rem = rem - above; }
+            // the bin that holds the rem-th largest key: suffix counts over the 256 bins by ONE wave (4 bins per lane, a shuffle scan
+            // over the lanes) -- 16 block barriers per digit as a Hillis-Steele scan in LDS
+            if (tid < 64) {
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int sl = h0 + h1 + h2 + h3;
+                int suf = sl;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int u = __shfl_down(suf, o);
+                    if (tid + o < 64) suf += u;
+                }
+                int above = suf - sl;                          // keys in the bins of higher lanes
+                const int hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {                 // bins 4 tid + 3 down to 4 tid
+                    if (above < rem && above + hh[q] >= rem) { sh_prefix = prefix | ((uint32_t)(4 * tid + q) << shift); sh_rem = rem - above; }
+                    above += hh[q];
+                }
             }
             __syncthreads();
             prefix = sh_prefix; rem = sh_rem; pmask |= 255u << shift;
@@ -157,6 +188,7 @@ __global__ __launch_bounds__(SEL_THREADS) void latent_select_kernel(const float*
     __syncthreads();
     // w, the packed rows (coalesced over y), zero rows where no latent lands (a short level: fewer than K valid latents)
     for (int r = tid; r < K; r += SEL_THREADS) w[r] = r < total ? 1.f : 0.f;
+#pragma unroll 4
     for (long e = tid; e < (long)K * D; e += SEL_THREADS) {
         const int r = (int)(e / D);
         y[e] = r < total ? lat[(long)inv[r] * D + (e % D)] : 0.f;
@@ -248,6 +280,7 @@ extern "C" int spn_latent_select(const float* lat, const uint8_t* valid, const u
                                  float* y, float* w, int* slot, float* dead, hipStream_t s) {
     SPN_REQUIRE(lat && valid && y && w && slot && dead && N > 0 && S > 0 && D > 0 && K > 0 && N % S == 0, "spn_latent_select: bad arguments");
     SPN_REQUIRE(N <= SEL_MAX_N && K <= SEL_MAX_K && N / S <= SEL_THREADS, "spn_latent_select: at most 262144 latents, 4096 selected, 1024 batch elements");
+    SPN_REQUIRE(((uintptr_t)valid & 15) == 0, "spn_latent_select: the validity bytes must be 16-byte aligned");
     hipLaunchKernelGGL(latent_select_kernel, dim3(1), dim3(SEL_THREADS), 0, s, lat, valid, dead_b, N, S, D, K, (uint32_t)seed, y, w, slot, dead);
     SPN_LAUNCH_CHECK();
     return SPN_OK;

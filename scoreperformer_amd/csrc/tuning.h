@@ -23,8 +23,6 @@ enum SpnTune {
                                    // 1 = two 4-wave workgroups per CU, 0 = ping-pong kernel; 2
     SPN_TUNE_GEMM_PERSIST_BWD,     // 1 = the persistent walk also for input-gradient GEMMs (N-contiguous B).  Only safe when no other kernel holds CUs
                                    // during the backward (a concurrent all-reduce starves the blocks that land on its CUs): the host sets it; 0
-    SPN_TUNE_GEMM_OW,              // 0 off; one-wave-per-SIMD kernels (128x128 wave tiles): 1 / 2 = LDS-DMA operands for K >= 2048 / wherever the ping-pong
-                                   // kernel is eligible, 3 / 4 = register-staged operands likewise; 0
     SPN_TUNE_GEMM_F32_MFMA,        // exact-fp32 GEMM with both operands contiguous along K: 1 = v_mfma_f32_32x32x2_f32 tiles, 0 = the VALU tile kernel; 1
     SPN_TUNE_COUNT
 };

@@ -801,7 +801,10 @@ def latent_select(lat: torch.Tensor, valid: torch.Tensor, deadpan: Optional[torc
     w = torch.empty(K, device=dev, dtype=F32)
     slot = torch.empty(b * S, device=dev, dtype=torch.int32)
     dead = torch.empty(3, device=dev, dtype=F32)
-    call("spn_latent_select", ptr(lat), ptr(_mask_u8(valid)), ptr(_mask_u8(deadpan)), c_int(b * S), c_int(S), c_int(D), c_int(K),
+    valid = _mask_u8(valid)
+    if valid.data_ptr() % 16:          # (a view at an odd offset: the kernel reads the bytes 16 at a time)
+        valid = valid.clone()
+    call("spn_latent_select", ptr(lat), ptr(valid), ptr(_mask_u8(deadpan)), c_int(b * S), c_int(S), c_int(D), c_int(K),
          ctypes.c_uint(seed & 0xFFFFFFFF), ptr(y), ptr(w), ptr(slot), ptr(dead), stream_ptr())
     return y, w, slot, dead
 

@@ -12,7 +12,7 @@ a = torch.randn((K, M) if TA else (M, K), device=dev).bfloat16(); b = torch.rand
 c = torch.empty(M, N, device=dev, dtype=torch.float32 if F32 else torch.bfloat16)
 dbg = torch.zeros(32, device=dev, dtype=torch.int64)
 if os.environ.get("OW"):   # one-wave-per-SIMD kernels: segments are block 0 / wait + barrier / block 1 / loop overhead per K tile of 32
-    lib.spn_set_tuning(b"gemm_ow", ctypes.c_double(float(os.environ["OW"])))
+    pass   # (round 6: the one-wave kernels are a variant build -- SPN_LIB=tools/_bin/<ow variant>.so -- not a knob)
 if hasattr(lib, "spn_gemm_set_debug"):
     lib.spn_gemm_set_debug(ctypes.c_void_p(dbg.data_ptr()))
 P = ctypes.c_void_p
