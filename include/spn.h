@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 9: round 6 added spn_latent_{select,unselect,scalars,drop,drop_bwd}; 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 9: round 6 added spn_latent_{select,unselect,scalars,drop,drop_bwd}, spn_segment_{sum,gather}_multi, the row strides of spn_segment_sum / spn_segment_gather; 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -179,9 +179,18 @@ int spn_ce_bwd(const void* logits, int dtype, long ld, const long* labels, long 
                spn_stream_t s);
 int spn_segment_count(const long* seg, float* counts /* ACCUMULATED */, int b, int t, int S, spn_stream_t s);
 int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
-                    const uint8_t* rowmask, float* out /* ACCUMULATED */, int b, int t, int S, int d, spn_stream_t s);
-int spn_segment_gather(const float* src, const long* seg, const float* counts, const uint8_t* rowmask, float* y, long y_ld,
-                       int b, int t, int S, int d, int accumulate, spn_stream_t s);
+                    const uint8_t* rowmask, float* out /* ACCUMULATED; row stride out_ld >= d */, long out_ld, int b, int t, int S, int d,
+                    spn_stream_t s);
+int spn_segment_gather(const float* src, long src_ld /* >= d */, const long* seg, const float* counts, const uint8_t* rowmask, float* y,
+                       long y_ld, int b, int t, int S, int d, int accumulate, spn_stream_t s);
+/* all latent levels in ONE pass over the hidden states (mmd_transformer.py:325-340 runs once per level): out_l[b, S_l, 0:d] (row stride
+ * out_ld[l], zeroed by the caller) += segment MEANS of x[b, t, 0:d] * rowmask under seg_l; host arrays of nl <= 8 entries; d % 4 == 0 */
+int spn_segment_sum_multi(const void* x, int dtype, long x_bs, long x_ts, const uint8_t* rowmask, int nl, const long* const* seg,
+                          const float* const* counts, float* const* out, const long* out_ld, const int* S, int b, int t, int d,
+                          spn_stream_t s);
+/* its backward, written once: y[b * t, 0:d] = rowmask * sum_l src_l[b, seg_l, 0:d] / max(counts_l, 1) */
+int spn_segment_gather_multi(int nl, const float* const* src, const long* src_ld, const long* const* seg, const float* const* counts,
+                             const int* S, const uint8_t* rowmask, float* y, long y_ld, int b, int t, int d, spn_stream_t s);
 int spn_mmd_fwd(const float* z, int Z, const float* y, const float* w, int N, int D, float* sums /* [4] ACCUMULATED */,
                 spn_stream_t s);
 int spn_mmd_bwd(const float* z, int Z, const float* y, const float* w, int N, int D, const float* coef, float* dy,

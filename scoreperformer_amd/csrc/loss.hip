@@ -203,7 +203,7 @@ __global__ void seg_count_kernel(const long* __restrict__ seg, float* __restrict
 // Rows are taken 8 at a time: the 8 ids and 8 values are loaded first (independent loads in flight), then folded in order.
 template <typename TX>
 __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, const long* __restrict__ seg,
-                               const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out,
+                               const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out, long out_ld,
                                int t, int S, int d, int t_chunk) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
@@ -231,13 +231,13 @@ __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, c
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (sg[u] != cur) {
-                if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
+                if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * out_ld + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
                 acc = 0.f; cur = sg[u];
             }
             acc += v[u];
         }
     }
-    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * d + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
+    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * out_ld + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
 }
 
 // y[b, t, c] = src[b, seg[b,t], c] * scale * (rowmask ? rowmask[b,t] : 1);  scale = 1/max(counts[b,seg],1) if counts
@@ -245,7 +245,7 @@ __global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, c
 template <int VEC>
 __global__ void seg_gather_kernel(const float* __restrict__ src, const long* __restrict__ seg, const float* __restrict__ counts,
                                   const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, unsigned BT, int t, int S, int d,
-                                  int accumulate) {
+                                  int accumulate, long src_ld) {
     const unsigned dv = (unsigned)d / VEC, total = BT * dv;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned r = idx / dv, c = (idx - r * dv) * VEC;
@@ -253,7 +253,7 @@ __global__ void seg_gather_kernel(const float* __restrict__ src, const long* __r
         const long sgm = seg[r];
         const bool live = !(rowmask && !rowmask[r]);
         const float den = counts ? fmaxf(counts[(long)b * S + sgm], 1.f) : 1.f;
-        const float* sp = src + ((long)b * S + sgm) * d + c;
+        const float* sp = src + ((long)b * S + sgm) * src_ld + c;
         float* yp = y + (long)r * y_ld + c;
         if (VEC == 4) {
             f32x4 v = *reinterpret_cast<const f32x4*>(sp);
@@ -434,28 +434,153 @@ extern "C" int spn_segment_count(const long* seg, float* counts, int b, int t, i
     return SPN_OK;
 }
 
-// out[b,S,d] fp32 (zeroed by caller) += segment sums (counts == null) or means (counts given) of x[b,t,d]
+// out[b,S,d] fp32 (row stride out_ld >= d: a column slice of a wider buffer; zeroed by caller) += segment sums (counts == null) or means
+// (counts given) of x[b,t,d]
 extern "C" int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
-                               const uint8_t* rowmask, float* out, int b, int t, int S, int d, hipStream_t s) {
-    SPN_REQUIRE(x && seg && out && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_sum: bad arguments");
+                               const uint8_t* rowmask, float* out, long out_ld, int b, int t, int S, int d, hipStream_t s) {
+    SPN_REQUIRE(x && seg && out && b > 0 && t > 0 && S > 0 && d > 0 && out_ld >= d, "spn_segment_sum: bad arguments");
     const int t_chunk = t > 256 ? 128 : t;
     dim3 grid(cdiv(d, 64), b, cdiv(t, t_chunk));
-    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d, t_chunk);
-    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, t, S, d, t_chunk);
+    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, out_ld, t, S, d, t_chunk);
+    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, out_ld, t, S, d, t_chunk);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
 
-// y[b*t, d] (row stride y_ld) (+)= src[b, seg, :] (/ counts) (* rowmask)
-extern "C" int spn_segment_gather(const float* src, const long* seg, const float* counts, const uint8_t* rowmask, float* y, long y_ld,
-                                  int b, int t, int S, int d, int accumulate, hipStream_t s) {
-    SPN_REQUIRE(src && seg && y && b > 0 && t > 0 && S > 0 && d > 0, "spn_segment_gather: bad arguments");
+// y[b*t, d] (row stride y_ld) (+)= src[b, seg, 0:d] (row stride src_ld >= d) (/ counts) (* rowmask)
+extern "C" int spn_segment_gather(const float* src, long src_ld, const long* seg, const float* counts, const uint8_t* rowmask, float* y,
+                                  long y_ld, int b, int t, int S, int d, int accumulate, hipStream_t s) {
+    SPN_REQUIRE(src && seg && y && b > 0 && t > 0 && S > 0 && d > 0 && src_ld >= d, "spn_segment_gather: bad arguments");
     SPN_REQUIRE((long)b * t * d < (1l << 31), "spn_segment_gather: b*t*d must be below 2^31");
-    const bool vec = d % 4 == 0 && y_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)y) & 15) == 0;
+    const bool vec = d % 4 == 0 && y_ld % 4 == 0 && src_ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)y) & 15) == 0;
     if (vec) hipLaunchKernelGGL(seg_gather_kernel<4>, dim3(grid_for((long)b * t * (d / 4))), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
-                                (unsigned)(b * t), t, S, d, accumulate);
+                                (unsigned)(b * t), t, S, d, accumulate, src_ld);
     else hipLaunchKernelGGL(seg_gather_kernel<1>, dim3(grid_for((long)b * t * d)), dim3(256), 0, s, src, seg, counts, rowmask, y, y_ld,
-                            (unsigned)(b * t), t, S, d, accumulate);
+                            (unsigned)(b * t), t, S, d, accumulate, src_ld);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// ---- all latent levels of the hierarchical heads in ONE pass over the hidden states (mmd_transformer.py:325-340 per level) ----------
+// Every level aggregates the SAME hidden states under its own segmentation (sequence mean, bars, beats, onsets); level by level that is
+// four passes over [b, t, d] forward (4 x 268 MB at C3) and four read-modify-write passes over the gradient backward.  Here a thread owns
+// one column of one sample's row chunk, keeps one running sum per level and flushes a level when ITS segment id changes:
+//   out_l[b, s, 0:d] += mean over the rows of segment s of x[b, t, 0:d] * rowmask[b, t]          (out_l has row stride ld_l >= d)
+// and the backward writes the hidden-state gradient once:  y[b, t, :] = rowmask * sum_l src_l[b, seg_l[b, t], 0:d] / max(count_l, 1).
+struct SegMulti {
+    const long* seg[8];
+    const float* counts[8];
+    float* out[8];           // gather: the sources
+    long ld[8];
+    int S[8];
+    int nl;
+};
+
+// One COLUMN per lane, like seg_sum_kernel: a wave's flush is one atomicAdd instruction over 64 consecutive floats = two whole cache lines
+// (four columns per lane with 16-byte loads were measured in round 4 for the one-level kernel: 247 us against 141 -- each of its four
+// atomic instructions touches a quarter of eight lines, and the kernel is bound by its per-run flushes, not by loads in flight).
+template <typename TX>
+__global__ __launch_bounds__(64) void seg_sum_multi_kernel(SegMulti a, const TX* __restrict__ x, long x_bs, long x_ts,
+                                                           const uint8_t* __restrict__ rowmask, int t, int d, int t_chunk) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (c >= d) return;
+    const int i_begin = blockIdx.z * t_chunk, i_end = min(t, i_begin + t_chunk);
+    if (i_begin >= i_end) return;
+    const TX* xb = x + (long)b * x_bs + c;
+    const uint8_t* mb = rowmask ? rowmask + (long)b * t : nullptr;
+    float acc[8];
+    long cur[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) { acc[l] = 0.f; cur[l] = l < a.nl ? a.seg[l][(long)b * t + i_begin] : 0; }
+    auto flush = [&](int l) {
+        const long row = (long)b * a.S[l] + cur[l];
+        if (acc[l] != 0.f) atomicAdd(a.out[l] + row * a.ld[l] + c, acc[l] / fmaxf(a.counts[l][row], 1.f));
+        acc[l] = 0.f;
+    };
+    for (int i = i_begin; i < i_end; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {          // eight rows requested before the first is folded
+            const int r = min(i + u, i_end - 1);
+            float xv;
+            if constexpr (sizeof(TX) == 4) xv = xb[(long)r * x_ts];
+            else xv = bf2f(xb[(long)r * x_ts]);
+            v[u] = (i + u < i_end && !(mb && mb[r] == 0)) ? xv : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = min(i + u, i_end - 1);
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                if (l >= a.nl) break;
+                const long sg = a.seg[l][(long)b * t + r];     // (block-uniform address: a scalar load)
+                if (sg != cur[l]) { flush(l); cur[l] = sg; }
+                acc[l] += v[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 8; ++l) if (l < a.nl) flush(l);
+}
+
+__global__ void seg_gather_multi_kernel(SegMulti a, const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, unsigned BT,
+                                        int t, int d) {
+    const unsigned dv = (unsigned)d / 4, total = BT * dv;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned r = idx / dv, c = (idx - r * dv) * 4;
+        const unsigned b = r / (unsigned)t;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(rowmask && !rowmask[r])) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                if (l >= a.nl) break;
+                const long row = (long)b * a.S[l] + a.seg[l][r];
+                v += *reinterpret_cast<const f32x4*>(a.out[l] + row * a.ld[l] + c) / fmaxf(a.counts[l][row], 1.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + (long)r * y_ld + c) = v;
+    }
+}
+
+static int fill_seg_multi(SegMulti& a, int nl, const long* const* seg, const float* const* counts, float* const* ptr, const long* ld,
+                          const int* S, int d) {
+    SPN_REQUIRE(nl > 0 && nl <= 8 && seg && counts && ptr && ld && S, "spn_segment_*_multi: 1..8 levels");
+    memset(&a, 0, sizeof(a));
+    a.nl = nl;
+    for (int l = 0; l < nl; ++l) {
+        SPN_REQUIRE(seg[l] && counts[l] && ptr[l] && S[l] > 0 && ld[l] >= d && (ld[l] % 4) == 0 && ((uintptr_t)ptr[l] & 15) == 0,
+                    "spn_segment_*_multi: every level needs ids, counts and a 16-byte aligned [b, S, >= d] buffer");
+        a.seg[l] = seg[l]; a.counts[l] = counts[l]; a.out[l] = ptr[l]; a.ld[l] = ld[l]; a.S[l] = S[l];
+    }
+    return SPN_OK;
+}
+
+// out_l[b, S_l, 0:d] (row stride ld_l; zeroed by the caller) += segment MEANS of x[b, t, 0:d] * rowmask under seg_l, for all levels in one
+// pass.  x fp32 / bf16 (dtype 0 / 1) with strides (x_bs, x_ts); d a multiple of 4; host arrays of nl <= 8 entries.
+extern "C" int spn_segment_sum_multi(const void* x, int dtype, long x_bs, long x_ts, const uint8_t* rowmask, int nl, const long* const* seg,
+                                     const float* const* counts, float* const* out, const long* out_ld, const int* S, int b, int t, int d,
+                                     hipStream_t s) {
+    SPN_REQUIRE(x && b > 0 && t > 0 && d > 0 && (d % 4) == 0, "spn_segment_sum_multi: bad arguments (d a multiple of 4)");
+    SegMulti a;
+    if (int rc = fill_seg_multi(a, nl, seg, counts, out, out_ld, S, d)) return rc;
+    const int t_chunk = t > 256 ? 128 : t;
+    dim3 grid(cdiv(d, 64), b, cdiv(t, t_chunk));
+    if (dtype == 0) hipLaunchKernelGGL((seg_sum_multi_kernel<float>), grid, dim3(64), 0, s, a, (const float*)x, x_bs, x_ts, rowmask, t, d, t_chunk);
+    else hipLaunchKernelGGL((seg_sum_multi_kernel<bf16_t>), grid, dim3(64), 0, s, a, (const bf16_t*)x, x_bs, x_ts, rowmask, t, d, t_chunk);
+    SPN_LAUNCH_CHECK();
+    return SPN_OK;
+}
+
+// y[b * t, 0:d] (row stride y_ld) = rowmask * sum_l src_l[b, seg_l, 0:d] / max(counts_l, 1): the backward of the above, written once
+extern "C" int spn_segment_gather_multi(int nl, const float* const* src, const long* src_ld, const long* const* seg,
+                                        const float* const* counts, const int* S, const uint8_t* rowmask, float* y, long y_ld, int b, int t,
+                                        int d, hipStream_t s) {
+    SPN_REQUIRE(y && b > 0 && t > 0 && d > 0 && (d % 4) == 0 && (y_ld % 4) == 0 && ((uintptr_t)y & 15) == 0 && (long)b * t * d < (1l << 31),
+                "spn_segment_gather_multi: d, y_ld multiples of 4, y 16-byte aligned, b*t*d below 2^31");
+    SegMulti a;
+    if (int rc = fill_seg_multi(a, nl, seg, counts, const_cast<float* const*>(src), src_ld, S, d)) return rc;
+    hipLaunchKernelGGL(seg_gather_multi_kernel, dim3(grid_for((long)b * t * (d / 4))), dim3(256), 0, s, a, rowmask, y, y_ld, (unsigned)(b * t), t, d);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

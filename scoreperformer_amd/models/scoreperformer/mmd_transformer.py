@@ -72,6 +72,9 @@ class MMDVAE(nn.Module):
         return F_.linear_f32(F_.cast(inputs, torch.float32), self.linear.weight, self.linear.bias)
 
 
+ONE_PASS_LEVELS = True     # False: the level-by-level path for every configuration (A/B and test aid)
+
+
 class HierLatentsFn(Function):
     """(hidden, mask, segments per level, head weights) -> (embeddings [b,n,sum L], latents_i [b,S_i,L_i] ...).
 
@@ -80,9 +83,97 @@ class HierLatentsFn(Function):
     """
 
     @staticmethod
+    def _one_pass(hidden, hierarchical, modes):
+        """Every level aggregates the same hidden states (sequence mean or a segmentation), so ONE pass over them serves all levels
+        (ops.segment_sum_multi / segment_gather_multi): the shipped recipes.  `same` levels and `hierarchical_with_context=False` keep the
+        level-by-level path."""
+        agg_modes = (EmbeddingAggregateModes.MEAN,) + SEGMENT_MODES
+        return (hidden.is_cuda and hidden.shape[-1] % 4 == 0 and len(modes) <= 8 and hierarchical != "no-context"
+                and all(m in agg_modes for m in modes) and hidden.dtype in (torch.float32, torch.bfloat16))
+
+    @staticmethod
+    def _forward_one_pass(ctx, hidden, mask, hierarchical, modes, segs, seg_sizes, wb):
+        b, n, d = hidden.shape
+        nl = len(modes)
+        Ws, bs = wb[:nl], wb[nl:]
+        Ls = [w.shape[0] for w in Ws]
+        offs = [sum(Ls[:i]) for i in range(nl)]
+        dev = hidden.device
+        E = torch.empty((b, n, sum(Ls)), device=dev, dtype=torch.float32)     # the levels' embeddings, scattered back to the notes
+        notmask = (~mask).long()
+        seg_a, seg_g, S, counts, aggs = [], [], [], [], []
+        for i, mode in enumerate(modes):
+            if mode == EmbeddingAggregateModes.MEAN:   # masked mean over the sequence (mmd_transformer.py:325-327): ids 0 = note, 1 = padding
+                seg_a.append(notmask); seg_g.append(torch.zeros_like(notmask)); S.append(2)
+            else:
+                sg = segs[i].contiguous()
+                seg_a.append(sg); seg_g.append(sg); S.append(int(seg_sizes[i]))
+            counts.append(ops.segment_count(seg_a[i], S[i]))
+            aggs.append(torch.zeros((b, S[i], d + offs[i] if hierarchical else d), device=dev, dtype=torch.float32))
+        x = hidden if hidden.stride(-1) == 1 else hidden.contiguous()
+        ops.segment_sum_multi(x, mask, seg_a, counts, [a[..., :d] for a in aggs], S)         # the one pass over [b, n, d]
+        latents, lmasks, used = [], [], []
+        for i, mode in enumerate(modes):
+            if hierarchical and i > 0:    # the embeddings of the levels before this one (mmd_transformer.py:259-261): a few columns
+                ops.segment_sum(E[..., :offs[i]], seg_a[i], S[i], counts=counts[i], out=aggs[i][..., d:])
+            if mode == EmbeddingAggregateModes.MEAN:
+                agg = aggs[i][:, :1].contiguous()
+                lmask = torch.ones((b, 1), device=dev, dtype=torch.bool)
+            else:
+                agg = aggs[i]
+                lmask = ops.rows_all_nonzero(agg)                     # mmd_transformer.py:342
+            lat = ops.gemm_f32(agg, Ws[i].detach(), bias=bs[i].detach(), rowmask=lmask).view(b, agg.shape[1], Ls[i])
+            ops.segment_gather(lat, seg_g[i], rowmask=mask, out=E[..., offs[i]:offs[i] + Ls[i]])
+            latents.append(lat); lmasks.append(lmask); used.append(agg)
+        ctx.one_pass = (seg_a, seg_g, S, counts, used, lmasks, offs)
+        ctx.wb = wb
+        ctx.meta = (b, n, d, Ls, modes, hierarchical)
+        ctx.save_for_backward(mask)
+        for m in lmasks:
+            ctx.mark_non_differentiable(m)
+        return (E, *latents, *lmasks)
+
+    @staticmethod
+    def _backward_one_pass(ctx, d_emb, rest):
+        (mask,) = ctx.saved_tensors
+        b, n, d, Ls, modes, hierarchical = ctx.meta
+        seg_a, seg_g, S, counts, used, lmasks, offs = ctx.one_pass
+        nl = len(modes)
+        d_lats = rest[:nl]
+        Ws = ctx.wb[:nl]
+        dev = mask.device
+        if d_emb is not None:
+            dE = ops.cast(d_emb.contiguous(), torch.float32, rowmask=mask)     # a fresh buffer: accumulated into below
+        else:
+            dE = torch.zeros((b, n, sum(Ls)), device=dev, dtype=torch.float32)
+        dWs, dbs, daggs = [None] * nl, [None] * nl, [None] * nl
+        for i in reversed(range(nl)):
+            agg = used[i]
+            S_g, d_in = agg.shape[1], agg.shape[2]
+            dlat = ops.segment_sum(dE[..., offs[i]:offs[i] + Ls[i]], seg_g[i], S_g, rowmask=mask)
+            if d_lats[i] is not None:
+                dlat = dlat + d_lats[i]
+            dlat = ops.mask_rows(dlat, lmasks[i])
+            dl2 = dlat.view(-1, Ls[i])
+            dWs[i] = ops.gemm_f32(dl2, agg.view(-1, d_in), ta=True, tb=True)
+            dbs[i] = ops.colsum(dl2)
+            dagg = ops.gemm_f32(dl2, Ws[i].detach(), tb=True).view(b, S_g, d_in)
+            if modes[i] == EmbeddingAggregateModes.MEAN:
+                dagg = torch.cat([dagg, torch.zeros_like(dagg)], dim=1)
+            if hierarchical and i > 0:     # into the embedding gradients of the levels before this one, before THEIR backward reads them
+                ops.segment_gather(dagg[..., d:], seg_a[i], counts=counts[i], out=dE[..., :offs[i]], accumulate=True)
+            daggs[i] = dagg
+        # the hidden-state gradient of all levels, written once (level by level: four read-modify-write passes over [b, n, d])
+        d_hidden = ops.segment_gather_multi([g[..., :d] for g in daggs], seg_a, counts, S, mask, d)
+        return (d_hidden, None, None, None, None, None, *dWs, *dbs)
+
+    @staticmethod
     def forward(ctx, hidden, mask, hierarchical, modes, segs, seg_sizes, *wb):
         # hierarchical: False, True (level i reads the hidden states AND the embeddings of the levels before it: a column prefix of `wide`)
         # or "no-context" (level i > 0 reads ONLY level i - 1's embeddings: `hierarchical_with_context=False`, mmd_transformer.py:255-262)
+        ctx.one_pass = None
+        if HierLatentsFn._one_pass(hidden, hierarchical, modes) and ONE_PASS_LEVELS:
+            return HierLatentsFn._forward_one_pass(ctx, hidden, mask, hierarchical, modes, segs, seg_sizes, wb)
         b, n, d = hidden.shape
         nl = len(modes)
         Ws, bs = wb[:nl], wb[nl:]
@@ -139,6 +230,8 @@ class HierLatentsFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, d_emb, *rest):
+        if ctx.one_pass is not None:
+            return HierLatentsFn._backward_one_pass(ctx, d_emb, rest)
         (mask,) = ctx.saved_tensors
         b, n, d, Ls, modes, hierarchical = ctx.meta
         nl = len(modes)

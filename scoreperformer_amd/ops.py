@@ -685,17 +685,64 @@ def segment_count(seg: torch.Tensor, S: int) -> torch.Tensor:
 
 
 def segment_sum(x: torch.Tensor, seg: torch.Tensor, S: int, *, counts: Optional[torch.Tensor] = None,
-                rowmask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [b,t,d] (fp32/bf16, unit inner stride) -> out fp32 [b,S,d]: per-segment sums, or means when counts is given."""
+                rowmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [b,t,d] (fp32/bf16, unit inner stride) -> out fp32 [b,S,d]: per-segment sums, or means when counts is given.  `out` (ACCUMULATED
+    into) may be a column slice `agg[..., c0:c0+d]` of a contiguous [b,S,W] buffer."""
     seg = seg.contiguous()
     if x.stride(-1) != 1:
         x = x.contiguous()
     b, t, d = x.shape
-    out = torch.zeros((b, S, d), device=x.device, dtype=F32)
+    if out is None:
+        out = torch.zeros((b, S, d), device=x.device, dtype=F32)
+    elif out.stride(-1) != 1 or out.stride(0) != S * out.stride(1) or tuple(out.shape) != (b, S, d) or out.dtype != F32:
+        raise SpnError("segment_sum: output must be an fp32 column slice of a contiguous [b,S,W] buffer")
     if rowmask is not None:
         rowmask = _mask_u8(rowmask.reshape(-1))
     call("spn_segment_sum", ptr(x), c_int(_dt(x)), c_long(x.stride(0)), c_long(x.stride(1)), ptr(seg), ptr(counts), ptr(rowmask),
-         ptr(out), c_int(b), c_int(t), c_int(S), c_int(d), stream_ptr())
+         ptr(out), c_long(out.stride(1)), c_int(b), c_int(t), c_int(S), c_int(d), stream_ptr())
+    return out
+
+
+def _level_arrays(segs, counts, bufs, S):
+    nl = len(segs)
+    keep = [s.contiguous() for s in segs]
+    if any(s.dtype != torch.int64 for s in keep):
+        raise SpnError("segment ids must be int64")
+    for bf, s_ in zip(bufs, S):
+        if bf.dtype != F32 or bf.stride(-1) != 1 or bf.stride(0) != s_ * bf.stride(1):
+            raise SpnError("per-level buffers must be fp32 column slices of contiguous [b,S,W] buffers")
+    a_seg = (ctypes.c_void_p * nl)(*[s.data_ptr() for s in keep])
+    a_cnt = (ctypes.c_void_p * nl)(*[c.data_ptr() for c in counts])
+    a_buf = (ctypes.c_void_p * nl)(*[bf.data_ptr() for bf in bufs])
+    a_ld = (ctypes.c_long * nl)(*[bf.stride(1) for bf in bufs])
+    a_S = (ctypes.c_int * nl)(*[int(v) for v in S])
+    return keep, a_seg, a_cnt, a_buf, a_ld, a_S
+
+
+def segment_sum_multi(x: torch.Tensor, rowmask: Optional[torch.Tensor], segs, counts, outs, S) -> None:
+    """All levels in one pass: outs[l][b, S_l, :d] (fp32, zeroed by the caller, may be column slices) += segment means of
+    x[b, t, :d] * rowmask under segs[l] (counts[l] from segment_count)."""
+    require_gpu(x)
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    b, t, d = x.shape
+    keep, a_seg, a_cnt, a_out, a_ld, a_S = _level_arrays(segs, counts, outs, S)
+    rm = None if rowmask is None else _mask_u8(rowmask.reshape(-1))
+    call("spn_segment_sum_multi", ptr(x), c_int(_dt(x)), c_long(x.stride(0)), c_long(x.stride(1)), ptr(rm), c_int(len(segs)), a_seg, a_cnt,
+         a_out, a_ld, a_S, c_int(b), c_int(t), c_int(d), stream_ptr())
+
+
+def segment_gather_multi(srcs, segs, counts, S, rowmask: Optional[torch.Tensor], d: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[b, t, :d] = rowmask * sum_l srcs[l][b, segs[l][b, t], :d] / max(counts[l], 1): the backward of segment_sum_multi, written once."""
+    b, t = segs[0].shape
+    if out is None:
+        out = torch.empty((b, t, d), device=srcs[0].device, dtype=F32)
+    if out.stride(-1) != 1 or out.stride(0) != t * out.stride(1):
+        raise SpnError("segment_gather_multi: output must be a column slice of a contiguous [b,t,W] buffer")
+    keep, a_seg, a_cnt, a_src, a_ld, a_S = _level_arrays(segs, counts, srcs, S)
+    rm = None if rowmask is None else _mask_u8(rowmask.reshape(-1))
+    call("spn_segment_gather_multi", c_int(len(segs)), a_src, a_ld, a_seg, a_cnt, a_S, ptr(rm), ptr(out), c_long(out.stride(1)), c_int(b),
+         c_int(t), c_int(d), stream_ptr())
     return out
 
 
@@ -703,10 +750,11 @@ def segment_gather(src: torch.Tensor, seg: torch.Tensor, *, counts: Optional[tor
                    rowmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                    accumulate: bool = False) -> torch.Tensor:
     """src fp32 [b,S,d] -> y fp32 [b,t,d] (+)= src[b, seg] (/counts) (*rowmask).  `out` may be a column slice
-    `wide[..., c0:c0+d]` of a contiguous [b,t,W] buffer."""
+    `wide[..., c0:c0+d]` of a contiguous [b,t,W] buffer, `src` a column slice of a contiguous [b,S,W] one."""
     seg = seg.contiguous()
-    src = src.contiguous()
     b, S, d = src.shape
+    if src.stride(-1) != 1 or src.stride(0) != S * src.stride(1):
+        src = src.contiguous()
     t = seg.shape[1]
     if out is None:
         out = torch.empty((b, t, d), device=src.device, dtype=F32)
@@ -714,7 +762,7 @@ def segment_gather(src: torch.Tensor, seg: torch.Tensor, *, counts: Optional[tor
         raise SpnError("segment_gather: output must be a column slice of a contiguous [b,t,W] buffer")
     if rowmask is not None:
         rowmask = _mask_u8(rowmask.reshape(-1))
-    call("spn_segment_gather", ptr(src), ptr(seg), ptr(counts), ptr(rowmask), ptr(out), c_long(out.stride(1)), c_int(b), c_int(t),
+    call("spn_segment_gather", ptr(src), c_long(src.stride(1)), ptr(seg), ptr(counts), ptr(rowmask), ptr(out), c_long(out.stride(1)), c_int(b), c_int(t),
          c_int(S), c_int(d), c_int(int(accumulate)), stream_ptr())
     return out
 

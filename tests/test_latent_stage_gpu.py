@@ -175,3 +175,51 @@ def test_latent_drop_draws_at_the_configured_rate_per_latent(dev):
     assert abs(rate - 0.3) < 0.03, rate
     out2, drop2 = ops.latent_drop(emb, mask, None, [(seg, lmask, S, 4, 0.3, None)], True, seed=100)
     assert not torch.equal(drop, drop2)
+
+
+@pytest.mark.parametrize("hierarchical", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_one_pass_hierarchical_heads_equal_the_level_by_level_path(dev, hierarchical, dtype):
+    """HierLatentsFn with ONE pass over the hidden states for all levels (ops.segment_sum_multi / segment_gather_multi) against its
+    level-by-level formulation (the path of rounds 1-5, pinned to the reference's fixtures by tests/test_model_gpu.py): same latent
+    masks, embeddings / latents / every gradient equal to fp32 summation order (1e-5 of each tensor's scale), ragged batch."""
+    from scoreperformer_amd.models.scoreperformer import mmd_transformer as M
+    b, n, d = 6, 200, 64
+    Ls = [8, 12, 4, 4]
+    modes = ("mean", "bar_mean", "beat_mean", "onset_mean")
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(n // 2, n + 1, (b,), generator=g)
+    mask = (torch.arange(n)[None] < lens[:, None]).to(dev)
+
+    def segs(p):
+        inc = (torch.rand(b, n, generator=g) < p).long(); inc[:, 0] = 0
+        return (4 + inc.cumsum(1)).to(dev) * mask
+    seg = (None, segs(1 / 16), segs(1 / 4), segs(1 / 2))
+    sizes = (1,) + tuple(int(s.max()) + 1 for s in seg[1:])
+    hidden0 = torch.randn(b, n, d, generator=g).to(dev).to(dtype)
+    d_ins = [d + sum(Ls[:i]) if hierarchical else d for i in range(4)]
+    Ws = [torch.randn(L, di, generator=g).to(dev) * 0.1 for L, di in zip(Ls, d_ins)]
+    bs = [torch.randn(L, generator=g).to(dev) * 0.1 for L in Ls]
+    w_emb = torch.randn(b, n, sum(Ls), generator=g).to(dev)
+    w_lat = [torch.randn(b, S, L, generator=g).to(dev) for S, L in zip(sizes, Ls)]
+    runs = []
+    for one_pass in (False, True):
+        M.ONE_PASS_LEVELS = one_pass
+        try:
+            h = hidden0.clone().requires_grad_(True)
+            W = [w.clone().requires_grad_(True) for w in Ws]
+            B = [x.clone().requires_grad_(True) for x in bs]
+            outs = M.HierLatentsFn.apply(h, mask, hierarchical, modes, seg, sizes, *W, *B)
+            emb, lats, lmasks = outs[0], outs[1:5], outs[5:]
+            ((emb * w_emb).sum() + sum((l * w).sum() for l, w in zip(lats, w_lat))).backward()
+            runs.append((emb.detach(), [l.detach() for l in lats], lmasks, h.grad, [w.grad for w in W], [x.grad for x in B]))
+        finally:
+            M.ONE_PASS_LEVELS = True
+
+    def close(a, b_):
+        return float((a.float() - b_.float()).abs().max()) <= 1e-5 * max(1e-6, float(b_.float().abs().max()))
+    (e0, l0, m0, gh0, gw0, gb0), (e1, l1, m1, gh1, gw1, gb1) = runs
+    assert all(torch.equal(a, b_) for a, b_ in zip(m0, m1)) and any(bool((~m).any()) for m in m0[1:])
+    assert close(e1, e0) and all(close(a, b_) for a, b_ in zip(l1, l0))
+    assert gh1.dtype == gh0.dtype and close(gh1, gh0) and float(gh1[~mask].abs().max()) == 0.0
+    assert all(close(a, b_) for a, b_ in zip(gw1, gw0)) and all(close(a, b_) for a, b_ in zip(gb1, gb0))
