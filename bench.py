@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — ScorePerformer train-step throughput on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""bench.py — ScorePerformer train-step throughput on MI355X (contract: see the task statement / DESIGN.md section 5).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -669,7 +669,7 @@ def decode_leg(args, dev):
             "notes": notes, "us_per_note": best / notes * 1e6, "notes_per_s": notes / best, "masks_left": int((out == 1).sum()),
             "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": per_note / (best / notes) / 1e9,
                          "frac": per_note / (best / notes) / 1e9 / 8000.0, "algorithmic_bytes_per_note": per_note,
-                         "note": "decoder weights (fp32) + mean K/V cache bytes per note; bound by the dependent hand-offs inside the persistent layer launch today (DESIGN.md §3 decode_layer.hip)"}}
+                         "note": "decoder weights (fp32) + mean K/V cache bytes per note; bound by the dependent hand-offs inside the persistent layer launch today (DESIGN.md section 3)"}}
 
 
 def _cpu_full_step(ref_cpu, cfg, cpu_state, batch, z, threads):

@@ -179,7 +179,7 @@ int spn_ce_bwd(const void* logits, int dtype, long ld, const long* labels, long 
                spn_stream_t s);
 int spn_segment_count(const long* seg, float* counts /* ACCUMULATED */, int b, int t, int S, spn_stream_t s);
 int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
-                    const uint8_t* rowmask, float* out /* ACCUMULATED; row stride out_ld >= d */, long out_ld, int b, int t, int S, int d,
+                    const uint8_t* rowmask, float* out /* ACCUMULATED (sums); ZERO on entry for means (counts given): whole runs are stored, not added; row stride out_ld >= d */, long out_ld, int b, int t, int S, int d,
                     spn_stream_t s);
 int spn_segment_gather(const float* src, long src_ld /* >= d */, const long* seg, const float* counts, const uint8_t* rowmask, float* y,
                        long y_ld, int b, int t, int S, int d, int accumulate, spn_stream_t s);

@@ -9,7 +9,7 @@
 // per-token but x, cond, y and the bf16 gamma rows the backward needs crosses the memory bus.  (A backward in the same style --
 // gamma recomputed by MFMA, d cond by MFMA against the transposed weight, dy * xhat rows out -- was built and measured in round 3: the
 // state it must hold between its two passes over a row (xhat, dy, d residual) does not fit 16-token MFMA tiles without spills, and at
-// 8 tokens per tile it ran 538 us against 272 us for the wave-per-row kernel it was to replace: not kept, DESIGN.md.)
+// 8 tokens per tile it ran 538 us against 272 us for the wave-per-row kernel it was to replace: not kept, docs/LOG.md section 7.)
 //
 // Orientation: gamma^T[f, t] = sum_k W[f, k] cond[t, k]  (v_mfma_f32_16x16x32_bf16: A = 16 weight rows x 32 k from LDS, B = 32 k x 16
 // tokens straight from global memory, 16 bytes per lane).  C/D layout: lane (c = lane & 15, g = lane >> 4) holds token c, features

@@ -392,7 +392,7 @@ static long long* g_dbg = nullptr;   // tuning aid (tools/gemm_timing.py): per-s
 // M / N edges: clamped loads + guarded stores.  K must be whole 64-tiles and >= 256; other shapes take the kernel above.
 constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_LEAD = 6;
 // DMA instructions a wave leaves in flight at the steady-state wait (2 per half-tile).  8 = the design point; tools/build_variant.py
-// builds 6 / 4 for the in-flight sensitivity probe of round 5
+// builds 6 / 4 for the in-flight sensitivity probe of round 5 (docs/LOG.md section 7)
 #ifndef PP_STEADY_VM
 #define PP_STEADY_VM 8
 #endif

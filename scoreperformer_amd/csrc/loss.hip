@@ -197,49 +197,6 @@ __global__ void seg_count_kernel(const long* __restrict__ seg, float* __restrict
     }
 }
 
-// out[b, s, c] += sum over maximal runs of equal ids of x[b, t, c] * scale(b, s);  one thread per (b, c), grid.y = b.
-// scale = 1 / max(counts, 1) when counts != null (mean) else 1 (sum).  Runs are flushed with one atomicAdd, so ids need
-// not be sorted (sorted ids -- the collator's contract -- give exactly one atomic per segment and column).
-// Rows are taken 8 at a time: the 8 ids and 8 values are loaded first (independent loads in flight), then folded in order.
-template <typename TX>
-__global__ void seg_sum_kernel(const TX* __restrict__ x, long x_bs, long x_ts, const long* __restrict__ seg,
-                               const float* __restrict__ counts, const uint8_t* __restrict__ rowmask, float* __restrict__ out, long out_ld,
-                               int t, int S, int d, int t_chunk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (c >= d) return;
-    const TX* xb = x + (long)b * x_bs;
-    const long* sb = seg + (long)b * t;
-    const int i_begin = blockIdx.z * t_chunk, i_end = min(t, i_begin + t_chunk);   // rows are split over blockIdx.z:
-    if (i_begin >= i_end) return;                                                  // a run cut by a chunk border is
-    float acc = 0.f;                                                               // completed by the atomics
-    long cur = sb[i_begin];
-    const uint8_t* mb = rowmask ? rowmask + (long)b * t : nullptr;
-    for (int i = i_begin; i < i_end; i += 8) {
-        long sg[8];
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int r = min(i + u, i_end - 1);
-            sg[u] = sb[r];
-            float xv;
-            if constexpr (sizeof(TX) == 4) xv = xb[(long)r * x_ts + c];
-            else xv = bf2f(xb[(long)r * x_ts + c]);
-            const bool live = (i + u < i_end) && (mb == nullptr || mb[r] != 0);
-            v[u] = live ? xv : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (sg[u] != cur) {
-                if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * out_ld + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
-                acc = 0.f; cur = sg[u];
-            }
-            acc += v[u];
-        }
-    }
-    if (acc != 0.f) atomicAdd(out + ((long)b * S + cur) * out_ld + c, acc * (counts ? 1.f / fmaxf(counts[(long)b * S + cur], 1.f) : 1.f));
-}
-
 // y[b, t, c] = src[b, seg[b,t], c] * scale * (rowmask ? rowmask[b,t] : 1);  scale = 1/max(counts[b,seg],1) if counts
 // VEC = 4: d, y_ld multiples of 4 and 16-byte aligned bases -> one float4 per thread; 32-bit index arithmetic (b*t*d < 2^31).
 template <int VEC>
@@ -436,15 +393,19 @@ extern "C" int spn_segment_count(const long* seg, float* counts, int b, int t, i
 
 // out[b,S,d] fp32 (row stride out_ld >= d: a column slice of a wider buffer; zeroed by caller) += segment sums (counts == null) or means
 // (counts given) of x[b,t,d]
+extern "C" int spn_segment_sum_multi(const void* x, int dtype, long x_bs, long x_ts, const uint8_t* rowmask, int nl, const long* const* seg,
+                                     const float* const* counts, float* const* out, const long* out_ld, const int* S, int b, int t, int d,
+                                     hipStream_t s);
 extern "C" int spn_segment_sum(const void* x, int dtype, long x_bs, long x_ts, const long* seg, const float* counts,
                                const uint8_t* rowmask, float* out, long out_ld, int b, int t, int S, int d, hipStream_t s) {
     SPN_REQUIRE(x && seg && out && b > 0 && t > 0 && S > 0 && d > 0 && out_ld >= d, "spn_segment_sum: bad arguments");
-    const int t_chunk = t > 256 ? 128 : t;
-    dim3 grid(cdiv(d, 64), b, cdiv(t, t_chunk));
-    if (dtype == 0) hipLaunchKernelGGL((seg_sum_kernel<float>), grid, dim3(64), 0, s, (const float*)x, x_bs, x_ts, seg, counts, rowmask, out, out_ld, t, S, d, t_chunk);
-    else hipLaunchKernelGGL((seg_sum_kernel<bf16_t>), grid, dim3(64), 0, s, (const bf16_t*)x, x_bs, x_ts, seg, counts, rowmask, out, out_ld, t, S, d, t_chunk);
-    SPN_LAUNCH_CHECK();
-    return SPN_OK;
+    // one level of the all-levels kernel (ids, counts and the row mask staged in LDS; whole runs stored, cut runs added atomically)
+    const long* segs[1] = {seg};
+    const float* cnts[1] = {counts};
+    float* outs[1] = {out};
+    const long lds[1] = {out_ld};
+    const int Ss[1] = {S};
+    return spn_segment_sum_multi(x, dtype, x_bs, x_ts, rowmask, 1, segs, counts ? cnts : nullptr, outs, lds, Ss, b, t, d, s);
 }
 
 // y[b*t, d] (row stride y_ld) (+)= src[b, seg, 0:d] (row stride src_ld >= d) (/ counts) (* rowmask)
@@ -479,79 +440,128 @@ struct SegMulti {
 // One COLUMN per lane, like seg_sum_kernel: a wave's flush is one atomicAdd instruction over 64 consecutive floats = two whole cache lines
 // (four columns per lane with 16-byte loads were measured in round 4 for the one-level kernel: 247 us against 141 -- each of its four
 // atomic instructions touches a quarter of eight lines, and the kernel is bound by its per-run flushes, not by loads in flight).
-template <typename TX>
-__global__ __launch_bounds__(64) void seg_sum_multi_kernel(SegMulti a, const TX* __restrict__ x, long x_bs, long x_ts,
-                                                           const uint8_t* __restrict__ rowmask, int t, int d, int t_chunk) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+template <typename TX, int NL>
+__global__ __launch_bounds__(256) void seg_sum_multi_kernel(SegMulti a, const TX* __restrict__ x, long x_bs, long x_ts,
+                                                            const uint8_t* __restrict__ rowmask, int t, int d, int t_chunk) {
+    // the chunk's ids (all levels), their counts and the row mask are staged in LDS once, by coalesced loads: fetched row by row inside
+    // the loop they are block-uniform SCALAR loads, a dependent trip to memory per eight rows that no number of resident waves hides
+    // (round 6: a pass that flushes nothing took 90 us for 134 MB; 34 us with the staging)
+    constexpr int MAXC = 256;
+    __shared__ int ids[NL][MAXC];
+    __shared__ float cnt[NL][MAXC];
+    __shared__ uint8_t live[MAXC];
     const int b = blockIdx.y;
-    if (c >= d) return;
     const int i_begin = blockIdx.z * t_chunk, i_end = min(t, i_begin + t_chunk);
     if (i_begin >= i_end) return;
-    const TX* xb = x + (long)b * x_bs + c;
-    const uint8_t* mb = rowmask ? rowmask + (long)b * t : nullptr;
-    float acc[8];
-    long cur[8];
+    const int rows = i_end - i_begin;
+    for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+        const long r = (long)b * t + i_begin + e;
 #pragma unroll
-    for (int l = 0; l < 8; ++l) { acc[l] = 0.f; cur[l] = l < a.nl ? a.seg[l][(long)b * t + i_begin] : 0; }
+        for (int l = 0; l < NL; ++l) {
+            const long sg = a.seg[l][r];
+            ids[l][e] = (int)sg;
+            cnt[l][e] = a.counts[l] ? a.counts[l][(long)b * a.S[l] + sg] : -1.f;      // -1: plain sums (no count to compare a run with)
+        }
+        live[e] = rowmask ? rowmask[r] : 1;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d) return;
+    const TX* xb = x + (long)b * x_bs + (long)i_begin * x_ts + c;
+    float acc[NL], len[NL], cn[NL];
+    int cur[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { acc[l] = 0.f; len[l] = 0.f; cur[l] = ids[l][0]; cn[l] = cnt[l][0]; }
+    // a run that holds EVERY row of its id in this sample (its length equals the id's count) is the only writer of its output row: a
+    // plain store; only runs cut by a chunk border (or ids that recur later: unsorted input) go through the L2's atomic unit
     auto flush = [&](int l) {
-        const long row = (long)b * a.S[l] + cur[l];
-        if (acc[l] != 0.f) atomicAdd(a.out[l] + row * a.ld[l] + c, acc[l] / fmaxf(a.counts[l][row], 1.f));
-        acc[l] = 0.f;
+        if (acc[l] != 0.f) {
+            float* o = a.out[l] + ((long)b * a.S[l] + cur[l]) * a.ld[l] + c;
+            const float v = cn[l] < 0.f ? acc[l] : acc[l] * (1.f / fmaxf(cn[l], 1.f));
+            if (len[l] == cn[l]) *o = v; else atomicAdd(o, v);
+        }
+        acc[l] = 0.f; len[l] = 0.f;
     };
-    for (int i = i_begin; i < i_end; i += 8) {
+    for (int i = 0; i < rows; i += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {          // eight rows requested before the first is folded
-            const int r = min(i + u, i_end - 1);
-            float xv;
-            if constexpr (sizeof(TX) == 4) xv = xb[(long)r * x_ts];
-            else xv = bf2f(xb[(long)r * x_ts]);
-            v[u] = (i + u < i_end && !(mb && mb[r] == 0)) ? xv : 0.f;
+            const int r = min(i + u, rows - 1);
+            if constexpr (sizeof(TX) == 4) v[u] = xb[(long)r * x_ts];
+            else v[u] = bf2f(xb[(long)r * x_ts]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int r = min(i + u, i_end - 1);
+            if (i + u >= rows) break;
+            const float xv = live[i + u] ? v[u] : 0.f;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                if (l >= a.nl) break;
-                const long sg = a.seg[l][(long)b * t + r];     // (block-uniform address: a scalar load)
-                if (sg != cur[l]) { flush(l); cur[l] = sg; }
-                acc[l] += v[u];
+            for (int l = 0; l < NL; ++l) {
+                const int sg = ids[l][i + u];
+                if (sg != cur[l]) { flush(l); cur[l] = sg; cn[l] = cnt[l][i + u]; }
+                acc[l] += xv; len[l] += 1.f;
             }
         }
     }
 #pragma unroll
-    for (int l = 0; l < 8; ++l) if (l < a.nl) flush(l);
+    for (int l = 0; l < NL; ++l) flush(l);
 }
 
-__global__ void seg_gather_multi_kernel(SegMulti a, const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld, unsigned BT,
-                                        int t, int d) {
-    const unsigned dv = (unsigned)d / 4, total = BT * dv;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned r = idx / dv, c = (idx - r * dv) * 4;
-        const unsigned b = r / (unsigned)t;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(rowmask && !rowmask[r])) {
+// y[b, t, c .. c + 3] = live * sum_l src_l[b, id_l, c ..] * scale_l with the ids and scales of the block's rows staged in LDS (a thread
+// looked its row's id up itself before: id -> source row, two dependent trips per element); four rows in flight per thread
+template <int NL>
+__global__ __launch_bounds__(256) void seg_gather_multi_kernel(SegMulti a, const uint8_t* __restrict__ rowmask, float* __restrict__ y, long y_ld,
+                                                               int t, int d, int t_chunk) {
+    constexpr int MAXC = 64;
+    __shared__ int ids[NL][MAXC];
+    __shared__ float scl[NL][MAXC];
+    __shared__ uint8_t live[MAXC];
+    const int b = blockIdx.y;
+    const int i_begin = blockIdx.x * t_chunk, i_end = min(t, i_begin + t_chunk);
+    if (i_begin >= i_end) return;
+    const int rows = i_end - i_begin;
+    for (int e = threadIdx.x; e < rows; e += blockDim.x) {
+        const long r = (long)b * t + i_begin + e;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) {
-                if (l >= a.nl) break;
-                const long row = (long)b * a.S[l] + a.seg[l][r];
-                v += *reinterpret_cast<const f32x4*>(a.out[l] + row * a.ld[l] + c) / fmaxf(a.counts[l][row], 1.f);
-            }
+        for (int l = 0; l < NL; ++l) {
+            const long sg = a.seg[l][r];
+            ids[l][e] = (int)sg;
+            scl[l][e] = a.counts[l] ? 1.f / fmaxf(a.counts[l][(long)b * a.S[l] + sg], 1.f) : 1.f;
         }
-        *reinterpret_cast<f32x4*>(y + (long)r * y_ld + c) = v;
+        live[e] = rowmask ? rowmask[r] : 1;
+    }
+    __syncthreads();
+    const int dv = d / 4;
+    for (int idx = threadIdx.x; idx < rows * dv; idx += 4 * blockDim.x) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id2 = idx + u * blockDim.x;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (id2 >= rows * dv) continue;
+            const int e = id2 / dv, c = (id2 - e * dv) * 4;
+            if (!live[e]) continue;
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                v[u] += *reinterpret_cast<const f32x4*>(a.out[l] + ((long)b * a.S[l] + ids[l][e]) * a.ld[l] + c) * scl[l][e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id2 = idx + u * blockDim.x;
+            if (id2 >= rows * dv) continue;
+            const int e = id2 / dv, c = (id2 - e * dv) * 4;
+            *reinterpret_cast<f32x4*>(y + ((long)b * t + i_begin + e) * y_ld + c) = v[u];
+        }
     }
 }
 
 static int fill_seg_multi(SegMulti& a, int nl, const long* const* seg, const float* const* counts, float* const* ptr, const long* ld,
                           const int* S, int d) {
-    SPN_REQUIRE(nl > 0 && nl <= 8 && seg && counts && ptr && ld && S, "spn_segment_*_multi: 1..8 levels");
+    SPN_REQUIRE(nl > 0 && nl <= 8 && seg && ptr && ld && S, "spn_segment_*_multi: 1..8 levels");
     memset(&a, 0, sizeof(a));
     a.nl = nl;
     for (int l = 0; l < nl; ++l) {
-        SPN_REQUIRE(seg[l] && counts[l] && ptr[l] && S[l] > 0 && ld[l] >= d && (ld[l] % 4) == 0 && ((uintptr_t)ptr[l] & 15) == 0,
-                    "spn_segment_*_multi: every level needs ids, counts and a 16-byte aligned [b, S, >= d] buffer");
-        a.seg[l] = seg[l]; a.counts[l] = counts[l]; a.out[l] = ptr[l]; a.ld[l] = ld[l]; a.S[l] = S[l];
+        SPN_REQUIRE(seg[l] && ptr[l] && S[l] > 0 && ld[l] >= d, "spn_segment_*_multi: every level needs ids and a [b, S, >= d] buffer");
+        a.seg[l] = seg[l]; a.counts[l] = counts ? counts[l] : nullptr; a.out[l] = ptr[l]; a.ld[l] = ld[l]; a.S[l] = S[l];
     }
     return SPN_OK;
 }
@@ -561,13 +571,21 @@ static int fill_seg_multi(SegMulti& a, int nl, const long* const* seg, const flo
 extern "C" int spn_segment_sum_multi(const void* x, int dtype, long x_bs, long x_ts, const uint8_t* rowmask, int nl, const long* const* seg,
                                      const float* const* counts, float* const* out, const long* out_ld, const int* S, int b, int t, int d,
                                      hipStream_t s) {
-    SPN_REQUIRE(x && b > 0 && t > 0 && d > 0 && (d % 4) == 0, "spn_segment_sum_multi: bad arguments (d a multiple of 4)");
+    SPN_REQUIRE(x && b > 0 && t > 0 && d > 0, "spn_segment_sum_multi: bad arguments");
     SegMulti a;
     if (int rc = fill_seg_multi(a, nl, seg, counts, out, out_ld, S, d)) return rc;
-    const int t_chunk = t > 256 ? 128 : t;
-    dim3 grid(cdiv(d, 64), b, cdiv(t, t_chunk));
-    if (dtype == 0) hipLaunchKernelGGL((seg_sum_multi_kernel<float>), grid, dim3(64), 0, s, a, (const float*)x, x_bs, x_ts, rowmask, t, d, t_chunk);
-    else hipLaunchKernelGGL((seg_sum_multi_kernel<bf16_t>), grid, dim3(64), 0, s, a, (const bf16_t*)x, x_bs, x_ts, rowmask, t, d, t_chunk);
+    const int t_chunk = t > 128 ? 128 : t;   // <= 256 rows (the LDS staging of the kernel)
+    const int TH = d >= 256 ? 256 : 64;
+    dim3 grid(cdiv(d, TH), b, cdiv(t, t_chunk));
+#define SPN_SEG_MULTI(NL_)                                                                                                                 \
+    case NL_:                                                                                                                              \
+        if (dtype == 0) hipLaunchKernelGGL((seg_sum_multi_kernel<float, NL_>), grid, dim3(TH), 0, s, a, (const float*)x, x_bs, x_ts, rowmask, t, d, t_chunk); \
+        else hipLaunchKernelGGL((seg_sum_multi_kernel<bf16_t, NL_>), grid, dim3(TH), 0, s, a, (const bf16_t*)x, x_bs, x_ts, rowmask, t, d, t_chunk);         \
+        break;
+    switch (nl) {
+        SPN_SEG_MULTI(1) SPN_SEG_MULTI(2) SPN_SEG_MULTI(3) SPN_SEG_MULTI(4) SPN_SEG_MULTI(5) SPN_SEG_MULTI(6) SPN_SEG_MULTI(7) SPN_SEG_MULTI(8)
+    }
+#undef SPN_SEG_MULTI
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }
@@ -580,7 +598,15 @@ extern "C" int spn_segment_gather_multi(int nl, const float* const* src, const l
                 "spn_segment_gather_multi: d, y_ld multiples of 4, y 16-byte aligned, b*t*d below 2^31");
     SegMulti a;
     if (int rc = fill_seg_multi(a, nl, seg, counts, const_cast<float* const*>(src), src_ld, S, d)) return rc;
-    hipLaunchKernelGGL(seg_gather_multi_kernel, dim3(grid_for((long)b * t * (d / 4))), dim3(256), 0, s, a, rowmask, y, y_ld, (unsigned)(b * t), t, d);
+    for (int l = 0; l < nl; ++l)
+        SPN_REQUIRE((src_ld[l] % 4) == 0 && ((uintptr_t)src[l] & 15) == 0, "spn_segment_gather_multi: sources 16-byte aligned, row strides multiples of 4");
+    const int t_chunk = 64;
+    dim3 grid(cdiv(t, t_chunk), b);
+#define SPN_SEG_GATHER(NL_) case NL_: hipLaunchKernelGGL((seg_gather_multi_kernel<NL_>), grid, dim3(256), 0, s, a, rowmask, y, y_ld, t, d, t_chunk); break;
+    switch (nl) {
+        SPN_SEG_GATHER(1) SPN_SEG_GATHER(2) SPN_SEG_GATHER(3) SPN_SEG_GATHER(4) SPN_SEG_GATHER(5) SPN_SEG_GATHER(6) SPN_SEG_GATHER(7) SPN_SEG_GATHER(8)
+    }
+#undef SPN_SEG_GATHER
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

@@ -686,8 +686,9 @@ def segment_count(seg: torch.Tensor, S: int) -> torch.Tensor:
 
 def segment_sum(x: torch.Tensor, seg: torch.Tensor, S: int, *, counts: Optional[torch.Tensor] = None,
                 rowmask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x [b,t,d] (fp32/bf16, unit inner stride) -> out fp32 [b,S,d]: per-segment sums, or means when counts is given.  `out` (ACCUMULATED
-    into) may be a column slice `agg[..., c0:c0+d]` of a contiguous [b,S,W] buffer."""
+    """x [b,t,d] (fp32/bf16, unit inner stride) -> out fp32 [b,S,d]: per-segment sums, or means when counts is given.  `out` may be a
+    column slice `agg[..., c0:c0+d]` of a contiguous [b,S,W] buffer; sums are ADDED to it, means need it ZERO on entry (a run that holds
+    every row of its id is stored, not added)."""
     seg = seg.contiguous()
     if x.stride(-1) != 1:
         x = x.contiguous()

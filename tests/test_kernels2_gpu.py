@@ -80,6 +80,30 @@ def test_segment_count_sum_gather(d, S, mode):
     means = ops.segment_sum(x, seg, S, counts=counts, rowmask=mask)
     want_m = torch.einsum("bts,btd->bsd", onehot, x * mask[..., None]) / counts.clamp_min(1)[..., None]
     assert rel_err(means, want_m) < 1e-5
+    # all levels in one pass (spn_segment_sum_multi / _gather_multi): this segmentation, a second one (sorted runs) and the sequence mean,
+    # into column slices of wider per-level buffers; unsorted ids exercise the atomic path, whole runs the plain-store path
+    seg2 = torch.cumsum((torch.rand(b, t, generator=g) < 0.3).long(), 1).to(DEV)
+    S2 = int(seg2.max()) + 1
+    seg3 = (~mask).long()
+    levels = [(seg, S), (seg2, S2), (seg3, 2)]
+    cnts = [ops.segment_count(sg_, k) for sg_, k in levels]
+    if d % 4 == 0:
+        bufs = [torch.zeros(b, k, d + 4 * i, device=DEV) for i, (_, k) in enumerate(levels)]
+        for dt in (torch.float32, torch.bfloat16):
+            for bf in bufs:
+                bf.zero_()
+            xin = x.to(dt)
+            ops.segment_sum_multi(xin, mask, [l[0] for l in levels], cnts, [bf[..., :d] for bf in bufs], [l[1] for l in levels])
+            for (sg_, k), cn, bf in zip(levels, cnts, bufs):
+                oh = F.one_hot(sg_, k).float()
+                want_l = torch.einsum("bts,btd->bsd", oh, xin.float() * mask[..., None]) / cn.clamp_min(1)[..., None]
+                assert rel_err(bf[..., :d], want_l) < 1e-5
+                assert float(bf[..., d:].abs().max()) == 0.0 if bf.shape[-1] > d else True
+        srcs = [torch.randn(b, k, d + 4 * i, generator=g).to(DEV) for i, (_, k) in enumerate(levels)]
+        got = ops.segment_gather_multi([s_[..., :d] for s_ in srcs], [l[0] for l in levels], cnts, [l[1] for l in levels], mask, d)
+        want_g = sum(torch.gather(s_[..., :d] / cn.clamp_min(1)[..., None], 1, sg_[..., None].expand(b, t, d))
+                     for s_, cn, (sg_, _) in zip(srcs, cnts, levels)) * mask[..., None]
+        assert rel_err(got, want_g) < 1e-6
     src = torch.randn(b, S, d, generator=g).to(DEV)
     y = ops.segment_gather(src, seg, counts=counts, rowmask=mask)
     want_y = torch.gather(src / counts.clamp_min(1)[..., None], 1, seg[..., None].expand(b, t, d)) * mask[..., None]
