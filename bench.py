@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the child command and exit")
     ap.add_argument("--no-decode", action="store_true", help="skip the C5 decode object (N = 1 only)")
     ap.add_argument("--decode-seq", type=int, default=4096)
+    ap.add_argument("--no-phases", action="store_true", help="skip the `phases` object (5 more steps with events; profiling runs)")
     ap.add_argument("--sustained-seconds", type=float, default=25.0,
                     help="N = 1 only, after the timed region: keep stepping for this long (>= 50 steps) and report ms/step, its drift and the "
                          "mean shader clock / socket power from rocm-smi -- the chip runs this step at its power limit and a 20-step line "
@@ -235,7 +236,8 @@ def main():
         roof = roofline_leg(ops, step, args)
         if rank == 0:
             result["roofline"] = roof
-    result["phases"] = phases_leg(model, batch, opt, holder, world)           # every rank runs it (it contains the all-reduce)
+    if not args.no_phases:
+        result["phases"] = phases_leg(model, batch, opt, holder, world)       # every rank runs it (it contains the all-reduce)
     if rank == 0 and world == 1 and args.sustained_seconds > 0:
         result["sustained"] = sustained_leg(step, args.sustained_seconds, local_rank, args.batch * args.seq)
     if rank == 0 and world == 1 and dist is None and not args.no_dp1_forced:

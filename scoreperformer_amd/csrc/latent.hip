@@ -232,39 +232,52 @@ struct DropArgs {
     int nl, inclusive;
 };
 
-// thread = 4 consecutive columns of one note.  emb / out [b * n, W] fp32, drop [b * n, W] bytes (bool)
-__global__ void latent_drop_kernel(DropArgs a, const float* __restrict__ emb, const uint8_t* __restrict__ mask,
-                                   const uint8_t* __restrict__ deadpan, int n, int W, long rows, uint32_t seed, float* __restrict__ out,
-                                   uint8_t* __restrict__ drop) {
-    const int per = (W + 3) / 4;
-    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= rows * per) return;
-    const long r = q / per;
-    const int c0 = (int)(q % per) * 4;
-    const int bi = (int)(r / n), t = (int)(r % n);
-    const bool live = mask[r] && !(deadpan && deadpan[bi]);
-    bool prior = false;
-    bool hit[8];
-    for (int l = 0; l < a.nl; ++l) {
-        const DropLevel& L = a.lv[l];
-        bool d = false;
-        if (L.given || L.thr24) {
-            const long s = L.seg ? L.seg[r] : (L.S == 1 ? 0 : t);
-            if (s >= 0 && s < L.S) {
-                const long li = (long)bi * L.S + s;
-                if (L.given) d = L.given[li] != 0;
-                else d = L.lmask[li] && (spn_hash32(seed + (uint32_t)l * 0x632BE5ABu + spn_hash32((uint32_t)li * 0x9E3779B1u + 0x51ED27u)) >> 8) < L.thr24;
+// One block = 64 notes of one sequence.  Phase 1: one thread per note decides, level by level, whether the note's latent is dropped (the
+// dependent chain segment id -> latent mask -> hash runs ONCE per note, its result -- a bit per level -- goes to LDS); phase 2: all threads
+// stream the block's [64, W] slab of embeddings, four columns each.  emb / out [b * n, W] fp32, drop [b * n, W] bytes (bool).
+constexpr int DROP_ROWS = 64;
+__global__ __launch_bounds__(256) void latent_drop_kernel(DropArgs a, const float* __restrict__ emb, const uint8_t* __restrict__ mask,
+                                                          const uint8_t* __restrict__ deadpan, int n, int W, uint32_t seed,
+                                                          float* __restrict__ out, uint8_t* __restrict__ drop) {
+    __shared__ uint32_t hits[DROP_ROWS];
+    const int bi = blockIdx.y, t0 = blockIdx.x * DROP_ROWS;
+    const int rows = min(DROP_ROWS, n - t0);
+    if (threadIdx.x < rows) {
+        const int t = t0 + threadIdx.x;
+        const long r = (long)bi * n + t;
+        uint32_t bits = 0u;
+        if (mask[r] && !(deadpan && deadpan[bi])) {
+            bool prior = false;
+            for (int l = 0; l < a.nl; ++l) {
+                const DropLevel& L = a.lv[l];
+                bool d = false;
+                if (L.given || L.thr24) {
+                    const long s = L.seg ? L.seg[r] : (L.S == 1 ? 0 : t);
+                    if (s >= 0 && s < L.S) {
+                        const long li = (long)bi * L.S + s;
+                        if (L.given) d = L.given[li] != 0;
+                        else d = L.lmask[li] && (spn_hash32(seed + (uint32_t)l * 0x632BE5ABu + spn_hash32((uint32_t)li * 0x9E3779B1u + 0x51ED27u)) >> 8) < L.thr24;
+                    }
+                }
+                if (a.inclusive) { prior = prior || d; d = prior; }
+                bits |= d ? 1u << l : 0u;
             }
         }
-        if (a.inclusive) { prior = prior || d; d = prior; }
-        hit[l] = d;
+        hits[threadIdx.x] = bits;
     }
-    for (int c = c0; c < min(c0 + 4, W); ++c) {
-        bool d = false;
-        for (int l = 0; l < a.nl; ++l) if (c >= a.lv[l].col0 && c < a.lv[l].col1) d = hit[l];
-        d = d && live;
-        drop[r * W + c] = d ? 1 : 0;
-        out[r * W + c] = d ? 0.f : emb[r * W + c];
+    __syncthreads();
+    const int per = (W + 3) / 4;
+    const long base = ((long)bi * n + t0) * W;
+    for (int q = threadIdx.x; q < rows * per; q += blockDim.x) {
+        const int e = q / per, c0 = (q - e * per) * 4;
+        const uint32_t bits = hits[e];
+        for (int c = c0; c < min(c0 + 4, W); ++c) {
+            bool d = false;
+            for (int l = 0; l < a.nl; ++l) if (c >= a.lv[l].col0 && c < a.lv[l].col1) d = (bits >> l) & 1u;
+            const long o = base + (long)e * W + c;
+            drop[o] = d ? 1 : 0;
+            out[o] = d ? 0.f : emb[o];
+        }
     }
 }
 
@@ -322,8 +335,7 @@ extern "C" int spn_latent_drop(int nl, const long* const* seg, const uint8_t* co
         a.lv[l].given = given ? given[l] : nullptr;
         SPN_REQUIRE(a.lv[l].lmask || a.lv[l].given || a.lv[l].thr24 == 0, "spn_latent_drop: a drawing level needs its latent mask");
     }
-    const long rows = (long)b * n, q = rows * ((W + 3) / 4);
-    hipLaunchKernelGGL(latent_drop_kernel, dim3(cdiv(q, 256)), dim3(256), 0, s, a, emb, mask, deadpan, n, W, rows, (uint32_t)seed, out, drop);
+    hipLaunchKernelGGL(latent_drop_kernel, dim3(cdiv(n, DROP_ROWS), b), dim3(256), 0, s, a, emb, mask, deadpan, n, W, (uint32_t)seed, out, drop);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
 }

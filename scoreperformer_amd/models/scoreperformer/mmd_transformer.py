@@ -83,12 +83,14 @@ class HierLatentsFn(Function):
     """
 
     @staticmethod
-    def _one_pass(hidden, hierarchical, modes):
+    def _one_pass(hidden, hierarchical, modes, Ls):
         """Every level aggregates the same hidden states (sequence mean or a segmentation), so ONE pass over them serves all levels
         (ops.segment_sum_multi / segment_gather_multi): the shipped recipes.  `same` levels and `hierarchical_with_context=False` keep the
         level-by-level path."""
         agg_modes = (EmbeddingAggregateModes.MEAN,) + SEGMENT_MODES
-        return (hidden.is_cuda and hidden.shape[-1] % 4 == 0 and len(modes) <= 8 and hierarchical != "no-context"
+        # (the one-pass backward reads 16-byte pieces of every level's [b, S, d + earlier latent widths] gradient: widths on the 4-float grid)
+        on_grid = all(sum(Ls[:i]) % 4 == 0 for i in range(len(Ls))) or not hierarchical
+        return (hidden.is_cuda and hidden.shape[-1] % 4 == 0 and len(modes) <= 8 and hierarchical != "no-context" and on_grid
                 and all(m in agg_modes for m in modes) and hidden.dtype in (torch.float32, torch.bfloat16))
 
     @staticmethod
@@ -172,7 +174,7 @@ class HierLatentsFn(Function):
         # hierarchical: False, True (level i reads the hidden states AND the embeddings of the levels before it: a column prefix of `wide`)
         # or "no-context" (level i > 0 reads ONLY level i - 1's embeddings: `hierarchical_with_context=False`, mmd_transformer.py:255-262)
         ctx.one_pass = None
-        if HierLatentsFn._one_pass(hidden, hierarchical, modes) and ONE_PASS_LEVELS:
+        if ONE_PASS_LEVELS and HierLatentsFn._one_pass(hidden, hierarchical, modes, [w.shape[0] for w in wb[:len(modes)]]):
             return HierLatentsFn._forward_one_pass(ctx, hidden, mask, hierarchical, modes, segs, seg_sizes, wb)
         b, n, d = hidden.shape
         nl = len(modes)

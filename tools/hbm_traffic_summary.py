@@ -29,9 +29,10 @@ alg = [
     ("attn_bwd_dkv_kernel<true>", "Q + dO 268 MB read (8 heads share K/V), keep bits 268 MB read, K + V 33.5 MB read, dK + dV 33.5 MB written, lse / delta 8 MB", 268.4e6 + 268.4e6 + 33.5e6 + 33.5e6 + 8.4e6),
     ("gemm_duo8_glu_bwd_kernel<0>", "u read + du written 2 x 1074 MB, dy operand 134 MB, W2 2 MB, column-sum partials 17 MB", 2 * 1073.7e6 + 134.2e6 + 2.1e6 + 16.8e6),
     ("gemm_pp_kernel<false, false, unsigned short, 1, true>", "x operand 134 MB + W1 4 MB read, u 1074 MB + g 537 MB written", 134.2e6 + 4.2e6 + 1073.7e6 + 536.9e6),
+    ("seg_sum_multi_kernel<float, 4>", "round 6: the hidden states fp32 [T, 512] read ONCE for all four latent levels + ids 32 B per row + the levels' means written (S = 2 + 155 + 561 + 1082 slots x 64 sequences x 512 x 4 B)", 4 * T * D + 32 * T + (2 + 155 + 561 + 1082) * 64 * D * 4),
     ("adamw_kernel", "30 B per parameter (p, g, m, v read; p, m, v, bf16 copy written; g zeroed): 71.9 M parameters", 71895400 * 30),
 ]
-ROUND = sys.argv[4] if len(sys.argv) > 4 else "round 4"
+ROUND = sys.argv[4] if len(sys.argv) > 4 else "round 6"
 out = {"measured": ROUND + ", tools/pmc_step_traffic.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, C3 step b=64 n=2048 dropout 0.1, final tree)",
        "correction": "FETCH_SIZE x 2 (gfx950: wide streaming reads tallied at half their bytes, MI355X_MICROARCH.md); WRITE_SIZE as printed; both count Infinity-Cache hits",
        "kernels": {}}
