@@ -228,7 +228,9 @@ extern "C" int spn_gemm_f32(const float* a, long sam, long sak, const float* b, 
                             hipStream_t stream) {
     SPN_REQUIRE(a && b && c && M > 0 && N > 0 && K > 0, "spn_gemm_f32: bad arguments");
     // both operands contiguous along K, float4-loadable: the fp32 MFMA kernels -- 128-tiles when they fill the chip twice over, else 64-tiles
-    if (sak == 1 && sbk == 1 && (K & 3) == 0 && (sam & 3) == 0 && (sbn & 3) == 0 && M >= 48 && N >= 64 &&
+    // (round 6: also the tall products with a handful of output columns -- the VAE head projections, M = all latents of a level, N = 4..32:
+    // they stream A once, and the 64-tile kernel streams it at 2-3x the rate of the VALU tiles whatever fraction of its columns is padding)
+    if (sak == 1 && sbk == 1 && (K & 3) == 0 && (sam & 3) == 0 && (sbn & 3) == 0 && M >= 48 && (N >= 64 || (N >= 4 && M >= 4096)) &&
         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && spn_tune_i(SPN_TUNE_GEMM_F32_MFMA) != 0) {
         const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64);
 #define MF(TT_, TK__, SP_) launch_mfma<TT_, TK__, SP_>(a, sam, b, sbn, c, ldc, bias, M, N, K, alpha, accumulate, rowmask, stream)

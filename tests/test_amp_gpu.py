@@ -5,7 +5,7 @@ tests run the same call with and without an enabled fp16 autocast context and re
 of both bindings, the module-level operators a user may call on their own, the evaluator, and the cached greedy decode on both the
 engine and the module path.  "The same" is bit-identical wherever the kernels are run-to-run deterministic (logits, tokens, module
 outputs) and 3e-6 relative where sums go through float atomics (loss entries, gradients: two plain runs differ by 1-3e-7 there,
-`tools/scratch/det_probe.py`) -- three orders of magnitude below what a recast to fp16 of any intermediate would leave."""
+`tools/det_probe.py`) -- three orders of magnitude below what a recast to fp16 of any intermediate would leave."""
 import os
 
 import numpy as np

@@ -1,3 +1,6 @@
+"""Run-to-run noise of one tiny train step (loss entries, logits, gradients) with autocast off / off / on, both bindings: the tolerances of
+tests/test_amp_gpu.py come from here (sums through float atomics differ by 1-3e-7 between two plain runs; logits are bit-identical).
+    python tools/det_probe.py"""
 import sys, torch
 sys.path.insert(0, ".")
 from oracle.weights import filled_state_dict

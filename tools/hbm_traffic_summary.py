@@ -46,10 +46,13 @@ for name, desc, a in alg:
                          "counter_over_algorithmic": round(r["hbm_bytes_per_launch"] / a, 3), "algorithmic": desc}
 if "dec_pair_kernel" in dec:
     r = dec["dec_pair_kernel"]
-    out["kernels"]["dec_pair_kernel"] = {"launches_sampled": r["launches"], "counter_bytes_per_launch": round(r["hbm_bytes_per_launch"]), "fetch_bytes_x2": round(r["fetch_bytes_x2"]),
+    NOTES = 383                                 # tools/pmc_step_traffic.sh decodes L = 384 positions; a launch carries up to 16 notes since round 5
+    per_note = r["hbm_bytes_per_launch"] * r["launches"] / NOTES
+    out["kernels"]["dec_pair_kernel"] = {"launches_sampled": r["launches"], "notes": NOTES, "counter_bytes_per_launch": round(per_note),
+                                         "counter_bytes_per_kernel_launch": round(r["hbm_bytes_per_launch"]), "fetch_bytes_x2": round(r["fetch_bytes_x2"]),
                                          "write_bytes": round(r["write_bytes"]), "algorithmic_bytes_per_launch": round(107.9e6),
-                                         "counter_over_algorithmic": round(r["hbm_bytes_per_launch"] / 107.9e6, 3),
-                                         "algorithmic": "one note of the C5 decoder (L = 384 in this pass): 6 layer pairs of fp32 weights (15 MB each) + projections + K/V rows inside the ALiBi reach"}
+                                         "counter_over_algorithmic": round(per_note / 107.9e6, 3),
+                                         "algorithmic": "PER NOTE of the C5 decoder (L = 384 in this pass; `counter_bytes_per_launch` is per note too: kernel launches x bytes / 383 notes): 6 layer pairs of fp32 weights (15 MB each) + projections + K/V rows inside the ALiBi reach"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["kernels"].items():
     print(f"{v['counter_over_algorithmic']:6.2f}  {v['counter_bytes_per_launch'] / 1e6:8.1f} MB vs {v['algorithmic_bytes_per_launch'] / 1e6:8.1f}  {k}")
