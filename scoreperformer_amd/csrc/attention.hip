@@ -732,6 +732,7 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
     const int off = a.nk - a.nq;
     const bool is_q = x < a.nqt64;
     if (!is_q && hi >= a.kvh) return;
+    if (is_q && band_head_unbounded(a, a.slopes[hi] * LOG2E)) return;   // this head never skips: band_reach will not read its entries
     const int n = is_q ? a.nq : a.nk;
     const long nq_part = (long)a.b * a.h * a.nqt64;
     const int ch = lane & 7;

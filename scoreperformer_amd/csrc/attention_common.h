@@ -46,8 +46,15 @@ struct AttnArgs {
 // every probability of the tile's rows is below 2^-band_log2 of its row's largest one.  (Until round 2 the row maximum was bounded by
 // -c1 |q_i| max|k| instead of the actual diagonal score: 2 c1 max|q| max|k| in the numerator, a ~1.7x longer reach at initialisation.)
 // band layout: [b*h*nqt64] max |q_i|^2 per 64-row tile (+inf: never skip), [b*h*nqt64] min q_i.k_i' per tile, [b*kvh] max |k_j|^2.
+// A head whose slope is so shallow that even the numerator's floor (band_log2: Cauchy-Schwarz makes the rest non-negative) reaches past
+// every distance of the problem can never skip a tile: the pre-pass does not compute its row norms (round 6: 2 of 8 heads at the
+// initial slopes, a quarter of the pre-pass's pass over q) and band_reach answers "unbounded" without reading them -- the same test on
+// both sides, so the three kernels and the pre-pass stay consistent.
+__device__ __forceinline__ bool band_head_unbounded(const AttnArgs& a, float slope2) {
+    return !(slope2 > 0.f) || a.band_log2 >= slope2 * (float)(a.nq + a.nk);
+}
 __device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, int kh, int qtile64, int ntiles, float c1, float slope2) {
-    if (!a.band || !(slope2 > 0.f)) return 3.0e38f;
+    if (!a.band || band_head_unbounded(a, slope2)) return 3.0e38f;
     const long nq_part = (long)a.b * a.h * a.nqt64;
     const float* qt = a.band + ((long)(bi * a.h + hi)) * a.nqt64 + qtile64;
     float qm = qt[0], dm = qt[nq_part];

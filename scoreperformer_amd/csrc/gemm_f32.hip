@@ -234,7 +234,7 @@ extern "C" int spn_gemm_f32(const float* a, long sam, long sak, const float* b, 
         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && spn_tune_i(SPN_TUNE_GEMM_F32_MFMA) != 0) {
         const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64);
 #define MF(TT_, TK__, SP_) launch_mfma<TT_, TK__, SP_>(a, sam, b, sbn, c, ldc, bias, M, N, K, alpha, accumulate, rowmask, stream)
-        if ((long)cdiv(M, 128) * cdiv(N, 128) >= 512) MF(128, 16, 1);
+        if (N >= 64 && (long)cdiv(M, 128) * cdiv(N, 128) >= 512) MF(128, 16, 1);   // (a skinny product's second 64 columns would be padding)
         else if (wg64 >= 384 || K < 256) MF(64, 64, 1);      // every CU has its workgroup(s) already, or there is hardly a K loop
         else if (K >= 2048) MF(64, 32, 4);                   // few workgroups, long K: four K groups per tile
         else MF(64, 64, 2);
