@@ -21,7 +21,7 @@ constexpr int SEL_MAX_K = 4096;            // so does the slot -> latent map (16
 
 // random key of latent i: never 0 for a valid latent (0 = "not a candidate")
 __device__ __forceinline__ uint32_t sel_key(uint32_t seed, uint32_t i, const uint32_t* bits) {
-    return ((bits[i >> 5] >> (i & 31u)) & 1u) ? (spn_hash32(seed ^ spn_hash32(i * 0x9E3779B1u + 0x7F4A7C15u)) | 1u) : 0u;
+    return ((bits[i >> 5] >> (i & 31u)) & 1u) ? (spn_hash32(seed + i * 0x9E3779B1u) | 1u) : 0u;   // (one finaliser round: the key is recomputed in every pass)
 }
 
 // exclusive prefix sums of (a, b) over the 1024 threads of the block, in thread order; totals in ta / tb.  scratch: 2 x 16 ints.
