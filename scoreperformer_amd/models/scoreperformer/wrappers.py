@@ -294,21 +294,31 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
     def _engine_for(self, filled: Tensor, mask: Tensor, caches, banned, filter_logits_fn, filter_kwargs):
         """The hipGraph-replayed fp32 decode engine (decode.py) serves the common call: greedy, fresh caches -- one sequence, or (round 5)
         several with the SAME layout of MASK sub-tokens, which is what the reference's loop assumes anyway (it takes the layout of batch
-        element 0 for all, wrappers.py:385-396): the sequences then go through the engine one after the other.  RIGHT-padded batches too: a
-        causal decoder's valid positions never see the padded keys behind them, so every sequence runs over its own valid prefix and its
-        padded tail is left as given (the reference writes draws from padded rows there: don't-care values).  Returns (engine, valid
-        lengths or None); (None, None) = module path."""
+        element 0 for all, wrappers.py:385-396): the sequences then go through the engine one after the other.  PADDED batches too, when
+        every sequence's notes are one contiguous block (right-padded, front-padded or both): a causal decoder's valid positions never
+        see the padded keys behind them, masked keys in front of them are invisible, and every position-dependent term (ALiBi, the
+        per-note context / style) is relative or per note -- so every sequence runs over its own valid block and the padded positions are
+        left as given (the reference writes draws from padded rows there: don't-care values).  Holed masks take the module path.  Returns
+        (engine, per-sequence (first, end) spans or None); (None, None) = module path."""
         usable = (filled.is_cuda and caches is None and not banned
                   and is_greedy(filter_logits_fn, filter_kwargs) and getattr(self, "use_decode_engine", True))
         lens = None
         if usable and not bool(mask.all()):
             m = mask.bool()
-            usable = bool(m[:, 0].all()) and bool((m[:, 1:] <= m[:, :-1]).all())     # padding only BEHIND the notes
+            mi = m.int()
+            edges = (mi[:, 1:] - mi[:, :-1])
+            # the notes of every sequence are ONE block: at most one rising and one falling edge, in that order, and at least one note
+            usable = bool(((edges == 1).sum(1) + mi[:, 0] == 1).all()) and bool(((edges == -1).sum(1) <= 1).all())
             if usable:
+                first = torch.argmax(mi, dim=1)
+                count = mi.sum(dim=1)
                 holes = (filled == self.mask_token_id) & m[..., None]
-                # one MASK layout on every valid position (and nothing to decode where element 0, whose layout the reference uses, is padded)
-                usable = bool(((holes == holes[:1]) | ~m[..., None]).all()) and not bool((holes & ~m[:1, :, None]).any())
-                lens = [int(n) for n in m.sum(dim=1).tolist()]
+                # one MASK layout on every valid position, nothing to decode where element 0 (whose layout the reference uses) is padded,
+                # and nothing to decode at a block's own first note behind padding (it has no valid predecessor to be predicted from)
+                at_first = holes[torch.arange(holes.shape[0], device=holes.device), first].any(dim=1) & (first > 0)
+                usable = (bool(((holes == holes[:1]) | ~m[..., None]).all()) and not bool((holes & ~m[:1, :, None]).any())
+                          and not bool(at_first.any()))
+                lens = [(int(a), int(a) + int(c)) for a, c in zip(first.tolist(), count.tolist())]
         elif usable and filled.shape[0] > 1:
             holes = filled == self.mask_token_id
             usable = bool((holes == holes[:1]).all())
@@ -323,17 +333,23 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
             return None, None
 
     @staticmethod
-    def _stack_caches(per_seq):
+    def _stack_caches(per_seq, spans=None):
         """Caches of single-sequence engine runs -> one TupleTransformerCaches with the batch in front (the reference's layout).  Runs over
-        prefixes of different lengths (a right-padded batch) are zero-padded to the longest along the position axis."""
+        blocks of different extents (a padded batch; `spans` = their (first, end) positions) are zero-padded along the position axis: in
+        front up to the block's first position, behind up to the longest end."""
         from .transformer import TupleTransformerCaches
         from ...modules.transformer.attend import AttentionIntermediates
         from ...modules.transformer.transformer import TransformerIntermediates
+        spans = spans or [(0, None)] * len(per_seq)
 
         def cat(ts, pos_dim):
-            n = max(t.shape[pos_dim] for t in ts)
-            ts = [t if t.shape[pos_dim] == n else F.pad(t, (0, 0) * (t.ndim - 1 - pos_dim) + (0, n - t.shape[pos_dim])) for t in ts]
-            return torch.cat(ts, dim=0)
+            # a cache tensor of run i covers positions first_i .. first_i + its own length (the shifted input drops the last note)
+            n = max(a + t.shape[pos_dim] for t, (a, _) in zip(ts, spans))
+            out = []
+            for t, (a, _) in zip(ts, spans):
+                back = n - a - t.shape[pos_dim]
+                out.append(t if a == 0 and back == 0 else F.pad(t, (0, 0) * (t.ndim - 1 - pos_dim) + (a, back)))
+            return torch.cat(out, dim=0)
 
         first = per_seq[0]
         hid = [cat([c.transformer.hiddens[i] for c in per_seq], 1) for i in range(len(first.transformer.hiddens))]
@@ -366,23 +382,23 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
                 L = filled.shape[1]
                 per_note_ctx = self.model.context_emb_mode == "cat"      # else: a whole cross-attended sequence with its own mask
 
-                def pick(t, i, n, per_note=True):
-                    return None if t is None else (t[i:i + 1, :n] if per_note else t[i:i + 1])
+                def pick(t, i, a, e, per_note=True):
+                    return None if t is None else (t[i:i + 1, a:e] if per_note else t[i:i + 1])
 
                 rows, per_seq = [], []
                 for i in range(filled.shape[0]):
-                    n = L if lens is None else lens[i]
-                    row, _ = engine.run(filled[i:i + 1, :n], masked_view[i:i + 1, :n], pick(kwargs.get("context"), i, n, per_note_ctx),
-                                        pick(kwargs.get("style_embeddings"), i, n), self.mask_token_id,
-                                        context_mask=pick(kwargs.get("context_mask"), i, n, False))
-                    rows.append(row.clone() if n == L else torch.cat([row, filled[i:i + 1, n:]], dim=1))
+                    a, e = (0, L) if lens is None else lens[i]
+                    row, _ = engine.run(filled[i:i + 1, a:e], masked_view[i:i + 1, a:e], pick(kwargs.get("context"), i, a, e, per_note_ctx),
+                                        pick(kwargs.get("style_embeddings"), i, a, e), self.mask_token_id,
+                                        context_mask=pick(kwargs.get("context_mask"), i, a, e, False))
+                    rows.append(row.clone() if (a, e) == (0, L) else torch.cat([filled[i:i + 1, :a], row, filled[i:i + 1, e:]], dim=1))
                     if return_caches:    # the engine's buffers are overwritten by the next sequence
                         c = engine.caches()
                         per_seq.append(type(c)(token_emb=c.token_emb.clone(), transformer=type(c.transformer)(
                             hiddens=[h.clone() for h in c.transformer.hiddens],
                             attention=[type(a)(keys=a.keys.clone(), values=a.values.clone()) for a in c.transformer.attention])))
                 filled = torch.cat(rows, dim=0)
-                caches = self._stack_caches(per_seq) if return_caches else None
+                caches = self._stack_caches(per_seq, lens) if return_caches else None
             else:
                 holes = filled == self.mask_token_id
                 holes_host = holes[0].cpu()   # ONE host read of the mask layout per window (the reference reads it per note: :385-390)

@@ -574,7 +574,8 @@ def test_decode_engine_serves_a_batch_of_sequences_with_one_mask_layout(dev):
     un-padded sequences with one layout go through the fp32 decode engine one after the other.  Row 0 is the reference's own fixture and
     must come out token for token; every row equals its own single-sequence engine call bit for bit (tokens AND caches, in the reference's
     batch-first layouts); the CPU oracle's greedy loop confirms a perturbed row; a RIGHT-padded batch takes the engine too (every sequence over
-    its valid prefix); padding in front of the notes, holes in the mask, or rows with different layouts still take the module path."""
+    its valid prefix) and so does a FRONT-padded one whose blocks start with a given note (round 6); a block whose first note is itself to be
+    decoded, holes in the mask, or rows with different layouts still take the module path."""
     from oracle import ref_cpu
     from oracle.weights import filled_state_dict
     from scoreperformer_amd.arena import ParamArena
@@ -653,12 +654,50 @@ def test_decode_engine_serves_a_batch_of_sequences_with_one_mask_layout(dev):
         assert torch.equal(caches_t.transformer.hiddens[-1][0], caches_p.transformer.hiddens[-1][2, :nt])
         kt, kp = caches_t.transformer.attention[0].keys, caches_p.transformer.attention[0].keys
         assert torch.equal(kt[0], kp[2, :nt] if kp.ndim == 3 else kp[2, :, :nt])
-        # padding in FRONT of the notes, or holes in the mask, keep the module path
+        # padding in FRONT of the notes (round 6): the engine runs every sequence over its own block of notes -- masked keys in front are
+        # invisible and every position-dependent term is relative (ALiBi) or per note.  The block's first note must be given (it has no
+        # valid predecessor to be predicted from), here in every row because the rows share one MASK layout.
+        n_before = len(runs)
+        front = 3
+        f_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
+        f_mask[:, :front] = False
+        f_mask[2, cut:] = False                                      # row 2: padded on both sides
+        tok_f, msk_f = tok_b.clone(), msk_b.clone()
+        tok_f[:, :front], msk_f[:, :front] = 0, 0
+        tok_f[2, cut:], msk_f[2, cut:] = 0, 0
+        tok_f[:, front] = out_b[:, front].cpu()                      # the block's first note: given in full (no MASK sub-token)
+        msk_f[:, front] = tok_f[:, front]
+        out_f, caches_f = dec.unmask_tokens(tok_f.to(dev), msk_f.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev),
+                                            mask=f_mask.to(dev), **kw)
+        assert len(runs) == n_before + 3 and tuple(out_f.shape) == tuple(tok_b.shape)
+        assert int((out_f[:, :front].cpu() != 0).sum()) == 0 and int((out_f[2, cut:].cpu() != 0).sum()) == 0     # padding left alone
+        assert int((out_f.cpu()[f_mask] == 1).sum()) == 0                                                         # every note decoded
+        for r, end in ((0, Lb), (1, Lb), (2, cut)):
+            out_t, caches_t = dec.unmask_tokens(tok_f[r:r + 1, front:end].to(dev), msk_f[r:r + 1, front:end].to(dev),
+                                                context=ctx_b[r:r + 1, front:end].to(dev), style_embeddings=sty_b[r:r + 1, front:end].to(dev), **kw)
+            assert torch.equal(out_t[0], out_f[r, front:end])        # = the trimmed single-sequence call, bit for bit
+            nt = caches_t.token_emb.shape[1]
+            assert torch.equal(caches_t.token_emb[0], caches_f.token_emb[r, front:front + nt]) and not caches_f.token_emb[r, :front].any()
+            kt, kf = caches_t.transformer.attention[0].keys, caches_f.transformer.attention[0].keys
+            assert torch.equal(kt[0], kf[r, front:front + nt] if kf.ndim == 3 else kf[r, :, front:front + nt])
+        # and the module path (concatenated caches, bf16 GEMMs, the full mask) decodes the same notes up to bf16 near-ties
+        dec.use_decode_engine = False
+        out_m = dec.unmask_tokens(tok_f.to(dev), msk_f.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=f_mask.to(dev),
+                                  filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        dec.use_decode_engine = True
+        valid = f_mask[..., None].expand_as(out_f).to(dev)
+        assert float((out_m[valid] == out_f[valid]).float().mean()) > 0.97
+        # a first note that is itself to be decoded, or holes in the mask, keep the module path
         n_before = len(runs)
         odd_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
         odd_mask[1, :3] = False
         out_o = dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=odd_mask.to(dev),
                                   filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
         assert len(runs) == n_before and tuple(out_o.shape) == tuple(tok_b.shape)
+        hole_mask = torch.ones(tok_b.shape[:2], dtype=torch.bool)
+        hole_mask[0, 7] = False
+        dec.unmask_tokens(tok_b.to(dev), msk_b.to(dev), context=ctx_b.to(dev), style_embeddings=sty_b.to(dev), mask=hole_mask.to(dev),
+                          filter_logits_fn=top_k, filter_kwargs={"k": 1}, disable_tqdm=True)
+        assert len(runs) == n_before
     finally:
         decode.GreedyDecoder.run = real_run
