@@ -270,10 +270,16 @@ inline int grid_for(long total, int block = 256) { long g = (total + block - 1) 
 // x[r, :] = 0 for the rows with m[r] == 0, in place (bf16 [R, D], D % 8 == 0): only the masked rows are touched, so a batch
 // without padding costs one pass over the mask bytes
 __global__ void zero_masked_rows_kernel(bf16_t* __restrict__ x, long ldx, const uint8_t* __restrict__ m, long R, int D) {
+    // a wave looks at 64 rows' mask bytes with ONE coalesced load and walks only the masked ones (a row's byte fetched by the whole wave
+    // is a scalar load: one dependent trip to memory per row and wave, whether or not anything is masked)
     const int lane = threadIdx.x & 63;
-    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
-        if (m[r]) continue;
-        for (int c = lane * 8; c < D; c += 512) *reinterpret_cast<uint4*>(x + r * ldx + c) = uint4{0u, 0u, 0u, 0u};
+    for (long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; r0 < R; r0 += (long)gridDim.x * 4 * 64) {
+        unsigned long long dead = __ballot(r0 + lane < R && m[r0 + lane] == 0);
+        while (dead) {
+            const int i = __builtin_ctzll(dead);
+            dead &= dead - 1;
+            for (int c = lane * 8; c < D; c += 512) *reinterpret_cast<uint4*>(x + (r0 + i) * ldx + c) = uint4{0u, 0u, 0u, 0u};
+        }
     }
 }
 
@@ -429,8 +435,8 @@ extern "C" int spn_mish_bwd(const float* x, const float* dy, float* dx, long n, 
 
 extern "C" int spn_zero_masked_rows(void* x, long ldx, const uint8_t* m, long R, int D, hipStream_t s) {
     SPN_REQUIRE(x && m && R > 0 && D > 0 && D % 8 == 0 && ldx % 8 == 0 && (((uintptr_t)x) & 15) == 0, "spn_zero_masked_rows: bf16 rows of 8-element pieces");
-    long g = (R + 3) / 4;
-    if (g > 8192) g = 8192;
+    long g = (R + 255) / 256;      // a wave takes 64 rows per trip, four waves per block
+    if (g > 2048) g = 2048;
     hipLaunchKernelGGL(zero_masked_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, (bf16_t*)x, ldx, m, R, D);
     SPN_LAUNCH_CHECK();
     return SPN_OK;
