@@ -51,7 +51,7 @@ struct AttnArgs {
 // initial slopes, a quarter of the pre-pass's pass over q) and band_reach answers "unbounded" without reading them -- the same test on
 // both sides, so the three kernels and the pre-pass stay consistent.
 __device__ __forceinline__ bool band_head_unbounded(const AttnArgs& a, float slope2) {
-    return !(slope2 > 0.f) || a.band_log2 >= slope2 * (float)(a.nq + a.nk);
+    return !(slope2 > 0.f) || a.band_log2 >= slope2 * (float)(a.nq > a.nk ? a.nq : a.nk);   // |j - i - (nk - nq)| < max(nq, nk)
 }
 __device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, int kh, int qtile64, int ntiles, float c1, float slope2) {
     if (!a.band || band_head_unbounded(a, slope2)) return 3.0e38f;
