@@ -158,6 +158,19 @@ class _decode_call:
         return tokens[0] if self.unbatched else tokens
 
 
+def contiguous_note_spans(mask: Tensor):
+    """[(first, end)] per sequence when the True entries of every row of `mask` [b, n] form ONE non-empty contiguous block (un-padded,
+    right-padded, front-padded or both), else None (a hole, or an empty row).  One host read."""
+    mi = mask.int()
+    edges = mi[:, 1:] - mi[:, :-1]
+    rising = (edges == 1).sum(1) + mi[:, 0]          # blocks per row: a block starts at position 0 or at a rising edge
+    if not bool((rising == 1).all()):
+        return None
+    first = torch.argmax(mi, dim=1)
+    count = mi.sum(dim=1)
+    return [(int(a), int(a) + int(c)) for a, c in zip(first.tolist(), count.tolist())]
+
+
 def _forbid(logits: Tensor, ids) -> Tensor:
     """A copy of `logits` [rows, V] in which the given ids (slice, list or int) can never be drawn."""
     logits = logits.clone()
@@ -305,20 +318,17 @@ class ScorePerformerMixedLMWrapper(ScorePerformerLMWrapper):
         lens = None
         if usable and not bool(mask.all()):
             m = mask.bool()
-            mi = m.int()
-            edges = (mi[:, 1:] - mi[:, :-1])
-            # the notes of every sequence are ONE block: at most one rising and one falling edge, in that order, and at least one note
-            usable = bool(((edges == 1).sum(1) + mi[:, 0] == 1).all()) and bool(((edges == -1).sum(1) <= 1).all())
+            spans = contiguous_note_spans(m)
+            usable = spans is not None
             if usable:
-                first = torch.argmax(mi, dim=1)
-                count = mi.sum(dim=1)
+                first = torch.tensor([a for a, _ in spans], device=m.device)
                 holes = (filled == self.mask_token_id) & m[..., None]
                 # one MASK layout on every valid position, nothing to decode where element 0 (whose layout the reference uses) is padded,
                 # and nothing to decode at a block's own first note behind padding (it has no valid predecessor to be predicted from)
                 at_first = holes[torch.arange(holes.shape[0], device=holes.device), first].any(dim=1) & (first > 0)
                 usable = (bool(((holes == holes[:1]) | ~m[..., None]).all()) and not bool((holes & ~m[:1, :, None]).any())
                           and not bool(at_first.any()))
-                lens = [(int(a), int(a) + int(c)) for a, c in zip(first.tolist(), count.tolist())]
+                lens = spans
         elif usable and filled.shape[0] > 1:
             holes = filled == self.mask_token_id
             usable = bool((holes == holes[:1]).all())

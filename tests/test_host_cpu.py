@@ -135,3 +135,44 @@ def test_small_zero_slices_do_not_share_a_version_counter():
     assert a._version == va                      # leaves this slice's version alone
     y.sum().backward()
     assert torch.equal(x.grad, torch.full((3,), 2.0))
+
+
+def test_contiguous_note_spans_of_a_padding_mask():
+    """Host logic of the decode engine's batch path (models/scoreperformer/wrappers.py): a padded batch goes through the engine when every
+    sequence's notes are one contiguous block; holes or an empty row keep the module path."""
+    import torch
+    from scoreperformer_amd.models.scoreperformer.wrappers import contiguous_note_spans
+    T, F = True, False
+    m = torch.tensor([[T, T, T, T, T, T], [T, T, T, F, F, F], [F, F, T, T, T, T], [F, T, T, T, F, F], [F, F, F, F, F, T]])
+    assert contiguous_note_spans(m) == [(0, 6), (0, 3), (2, 6), (1, 4), (5, 6)]
+    assert contiguous_note_spans(torch.tensor([[T, T, F, T, T, T]])) is None            # a hole
+    assert contiguous_note_spans(torch.tensor([[T, F, T, F, T, F]])) is None
+    assert contiguous_note_spans(torch.tensor([[T, T, T], [F, F, F]])) is None          # an empty row
+    assert contiguous_note_spans(torch.ones(2, 1, dtype=torch.bool)) == [(0, 1), (0, 1)]
+
+
+def test_autocast_fence_is_transparent_without_autocast():
+    """utils/amp.no_autocast: a plain call when autocast is off (the usual case: one flag read), name / docstring kept; under CPU autocast
+    (the CUDA flag stays off) still a plain call."""
+    import torch
+    from scoreperformer_amd.utils.amp import no_autocast
+    calls = []
+
+    @no_autocast
+    def f(x, *, k=1):
+        """doc"""
+        calls.append(torch.is_autocast_enabled("cuda"))
+        return x * k
+    assert f(3, k=2) == 6 and f.__name__ == "f" and f.__doc__ == "doc"
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        assert f(2) == 2
+    assert calls == [False, False]
+
+
+def test_latent_levels_fit_the_select_kernel_limits():
+    """functional.latent_levels_fit: levels beyond the select kernel's LDS-resident bitmask / slot map keep the tensor-op path."""
+    from scoreperformer_amd import functional as F_, ops
+    assert F_.latent_levels_fit([(64, 1), (64, 155), (64, 1082)], 4096)
+    assert not F_.latent_levels_fit([(64, ops.LATENT_SELECT_MAX_N // 64 + 1)], 4096)
+    assert not F_.latent_levels_fit([(ops.LATENT_SELECT_MAX_B + 1, 4)], 4096)
+    assert not F_.latent_levels_fit([(64, 100)], ops.LATENT_SELECT_MAX_K + 1)
