@@ -100,10 +100,10 @@ def test_c2_loss_and_gradients_match_the_cpu_oracle(dev):
     rows = grad_errors(model, sdg, names)
     bad = [(k, e * n, n) for k, e, n in rows if not e * n <= REL * n + FLOOR]   # (tensor, absolute L2 error, reference norm)
     assert not bad, ([b for b in bad if b[0] in NAMED], bad[:10])
-    # and the gradient as one vector: relative L2 error <= 5 %, norm within 1 %
+    # and the gradient as one vector: relative L2 error <= 2.5 % (measured 1.32 %, tools/parity_measure.py, round 6), norm within 1 %
     err2 = sum((e * n) ** 2 for _, e, n in rows) ** 0.5
     ref2 = sum(n ** 2 for _, _, n in rows) ** 0.5
-    assert err2 <= 0.05 * ref2, (err2, ref2)
+    assert err2 <= 0.025 * ref2, (err2, ref2)
     named = dict(model.named_parameters())
     got2 = sum(float(named[k].grad.double().pow(2).sum()) for k in names) ** 0.5
     assert abs(got2 - ref2) <= 1e-2 * ref2, (got2, ref2)
@@ -113,7 +113,9 @@ def test_c3_step_matches_oracle(dev):
     """BASELINE config 3's workload as a test (the bench line's parity leg, moved into pytest): the C3 model (max_seq_len 2048),
     2 sequences x 2048 notes, one ragged, training mode, dropout 0, forward + backward through the HIP path against the fp32 CPU oracle
     on identical inputs, weights and N(0, I) samples.  |loss_HIP - loss_CPU| <= 1e-3 (north_star), every loss-dict entry within 1e-3,
-    the whole gradient as one vector within 5 % relative L2 and 1 % in norm (per-tensor bounds: the C2 test above)."""
+    the whole gradient as one vector within 2.5 % relative L2 (measured 1.40 %) and 1 % in norm, and -- since round 6 -- EVERY one of the
+    314 gradient tensors within 7 % + 5e-4 of its reference (measured: median 3.5 %, at most 4.0 % for tensors of norm > 1e-2; twice the
+    depth in tokens of the C2 test, whose 6 % rule the worst tensor here meets at 0.96 of the bound)."""
     model, out, ref, sdg = run_c2(dev, preset="c3", seq=2048, seed=33)
     got, want = float(out.loss.detach()), float(ref["loss"].detach())
     assert abs(got - want) <= 1e-3, (got, want)
@@ -122,9 +124,11 @@ def test_c3_step_matches_oracle(dev):
     names = all_grad_names(model, sdg)
     assert len(names) >= 300
     rows = grad_errors(model, sdg, names)
+    bad = [(k, e * n, n) for k, e, n in rows if not e * n <= 0.07 * n + FLOOR]
+    assert not bad, bad[:10]
     err2 = sum((e * n) ** 2 for _, e, n in rows) ** 0.5
     ref2 = sum(n ** 2 for _, _, n in rows) ** 0.5
-    assert err2 <= 0.05 * ref2, (err2, ref2)
+    assert err2 <= 0.025 * ref2, (err2, ref2)
     named = dict(model.named_parameters())
     got2 = sum(float(named[k].grad.double().pow(2).sum()) for k in names) ** 0.5
     assert abs(got2 - ref2) <= 1e-2 * ref2, (got2, ref2)
