@@ -1191,8 +1191,9 @@ class LatentLossFn(Function):
         out = ops.latent_scalars(sums, z.shape[0], dead, lat.shape[-1], weight)
         ctx.save_for_backward(lat, lmask, deadpan, z, y, w, slot, dead, sums)
         ctx.weight = weight
-        ctx.mark_non_differentiable(out[2])
-        return out[0], out[1], out[2]
+        mmd, dead_loss, dead_flag = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(dead_flag)        # (the very tensor object that is returned)
+        return mmd, dead_loss, dead_flag
 
     @staticmethod
     @once_differentiable
