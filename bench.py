@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true", help="--gpus N > 1 without a launcher: print the child command and exit")
     ap.add_argument("--no-decode", action="store_true", help="skip the C5 decode object (N = 1 only)")
     ap.add_argument("--decode-seq", type=int, default=4096)
+    ap.add_argument("--ragged", action="store_true", help="the second input variant of SURVEY.md section 8(d): sequence lengths ~ U{n/2..n}, right-padded "
+                    "(masks False, segments 0 behind the notes); `value` still counts b * n rows per step, `config.valid_note_fraction` says how "
+                    "many of them are notes")
     ap.add_argument("--no-phases", action="store_true", help="skip the `phases` object (5 more steps with events; profiling runs)")
     ap.add_argument("--sustained-seconds", type=float, default=25.0,
                     help="N = 1 only, after the timed region: keep stepping for this long (>= 50 steps) and report ms/step, its drift and the "
@@ -178,7 +181,8 @@ def main():
     holder = {"sync": sync}
     # segment-slot counts are known to the (host-side) input pipeline: they travel with the batch as python ints (`segment_bounds`, what
     # data.MixedLMScorePerformanceCollator emits for a real batch), so the forward reads nothing back from the device
-    batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev, with_bounds=True)
+    batch = synthetic_batch(args.batch, args.seq, seed=1234 + rank, device=dev, with_bounds=True, ragged=args.ragged)
+    valid_fraction = float(batch["perf_mask"].float().mean())
     torch.manual_seed(4321 + rank)  # distinct MMD samples per rank
 
     def step():
@@ -220,7 +224,7 @@ def main():
                                f"tied LM head, seq={args.seq}, batch={args.batch}/GPU, attention+FFN dropout {args.dropout} (fused in-kernel), "
                                f"latent dropout {list(cfg.perf_encoder.latent_dropout)} inclusive (recipes/scoreperformer/base.yaml:119-126)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
-                   "tokens_per_s_per_gpu": value / world, "final_loss": loss,
+                   "tokens_per_s_per_gpu": value / world, "final_loss": loss, "ragged": bool(args.ragged), "valid_note_fraction": valid_fraction,
                    "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
                    "dist_backend": (args.dist_backend + (" on ONE device: a test run, not a measurement" if args.one_device else "")) if dist is not None else None,
                    "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
