@@ -29,7 +29,7 @@ extern "C" {
 
 typedef struct ihipStream_t* spn_stream_t; /* hipStream_t */
 
-int spn_abi_version(void); /* 9: round 6 added spn_latent_{select,unselect,scalars,drop,drop_bwd}, spn_segment_{sum,gather}_multi, the row strides of spn_segment_sum / spn_segment_gather; 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
+int spn_abi_version(void); /* 10: round 6 added the qmask argument of spn_attn_fwd / spn_attn_bwd; 9: round 6 added spn_latent_{select,unselect,scalars,drop,drop_bwd}, spn_segment_{sum,gather}_multi, the row strides of spn_segment_sum / spn_segment_gather; 8: round 5 added spn_dec_pairs_notes + spn_dec_chain_ext.gt; 7: round 5 added spn_sumsq_det (+ the gemm_ow tuning knob); 6: round 4 added spn_comm_available, spn_mmd_scalars, spn_dropout, spn_layernorm_bwd_gb16_colsum, spn_dec_struct_size, the head / embed phases of spn_dec_chain_ext; 5: round 3 added spn_adaln_*, spn_dec_xattn_dyn, spn_dec_lookup, spn_dec_pair* */
 const char* spn_last_error(void);
 void spn_set_error(const char* msg);
 int spn_set_tuning(const char* name, double value); /* 0, or -1 for an unknown knob */
@@ -58,9 +58,14 @@ int spn_gemm_f32(const float* a, long sam, long sak, const float* b, long sbk, l
 /* ---- attention core (modules/transformer/attend.py:58-126 + mask/ALiBi assembly attention.py:162-197,
  *      modules/transformer/embeddings.py:294-315).  head dim 64; q [b,nq,h,64], k/v [b,nk,kvh,64] through strides;
  *      kvh = 1 is multi-query.  strides: {q_bs,q_ns,q_hs, k_.., v_.., o_..} (+ {dq_.., dk_.., dv_..} for bwd). */
-int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const float* slopes,
-                 int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, float p_drop,
-                 unsigned seed, void* dropbits, float* band, spn_stream_t stream);
+int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const uint8_t* qmask,
+                 const float* slopes, int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides,
+                 float p_drop, unsigned seed, void* dropbits, float* band, spn_stream_t stream);
+/* qmask [b,nq] or null: the module's query-side `mask`.  attention.py:216-218 multiplies the block's output by it, so what the core
+ * computes for a row with qmask = 0 is never seen: such a row's o is written as zeros and its lse as a dead marker (-1.7e38) that
+ * makes spn_attn_bwd give it (and take from it) no gradient, and 128-row blocks / 64-row tiles made of such rows only are not
+ * walked at all.  Key tiles with masked keys only are not walked either (they add exp(-1.7e38 - m) = 0 to every live row).
+ * In a right-padded ragged batch that is the padding's share of the attention work. */
 /* p_drop > 0: attention dropout (attend.py:122).  The mask is a pure function of (seed, b, h, i, j); the forward also writes
  * it as keep bits (1 bit per score) into `dropbits` (spn_attn_dropbits_elems() uint16 words), which the backward reads back.
  * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
@@ -75,9 +80,9 @@ void spn_attn_set_band(float log2_threshold);
  * q / k / mask reads it back.  null (or no slopes, or slopes <= 0, or a row whose own key is masked): every tile is visited. */
 long spn_attn_band_elems(int b, int h, int kvh, int nq);
 int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta,
-                 void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const float* slopes, int b, int h, int kvh,
-                 int nq, int nk, int causal, float scale, const long* strides, float p_drop, const void* dropbits,
-                 const float* band, spn_stream_t stream);
+                 void* dq, void* dk, void* dv, float* dslope, const uint8_t* kmask, const uint8_t* qmask, const float* slopes,
+                 int b, int h, int kvh, int nq, int nk, int causal, float scale, const long* strides, float p_drop,
+                 const void* dropbits, const float* band, spn_stream_t stream);
 
 /* ---- LayerNorm / AdaptiveLayerNorm (modules/transformer/transformer.py:106,123-125,192-193,217;
  *      modules/layers.py:31-47).  gb = [T,2D] fp32 per-token (gamma|beta).  bwd: dy bf16; dgamma/dbeta ACCUMULATED. */

@@ -177,6 +177,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qf[qb][ks] = load_row_frag(qp, a.q_ns, q0 + 32 * w + 16 * qb + c, a.nq, ks, lane);
     }
+    // The key padding of a ragged batch is not walked: the live key tiles come from the band pre-pass (band_key_tiles), or, without a
+    // band buffer (no ALiBi: cross-attention), from a scan of the mask row that starts here
+    const KeyScan kscan = key_scan_begin(a.band ? nullptr : mp, a.nk, lane);
+    // Padding rows (qmask == 0): a block of nothing else walks no tile, a wave of nothing else sits out every tile (it gets an empty band
+    // below) -- in a right-padded ragged batch these rows would otherwise walk EVERY key tile (no ALiBi band without a live own key).
+    // Every wave reads the block's 128 mask bytes itself (two coalesced byte loads, behind the q loads so that all of the prologue's
+    // loads are in flight together): no barrier, nothing live across the tile loop (the epilogue reads its rows' bytes again; parking them
+    // in LDS or in a register cost more in spills than the two loads), and no branch (an early return put a wait for these loads in
+    // front of the band loads and the first tile request: +7 % on a full-length batch).
+    bool wave_dead = false, block_dead = false;
+    if (a.qmask) {
+        const uint8_t* qm = a.qmask + (long)bi * a.nq;
+        const int ia = q0 + lane, ib = q0 + 64 + lane;
+        const uint8_t ma = ia < a.nq ? qm[ia] : 0, mb = ib < a.nq ? qm[ib] : 0;
+        const unsigned long long la = __ballot(ma != 0), lb = __ballot(mb != 0);
+        block_dead = (la | lb) == 0ull;   // walks no tile at all (nt = t_lo below); the epilogue stores its zeros and dead lse
+        wave_dead = (uint32_t)((w < 2 ? la : lb) >> (32 * (w & 1))) == 0u;
+    }
+
     const int wv = __builtin_amdgcn_readfirstlane(w);   // the wave index as a scalar: tile classes must be wave-uniform FOR THE COMPILER
     const int i_lo = q0 + 32 * wv + off, i_hi = i_lo + 31;
     uint32_t rowc[2] = {0, 0};
@@ -211,6 +230,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
             wave_lo = i_lo - d; wave_hi = i_hi + d;     // the block walks the union of its four waves' ranges; a wave sits out the rest
         }
     }
+    if (wave_dead) { wave_lo = 0x40000000; wave_hi = -0x40000000; }   // padding rows only: every tile is "outside this wave's band"
+    if (a.band) band_key_tiles(a, bi, t_lo, nt); else key_scan_finish(kscan, mp, a.nk, lane, t_lo, nt);
+    if (block_dead) nt = t_lo;
 
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
         // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
         const int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
-        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band
+        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band (padding rows: all)
         const float j0f = (float)j0;
         uint32_t thr_t = a.thr8;
         if (DROP && a.thr_frac) {   // this block's threshold: thr8 + Bernoulli(frac16 / 65536), all-scalar (set_dropout)
@@ -317,11 +339,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
         }
     }
 
+    AttnKernargPtr ae = attn_kernarg();   // the mask pointer is not held in registers across the tile loop (attention_common.h)
+    asm volatile("" : "+s"(ae));
+    const uint8_t* qm_e = ae->qmask;
+    bool row_live[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int i = q0 + 32 * w + 16 * qb + c;
+        row_live[qb] = !qm_e || (i < a.nq && qm_e[(long)bi * a.nq + i] != 0);
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int i = q0 + 32 * w + 16 * qb + c;
         const float l = group_sum(l_run[qb]);
-        const float inv = (l > 0.f ? 1.f / l : 0.f) * (DROP ? a.inv_keep : 1.f);
+        const float inv = (l > 0.f && row_live[qb] ? 1.f / l : 0.f) * (DROP ? a.inv_keep : 1.f);
         if (i < a.nq) {
             bf16_t* op = a.o + bi * a.o_bs + (long)i * a.o_ns + hi * a.o_hs;
 #pragma unroll
@@ -331,7 +362,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnArgs a) {
                 pk.y = pack_bf2(o[db][qb][2] * inv, o[db][qb][3] * inv);
                 *reinterpret_cast<uint2*>(op + 16 * db + 4 * g) = pk;
             }
-            if (g == 0) a.lse[((long)bi * a.h + hi) * a.nq + i] = (m_run[qb] + log2f(l)) * LN2;
+            if (g == 0) a.lse[((long)bi * a.h + hi) * a.nq + i] = row_live[qb] ? (m_run[qb] + log2f(l)) * LN2 : NEG_FILL;
         }
     }
 }
@@ -423,6 +454,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const float c1 = a.scale * LOG2E;
     const float keep_prob = DROP ? 1.f / a.inv_keep : 1.f;
 
+    // the block's 128 lse values, requested by every wave itself (two coalesced loads, in flight with the row loads below): see the
+    // dead-block test behind them
+    float lse_a, lse_b;
+    {
+        const float* lb = a.lse + ((long)bi * a.h + hi) * a.nq;
+        const int ia = q0 + lane, ib = q0 + 64 + lane;
+        lse_a = ia < a.nq ? lb[ia] : NEG_FILL; lse_b = ib < a.nq ? lb[ib] : NEG_FILL;
+    }
+    const KeyScan kscan = key_scan_begin(a.band ? nullptr : mp, a.nk, lane);   // see attn_fwd_kernel
     bf16x8 qf[2][2], dof[2][2];
     float l2[2], dl[2], i_f[2];
 #pragma unroll
@@ -435,8 +475,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             dof[qb][ks] = load_row_frag(dop, a.o_ns, i, a.nq, ks, lane);
         }
         const long si = ((long)bi * a.h + hi) * a.nq + i;
-        // rows outside the problem, and rows whose keys were ALL masked (lse ~ -1e38: degenerate uniform attention whose
-        // output the caller zeroes), get p = 0
+        // Dead rows -- outside the problem, padding rows of the forward's qmask (lse = NEG_FILL), and rows whose keys were ALL masked
+        // (lse ~ -1e38: degenerate uniform attention whose output the caller zeroes) -- get p = 0
         const float lse_i = i < a.nq ? a.lse[si] : NEG_FILL;
         l2[qb] = lse_i > -1e37f ? lse_i * LOG2E : 1e30f;
         // delta_i = sum_d O[i, d] * dO[i, d] (bf16 inputs, fp32 sum): this lane holds 16 of the row's 64 dO values, its three
@@ -457,6 +497,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         dl[qb] = group_sum(dsum);
         if (g == 0 && i < a.nq) const_cast<float*>(a.delta)[si] = dl[qb];
     }
+    // A block of dead rows only walks no tile at all (nt = t_lo below; its accumulators store zeros), a wave of dead rows only sits out
+    // every tile (it gets an empty band).  No early return: a branch here would put a wait for the loads above in front of the band
+    // loads and the first tile request (measured: +7 % on the full-length batch).
+    const bool block_dead = !__any(lse_a > -1e37f || lse_b > -1e37f);
+    const bool wave_dead = !__any(l2[0] < 1e29f || l2[1] < 1e29f);
     const int wv = __builtin_amdgcn_readfirstlane(w);       // the wave index as a scalar: tile classes must be wave-uniform FOR THE COMPILER
     const int i_lo = q0 + 32 * wv + off, i_hi = i_lo + 31;
     const long bstride = (long)a.nkt64 * 64;
@@ -514,6 +559,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
             wave_lo = i_lo - d; wave_hi = i_hi + d;
         }
     }
+    if (wave_dead) { wave_lo = 0x40000000; wave_hi = -0x40000000; }   // dead rows only: every tile is "outside this wave's band"
+    // masked keys only: P = exp2(NEG_FILL - lse) = 0 for every live row, as in the forward
+    if (a.band) band_key_tiles(a, bi, t_lo, nt); else key_scan_finish(kscan, mp, a.nk, lane, t_lo, nt);
+    if (block_dead) nt = t_lo;
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)(((long)(a.nk - 1) * a.k_ns + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)(((long)(a.nk - 1) * a.v_ns + 64) * 2), 0x00020000);
     uint32_t voKa[2], voKt[2], voV[2];
@@ -564,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const bool rows_ok = q0 + 32 * wv + 31 < a.nq;
         // wave-uniform by construction, but read through LDS: say so, or every branch on it becomes an exec-masked region
         int cls = classify(j0, i_lo, i_hi, __builtin_amdgcn_readfirstlane(*full_flag) != 0, a.causal != 0);
-        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band
+        if (cls == T_SKIP || j0 > wave_hi || j0 + 63 < wave_lo) continue;   // causal future, or outside this wave's own band (dead rows: all)
         if (!rows_ok && SLOPE_GRAD) cls = T_GEN;
         const float j0f = (float)j0;
 
@@ -740,13 +789,22 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
     // all eight passes' rows are requested before the first one is reduced (rows past the end re-read the last row and are not counted):
     // pass by pass, every load was waited for before the next was issued -- eight serial trips to memory per 64-row tile
     uint4 u[8], uk[8];
-    bool own[8];
+    bool own[8], qdead[8];
+    // the tile's 64 mask bytes -- of the rows' own keys, and of the rows themselves -- by one coalesced load each, handed to the eight
+    // lanes of a row by shuffle (a byte load per lane and pass put 16 dependent loads in front of the row loads)
+    int km_l = 0, qm_l = 1;
+    if (is_q) {
+        const int r64 = x * 64 + lane, jd = r64 + off;
+        if (r64 < a.nq && jd >= 0 && jd < a.nk) km_l = a.kmask ? a.kmask[(long)bi * a.nk + jd] : 1;
+        if (a.qmask && r64 < a.nq) qm_l = a.qmask[(long)bi * a.nq + r64];
+    }
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int row = min((is_q ? x : x - a.nqt64) * 64 + pass * 8 + (lane >> 3), n - 1);
         const bf16_t* p = is_q ? a.q + bi * a.q_bs + (long)row * a.q_ns + hi * a.q_hs : a.k + bi * a.k_bs + (long)row * a.k_ns + hi * a.k_hs;
         const int jd = row + off;   // the row's own key: its score bounds the row maximum from below
-        own[pass] = is_q && jd >= 0 && jd < a.nk && !(a.kmask && a.kmask[(long)bi * a.nk + jd] == 0);
+        qdead[pass] = __shfl(qm_l, pass * 8 + (lane >> 3), 64) == 0;   // padding row: no output, no bound to hold
+        own[pass] = __shfl(km_l, pass * 8 + (lane >> 3), 64) != 0;     // rows past nq: 0 (they re-read the last row and are not counted)
         const bf16_t* pk = own[pass] ? a.k + bi * a.k_bs + (long)jd * a.k_ns + (a.kvh == 1 ? 0 : hi) * a.k_hs : p;
         u[pass] = *reinterpret_cast<const uint4*>(p + ch * 8);
         uk[pass] = *reinterpret_cast<const uint4*>(pk + ch * 8);
@@ -768,20 +826,29 @@ __global__ __launch_bounds__(64) void attn_band_kernel(AttnArgs a, float* __rest
         // the row's eight partial sums (lanes 8r .. 8r + 7)
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
         d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-        if (row < n) {
+        if (row < n && !qdead[pass]) {
             if (is_q && !own_ok) v = __builtin_inff();   // no lower bound on this row's maximum: the tile is never skipped
             vmax = fmaxf(vmax, v);
             if (own_ok) dmin = fminf(dmin, d);
         }
     }
     const float v = wave_max(vmax);
-    const float dot = is_q ? -wave_max(-dmin) : 0.f;   // minimum over the tile's rows (rows past nq: +inf)
+    const float dot = is_q ? -wave_max(-dmin) : 0.f;   // minimum over the tile's live rows (none: +inf next to v = 0 -> reach 0, band_reach)
     if (lane == 0) {
         if (is_q) {
             band[((long)(bi * a.h + hi)) * a.nqt64 + x] = v;
             band[nq_part + ((long)(bi * a.h + hi)) * a.nqt64 + x] = dot;
         } else {
             atomicMax(reinterpret_cast<unsigned int*>(band + 2 * nq_part + bi * a.kvh + hi), __float_as_uint(v));   // v >= 0
+        }
+    }
+    if (!is_q && hi == 0 && a.kmask) {   // the live key tiles of this batch row (band_key_tiles): this tile has a live key -> widen the range
+        const int kt = x - a.nqt64, j = kt * 64 + lane;
+        const bool any = __any(j < a.nk && a.kmask[(long)bi * a.nk + j] != 0);
+        if (any && lane == 0) {
+            unsigned int* kr = reinterpret_cast<unsigned int*>(band + 2 * nq_part + (long)a.b * a.kvh) + 2 * bi;
+            atomicMax(kr, (unsigned)(kt + 1));
+            atomicMax(kr + 1, (unsigned)((a.nk + 63) / 64 - kt));
         }
     }
 }
@@ -798,7 +865,7 @@ int prepare_band(AttnArgs& a, hipStream_t stream, float* own, bool reuse) {
     a.band = own;
     if (reuse) return SPN_OK;
     const size_t nq_part = (size_t)a.b * a.h * a.nqt64;
-    (void)hipMemsetAsync(own + 2 * nq_part, 0, (size_t)a.b * a.kvh * 4, stream);
+    (void)hipMemsetAsync(own + 2 * nq_part, 0, ((size_t)a.b * a.kvh + 2 * (size_t)a.b) * 4, stream);
     hipLaunchKernelGGL(attn_band_kernel, dim3(a.nqt64 + (a.nk + 63) / 64, a.h, a.b), dim3(64), 0, stream, a, own);
     return SPN_OK;
 }
@@ -845,14 +912,14 @@ extern "C" int spn_set_tuning(const char* name, double value);
 extern "C" void spn_attn_set_band(float log2_threshold) { spn_set_tuning("attn_band", log2_threshold < 0.f ? 0.f : log2_threshold); }
 
 // floats of a caller-owned band buffer (spn_attn_fwd fills it, spn_attn_bwd of the same problem reuses it instead of recomputing)
-extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return 2l * b * h * ((nq + 63) / 64) + (long)b * kvh; }
+extern "C" long spn_attn_band_elems(int b, int h, int kvh, int nq) { return 2l * b * h * ((nq + 63) / 64) + (long)b * kvh + 2l * b; }
 
 // uint16 words of the dropout keep-bit buffer for a [b, h, nq, nk] attention (1 bit per score, whole 128x128 blocks)
 extern "C" long spn_attn_dropbits_elems(int b, int h, int nq, int nk) {
     return (long)b * h * dropbits_nqt16(nq) * dropbits_nkt64(nk) * 64;
 }
 
-extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const uint8_t* qmask,
                             const float* slopes, int b, int h, int kvh, int nq, int nk, int causal, float scale,
                             const long* strides, float p_drop, unsigned seed, void* dropbits, float* band, hipStream_t stream) {
     AttnArgs a;
@@ -860,7 +927,7 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
     set_dropout(a, p_drop, seed, dropbits, nq, nk);
     SPN_REQUIRE(!a.drop_on || dropbits, "spn_attn_fwd: dropout needs the keep-bit buffer (spn_attn_dropbits_elems uint16 words)");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
-    a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk; a.causal = causal;
+    a.kmask = kmask; a.qmask = qmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk; a.causal = causal;
     a.scale = scale;
     a.q_bs = strides[0]; a.q_ns = strides[1]; a.q_hs = strides[2];
     a.k_bs = strides[3]; a.k_ns = strides[4]; a.k_hs = strides[5];
@@ -883,7 +950,7 @@ extern "C" int spn_attn_fwd(const void* q, const void* k, const void* v, void* o
 // delta: workspace of b*h*nq floats.  dslope: [h] fp32, accumulated with atomics (zero it first), or null.
 extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                             const float* lse, float* delta, void* dq, void* dk, void* dv, float* dslope,
-                            const uint8_t* kmask, const float* slopes, int b, int h, int kvh, int nq, int nk,
+                            const uint8_t* kmask, const uint8_t* qmask, const float* slopes, int b, int h, int kvh, int nq, int nk,
                             int causal, float scale, const long* strides, float p_drop, const void* dropbits, const float* band,
                             hipStream_t stream) {
     AttnArgs a;
@@ -892,7 +959,7 @@ extern "C" int spn_attn_bwd(const void* q, const void* k, const void* v, const v
     SPN_REQUIRE(!a.drop_on || dropbits, "spn_attn_bwd: dropout needs the keep bits written by spn_attn_fwd");
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.d_o = (const bf16_t*)d_o;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
-    a.dslope = dslope; a.kmask = kmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk;
+    a.dslope = dslope; a.kmask = kmask; a.qmask = qmask; a.slopes = slopes; a.b = b; a.h = h; a.kvh = kvh; a.nq = nq; a.nk = nk;
     a.causal = causal; a.scale = scale;
     a.q_bs = strides[0]; a.q_ns = strides[1]; a.q_hs = strides[2];
     a.k_bs = strides[3]; a.k_ns = strides[4]; a.k_hs = strides[5];

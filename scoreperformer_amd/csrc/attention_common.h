@@ -16,6 +16,7 @@ struct AttnArgs {
     const bf16_t* d_o; const float* delta;   // backward only
     bf16_t* dq; bf16_t* dk; bf16_t* dv; float* dslope;
     const uint8_t* kmask;   // [b, nk] or null
+    const uint8_t* qmask;   // [b, nq] or null: rows with 0 are padding -- output rows of zeros, lse = NEG_FILL (dead: no gradient either way)
     const float* slopes;    // [h] or null
     int b, h, kvh, nq, nk, causal;
     long q_bs, q_ns, q_hs;
@@ -45,7 +46,8 @@ struct AttnArgs {
 // So t_ij - m_i <= c1 (|q_i| max|k| - q_i.k_i') - slope2 |d|, and beyond D = (band_log2 + c1 (max|q| max|k| - min q_i.k_i')) / slope2
 // every probability of the tile's rows is below 2^-band_log2 of its row's largest one.  (Until round 2 the row maximum was bounded by
 // -c1 |q_i| max|k| instead of the actual diagonal score: 2 c1 max|q| max|k| in the numerator, a ~1.7x longer reach at initialisation.)
-// band layout: [b*h*nqt64] max |q_i|^2 per 64-row tile (+inf: never skip), [b*h*nqt64] min q_i.k_i' per tile, [b*kvh] max |k_j|^2.
+// band layout: [b*h*nqt64] max |q_i|^2 per 64-row tile (+inf: never skip), [b*h*nqt64] min q_i.k_i' per tile, [b*kvh] max |k_j|^2,
+// [b][2] uint32 the live key tiles of the batch row (band_key_tiles below).
 // A head whose slope is so shallow that even the numerator's floor (band_log2: Cauchy-Schwarz makes the rest non-negative) reaches past
 // every distance of the problem can never skip a tile: the pre-pass does not compute its row norms (round 6: 2 of 8 heads at the
 // initial slopes, a quarter of the pre-pass's pass over q) and band_reach answers "unbounded" without reading them -- the same test on
@@ -62,7 +64,50 @@ __device__ __forceinline__ float band_reach(const AttnArgs& a, int bi, int hi, i
         if (qtile64 + t < a.nqt64) { qm = fmaxf(qm, qt[t]); dm = fminf(dm, qt[nq_part + t]); }
     const float km = a.band[2 * nq_part + bi * a.kvh + kh];
     const float D = (a.band_log2 + c1 * (sqrtf(qm * km) - dm)) / slope2;
-    return D < 1.0e9f ? D : 3.0e38f;   // inf / nan (never-skip tiles) -> unbounded
+    return D < 1.0e9f ? fmaxf(D, 0.f) : 3.0e38f;   // +inf / nan (never-skip tiles) -> unbounded; -inf (padding rows only: qm = 0, dm = +inf) -> 0
+}
+
+// The live key tiles of batch row bi, as the band pre-pass left them ([2 bi] = 1 + the last 64-key tile with a live key, [2 bi + 1] =
+// number of tiles - the first one; both zero: no mask, or no live key at all -- the walk stays unclamped, see key_scan_finish): two
+// scalar loads next to band_reach's, instead of every wave scanning the mask row.
+__device__ __forceinline__ void band_key_tiles(const AttnArgs& a, int bi, int& kt_lo, int& kt_hi) {
+    const uint32_t* kr = reinterpret_cast<const uint32_t*>(a.band + 2 * (long)a.b * a.h * a.nqt64 + (long)a.b * a.kvh) + 2 * bi;
+    const uint32_t hi = kr[0], lo = kr[1];
+    if (hi) { kt_lo = max(kt_lo, (a.nk + 63) / 64 - (int)lo); kt_hi = min(kt_hi, (int)hi); }
+}
+
+// Key tiles (64 keys) outside [kt_lo, kt_hi) hold masked keys only -- the padding of a ragged batch, at either end -- and add
+// exp(NEG_FILL - m) = 0 to every row that has a live key: the forward and dQ walks are clamped to the range.  Without a band buffer
+// (no ALiBi: cross-attention) every wave scans the mask row itself (32 bytes per lane and 2048-key chunk, one ballot, scalar bit scans): no barrier, no LDS, and nothing added to the tile
+// loop.  In two halves, so that the loads of the first chunk are in flight together with the prologue's other loads (q rows, band
+// bounds) instead of in front of them.  Needs 16-byte aligned mask rows (nk % 16 == 0); otherwise, and for a row without a single live
+// key (whose degenerate uniform average the full walk keeps, attend.py:102), the range stays [0, number of tiles).
+struct KeyScan { uint4 x, y; bool on; };
+__device__ __forceinline__ void key_scan_chunk(const uint8_t* mp, int nk, int at, uint4& x, uint4& y) {
+    x = uint4{0u, 0u, 0u, 0u}; y = x;
+    if (at < nk) x = *reinterpret_cast<const uint4*>(mp + at);
+    if (at + 16 < nk) y = *reinterpret_cast<const uint4*>(mp + at + 16);
+}
+__device__ __forceinline__ KeyScan key_scan_begin(const uint8_t* mp, int nk, int lane) {
+    KeyScan ks;
+    ks.on = mp && ((reinterpret_cast<uintptr_t>(mp) | (uintptr_t)nk) & 15) == 0;
+    ks.x = uint4{0u, 0u, 0u, 0u}; ks.y = ks.x;
+    if (ks.on) key_scan_chunk(mp, nk, 32 * lane, ks.x, ks.y);
+    return ks;
+}
+__device__ __forceinline__ void key_scan_finish(const KeyScan& ks, const uint8_t* mp, int nk, int lane, int& kt_lo, int& kt_hi) {
+    if (!ks.on) return;
+    int lo = 0x7fffffff, hi = -1;
+    uint4 x = ks.x, y = ks.y;
+    for (int base = 0; base < nk; base += 2048) {
+        if (base) key_scan_chunk(mp, nk, base + 32 * lane, x, y);
+        const unsigned long long segs = __ballot(((x.x | x.y | x.z | x.w) | (y.x | y.y | y.z | y.w)) != 0u);   // bit l: keys [32 l, 32 l + 32) of the chunk
+        if (segs) {
+            lo = min(lo, base / 64 + (__builtin_ctzll(segs) >> 1));
+            hi = max(hi, base / 64 + ((63 - __builtin_clzll(segs)) >> 1));
+        }
+    }
+    if (hi >= 0) { kt_lo = max(kt_lo, lo); kt_hi = min(kt_hi, hi + 1); }
 }
 
 // The kernel arguments again, straight from the kernel-argument segment (constant address space: scalar loads through the constant

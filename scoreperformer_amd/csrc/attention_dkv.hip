@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         }
     }
     const bool keys_full = __all(key_ok[0] && key_ok[1]);
+    const bool keys_none = !__any(key_ok[0] || key_ok[1]);   // this wave's 32 keys are all masked: P = 0 for every live row, dK = dV = 0
     const int wv = __builtin_amdgcn_readfirstlane(w);   // the wave index as a scalar: tile classes must be wave-uniform FOR THE COMPILER
     const int jw_lo = j0 + 32 * wv, jw_hi = jw_lo + 31;
 
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         const int i_min = j0 - off;
         t_first = i_min <= 0 ? 0 : i_min / 64;
     }
-    const int n_iter = (nqt - t_first) > 0 ? (nqt - t_first) * heads_per_kv : 0;
+    // a block whose 128 keys are all masked (the padding of a ragged batch) walks nothing and stores zeros
+    const int n_iter = ((nqt - t_first) > 0 && !__syncthreads_and(keys_none)) ? (nqt - t_first) * heads_per_kv : 0;
 
     // keep bits of the forward: this lane's key column c of key block kb sits in forward lanes (c>>2)*16 + 4g + r (r = its 4 rows),
     // bit 4*kb_f + (c&3) with kb_f = the 16-key block index inside the forward's 64-key tile
@@ -229,18 +231,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
         return (float)j0 <= r_lo + 63.f + reach && (float)(j0 + 127) >= r_lo - reach;
     };
     const bool masked_walk = n_iter <= 64 * LIVE_WORDS;
+    // query tiles of padding rows only (the forward's qmask: zero output rows, lse = NEG_FILL) are not requested at all: one bit per
+    // 64-row tile, wave by wave from the tile's 64 mask bytes.  (Padding rows inside a live tile are dead through their lse.)
+    __shared__ unsigned long long qtile_live[LIVE_WORDS];
+    __shared__ int wave_keys_none[4];   // a wave whose 32 keys are all masked sits out every tile: its live_wave bits stay zero
+    const bool q_tiles_known = a.qmask && nqt <= 64 * LIVE_WORDS && n_iter > 0;
+    if (n_iter > 0) {
+        if (tid < LIVE_WORDS) qtile_live[tid] = 0ull;
+        if (lane == 0) wave_keys_none[w] = keys_none ? 1 : 0;
+        __syncthreads();
+        if (q_tiles_known) {   // 16 mask bytes per thread, one trip for up to 4096 rows
+            const uint8_t* qm = a.qmask + (long)bi * a.nq;
+            const bool vec = ((reinterpret_cast<uintptr_t>(qm) | (uintptr_t)a.nq) & 15) == 0;
+            for (int ch = t_first * 4 + tid; ch * 16 < a.nq; ch += 256) {
+                bool any = false;
+                if (vec) {
+                    const uint4 x = *reinterpret_cast<const uint4*>(qm + ch * 16);
+                    any = (x.x | x.y | x.z | x.w) != 0u;
+                } else {
+                    for (int e = 0; e < 16; ++e) any |= ch * 16 + e < a.nq && qm[ch * 16 + e] != 0;
+                }
+                if (any) atomicOr(&qtile_live[ch >> 8], 1ull << ((ch >> 2) & 63));
+            }
+        }
+        __syncthreads();
+    }
+    auto qtile_ok = [&](int it) {
+        if (!q_tiles_known) return true;
+        const int tq = t_first + it % (nqt - t_first);
+        return ((qtile_live[tq >> 6] >> (tq & 63)) & 1ull) != 0ull;
+    };
     if (masked_walk) {
         for (int base = 0; base < n_iter; base += 256) {
             const int it = base + tid;
             float r_lo = 0.f;
             const float reach = it < n_iter ? reach_of(it, r_lo) : -1.f;
-            const bool in = it < n_iter;
+            const bool in = it < n_iter && qtile_ok(it);
             const unsigned long long m = __ballot(in && (float)j0 <= r_lo + 63.f + reach && (float)(j0 + 127) >= r_lo - reach);
             if (lane == 0) live_mask[(base >> 6) + w] = m;
 #pragma unroll
             for (int wq = 0; wq < 4; ++wq) {
                 const float jl = (float)(j0 + 32 * wq);
-                const unsigned long long mw = __ballot(in && jl <= r_lo + 63.f + reach && jl + 31.f >= r_lo - reach);
+                const unsigned long long mw = __ballot(in && !wave_keys_none[wq] && jl <= r_lo + 63.f + reach && jl + 31.f >= r_lo - reach);
                 if (lane == 0) live_wave[wq][(base >> 6) + w] = mw;
             }
         }
@@ -256,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs a) {
             return min(it, n_iter);
         }
         for (; it < n_iter; ++it)
-            if (is_live(it)) break;
+            if (qtile_ok(it) && is_live(it)) break;
         return it;
     };
     int it = next_live(0);

@@ -8,7 +8,7 @@ extern "C" void spn_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", 
 extern "C" const char* spn_last_error(void) { return g_err; }
 // 2: caller-owned workspaces (spn_gemm_workspace_bytes, band buffers), spn_set_tuning instead of environment reads, trainable mask in spn_adamw_step
 // 3: spn_dec_head / spn_dec_head_sample take the next step's position scalar (pos_next); spn_dec_step_begin, spn_dec_cat_gemv
-extern "C" int spn_abi_version(void) { return 9; }
+extern "C" int spn_abi_version(void) { return 10; }
 
 namespace {
 struct Knob { const char* name; double def; };

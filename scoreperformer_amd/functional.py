@@ -467,10 +467,13 @@ def ada_layer_norm(x, cond, weight, bias, *, out_fp32=False, eps=1e-5, fork=Fals
 # ---------------------------------------------------------------------------------------------------------
 
 class SelfAttnFn(Function):
-    """qkv: [b, n, (h + 2*kvh)*64] bf16 fused projection (q | k | v);  returns o [b, n, h*64] bf16."""
+    """qkv: [b, n, (h + 2*kvh)*64] bf16 fused projection (q | k | v);  returns o [b, n, h*64] bf16.
+
+    `qmask` [b, n]: the module's padding mask of the QUERY rows (attention.py:216-218 multiplies the block's output by it): rows with
+    False come back as zeros and carry no gradient, and the kernels skip the blocks made of them (ops.attn_fwd)."""
 
     @staticmethod
-    def forward(ctx, qkv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0):
+    def forward(ctx, qkv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0, qmask=None):
         b, n, _ = qkv.shape
         q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
         k = qkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
@@ -478,16 +481,17 @@ class SelfAttnFn(Function):
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
         ctx.band = ops.attn_band_buffer(q, k) if sl is not None else None   # ALiBi band bounds: computed once, reused by the backward
-        o, lse, *bits = ops.attn_fwd(q, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed, band=ctx.band)
+        o, lse, *bits = ops.attn_fwd(q, k, v, kmask=kmask, qmask=qmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed,
+                                     band=ctx.band)
         ctx.dropbits = bits[0] if bits else None
-        ctx.save_for_backward(qkv, o, lse, sl, kmask)
+        ctx.save_for_backward(qkv, o, lse, sl, kmask, qmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, n, heads * 64)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_o):
-        qkv, o, lse, sl, kmask = ctx.saved_tensors
+        qkv, o, lse, sl, kmask, qmask = ctx.saved_tensors
         heads, kv_heads, causal, scale, sshape, p_drop, seed = ctx.cfg
         b, n, _ = qkv.shape
         q = qkv[..., :heads * 64].unflatten(-1, (heads, 64))
@@ -498,16 +502,16 @@ class SelfAttnFn(Function):
         dk = dqkv[..., heads * 64:(heads + kv_heads) * 64].unflatten(-1, (kv_heads, 64))
         dv = dqkv[..., (heads + kv_heads) * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, n, heads, 64)
-        dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, slopes=sl, causal=causal, scale=scale,
+        dsl = ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, qmask=qmask, slopes=sl, causal=causal, scale=scale,
                            want_dslope=sl is not None and ctx.needs_input_grad[1], p_drop=p_drop, dropbits=ctx.dropbits, band=ctx.band)
-        return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
+        return dqkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None, None
 
 
 class CrossAttnFn(Function):
     """q: [b, nq, h*64]; kv: [b, nk, 2*kvh*64] (k | v) fused projection of the context."""
 
     @staticmethod
-    def forward(ctx, q, kv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0):
+    def forward(ctx, q, kv, slopes, kmask, heads: int, kv_heads: int, causal: bool, scale: float, p_drop: float = 0.0, qmask=None):
         b, nq, _ = q.shape
         q4 = q.unflatten(-1, (heads, 64))
         k = kv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
@@ -515,16 +519,17 @@ class CrossAttnFn(Function):
         sl = slopes.detach().reshape(-1).contiguous() if slopes is not None else None
         seed = next_seed() if p_drop > 0 else 0
         ctx.band = ops.attn_band_buffer(q4, k) if sl is not None else None
-        o, lse, *bits = ops.attn_fwd(q4, k, v, kmask=kmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed, band=ctx.band)
+        o, lse, *bits = ops.attn_fwd(q4, k, v, kmask=kmask, qmask=qmask, slopes=sl, causal=causal, scale=scale, p_drop=p_drop, seed=seed,
+                                     band=ctx.band)
         ctx.dropbits = bits[0] if bits else None
-        ctx.save_for_backward(q, kv, o, lse, sl, kmask)
+        ctx.save_for_backward(q, kv, o, lse, sl, kmask, qmask)
         ctx.cfg = (heads, kv_heads, causal, scale, slopes.shape if slopes is not None else None, p_drop, seed)
         return o.view(b, nq, heads * 64)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, d_o):
-        q, kv, o, lse, sl, kmask = ctx.saved_tensors
+        q, kv, o, lse, sl, kmask, qmask = ctx.saved_tensors
         heads, kv_heads, causal, scale, sshape, p_drop, seed = ctx.cfg
         b, nq, _ = q.shape
         q4 = q.unflatten(-1, (heads, 64))
@@ -535,10 +540,10 @@ class CrossAttnFn(Function):
         dk = dkv[..., :kv_heads * 64].unflatten(-1, (kv_heads, 64))
         dv = dkv[..., kv_heads * 64:].unflatten(-1, (kv_heads, 64))
         d_o = to_bf16(d_o).contiguous().view(b, nq, heads, 64)
-        dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, slopes=sl,
+        dsl = ops.attn_bwd(q4, k, v, o, d_o, lse, dq=dq.unflatten(-1, (heads, 64)), dk=dk, dv=dv, kmask=kmask, qmask=qmask, slopes=sl,
                            causal=causal, scale=scale, want_dslope=sl is not None and ctx.needs_input_grad[2], p_drop=p_drop,
                            dropbits=ctx.dropbits, band=ctx.band)
-        return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None
+        return dq, dkv, (dsl.view(sshape) if dsl is not None else None), None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -42,7 +42,7 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 TUNING_EPOCH = 0
 
 # The library itself never reads the environment (include/spn.h): tuning knobs are set explicitly.  For A/B runs from the

@@ -148,9 +148,16 @@ class Attention(nn.Module, Constructor):
         if has_memkv and key_mask is not None:     # attention.py:151-152: the memories are always visible
             key_mask = nn.functional.pad(key_mask, (self.num_mem_kv, 0), value=True)
 
+        # the rows this block's output is multiplied by at the end (attention.py:216-218): handed to the attention core as well, which
+        # then neither computes nor differentiates the padding rows of a ragged batch
+        qmask = mask
+        if mask is not None and has_cache:
+            qmask = mask[:, -1:]
+        core_qmask = qmask if qmask is not None and qmask.shape[1] == n else None
+
         if not has_context and not has_cache and not has_memkv:
             qkv = F_.linear(x, self._fused("_w_qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight)))
-            o = F_.SelfAttnFn.apply(qkv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop)
+            o = F_.SelfAttnFn.apply(qkv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop, core_qmask)
             k_view, v_view = qkv[..., h * 64:(h + kvh) * 64], qkv[..., (h + kvh) * 64:]
         else:
             q = F_.linear(x, self._head_rows(self.to_q.weight))
@@ -160,12 +167,9 @@ class Attention(nn.Module, Constructor):
             if has_cache:  # attention.py:155-156 (K/V of earlier positions; layout b n (kvh d))
                 ck, cv = self._cache_rows(cache.keys), self._cache_rows(cache.values)
                 kv = torch.cat([torch.cat([ck, kv[..., :kvh * 64]], dim=1), torch.cat([cv, kv[..., kvh * 64:]], dim=1)], dim=-1)
-            o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop)
+            o = F_.CrossAttnFn.apply(q, kv, slopes, key_mask, h, kvh, self.causal, self.scale, p_drop, core_qmask)
             k_view, v_view = kv[..., :kvh * 64], kv[..., kvh * 64:]
 
-        qmask = mask
-        if mask is not None and has_cache:
-            qmask = mask[:, -1:]
         out = F_.linear(o, self._head_cols(self.to_out.weight), residual=residual, rowmask=qmask.contiguous() if qmask is not None else None,
                         out_fp32=residual is not None)
         if kvh != 1:  # reference layout b h n d

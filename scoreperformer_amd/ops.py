@@ -238,12 +238,14 @@ def _mask_u8(m: Optional[torch.Tensor]):
     return m.view(torch.uint8) if m.dtype == torch.bool else m
 
 
-def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0, band=None):
+def attn_fwd(q, k, v, *, kmask=None, qmask=None, slopes=None, causal=False, scale=None, p_drop: float = 0.0, seed: int = 0, band=None):
     """q [b,nq,h,64], k/v [b,nk,kvh,64] (kvh = 1 or h), kmask [b,nk] bool, slopes [h] fp32 -> o [b,nq,h,64], lse [b,h,nq].
 
     With p_drop > 0 a third value is returned: the dropout keep bits (int16 words, 1 bit per score) that `attn_bwd` needs.
     `band`: fp32 buffer from `attn_band_buffer` that receives the ALiBi band bounds, for `attn_bwd` to reuse; with slopes and
-    no buffer one is allocated here (the library owns no memory), without slopes there is no band."""
+    no buffer one is allocated here (the library owns no memory), without slopes there is no band.
+    `qmask` [b,nq] bool: the query-side padding mask -- rows with False come back as zeros (the module multiplies its output by
+    this mask anyway, attention.py:216-218) with a dead lse, and blocks of such rows are not computed (include/spn.h)."""
     if band is None and slopes is not None:
         band = attn_band_buffer(q, k)
     require_gpu(q, k, v)
@@ -255,11 +257,13 @@ def attn_fwd(q, k, v, *, kmask=None, slopes=None, causal=False, scale=None, p_dr
     if kvh == 1:
         ks, vs = (ks[0], ks[1], 0), (vs[0], vs[1], 0)
     strides = (c_long * 12)(*_bnhd_strides(q), *ks, *vs, *_bnhd_strides(o))
-    kmask = _mask_u8(kmask)
+    kmask, qmask = _mask_u8(kmask), _mask_u8(qmask)
+    if qmask is not None and tuple(qmask.shape) != (b, nq):
+        raise SpnError(f"attn_fwd: qmask must be [b, nq] = {(b, nq)}, got {tuple(qmask.shape)}")
     bits = None
     if p_drop > 0:
         bits = torch.empty(load().spn_attn_dropbits_elems(c_int(b), c_int(h), c_int(nq), c_int(nk)), device=q.device, dtype=torch.int16)
-    call("spn_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh),
+    call("spn_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), ptr(qmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh),
          c_int(nq), c_int(nk), c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides,
          c_float(p_drop), ctypes.c_uint(seed & 0xFFFFFFFF), ptr(bits), ptr(band), stream_ptr())
     return (o, lse) if bits is None else (o, lse, bits)
@@ -277,10 +281,10 @@ def attn_set_band(log2_threshold: float) -> None:
     load().spn_attn_set_band(c_float(log2_threshold))
 
 
-def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
+def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, qmask=None, slopes=None, causal=False, scale=None, want_dslope=False,
              p_drop: float = 0.0, dropbits=None, band=None):
     """Writes dq/dk/dv ([b,n,h|kvh,64] bf16 views, e.g. slices of a fused dqkv buffer); returns dslope [h] fp32 or None.
-    `dropbits`: the keep bits returned by `attn_fwd` when p_drop > 0."""
+    `dropbits`: the keep bits returned by `attn_fwd` when p_drop > 0; `qmask`: the forward's (its padding rows get dq = 0)."""
     if p_drop > 0 and dropbits is None:
         raise SpnError("attn_bwd: p_drop > 0 needs the keep bits of the forward")
     b, nq, h, dh = q.shape
@@ -295,9 +299,9 @@ def attn_bwd(q, k, v, o, d_o, lse, *, dq, dk, dv, kmask=None, slopes=None, causa
     strides = (c_long * 21)(*_bnhd_strides(q), *ks, *vs, *_bnhd_strides(o), *_bnhd_strides(dq), *dks, *dvs)
     delta = torch.empty((b, h, nq), device=q.device, dtype=F32)
     dslope = zeros_small(h, q.device) if want_dslope else None
-    kmask = _mask_u8(kmask)
+    kmask, qmask = _mask_u8(kmask), _mask_u8(qmask)
     call("spn_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-         ptr(dslope), ptr(kmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
+         ptr(dslope), ptr(kmask), ptr(qmask), ptr(slopes), c_int(b), c_int(h), c_int(kvh), c_int(nq), c_int(nk),
          c_int(1 if causal else 0), c_float(scale if scale is not None else dh ** -0.5), strides, c_float(p_drop),
          ptr(dropbits), ptr(band), stream_ptr())
     return dslope

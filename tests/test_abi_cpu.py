@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     missing = [s for s in syms if not hasattr(handle, s)]
     assert not missing, missing
-    assert handle.spn_abi_version() == 9
+    assert handle.spn_abi_version() == 10
 
 
 def test_python_bindings_call_only_declared_symbols():

@@ -194,6 +194,58 @@ def test_attention_fwd_bwd(dev, mqa, causal, b, h, nq, nk):
     assert rel_err(dslope, sr.grad) < 3e-2
 
 
+@pytest.mark.parametrize("band", [0.0, 30.0])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("cross", [False, True])
+def test_attention_query_mask_drops_padding_rows_and_nothing_else(dev, cross, causal, p_drop, band):
+    """qmask (the module's output mask, attention.py:216-218): rows with 0 come back as zeros with a dead lse and carry no gradient in
+    either direction, whatever dO holds there; every other row, and dK / dV / d slope, are those of the same call without qmask and
+    with dO zeroed on the padding rows -- bit for bit when the ALiBi band is off (with it, the padding rows no longer widen the bound
+    of the tile they share with live rows: differences below the band's own 2^-19)."""
+    from scoreperformer_amd import ops
+    b, h, nk = 5, 4, 640
+    nq = 384 if cross else nk
+    g = torch.Generator().manual_seed(17 + int(cross) + 2 * int(causal))
+    q = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+    k = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
+    v = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
+    klens = torch.tensor([640, 400, 129, 64, 577])
+    qlens = torch.tensor([384, 200, 1, 128, 300]) if cross else klens   # whole blocks, whole tiles, waves and single rows of padding
+    kmask = (torch.arange(nk)[None, :] < klens[:, None]).to(dev)
+    qmask = (torch.arange(nq)[None, :] < qlens[:, None]).to(dev)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / h) for i in range(h)], device=dev)
+    d_o = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
+    d_o_zeroed = d_o * qmask[:, :, None, None]
+    kw = dict(kmask=kmask, slopes=slopes, causal=causal, scale=0.125)
+
+    def run(qm, dout):
+        fw = ops.attn_fwd(q, k, v, qmask=qm, p_drop=p_drop, seed=5, **kw)
+        o, lse = fw[0], fw[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dsl = ops.attn_bwd(q, k, v, o, dout, lse, dq=dq, dk=dk, dv=dv, qmask=qm, want_dslope=True, p_drop=p_drop,
+                           dropbits=fw[2] if p_drop > 0 else None, **kw)
+        return o, lse, dq, dk, dv, dsl
+
+    ops.attn_set_band(band)
+    try:
+        o0, lse0, dq0, dk0, dv0, ds0 = run(None, d_o_zeroed)
+        o1, lse1, dq1, dk1, dv1, ds1 = run(qmask, d_o)
+    finally:
+        ops.attn_set_band(30.0)
+    dead = ~qmask
+    assert o1[dead].abs().max().item() == 0.0 and dq1[dead].abs().max().item() == 0.0
+    assert (lse1.transpose(1, 2)[dead] < -1e37).all()
+    live = qmask
+    if band == 0.0:
+        assert torch.equal(o1[live], o0[live]) and torch.equal(lse1.transpose(1, 2)[live], lse0.transpose(1, 2)[live])
+        assert torch.equal(dq1[live], dq0[live]) and torch.equal(dk1, dk0) and torch.equal(dv1, dv0)
+    else:
+        assert rel_err(o1[live], o0[live]) < 1e-3 and rel_err(dq1[live], dq0[live]) < 1e-3
+        assert rel_err(dk1, dk0) < 1e-3 and rel_err(dv1, dv0) < 1e-3
+    assert rel_err(ds1, ds0) < 1e-4   # float atomics over the blocks: order-dependent in the last bits
+
+
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("use_slopes,use_mask", [(True, False), (False, False), (True, True)])
 def test_attention_fast_paths_and_rescale(dev, causal, use_slopes, use_mask):

@@ -18,24 +18,35 @@ def main():
     d_o = torch.randn(b, n, h, 64, device=dev).bfloat16()
     dqkv = torch.empty_like(qkv)
     dq = dqkv[..., :h * 64].unflatten(-1, (h, 64)); dk = dqkv[..., h * 64:(h + 1) * 64].unflatten(-1, (1, 64)); dv = dqkv[..., (h + 1) * 64:].unflatten(-1, (1, 64))
+    kmask = None
+    if os.environ.get("RAGGED") == "1":   # SURVEY 8(d)'s ragged variant: lengths ~ U{n/2..n}, right-padded
+        gen = torch.Generator().manual_seed(0)
+        lens = torch.randint(n // 2, n + 1, (b,), generator=gen)
+        kmask = (torch.arange(n)[None, :] < lens[:, None]).to(dev)
+        print(f"ragged: valid fraction {kmask.float().mean().item():.3f}")
+    if os.environ.get("FULLMASK") == "1":   # a mask tensor without a single False: what a full-length batch hands the kernels
+        kmask = torch.ones(b, n, dtype=torch.bool, device=dev)
+    qmask = kmask if os.environ.get("QMASK", "1") == "1" else None   # self-attention: the padding rows are the padding keys
+    import inspect
+    qkw = {"qmask": qmask} if "qmask" in inspect.signature(getattr(ops, "_attn_fwd_raw", ops.attn_fwd)).parameters else {}   # older trees (A/B)
     p_drop = float(os.environ.get("DROP", 0))   # attention dropout (the benchmark's 0.1)
     dkw = {"p_drop": p_drop, "seed": 7} if p_drop > 0 else {}
     for causal in (False, True):
         fl = 4.0 * b * h * n * n * 64 * (0.5 if causal else 1.0)
-        res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, **dkw)
+        res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, kmask=kmask, **qkw, **dkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, **dkw)
+            res = ops.attn_fwd(q, k, v, slopes=slopes, causal=causal, kmask=kmask, **qkw, **dkw)
         torch.cuda.synchronize()
         tf = (time.perf_counter() - t0) / reps
         o, lse = res[0], res[1]
         bkw = {"p_drop": p_drop, "dropbits": res[2]} if p_drop > 0 else {}
-        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
+        ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, **qkw, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
+            ops.attn_bwd(q, k, v, o, d_o, lse, dq=dq, dk=dk, dv=dv, kmask=kmask, **qkw, slopes=slopes, causal=causal, want_dslope=(slopes is not None and os.environ.get("DSLOPE", "1") != "0"), **bkw)
         torch.cuda.synchronize()
         tb = (time.perf_counter() - t0) / reps
         print(f"causal={causal}: fwd {tf*1e3:.3f} ms {fl/tf/1e12:.0f} TF/s | bwd {tb*1e3:.3f} ms {2.5*fl/tb/1e12:.0f} TF/s (5-matmul flops)")
