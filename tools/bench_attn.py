@@ -24,6 +24,8 @@ def main():
         lens = torch.randint(n // 2, n + 1, (b,), generator=gen)
         kmask = (torch.arange(n)[None, :] < lens[:, None]).to(dev)
         print(f"ragged: valid fraction {kmask.float().mean().item():.3f}")
+    if os.environ.get("LEN_FRAC"):   # every sequence the same length: separates the cost of padding from the imbalance of a ragged batch
+        kmask = (torch.arange(n)[None, :] < int(n * float(os.environ["LEN_FRAC"]))).expand(b, n).contiguous().to(dev)
     if os.environ.get("FULLMASK") == "1":   # a mask tensor without a single False: what a full-length batch hands the kernels
         kmask = torch.ones(b, n, dtype=torch.bool, device=dev)
     qmask = kmask if os.environ.get("QMASK", "1") == "1" else None   # self-attention: the padding rows are the padding keys
