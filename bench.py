@@ -225,6 +225,8 @@ def main():
                                f"latent dropout {list(cfg.perf_encoder.latent_dropout)} inclusive (recipes/scoreperformer/base.yaml:119-126)",
                    "preset": args.preset, "global_batch": world * args.batch, "seq_len": args.seq, "parallelism": f"dp{world}",
                    "tokens_per_s_per_gpu": value / world, "final_loss": loss, "ragged": bool(args.ragged), "valid_note_fraction": valid_fraction,
+                   # `value` counts every position of the [batch, seq] grid (the metric's definition); on a ragged batch this is the rate of real notes
+                   "valid_note_tokens_per_s": value * valid_fraction,
                    "dp_transport": transport if dist is not None else None, "dp_transport_note": transport_note,
                    "dist_backend": (args.dist_backend + (" on ONE device: a test run, not a measurement" if args.one_device else "")) if dist is not None else None,
                    "gemm_persist_bwd": int(lib_mod.get_tuning("gemm_persist_bwd")),
