@@ -65,7 +65,11 @@ int spn_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
  * computes for a row with qmask = 0 is never seen: such a row's o is written as zeros and its lse as a dead marker (-1.7e38) that
  * makes spn_attn_bwd give it (and take from it) no gradient, and 128-row blocks / 64-row tiles made of such rows only are not
  * walked at all.  Key tiles with masked keys only are not walked either (they add exp(-1.7e38 - m) = 0 to every live row).
- * In a right-padded ragged batch that is the padding's share of the attention work. */
+ * In a right-padded ragged batch that is the padding's share of the attention work.  A LIVE row without a single live key in its
+ * visible range (causal rows in front of a front-padded sequence when no qmask is given, a context that is masked entirely) has no
+ * defined attention: the reference averages V uniformly over the masked keys (attend.py:102 fills with a finite value); this core
+ * returns that average when no live key exists in the batch row at all, and zeros for rows that merely lie outside the live key
+ * range -- the module zeroes such rows either way. */
 /* p_drop > 0: attention dropout (attend.py:122).  The mask is a pure function of (seed, b, h, i, j); the forward also writes
  * it as keep bits (1 bit per score) into `dropbits` (spn_attn_dropbits_elems() uint16 words), which the backward reads back.
  * delta: workspace b*h*nq floats; dslope [h] ACCUMULATED (may be null) */
