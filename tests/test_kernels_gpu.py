@@ -198,20 +198,22 @@ def test_attention_fwd_bwd(dev, mqa, causal, b, h, nq, nk):
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("cross", [False, True])
-def test_attention_query_mask_drops_padding_rows_and_nothing_else(dev, cross, causal, p_drop, band):
+@pytest.mark.parametrize("odd", [False, True])
+def test_attention_query_mask_drops_padding_rows_and_nothing_else(dev, odd, cross, causal, p_drop, band):
     """qmask (the module's output mask, attention.py:216-218): rows with 0 come back as zeros with a dead lse and carry no gradient in
     either direction, whatever dO holds there; every other row, and dK / dV / d slope, are those of the same call without qmask and
     with dO zeroed on the padding rows -- bit for bit when the ALiBi band is off (with it, the padding rows no longer widen the bound
     of the tile they share with live rows: differences below the band's own 2^-19)."""
     from scoreperformer_amd import ops
-    b, h, nk = 5, 4, 640
-    nq = 384 if cross else nk
+    b, h, nk = 5, 4, (333 if odd else 640)   # odd: mask rows off the 16-byte grid (no vector scans), ragged last tiles
+    nq = (300 if odd else 384) if cross else nk
     g = torch.Generator().manual_seed(17 + int(cross) + 2 * int(causal))
     q = torch.randn(b, nq, h, 64, generator=g).to(dev).bfloat16()
     k = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
     v = torch.randn(b, nk, 1, 64, generator=g).to(dev).bfloat16()
-    klens = torch.tensor([640, 400, 129, 64, 577])
-    qlens = torch.tensor([384, 200, 1, 128, 300]) if cross else klens   # whole blocks, whole tiles, waves and single rows of padding
+    klens = torch.tensor([333, 200, 129, 64, 301]) if odd else torch.tensor([640, 400, 129, 64, 577])
+    # whole blocks, whole tiles, waves and single rows of padding
+    qlens = (torch.tensor([300, 200, 1, 128, 257]) if odd else torch.tensor([384, 200, 1, 128, 300])) if cross else klens
     kmask = (torch.arange(nk)[None, :] < klens[:, None]).to(dev)
     qmask = (torch.arange(nq)[None, :] < qlens[:, None]).to(dev)
     slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / h) for i in range(h)], device=dev)
